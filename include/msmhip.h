@@ -1,0 +1,185 @@
+/*
+ * msmhip.h -- C ABI of libmsmhip.so, the MI355X (gfx950) implementation of the
+ * MSMBuilder tICA + geometric-clustering hot path.
+ *
+ * Plain C, caller-owned buffers, no exceptions, no stdout/stderr chatter.
+ * Every entry point returns an int status (MSM_OK == 0, negative = error; the
+ * message is available from msm_last_error()) unless noted.
+ *
+ * Pointer placement.  Functions that take `on_device` accept either host
+ * pointers (on_device = 0: the library stages through its own device buffers)
+ * or device pointers in the current HIP device's address space (on_device = 1:
+ * e.g. torch.Tensor.data_ptr()).  `on_device` applies to the PER-ROW arrays
+ * (X, X_indices, assignments, per-row distances, cdist's `out`); per-centre
+ * arrays (y, Y, ids) and scalar outputs are always host memory.
+ *
+ * Threading: one host thread drives one device; handles are not thread-safe.
+ * All work is enqueued on the stream set with msm_set_stream() (default: the
+ * null stream, which is torch's default current stream).
+ *
+ * What each group replaces in the reference (paths under
+ * /root/reference/msmbuilder):
+ *   msm_tica_*        decomposition/tica.py:150-165 (_initialize), :401-424 (_fit),
+ *                     :228-259 (the sums those properties read), :312-354 (transform)
+ *   msm_dist_*        libdistance/src/dist.hpp:4-80     (via libdistance.pyx:229-270)
+ *   msm_cdist_*       libdistance/src/cdist.hpp:4-49    (via libdistance.pyx:134-179)
+ *   msm_assign_nearest_*  libdistance/src/assign.hpp:6-91 (via libdistance.pyx:82-131)
+ *   msm_kcenters_fit_*    cluster/kcenters.py:79-102 (_KCenters.fit's k-pass loop)
+ *   msm_kmeans_* / msm_mbk_*  sklearn MiniBatchKMeans arithmetic behind
+ *                     cluster/__init__.py:67-69 (third-party)
+ * The exact reference signatures of libdistance are additionally exported,
+ * unprefixed, from include/msmhip_libdistance.h.
+ */
+#ifndef MSMHIP_H
+#define MSMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t msm_idx_t; /* npy_intp on LP64 */
+
+enum msm_status {
+    MSM_OK = 0,
+    MSM_ERR_INVALID = -1,   /* bad argument (shape, null pointer, dtype code) */
+    MSM_ERR_METRIC = -2,    /* unknown metric name (reference: prints "Error", returns -1) */
+    MSM_ERR_HIP = -3,       /* a HIP runtime call failed */
+    MSM_ERR_NODEVICE = -4,  /* no usable GPU */
+    MSM_ERR_NONFINITE = -5, /* input contains NaN/Inf (reference: ValueError, validation.py:68-74) */
+    MSM_ERR_STATE = -6      /* handle used before data / after destroy */
+};
+
+/* accumulate precision of the tICA covariance kernel */
+enum msm_tica_mode {
+    MSM_TICA_F32 = 0,  /* v_mfma_f32_32x32x2_f32, fp32 partials per <=4096-row chunk, fp64 merge */
+    MSM_TICA_F64 = 1   /* v_mfma_f64_16x16x4_f64 on fp64-widened inputs: the reference's arithmetic */
+};
+
+/* ---- runtime ---------------------------------------------------------- */
+const char* msm_last_error(void);
+const char* msm_version(void);
+int msm_device_count(void);          /* number of visible GPUs, 0 if none (never negative) */
+int msm_init(int device);            /* hipSetDevice + arch check (gfx950) */
+int msm_set_stream(void* hip_stream); /* hipStream_t; NULL = null stream */
+int msm_synchronize(void);
+int msm_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+
+/* device memory helpers (so callers without torch can keep data resident) */
+int msm_malloc(void** dptr, size_t bytes);
+int msm_free(void* dptr);
+int msm_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int msm_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int msm_memcpy_d2d(void* dst, const void* src, size_t bytes);
+/* out[i, :] = X[rows[i], :]  (X device or host per on_device; rows/out follow it) */
+int msm_gather_rows(const void* X, int elem_size, msm_idx_t n_features, const msm_idx_t* rows,
+                    msm_idx_t n_rows, void* out, int on_device);
+/* HIP-event timing on the library's stream (bench.py's roofline leg) */
+int msm_event_create(void** ev);
+int msm_event_record(void* ev);
+int msm_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int msm_event_destroy(void* ev);
+
+/* ---- tICA second-moment accumulation ---------------------------------- */
+typedef struct msm_tica msm_tica_t;
+
+int msm_tica_create(msm_tica_t** h, msm_idx_t n_features, msm_idx_t lag_time, int mode);
+int msm_tica_destroy(msm_tica_t* h);
+int msm_tica_reset(msm_tica_t* h); /* zero all accumulators and counters */
+
+/* One trajectory X[n_rows, n_features] (row stride ld elements), dtype_bytes = 4 (f32) or 8 (f64).
+ * Lagged pairs never span calls.  n_rows <= lag_time is a no-op with *skipped = 1
+ * (tica.py:410-412).  check_finite != 0: the call synchronises and returns
+ * MSM_ERR_NONFINITE, state unchanged, if X holds NaN/Inf; check_finite == 0: fully
+ * asynchronous, a sticky flag is kept (msm_tica_nonfinite). */
+int msm_tica_accumulate(msm_tica_t* h, const void* X, int dtype_bytes, msm_idx_t n_rows,
+                        msm_idx_t ld, int on_device, int check_finite, int* skipped);
+/* Many trajectories in one launch: X_ptrs[s] -> n_rows[s] x n_features, common ld.
+ * X_ptrs / n_rows are host arrays of length n_seq; the trajectories themselves are
+ * device-resident (on_device = 1) or host (0).  *n_skipped counts too-short ones. */
+int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
+                              msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int on_device,
+                              int check_finite, msm_idx_t* n_skipped);
+int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until reset */
+
+/* Accumulators as the reference defines them (float64, row-major F x F / F):
+ *   C    = sum_traj X[:-tau].T @ X[tau:]                    (tica.py:417)
+ *   G    = sum_traj X[:-tau].T @ X[:-tau] + X[tau:].T @ X[tau:]   (tica.py:421-422, only their sum is ever read: :245)
+ *   s0   = sum_traj X[:-tau].sum(0)   stau = sum_traj X[tau:].sum(0)   (tica.py:418-419)
+ *   n_observations, n_sequences                               (tica.py:414-415)
+ * Host pointers. */
+int msm_tica_export(msm_tica_t* h, double* C, double* G, double* s0, double* stau,
+                    msm_idx_t* n_observations, msm_idx_t* n_sequences);
+int msm_tica_import(msm_tica_t* h, const double* C, const double* G, const double* s0,
+                    const double* stau, msm_idx_t n_observations, msm_idx_t n_sequences);
+/* Packed form for one RCCL all-reduce(sum) over xGMI (torch.distributed):
+ * doubles [C (F*F) | G (F*F) | s0 (F) | stau (F) | n_observations | n_sequences]. */
+msm_idx_t msm_tica_packed_size(msm_tica_t* h); /* number of doubles */
+int msm_tica_export_packed(msm_tica_t* h, double* buf, int on_device);
+int msm_tica_import_packed(msm_tica_t* h, const double* buf, int on_device);
+
+/* out[n, k] (float64) = (X - mean) @ comps.T, comps is k x F row-major, mean/comps host
+ * float64 (tica.py:329-333; any kinetic/commute column scaling is folded into comps by
+ * the caller).  X / out follow on_device.  check_finite as above. */
+int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features,
+                     msm_idx_t ld, const double* mean, const double* comps, msm_idx_t k,
+                     double* out, int on_device, int check_finite);
+
+/* ---- libdistance: exact-arithmetic vector metrics --------------------- */
+/* metric in {"euclidean","sqeuclidean","cityblock","chebyshev","canberra",
+ *            "braycurtis","hamming","jaccard"}; results are bit-identical to the
+ * reference's scalar loops (float subtract -> double accumulate, feature order,
+ * sqrt before compare, strict <, lowest index wins).  out/min_dist are float64. */
+int msm_dist_f32(const float* X, const float* y, const char* metric, msm_idx_t n, msm_idx_t m,
+                 const msm_idx_t* X_indices, msm_idx_t n_X_indices, double* out, int on_device);
+int msm_dist_f64(const double* X, const double* y, const char* metric, msm_idx_t n, msm_idx_t m,
+                 const msm_idx_t* X_indices, msm_idx_t n_X_indices, double* out, int on_device);
+int msm_cdist_f32(const float* XA, const float* XB, const char* metric, msm_idx_t na,
+                  msm_idx_t nb, msm_idx_t m, double* out, int on_device);
+int msm_cdist_f64(const double* XA, const double* XB, const char* metric, msm_idx_t na,
+                  msm_idx_t nb, msm_idx_t m, double* out, int on_device);
+/* assignments[i] = argmin_j metric(X[i or X_indices[i]], Y[j]); min_dist nullable;
+ * *inertia = sum_i min_dist[i] (fp64 tree sum; the reference sums sequentially). */
+int msm_assign_nearest_f32(const float* X, const float* Y, const char* metric,
+                           const msm_idx_t* X_indices, msm_idx_t n_X, msm_idx_t n_Y,
+                           msm_idx_t n_features, msm_idx_t n_X_indices, msm_idx_t* assignments,
+                           double* min_dist, double* inertia, int on_device);
+int msm_assign_nearest_f64(const double* X, const double* Y, const char* metric,
+                           const msm_idx_t* X_indices, msm_idx_t n_X, msm_idx_t n_Y,
+                           msm_idx_t n_features, msm_idx_t n_X_indices, msm_idx_t* assignments,
+                           double* min_dist, double* inertia, int on_device);
+
+/* Gonzalez k-centers (kcenters.py:79-102): K fused dist + running-min + argmax passes,
+ * no host round trip inside the loop.  ids (host, K) = chosen row indices, first =
+ * seed_index; labels (int64) / distances (float64) per row follow on_device;
+ * *inertia = sum(distances). */
+int msm_kcenters_fit_f32(const float* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters,
+                         const char* metric, msm_idx_t seed_index, msm_idx_t* ids,
+                         msm_idx_t* labels, double* distances, double* inertia, int on_device);
+int msm_kcenters_fit_f64(const double* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters,
+                         const char* metric, msm_idx_t seed_index, msm_idx_t* ids,
+                         msm_idx_t* labels, double* distances, double* inertia, int on_device);
+
+/* ---- k-means labelling / mini-batch step (fp32, GEMM form on MFMA) ---- */
+/* labels[i] = argmin_j ||X[i]-C[j]||^2 computed as ||c||^2 - 2 x.c (+||x||^2 for the
+ * inertia), fp32 like scikit-learn's _labels_inertia; centers host [K, m].
+ * labels int32 (sklearn's dtype) follow on_device; *inertia fp64 sum of fp32 terms. */
+int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* centers,
+                         msm_idx_t K, int32_t* labels, double* inertia, int on_device);
+/* One MiniBatchKMeans step on the rows X[batch_idx[b]] (batch_idx host int64, length B):
+ * label, then per-centre streaming mean c <- (c*w + sum x)/(w + n) with cumulative
+ * counts (sklearn _k_means_minibatch.pyx:59-109, unit sample weights).  centers
+ * [K, m] and counts [K] are host, updated in place; sums/counts partials are
+ * exported for the multi-GPU all-reduce when apply_update == 0:
+ *   batch_sums [K, m] float64, batch_counts [K] float64 (host, nullable). */
+int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* batch_idx,
+                     msm_idx_t B, float* centers, float* counts, msm_idx_t K,
+                     double* batch_inertia, double* batch_sums, double* batch_counts,
+                     int apply_update, int on_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSMHIP_H */

@@ -1,0 +1,207 @@
+"""ctypes binding of libmsmhip.so (include/msmhip.h).
+
+The product path has no CPU fallback: if the shared library is missing, cannot
+be loaded, or no gfx950 device is visible when a compute entry point is called,
+an exception is raised -- nothing is silently routed elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsmhip.so")
+
+MSM_OK = 0
+MSM_ERR_INVALID = -1
+MSM_ERR_METRIC = -2
+MSM_ERR_HIP = -3
+MSM_ERR_NODEVICE = -4
+MSM_ERR_NONFINITE = -5
+MSM_ERR_STATE = -6
+
+TICA_F32 = 0
+TICA_F64 = 1
+
+_i64 = C.c_int64
+_p = C.c_void_p
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+_lib = None
+_initialized_device = None
+
+
+class MsmHipError(RuntimeError):
+    pass
+
+
+class NoDeviceError(MsmHipError):
+    pass
+
+
+def _declare(lib):
+    def f(name, restype, *argtypes):
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    f("msm_last_error", C.c_char_p)
+    f("msm_version", C.c_char_p)
+    f("msm_device_count", C.c_int)
+    f("msm_init", C.c_int, C.c_int)
+    f("msm_set_stream", C.c_int, _p)
+    f("msm_synchronize", C.c_int)
+    f("msm_device_info", C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), _i64p)
+    f("msm_malloc", C.c_int, C.POINTER(_p), C.c_size_t)
+    f("msm_free", C.c_int, _p)
+    f("msm_memcpy_h2d", C.c_int, _p, _p, C.c_size_t)
+    f("msm_memcpy_d2h", C.c_int, _p, _p, C.c_size_t)
+    f("msm_memcpy_d2d", C.c_int, _p, _p, C.c_size_t)
+    f("msm_gather_rows", C.c_int, _p, C.c_int, _i64, _p, _i64, _p, C.c_int)
+    f("msm_event_create", C.c_int, C.POINTER(_p))
+    f("msm_event_record", C.c_int, _p)
+    f("msm_event_elapsed_ms", C.c_int, _p, _p, C.POINTER(C.c_float))
+    f("msm_event_destroy", C.c_int, _p)
+
+    f("msm_tica_create", C.c_int, C.POINTER(_p), _i64, _i64, C.c_int)
+    f("msm_tica_destroy", C.c_int, _p)
+    f("msm_tica_reset", C.c_int, _p)
+    f("msm_tica_accumulate", C.c_int, _p, _p, C.c_int, _i64, _i64, C.c_int, C.c_int, C.POINTER(C.c_int))
+    f("msm_tica_accumulate_batch", C.c_int, _p, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, C.c_int,
+      C.c_int, _i64p)
+    f("msm_tica_nonfinite", C.c_int, _p, C.POINTER(C.c_int))
+    f("msm_tica_export", C.c_int, _p, _p, _p, _p, _p, _i64p, _i64p)
+    f("msm_tica_import", C.c_int, _p, _p, _p, _p, _p, _i64, _i64)
+    f("msm_tica_packed_size", _i64, _p)
+    f("msm_tica_export_packed", C.c_int, _p, _p, C.c_int)
+    f("msm_tica_import_packed", C.c_int, _p, _p, C.c_int)
+    f("msm_tica_project", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, _i64, _p, C.c_int, C.c_int)
+
+    for sfx in ("f32", "f64"):
+        f("msm_dist_" + sfx, C.c_int, _p, _p, C.c_char_p, _i64, _i64, _p, _i64, _p, C.c_int)
+        f("msm_cdist_" + sfx, C.c_int, _p, _p, C.c_char_p, _i64, _i64, _i64, _p, C.c_int)
+        f("msm_assign_nearest_" + sfx, C.c_int, _p, _p, C.c_char_p, _p, _i64, _i64, _i64, _i64, _p, _p,
+          _f64p, C.c_int)
+        f("msm_kcenters_fit_" + sfx, C.c_int, _p, _i64, _i64, _i64, C.c_char_p, _i64, _p, _p, _p, _f64p,
+          C.c_int)
+    f("msm_kmeans_label_f32", C.c_int, _p, _i64, _i64, _p, _i64, _p, _f64p, C.c_int)
+    f("msm_mbk_step_f32", C.c_int, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _f64p, _p, _p, C.c_int,
+      C.c_int)
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsmHipError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C msmbuilder_amd/csrc` (hipcc --offload-arch=gfx950). "
+                "msmbuilder_amd has no CPU fallback." % LIB_PATH)
+        try:
+            # torch (if installed) must bring in ITS libamdhip64 first so both share one HIP runtime
+            import torch  # noqa: F401
+        except Exception:
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def last_error() -> str:
+    return lib().msm_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    if rc == MSM_OK:
+        return
+    msg = last_error()
+    if rc == MSM_ERR_NONFINITE:
+        raise ValueError(msg)
+    if rc == MSM_ERR_METRIC:
+        raise ValueError(msg)
+    if rc == MSM_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == MSM_ERR_NODEVICE:
+        raise NoDeviceError(msg + " (msmbuilder_amd needs an MI355X/gfx950 GPU; there is no CPU fallback)")
+    raise MsmHipError("libmsmhip error %d: %s" % (rc, msg))
+
+
+def device_count() -> int:
+    return lib().msm_device_count()
+
+
+def ensure_device(device=None):
+    """Select the GPU (LOCAL_RANK-aware) once per process and bind torch's current stream."""
+    global _initialized_device
+    L = lib()
+    if _initialized_device is None or (device is not None and device != _initialized_device):
+        if device is None:
+            device = int(os.environ.get("MSMBUILDER_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = L.msm_device_count()
+            if n > 0:
+                device %= n
+        check(L.msm_init(int(device)))
+        _initialized_device = int(device)
+    return _initialized_device
+
+
+def set_stream(stream_handle):
+    check(lib().msm_set_stream(C.c_void_p(stream_handle or 0)))
+
+
+def synchronize():
+    check(lib().msm_synchronize())
+
+
+# --------------------------------------------------------------------------
+# array plumbing: numpy (host) or torch CUDA tensors (device)
+# --------------------------------------------------------------------------
+def is_device_array(x) -> bool:
+    return hasattr(x, "data_ptr") and bool(getattr(x, "is_cuda", False))
+
+
+class Arr:
+    """(pointer, shape, dtype, on_device) view of a numpy array or torch CUDA tensor."""
+    __slots__ = ("ptr", "shape", "dtype", "on_device", "keep")
+
+    def __init__(self, x, dtype=None):
+        if is_device_array(x):
+            import torch
+            if dtype is not None:
+                want = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                        np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32}[np.dtype(dtype)]
+                if x.dtype != want:
+                    x = x.to(want)
+            x = x.contiguous()
+            ensure_device(x.device.index)
+            set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+            self.ptr = x.data_ptr()
+            self.shape = tuple(x.shape)
+            self.dtype = np.dtype(str(x.dtype).replace("torch.", ""))
+            self.on_device = 1
+        else:
+            x = np.ascontiguousarray(x, dtype=dtype)
+            ensure_device()
+            self.ptr = x.ctypes.data
+            self.shape = x.shape
+            self.dtype = x.dtype
+            self.on_device = 0
+        self.keep = x
+
+    @property
+    def vp(self):
+        return C.c_void_p(self.ptr)
+
+
+def empty_like_placement(ref: Arr, shape, dtype):
+    """Allocate an output next to `ref`: torch CUDA tensor for device inputs, numpy otherwise."""
+    if ref.on_device:
+        import torch
+        tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.int64): torch.int64,
+               np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}[np.dtype(dtype)]
+        return torch.empty(shape, dtype=tdt, device=ref.keep.device)
+    return np.zeros(shape, dtype=dtype)

@@ -1,0 +1,153 @@
+"""K-Centers (Gonzalez farthest-point) clustering on MI355X: drop-in for
+``msmbuilder.cluster.KCenters`` (reference: msmbuilder/cluster/kcenters.py:24-182).
+
+The reference runs ``n_clusters`` python iterations of ``libdistance.dist`` + numpy
+mask/argmax passes on one CPU thread (kcenters.py:91-97).  Here the whole loop is
+``msm_kcenters_fit_*`` in libmsmhip: one fused launch per centre (distance to the newest
+centre, strict running-min update of ``distances_``/``labels_``, per-block argmax) with
+no host round trip in between; ``predict`` is the exact ``assign_nearest`` kernel.
+Results are bit-identical to the reference: same centre ids, labels and float64
+distances, for float32 and float64 input and every vector metric.
+"""
+import ctypes as C
+
+import numpy as np
+from sklearn.base import ClusterMixin, TransformerMixin
+from sklearn.utils import check_random_state
+
+from .. import _lib, libdistance
+from .._lib import Arr, check, empty_like_placement, is_device_array
+from ..base import BaseEstimator
+from .base import MultiSequenceClusterMixin
+
+__all__ = ['KCenters']
+
+
+def _as_float(X):
+    """kcenters.py:80-82: anything that is not float32/float64 becomes float64."""
+    if isinstance(X, np.ndarray):
+        if not (X.dtype == 'float32' or X.dtype == 'float64'):
+            X = X.astype('float64')
+    elif is_device_array(X):
+        import torch
+        if X.dtype not in (torch.float32, torch.float64):
+            X = X.to(torch.float64)
+    return X
+
+
+class _KCenters(ClusterMixin, TransformerMixin):
+    """Single-array K-Centers; see :class:`KCenters` for the sequence-list estimator.
+
+    Parameters
+    ----------
+    n_clusters : int, optional, default: 8
+        The number of clusters to form as well as the number of centroids to generate.
+    metric : {"euclidean", "sqeuclidean", "cityblock", "chebyshev", "canberra",
+              "braycurtis", "hamming", "jaccard", "cityblock"}
+        The distance metric to use ("rmsd" needs mdtraj and is not supported here).
+    random_state : integer or numpy.RandomState, optional
+        Seeds the choice of the first centre, exactly as the reference does
+        (``check_random_state(random_state).randint(0, n_samples)``).
+
+    Attributes
+    ----------
+    cluster_ids_ : list, [n_clusters]
+        Index of the data point that each cluster label corresponds to.
+    cluster_centers_ : array, [n_clusters, n_features]
+    labels_ : array, [n_samples,]
+    distances_ : array, [n_samples,]
+        Distance from each sample to the cluster center it is assigned to.
+    inertia_ : float
+        Sum of distances of samples to their closest cluster center.
+    """
+
+    def __init__(self, n_clusters=8, metric='euclidean', random_state=None):
+        self.n_clusters = n_clusters
+        self.metric = metric
+        self.random_state = random_state
+
+    def fit(self, X, y=None):
+        X = _as_float(X)
+        n_samples = len(X)
+        seed = check_random_state(self.random_state).randint(0, n_samples)
+        metric = self.metric.decode() if isinstance(self.metric, bytes) else self.metric
+        if metric not in libdistance.VECTOR_METRICS:
+            raise ValueError('metric must be one of %s' %
+                             ', '.join("'%s'" % s for s in libdistance.VECTOR_METRICS))
+        ax = Arr(X)
+        if len(ax.shape) != 2:
+            raise ValueError("X must be 2-dimensional")
+        kind = "f64" if ax.dtype == np.float64 else "f32"
+        K = int(self.n_clusters)
+        ids = np.zeros(K, dtype=np.int64)
+        labels = empty_like_placement(ax, (n_samples,), np.int64)
+        distances = empty_like_placement(ax, (n_samples,), np.float64)
+        al, ad = Arr(labels, np.int64), Arr(distances, np.float64)
+        inertia = C.c_double(0.0)
+        fn = getattr(_lib.lib(), "msm_kcenters_fit_" + kind)
+        check(fn(ax.vp, n_samples, ax.shape[1], K, metric.encode(), int(seed), ids.ctypes.data,
+                 al.vp, ad.vp, C.byref(inertia), ax.on_device))
+        self.labels_ = labels
+        self.distances_ = distances
+        self.cluster_ids_ = [int(i) for i in ids]
+        self.cluster_centers_ = ax.keep[self.cluster_ids_]
+        # np.sum(distances_) as in kcenters.py:101 on the host; on the device the kernel's
+        # fp64 tree sum of the same values
+        self.inertia_ = np.sum(distances) if not ax.on_device else float(inertia.value)
+        return self
+
+    def predict(self, X):
+        """Index of the closest cluster centre for each sample in X
+        (kcenters.py:104-126 -> libdistance.assign_nearest)."""
+        X = _as_float(X)
+        centers = self.cluster_centers_
+        if is_device_array(centers):
+            centers = centers.detach().cpu().numpy()
+        xdt = np.dtype(str(X.dtype).replace("torch.", ""))
+        if centers.dtype != xdt:
+            raise TypeError('X and y must be both float32 or float64')
+        labels, inertia = libdistance.assign_nearest(X, np.ascontiguousarray(centers), metric=self.metric)
+        return labels
+
+    def fit_predict(self, X, y=None):
+        return self.fit(X, y).labels_
+
+
+class KCenters(MultiSequenceClusterMixin, _KCenters, BaseEstimator):
+    __doc__ = _KCenters.__doc__[: _KCenters.__doc__.find('Attributes')] + \
+        '''
+    Attributes
+    ----------
+    `cluster_centers_` : array, [n_clusters, n_features]
+        Coordinates of cluster centers
+
+    `labels_` : list of arrays, each of shape [sequence_length, ]
+        `labels_[i]` holds the label (an integer in [0, n_clusters)) of each
+        point of sequence `i`.
+
+    `distances_` : list of arrays, each of shape [sequence_length, ]
+        `distances_[i]` holds the distance from each point of sequence `i` to the
+        cluster center it is assigned to.
+    '''
+
+    def fit(self, sequences, y=None):
+        """Fit the kcenters clustering on a list of [sequence_length, n_features] arrays."""
+        MultiSequenceClusterMixin.fit(self, sequences)
+        self.distances_ = self._split(self.distances_)
+        return self
+
+    def summarize(self):
+        d = self.distances_
+        if len(d) and is_device_array(d[0]):
+            d = [x.detach().cpu().numpy() for x in d]
+        return """KCenters clustering
+--------------------
+n_clusters : {n_clusters}
+metric     : {metric}
+
+Inertia       : {inertia}
+Mean distance : {mean_distance}
+Max  distance : {max_distance}
+""".format(n_clusters=self.n_clusters, metric=self.metric,
+           inertia=self.inertia_, mean_distance=np.mean(np.concatenate(d)),
+           max_distance=np.max(np.concatenate(d)))

@@ -1,0 +1,406 @@
+"""Mini-batch k-means on MI355X: drop-in for ``msmbuilder.cluster.MiniBatchKMeans``.
+
+In the reference this class is a three-line subclass of scikit-learn's estimator
+(msmbuilder/cluster/__init__.py:67-69): every number comes from scikit-learn, which the
+reference leaves unpinned.  This module restates scikit-learn 1.7's algorithm
+(sklearn/cluster/_kmeans.py: ``MiniBatchKMeans.fit`` :2046-2196, ``_mini_batch_step``
+:1557-1676, ``_mini_batch_convergence`` :1963-2027, ``_random_reassign`` :2029-2043) with
+the same constructor arguments and the SAME host-side ``RandomState`` call sequence
+(validation subsample, init subsample, k-means++ draws, one ``randint`` batch per step,
+``choice`` for starved-centre reassignment), so that a given ``random_state`` walks the
+same minibatches as scikit-learn.  The arithmetic that scales with the data runs on
+the GPU (msmbuilder_amd/csrc/kmeans.hip): nearest-centre labelling as an fp32 MFMA
+contraction, the per-centre streaming-mean update, and the final full-data labelling.
+
+Parity definition (DESIGN.md "MiniBatchKMeans"): centres rtol 1e-4, inertia rtol 1e-4,
+labels equal except where the two best squared distances tie to fp32 rounding.
+
+Multi-GPU: with ``torch.distributed`` initialised, each rank owns a shard of the frames;
+every step all ranks draw the same global batch, label their share, and one RCCL
+all-reduce of [K x F sums | K counts | inertia] makes the update identical everywhere
+(see msmbuilder_amd/parallel.py).
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+from sklearn.base import ClusterMixin, TransformerMixin
+from sklearn.utils import check_random_state
+
+from .. import _lib
+from .._lib import Arr, check, empty_like_placement, is_device_array
+from ..base import BaseEstimator
+from .base import MultiSequenceClusterMixin
+
+__all__ = ['MiniBatchKMeans']
+
+
+def _rows_to_host(ax, idx):
+    """X[idx] as a host float32 array (device X: gather kernel + small D2H)."""
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    if not ax.on_device:
+        return np.ascontiguousarray(ax.keep[idx])
+    import torch
+    sel = ax.keep[torch.as_tensor(idx, device=ax.keep.device)]
+    return sel.detach().cpu().numpy()
+
+
+def label_inertia(X, centers):
+    """(labels int32, inertia) of every row of X against ``centers`` -- the GPU counterpart of
+    scikit-learn's ``_labels_inertia``.  X: numpy float32 or torch CUDA float32."""
+    ax = X if isinstance(X, Arr) else Arr(X, np.float32)
+    centers = np.ascontiguousarray(centers, dtype=np.float32)
+    labels = empty_like_placement(ax, (ax.shape[0],), np.int32)
+    al = Arr(labels, np.int32)
+    inertia = C.c_double(0.0)
+    check(_lib.lib().msm_kmeans_label_f32(ax.vp, ax.shape[0], ax.shape[1], centers.ctypes.data,
+                                          centers.shape[0], al.vp, C.byref(inertia), ax.on_device))
+    return labels, float(inertia.value)
+
+
+def kmeans_plusplus(X, n_clusters, random_state):
+    """Greedy k-means++ seeding on a (small, host) sample, mirroring scikit-learn's
+    ``_kmeans_plusplus`` draw for draw (sklearn/cluster/_kmeans.py:163-259): first centre by
+    ``choice``, then ``2 + log(k)`` candidates per round drawn by inverse-CDF sampling of the
+    current squared distances, keeping the candidate with the lowest potential."""
+    n_samples, n_features = X.shape
+    centers = np.empty((n_clusters, n_features), dtype=X.dtype)
+    n_local_trials = 2 + int(np.log(n_clusters))
+    sample_weight = np.ones(n_samples, dtype=X.dtype)
+    center_id = random_state.choice(n_samples, p=sample_weight / sample_weight.sum())
+    centers[0] = X[center_id]
+    xsq = np.einsum("ij,ij->i", X, X)
+
+    def sqdist(c):  # [len(c), n_samples], same ||x||^2 - 2 x.c + ||c||^2 form as sklearn
+        d = -2.0 * (c @ X.T)
+        d += xsq[None, :]
+        d += np.einsum("ij,ij->i", c, c)[:, None]
+        np.maximum(d, 0, out=d)
+        return d
+
+    closest = sqdist(centers[0:1])[0]
+    current_pot = closest @ sample_weight
+    for c in range(1, n_clusters):
+        rand_vals = random_state.uniform(size=n_local_trials) * current_pot
+        cum = np.cumsum(sample_weight * closest, dtype=np.float64)
+        candidate_ids = np.searchsorted(cum, rand_vals)
+        np.clip(candidate_ids, None, closest.size - 1, out=candidate_ids)
+        d_cand = sqdist(X[candidate_ids])
+        np.minimum(closest, d_cand, out=d_cand)
+        pots = (d_cand @ sample_weight.reshape(-1, 1)).ravel()
+        best = np.argmin(pots)
+        current_pot = pots[best]
+        closest = d_cand[best]
+        centers[c] = X[candidate_ids[best]]
+    return centers
+
+
+class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
+    """Single-array mini-batch k-means with scikit-learn 1.7's constructor."""
+
+    def __init__(self, n_clusters=8, init='k-means++', max_iter=100, batch_size=1024, verbose=0,
+                 compute_labels=True, random_state=None, tol=0.0, max_no_improvement=10,
+                 init_size=None, n_init='auto', reassignment_ratio=0.01):
+        self.n_clusters = n_clusters
+        self.init = init
+        self.max_iter = max_iter
+        self.batch_size = batch_size
+        self.verbose = verbose
+        self.compute_labels = compute_labels
+        self.random_state = random_state
+        self.tol = tol
+        self.max_no_improvement = max_no_improvement
+        self.init_size = init_size
+        self.n_init = n_init
+        self.reassignment_ratio = reassignment_ratio
+
+    # -- parameter resolution: _kmeans.py:868-907, 1922-1960 --
+    def _check_params_vs_input(self, n_samples):
+        if n_samples < self.n_clusters:
+            raise ValueError("n_samples=%d should be >= n_clusters=%d." % (n_samples, self.n_clusters))
+        init_is_array = hasattr(self.init, "__array__") or is_device_array(self.init)
+        self._n_init = self.n_init
+        if self._n_init == "auto":
+            if isinstance(self.init, str) and self.init == "k-means++":
+                self._n_init = 1
+            elif isinstance(self.init, str) and self.init == "random":
+                self._n_init = 3
+            elif callable(self.init):
+                self._n_init = 3
+            else:
+                self._n_init = 1
+        if init_is_array and self._n_init != 1:
+            warnings.warn("Explicit initial center position passed: performing only one init in "
+                          "MiniBatchKMeans instead of n_init=%d." % self._n_init, RuntimeWarning)
+            self._n_init = 1
+        self._batch_size = min(self.batch_size, n_samples)
+        self._init_size = self.init_size
+        if self._init_size is None:
+            self._init_size = 3 * self._batch_size
+            if self._init_size < self.n_clusters:
+                self._init_size = 3 * self.n_clusters
+        elif self._init_size < self.n_clusters:
+            warnings.warn("init_size=%d should be larger than n_clusters=%d. Setting it to "
+                          "min(3*n_clusters, n_samples)" % (self._init_size, self.n_clusters),
+                          RuntimeWarning)
+            self._init_size = 3 * self.n_clusters
+        self._init_size = min(self._init_size, n_samples)
+        if self.reassignment_ratio < 0:
+            raise ValueError("reassignment_ratio should be >= 0, got %s instead." % self.reassignment_ratio)
+
+    def _init_centroids(self, ax, shard, random_state):
+        """_kmeans.py:955-1045 (the init subsample is drawn even for an explicit array)."""
+        n_samples = shard.n_total
+        Xs = None
+        if self._init_size is not None and self._init_size < n_samples:
+            init_indices = random_state.randint(0, n_samples, self._init_size)
+            if isinstance(self.init, str) or callable(self.init):
+                Xs = self._rows(ax, shard, init_indices)
+        elif isinstance(self.init, str) or callable(self.init):
+            Xs = self._rows(ax, shard, np.arange(n_samples))
+        if isinstance(self.init, str) and self.init == "k-means++":
+            centers = kmeans_plusplus(Xs, self.n_clusters, random_state)
+        elif isinstance(self.init, str) and self.init == "random":
+            w = np.ones(len(Xs), dtype=Xs.dtype)
+            seeds = random_state.choice(len(Xs), size=self.n_clusters, replace=False, p=w / w.sum())
+            centers = Xs[seeds]
+        elif callable(self.init):
+            centers = np.asarray(self.init(Xs, self.n_clusters, random_state=random_state))
+        else:
+            init = self.init
+            if is_device_array(init):
+                init = init.detach().cpu().numpy()
+            centers = np.array(init, dtype=np.float32, copy=True, order="C")
+            if centers.shape != (self.n_clusters, ax.shape[1]):
+                raise ValueError("The shape of the initial centers %s does not match the number of "
+                                 "clusters %d / features %d." % (centers.shape, self.n_clusters, ax.shape[1]))
+        return np.ascontiguousarray(centers, dtype=np.float32)
+
+    def _random_reassign(self):
+        """_kmeans.py:2029-2043"""
+        self._n_since_last_reassign += self._batch_size
+        if (self._counts == 0).any() or self._n_since_last_reassign >= (10 * self.n_clusters):
+            self._n_since_last_reassign = 0
+            return True
+        return False
+
+    def _mini_batch_convergence(self, step, n_steps, n_samples, centers_squared_diff, batch_inertia):
+        """_kmeans.py:1963-2027"""
+        batch_inertia /= self._batch_size
+        step = step + 1
+        if step == 1:
+            if self.verbose:
+                print("Minibatch step %d/%d: mean batch inertia: %s" % (step, n_steps, batch_inertia))
+            return False
+        if self._ewa_inertia is None:
+            self._ewa_inertia = batch_inertia
+        else:
+            alpha = self._batch_size * 2.0 / (n_samples + 1)
+            alpha = min(alpha, 1)
+            self._ewa_inertia = self._ewa_inertia * (1 - alpha) + batch_inertia * alpha
+        if self.verbose:
+            print("Minibatch step %d/%d: mean batch inertia: %s, ewa inertia: %s"
+                  % (step, n_steps, batch_inertia, self._ewa_inertia))
+        if self._tol > 0.0 and centers_squared_diff <= self._tol:
+            if self.verbose:
+                print("Converged (small centers change) at step %d/%d" % (step, n_steps))
+            return True
+        if self._ewa_inertia_min is None or self._ewa_inertia < self._ewa_inertia_min:
+            self._no_improvement = 0
+            self._ewa_inertia_min = self._ewa_inertia
+        else:
+            self._no_improvement += 1
+        if self.max_no_improvement is not None and self._no_improvement >= self.max_no_improvement:
+            if self.verbose:
+                print("Converged (lack of improvement in inertia) at step %d/%d" % (step, n_steps))
+            return True
+        return False
+
+    def _step(self, ax, shard, batch_idx, centers, random_state, random_reassign):
+        """One ``_mini_batch_step`` (_kmeans.py:1557-1676): label + streaming-mean update on
+        the GPU, starved-centre reassignment on the host.  ``batch_idx`` are GLOBAL row numbers
+        (identical on every rank); each rank processes the rows it owns and, when sharded,
+        one all-reduce of [sums | counts | inertia] makes the update identical everywhere.
+        Updates ``centers`` / ``self._counts`` in place; returns the batch inertia (computed
+        before the update, as scikit-learn does)."""
+        from .. import parallel
+        K, F = centers.shape
+        B = len(batch_idx)
+        inertia = C.c_double(0.0)
+        L = _lib.lib()
+        if parallel.active():
+            _, sub = shard.local(batch_idx)
+            sub = np.ascontiguousarray(sub, dtype=np.int64)
+            sums = np.zeros((K, F), dtype=np.float64)
+            cnts = np.zeros(K, dtype=np.float64)
+            if len(sub):
+                check(L.msm_mbk_step_f32(ax.vp, ax.shape[0], F, sub.ctypes.data, len(sub), centers.ctypes.data,
+                                         self._counts.ctypes.data, K, C.byref(inertia), sums.ctypes.data,
+                                         cnts.ctypes.data, 0, ax.on_device))
+            packed = parallel.allreduce_array(np.concatenate([sums.ravel(), cnts, [inertia.value]]))
+            sums = packed[:K * F].reshape(K, F)
+            cnts = packed[K * F:K * F + K]
+            inertia_v = float(packed[-1])
+            upd = cnts > 0
+            w_new = (self._counts + cnts).astype(np.float32)
+            centers[upd] = ((centers[upd].astype(np.float64) * self._counts[upd, None] + sums[upd])
+                            / w_new[upd, None]).astype(np.float32)
+            self._counts[:] = w_new
+        else:
+            check(L.msm_mbk_step_f32(ax.vp, ax.shape[0], F, batch_idx.ctypes.data, B, centers.ctypes.data,
+                                     self._counts.ctypes.data, K, C.byref(inertia), None, None, 1,
+                                     ax.on_device))
+            inertia_v = float(inertia.value)
+
+        if random_reassign and self.reassignment_ratio > 0:
+            weight_sums = self._counts
+            to_reassign = weight_sums < self.reassignment_ratio * weight_sums.max()
+            # pick at most .5 * batch_size samples as new centers
+            if to_reassign.sum() > 0.5 * B:
+                keep = np.argsort(weight_sums)[int(0.5 * B):]
+                to_reassign[keep] = False
+            n_reassigns = to_reassign.sum()
+            if n_reassigns:
+                new_centers = random_state.choice(B, replace=False, size=n_reassigns)
+                if self.verbose:
+                    print("[MiniBatchKMeans] Reassigning %d cluster centers." % n_reassigns)
+                centers[to_reassign] = self._rows(ax, shard, batch_idx[new_centers])
+            # reset counts of reassigned centers, but don't reset them too small
+            weight_sums[to_reassign] = np.min(weight_sums[~to_reassign])
+        return inertia_v
+
+    @staticmethod
+    def _rows(ax, shard, global_idx):
+        """Rows of the (possibly row-sharded) data as a host float32 array."""
+        return shard.gather_rows(lambda loc: _rows_to_host(ax, loc), global_idx, ax.shape[1])
+
+    def fit(self, X, y=None):
+        if isinstance(X, np.ndarray) and X.dtype != np.float32:
+            X = X.astype(np.float32)  # GPU path computes in fp32 (sklearn keeps X's dtype)
+        ax = Arr(X, np.float32)
+        if len(ax.shape) != 2:
+            raise ValueError("Expected 2D array")
+        from ..parallel import RowShard
+        shard = RowShard(ax.shape[0])  # single process: the whole array
+        n_samples, n_features = shard.n_total, ax.shape[1]
+        self._check_params_vs_input(n_samples)
+        random_state = check_random_state(self.random_state)
+        self.n_features_in_ = n_features
+
+        if self.tol > 0:
+            if ax.on_device:
+                self._tol = float(ax.keep.var(dim=0, unbiased=False).mean().item()) * self.tol
+            else:
+                self._tol = float(np.mean(np.var(ax.keep, axis=0))) * self.tol
+        else:
+            self._tol = 0.0
+
+        # Validation set for the init
+        validation_indices = random_state.randint(0, n_samples, self._init_size)
+        X_valid = self._rows(ax, shard, validation_indices)
+
+        best_inertia = None
+        for init_idx in range(self._n_init):
+            cluster_centers = self._init_centroids(ax, shard, random_state)
+            _, inertia = label_inertia(X_valid, cluster_centers)
+            if best_inertia is None or inertia < best_inertia:
+                init_centers = cluster_centers
+                best_inertia = inertia
+
+        centers = np.ascontiguousarray(init_centers, dtype=np.float32)
+        self._counts = np.zeros(self.n_clusters, dtype=np.float32)
+        self._ewa_inertia = None
+        self._ewa_inertia_min = None
+        self._no_improvement = 0
+        self._n_since_last_reassign = 0
+
+        n_steps = (self.max_iter * n_samples) // self._batch_size
+        i = -1
+        for i in range(n_steps):
+            minibatch_indices = random_state.randint(0, n_samples, self._batch_size)
+            minibatch_indices = np.ascontiguousarray(minibatch_indices, dtype=np.int64)
+            prev = centers.copy() if self._tol > 0.0 else None
+            batch_inertia = self._step(ax, shard, minibatch_indices, centers, random_state,
+                                       self._random_reassign())
+            centers_squared_diff = np.sum((centers - prev) ** 2) if self._tol > 0.0 else 0
+            if self._mini_batch_convergence(i, n_steps, n_samples, centers_squared_diff, batch_inertia):
+                break
+
+        self.cluster_centers_ = centers
+        self.n_steps_ = i + 1
+        self.n_iter_ = int(np.ceil(((i + 1) * self._batch_size) / n_samples))
+
+        if self.compute_labels:
+            # embarrassingly parallel: every rank labels its own rows; inertia is summed
+            self.labels_, inertia = label_inertia(ax, self.cluster_centers_)
+            from .. import parallel
+            self.inertia_ = float(parallel.allreduce_array(np.array([inertia]))[0]) if parallel.active() else inertia
+        else:
+            self.inertia_ = self._ewa_inertia * n_samples
+        return self
+
+    def partial_fit(self, X, y=None):
+        """One mini-batch update on X itself (sklearn ``MiniBatchKMeans.partial_fit``)."""
+        if isinstance(X, np.ndarray) and X.dtype != np.float32:
+            X = X.astype(np.float32)
+        ax = Arr(X, np.float32)
+        n_samples = ax.shape[0]
+        has_centers = hasattr(self, "cluster_centers_")
+        if not has_centers:
+            self._check_params_vs_input(n_samples)
+            self._random_state = check_random_state(self.random_state)
+            self._tol = 0.0
+            self._batch_size = n_samples
+            from ..parallel import RowShard
+            self.cluster_centers_ = self._init_centroids(ax, RowShard(n_samples), self._random_state)
+            self._counts = np.zeros(self.n_clusters, dtype=np.float32)
+            self._n_since_last_reassign = 0
+            self.n_steps_ = 0
+        self._batch_size = n_samples
+        from ..parallel import RowShard
+        self._step(ax, RowShard(n_samples), np.arange(n_samples, dtype=np.int64), self.cluster_centers_,
+                   self._random_state, self._random_reassign())
+        if self.compute_labels:
+            self.labels_, self.inertia_ = label_inertia(ax, self.cluster_centers_)
+        self.n_steps_ += 1
+        return self
+
+    def predict(self, X):
+        """Index of the closest centre (squared euclidean, fp32 GEMM form) for each row of X."""
+        if isinstance(X, np.ndarray) and X.dtype != np.float32:
+            X = X.astype(np.float32)
+        labels, _ = label_inertia(X, self.cluster_centers_)
+        return labels
+
+    def fit_predict(self, X, y=None):
+        return self.fit(X).labels_
+
+    def score(self, X, y=None):
+        """Opposite of the k-means objective on X."""
+        if isinstance(X, np.ndarray) and X.dtype != np.float32:
+            X = X.astype(np.float32)
+        _, inertia = label_inertia(X, self.cluster_centers_)
+        return -inertia
+
+
+class MiniBatchKMeans(MultiSequenceClusterMixin, _MiniBatchKMeans, BaseEstimator):
+    __doc__ = """Mini-Batch K-Means clustering of a list of sequences (see module docstring).
+
+    Parameters are scikit-learn's ``MiniBatchKMeans`` parameters; ``labels_`` is a list of
+    int32 arrays, one per input sequence (msmbuilder/cluster/base.py:50-51).
+    """
+
+    def fit_predict(self, sequences, y=None):
+        self.fit(sequences)
+        return self.labels_
+
+    def summarize(self):
+        return """MiniBatchKMeans clustering
+--------------------------
+n_clusters : {n_clusters}
+batch_size : {batch_size}
+n_steps    : {n_steps}
+
+Inertia    : {inertia}
+""".format(n_clusters=self.n_clusters, batch_size=self.batch_size,
+           n_steps=getattr(self, "n_steps_", None), inertia=getattr(self, "inertia_", None))

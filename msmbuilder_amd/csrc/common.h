@@ -1,0 +1,55 @@
+// common.h -- shared host-side plumbing of libmsmhip (error state, stream, scratch buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/msmhip.h"
+
+namespace msm {
+
+// ---- error state (thread-local message, C-ABI status codes) --------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define MSM_HIP_CHECK(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::msm::fail(MSM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                            \
+    } while (0)
+
+hipStream_t stream();
+int num_cus();
+
+// RAII device scratch used when the caller hands over host pointers.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // grows, never shrinks; returns status
+    void release();
+    ~DevBuf() { release(); }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+// metric ids shared by host dispatch and device kernels
+enum Metric : int {
+    M_EUCLIDEAN = 0,
+    M_SQEUCLIDEAN,
+    M_CITYBLOCK,
+    M_CHEBYSHEV,
+    M_CANBERRA,
+    M_BRAYCURTIS,
+    M_HAMMING,
+    M_JACCARD,
+    M_COUNT
+};
+int metric_id(const char* name);  // -1 if unknown
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace msm

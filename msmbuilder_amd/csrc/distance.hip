@@ -1,0 +1,603 @@
+// distance.hip -- exact-arithmetic libdistance kernels (dist / cdist / assign_nearest)
+// and the fused k-centers pass for gfx950.
+//
+// Replaces /root/reference/msmbuilder/libdistance/src/{distance_kernels.h:41-293,
+// dist.hpp:4-80, cdist.hpp:4-49, assign.hpp:6-91} and the k-pass loop of
+// /root/reference/msmbuilder/cluster/kcenters.py:91-97.
+//
+// Bit-exactness contract (what makes integer labels identical to the CPU path):
+// every (row, centre) pair is owned by ONE lane, which visits the features in
+// order i = 0..m-1 with ONE fp64 accumulator; for float inputs u-v / u+v are
+// fp32 operations widened afterwards; multiply and add are separately rounded
+// (this file is compiled with -ffp-contract=off); euclidean takes the sqrt
+// before comparing; comparisons are strict `<` in ascending centre order, so
+// the lowest index wins.  Parallelism is over rows (and centre tiles), never
+// over the feature axis.  This is HBM/L2- and fp64-VALU-bound work: no MFMA.
+//
+// Tiling: a workgroup stages a [256 rows x FC features] tile of X through LDS
+// (coalesced in, row stride FC+1 so that lane-per-row reads are conflict-free)
+// and a [CJ centres x FC] tile of Y (wave-uniform broadcast reads).
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace msm {
+
+constexpr int DT = 256;  // threads = rows per tile
+constexpr int CJ = 8;    // centres per register tile
+constexpr int KC_MAXBLK = 1024;
+
+template <typename T> struct FeatChunk;
+template <> struct FeatChunk<float> { static constexpr int FC = 32; };
+template <> struct FeatChunk<double> { static constexpr int FC = 16; };
+
+// ---- per-element update / finalisation: distance_kernels.h:41-243 ---------
+template <typename T, int M>
+__device__ __forceinline__ void m_update(double& a, double& b, const T u, const T v)
+{
+    if (M == M_EUCLIDEAN || M == M_SQEUCLIDEAN) {
+        const T df = u - v;
+        const double d = (double)df;
+        a = a + d * d;
+    } else if (M == M_CITYBLOCK) {
+        const T df = u - v;
+        a = a + fabs((double)df);
+    } else if (M == M_CHEBYSHEV) {
+        const T df = u - v;
+        const double d = fabs((double)df);
+        if (d > a) a = d;
+    } else if (M == M_CANBERRA) {
+        const T df = u - v;
+        const double snum = fabs((double)df);
+        const double sdenom = fabs((double)u) + fabs((double)v);
+        if (sdenom > 0.0) a = a + snum / sdenom;
+    } else if (M == M_BRAYCURTIS) {
+        const T df = u - v;
+        const T sf = u + v;
+        a = a + fabs((double)df);
+        b = b + fabs((double)sf);
+    } else if (M == M_HAMMING) {
+        a = a + (double)(u != v);
+    } else if (M == M_JACCARD) {
+        const int nz = (u != (T)0) | (v != (T)0);
+        a = a + (double)((u != v) & nz);
+        b = b + (double)nz;
+    }
+}
+
+template <int M>
+__device__ __forceinline__ double m_final(double a, double b, long long n)
+{
+    if (M == M_EUCLIDEAN) return sqrt(a);
+    if (M == M_BRAYCURTIS || M == M_JACCARD) return a / b;
+    if (M == M_HAMMING) return a / (double)n;
+    return a;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_rows(T* Xs, const T* __restrict__ X,
+                                           const msm_idx_t* __restrict__ X_indices, long long row0,
+                                           long long n, long long m, int f0, int fw, int tid)
+{
+    constexpr int FC = FeatChunk<T>::FC;
+    for (int e = tid; e < DT * fw; e += DT) {
+        const int rr = e / fw, ff = e - rr * fw;
+        const long long i = row0 + rr;
+        T v = (T)0;
+        if (i < n) {
+            const long long r = X_indices ? X_indices[i] : i;
+            v = X[r * m + f0 + ff];
+        }
+        Xs[rr * (FC + 1) + ff] = v;
+    }
+}
+
+struct PairArgs {
+    const void* X;
+    const msm_idx_t* X_indices;
+    const void* Y;        // device [K, m]
+    long long n, K, m;
+    msm_idx_t* labels;    // assign
+    double* min_dist;     // assign (nullable)
+    double* partial;      // assign: per-block inertia partials
+    double* out;          // cdist / dist
+};
+
+// MODE 0: assign_nearest (assign.hpp:6-91), MODE 1: cdist (cdist.hpp) / dist (K == 1)
+template <typename T, int M, int MODE>
+__global__ __launch_bounds__(DT) void pair_kernel(PairArgs P)
+{
+    constexpr int FC = FeatChunk<T>::FC;
+    __shared__ T Xs[DT * (FC + 1)];
+    __shared__ T Ys[CJ * FC];
+    __shared__ double red[DT];
+    const T* X = static_cast<const T*>(P.X);
+    const T* Y = static_cast<const T*>(P.Y);
+    const int tid = threadIdx.x;
+    const bool single = P.m <= FC;
+    double inertia = 0.0;
+    const long long ntile = (P.n + DT - 1) / DT;
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long long row0 = t * DT;
+        const long long i = row0 + tid;
+        double min_d = 1.7976931348623157e308;  // DBL_MAX, assign.hpp:20
+        long long lab = 0;                      // np.zeros buffer, libdistance.pyx:383
+        if (single) {
+            __syncthreads();
+            stage_rows<T>(Xs, X, P.X_indices, row0, P.n, P.m, 0, (int)P.m, tid);
+        }
+        for (long long j0 = 0; j0 < P.K; j0 += CJ) {
+            double a[CJ], b[CJ];
+#pragma unroll
+            for (int c = 0; c < CJ; ++c) {
+                a[c] = 0.0;
+                b[c] = 0.0;
+            }
+            for (int f0 = 0; f0 < P.m; f0 += FC) {
+                const int fw = (int)((P.m - f0) < FC ? (P.m - f0) : FC);
+                __syncthreads();
+                if (!single) stage_rows<T>(Xs, X, P.X_indices, row0, P.n, P.m, f0, fw, tid);
+                for (int e = tid; e < CJ * fw; e += DT) {
+                    const int c = e / fw, ff = e - c * fw;
+                    Ys[c * FC + ff] = (j0 + c < P.K) ? Y[(j0 + c) * P.m + f0 + ff] : (T)0;
+                }
+                __syncthreads();
+                for (int ff = 0; ff < fw; ++ff) {
+                    const T x = Xs[tid * (FC + 1) + ff];
+#pragma unroll
+                    for (int c = 0; c < CJ; ++c) m_update<T, M>(a[c], b[c], x, Ys[c * FC + ff]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CJ; ++c) {
+                if (j0 + c < P.K) {
+                    const double d = m_final<M>(a[c], b[c], P.m);
+                    if (MODE == 0) {
+                        if (d < min_d) {
+                            min_d = d;
+                            lab = j0 + c;
+                        }
+                    } else if (i < P.n) {
+                        P.out[i * P.K + j0 + c] = d;
+                    }
+                }
+            }
+        }
+        if (MODE == 0 && i < P.n) {
+            P.labels[i] = lab;
+            if (P.min_dist) P.min_dist[i] = min_d;
+            inertia += min_d;
+        }
+    }
+    if (MODE == 0) {
+        red[tid] = inertia;
+        __syncthreads();
+        for (int s = DT / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) P.partial[blockIdx.x] = red[0];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One k-centers pass (kcenters.py:91-97), fused: (prologue) global argmax of the
+// previous pass's per-block partials -> new centre index c; d = metric(X, X[c]);
+// strict `d < distances_` update of distances_/labels_; per-block argmax partial
+// (max value, lowest row index) for the next pass.  One launch per centre, no
+// host round trip; the kernel boundary is the only inter-block synchronisation.
+// ---------------------------------------------------------------------------
+struct KcPartial {
+    double v;
+    long long i;
+};
+
+struct KcArgs {
+    const void* X;
+    long long n, m;
+    int it;
+    long long seed;
+    const KcPartial* prev;  // [nblk] partials of pass it-1
+    KcPartial* next;        // [nblk]
+    int nblk;
+    double* dist;
+    msm_idx_t* labels;
+    msm_idx_t* ids;         // device [K]
+};
+
+__device__ __forceinline__ bool kc_better(double v, long long i, double bv, long long bi)
+{
+    // numpy argmax: first occurrence of the maximum
+    return (v > bv) || (v == bv && i < bi);
+}
+
+template <typename T, int M>
+__global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
+{
+    constexpr int FC = FeatChunk<T>::FC;
+    __shared__ T Xs[DT * (FC + 1)];
+    __shared__ T ys[FC];
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    const T* X = static_cast<const T*>(P.X);
+    const int tid = threadIdx.x;
+
+    // ---- prologue: centre of this pass ----
+    long long cidx;
+    if (P.it == 0) {
+        cidx = P.seed;
+    } else {
+        double bv = -1.0;
+        long long bi = 0x7fffffffffffffffLL;
+        for (int k = tid; k < P.nblk; k += DT) {
+            const KcPartial q = P.prev[k];
+            if (q.i >= 0 && kc_better(q.v, q.i, bv, bi)) {
+                bv = q.v;
+                bi = q.i;
+            }
+        }
+        rv[tid] = bv;
+        ri[tid] = bi;
+        __syncthreads();
+        for (int s = DT / 2; s > 0; s >>= 1) {
+            if (tid < s && kc_better(rv[tid + s], ri[tid + s], rv[tid], ri[tid])) {
+                rv[tid] = rv[tid + s];
+                ri[tid] = ri[tid + s];
+            }
+            __syncthreads();
+        }
+        cidx = ri[0];
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
+    const T* y = X + cidx * P.m;
+
+    double bv = -1.0;
+    long long bi = -1;
+    const long long ntile = (P.n + DT - 1) / DT;
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long long row0 = t * DT;
+        const long long i = row0 + tid;
+        double a = 0.0, b = 0.0;
+        for (int f0 = 0; f0 < P.m; f0 += FC) {
+            const int fw = (int)((P.m - f0) < FC ? (P.m - f0) : FC);
+            __syncthreads();
+            stage_rows<T>(Xs, X, nullptr, row0, P.n, P.m, f0, fw, tid);
+            if (tid < fw) ys[tid] = y[f0 + tid];
+            __syncthreads();
+            for (int ff = 0; ff < fw; ++ff) m_update<T, M>(a, b, Xs[tid * (FC + 1) + ff], ys[ff]);
+        }
+        if (i < P.n) {
+            const double d = m_final<M>(a, b, P.m);
+            double cur = (P.it == 0) ? INFINITY : P.dist[i];  // distances_.fill(inf), kcenters.py:87-88
+            const bool upd = d < cur;                          // strict, kcenters.py:93
+            if (upd) cur = d;
+            if (P.it == 0 || upd) {
+                P.dist[i] = cur;
+                P.labels[i] = upd ? P.it : 0;
+            }
+            // NaN never enters distances_ (NaN < x is false), so plain compares are numpy's argmax
+            if (bi < 0 || kc_better(cur, i, bv, bi)) {
+                bv = cur;
+                bi = i;
+            }
+        }
+    }
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int s = DT / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const long long oi = ri[tid + s];
+            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + s], oi, rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + s];
+                ri[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        KcPartial q;
+        q.v = rv[0];
+        q.i = ri[0];
+        P.next[blockIdx.x] = q;
+    }
+}
+
+// deterministic per-block fp64 sums of a vector (inertia = np.sum(distances_))
+__global__ __launch_bounds__(DT) void sum_partial_kernel(const double* __restrict__ v, long long n,
+                                                         double* __restrict__ partial)
+{
+    __shared__ double red[DT];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * DT + threadIdx.x; i < n; i += (long long)gridDim.x * DT) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// ---- host-side dispatch ----------------------------------------------------
+template <typename T, int MODE>
+void launch_pair(int metric, int grid, const PairArgs& P)
+{
+#define MSM_CASE(MM)                                                                              \
+    case MM:                                                                                      \
+        hipLaunchKernelGGL((pair_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P);     \
+        break;
+    switch (metric) {
+        MSM_CASE(M_EUCLIDEAN)
+        MSM_CASE(M_SQEUCLIDEAN)
+        MSM_CASE(M_CITYBLOCK)
+        MSM_CASE(M_CHEBYSHEV)
+        MSM_CASE(M_CANBERRA)
+        MSM_CASE(M_BRAYCURTIS)
+        MSM_CASE(M_HAMMING)
+        MSM_CASE(M_JACCARD)
+    }
+#undef MSM_CASE
+}
+
+template <typename T>
+void launch_kc(int metric, int grid, const KcArgs& P)
+{
+#define MSM_CASE(MM)                                                                              \
+    case MM:                                                                                      \
+        hipLaunchKernelGGL((kcenters_pass_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P);  \
+        break;
+    switch (metric) {
+        MSM_CASE(M_EUCLIDEAN)
+        MSM_CASE(M_SQEUCLIDEAN)
+        MSM_CASE(M_CITYBLOCK)
+        MSM_CASE(M_CHEBYSHEV)
+        MSM_CASE(M_CANBERRA)
+        MSM_CASE(M_BRAYCURTIS)
+        MSM_CASE(M_HAMMING)
+        MSM_CASE(M_JACCARD)
+    }
+#undef MSM_CASE
+}
+
+static int sum_partials_host(const double* dpartial, int n, double* out)
+{
+    std::vector<double> h((size_t)n);
+    MSM_HIP_CHECK(hipMemcpyAsync(h.data(), dpartial, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += h[i];
+    *out = s;
+    return MSM_OK;
+}
+
+template <typename T>
+int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_idx_t* X_indices,
+                        msm_idx_t n_X, msm_idx_t n_Y, msm_idx_t m, msm_idx_t n_idx,
+                        msm_idx_t* assignments, double* min_dist, double* inertia, int on_device)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!X || !Y || !assignments) return fail(MSM_ERR_INVALID, "assign_nearest: null pointer");
+    if (n_X < 0 || n_Y < 0 || m < 1) return fail(MSM_ERR_INVALID, "assign_nearest: bad shape");
+    const long long n = X_indices ? n_idx : n_X;
+    if (inertia) *inertia = 0.0;
+    if (n == 0) return MSM_OK;
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    int rc;
+    DevBuf dX, dY, dIdx, dLab, dMin, dPart;
+    const int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
+    if ((rc = dY.reserve((size_t)(n_Y ? n_Y : 1) * m * sizeof(T)))) return rc;
+    if (n_Y) MSM_HIP_CHECK(hipMemcpyAsync(dY.p, Y, (size_t)n_Y * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+    if ((rc = dPart.reserve((size_t)grid * sizeof(double)))) return rc;
+    PairArgs P;
+    memset(&P, 0, sizeof(P));
+    P.Y = dY.p;
+    P.n = n;
+    P.K = n_Y;
+    P.m = m;
+    P.partial = dPart.as<double>();
+    if (on_device) {
+        P.X = X;
+        P.X_indices = X_indices;
+        P.labels = assignments;
+        P.min_dist = min_dist;
+    } else {
+        if ((rc = dX.reserve((size_t)n_X * m * sizeof(T)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n_X * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        P.X = dX.p;
+        if (X_indices) {
+            if ((rc = dIdx.reserve((size_t)n * sizeof(msm_idx_t)))) return rc;
+            MSM_HIP_CHECK(hipMemcpyAsync(dIdx.p, X_indices, (size_t)n * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+            P.X_indices = dIdx.as<msm_idx_t>();
+        }
+        if ((rc = dLab.reserve((size_t)n * sizeof(msm_idx_t)))) return rc;
+        P.labels = dLab.as<msm_idx_t>();
+        if (min_dist) {
+            if ((rc = dMin.reserve((size_t)n * sizeof(double)))) return rc;
+            P.min_dist = dMin.as<double>();
+        }
+    }
+    launch_pair<T, 0>(mid, grid, P);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (!on_device) {
+        MSM_HIP_CHECK(hipMemcpyAsync(assignments, P.labels, (size_t)n * sizeof(msm_idx_t), hipMemcpyDeviceToHost, stream()));
+        if (min_dist)
+            MSM_HIP_CHECK(hipMemcpyAsync(min_dist, P.min_dist, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    }
+    double s = 0.0;
+    if ((rc = sum_partials_host(P.partial, grid, &s))) return rc;  // synchronises
+    if (inertia) *inertia = s;
+    return MSM_OK;
+}
+
+template <typename T>
+int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_idx_t nb,
+               msm_idx_t m, const msm_idx_t* X_indices, msm_idx_t n_idx, double* out, int on_device)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!XA || !XB || !out) return fail(MSM_ERR_INVALID, "cdist/dist: null pointer");
+    if (na < 0 || nb < 0 || m < 1) return fail(MSM_ERR_INVALID, "cdist/dist: bad shape");
+    const long long n = X_indices ? n_idx : na;
+    if (n == 0 || nb == 0) return MSM_OK;
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    int rc;
+    DevBuf dX, dY, dIdx, dOut;
+    const int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
+    if ((rc = dY.reserve((size_t)nb * m * sizeof(T)))) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(dY.p, XB, (size_t)nb * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+    PairArgs P;
+    memset(&P, 0, sizeof(P));
+    P.Y = dY.p;
+    P.n = n;
+    P.K = nb;
+    P.m = m;
+    if (on_device) {
+        P.X = XA;
+        P.X_indices = X_indices;
+        P.out = out;
+    } else {
+        if ((rc = dX.reserve((size_t)na * m * sizeof(T)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, XA, (size_t)na * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        P.X = dX.p;
+        if (X_indices) {
+            if ((rc = dIdx.reserve((size_t)n * sizeof(msm_idx_t)))) return rc;
+            MSM_HIP_CHECK(hipMemcpyAsync(dIdx.p, X_indices, (size_t)n * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+            P.X_indices = dIdx.as<msm_idx_t>();
+        }
+        if ((rc = dOut.reserve((size_t)n * nb * sizeof(double)))) return rc;
+        P.out = dOut.as<double>();
+    }
+    launch_pair<T, 1>(mid, grid, P);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (!on_device)
+        MSM_HIP_CHECK(hipMemcpyAsync(out, P.out, (size_t)n * nb * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // scratch (and the staged Y) die with this frame
+    return MSM_OK;
+}
+
+template <typename T>
+int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char* metric,
+                  msm_idx_t seed, msm_idx_t* ids, msm_idx_t* labels, double* distances,
+                  double* inertia, int on_device)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!X || !ids || !labels || !distances) return fail(MSM_ERR_INVALID, "kcenters_fit: null pointer");
+    if (n < 1 || m < 1 || K < 1) return fail(MSM_ERR_INVALID, "kcenters_fit: bad shape");
+    if (seed < 0 || seed >= n) return fail(MSM_ERR_INVALID, "kcenters_fit: seed_index out of range");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    int rc;
+    DevBuf dX, dLab, dDist, dPart, dIds, dSum;
+    const int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
+    if ((rc = dPart.reserve((size_t)2 * nblk * sizeof(KcPartial)))) return rc;
+    if ((rc = dIds.reserve((size_t)K * sizeof(msm_idx_t)))) return rc;
+    if ((rc = dSum.reserve((size_t)nblk * sizeof(double)))) return rc;
+    KcArgs P;
+    memset(&P, 0, sizeof(P));
+    P.n = n;
+    P.m = m;
+    P.seed = seed;
+    P.nblk = nblk;
+    P.ids = dIds.as<msm_idx_t>();
+    if (on_device) {
+        P.X = X;
+        P.labels = labels;
+        P.dist = distances;
+    } else {
+        if ((rc = dX.reserve((size_t)n * m * sizeof(T)))) return rc;
+        if ((rc = dLab.reserve((size_t)n * sizeof(msm_idx_t)))) return rc;
+        if ((rc = dDist.reserve((size_t)n * sizeof(double)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        P.X = dX.p;
+        P.labels = dLab.as<msm_idx_t>();
+        P.dist = dDist.as<double>();
+    }
+    KcPartial* part = dPart.as<KcPartial>();
+    for (msm_idx_t it = 0; it < K; ++it) {
+        P.it = (int)it;
+        P.prev = part + (size_t)((it + 1) & 1) * nblk;
+        P.next = part + (size_t)(it & 1) * nblk;
+        launch_kc<T>(mid, nblk, P);
+    }
+    MSM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nblk), dim3(DT), 0, stream(), P.dist, (long long)n, dSum.as<double>());
+    MSM_HIP_CHECK(hipGetLastError());
+    MSM_HIP_CHECK(hipMemcpyAsync(ids, P.ids, (size_t)K * sizeof(msm_idx_t), hipMemcpyDeviceToHost, stream()));
+    if (!on_device) {
+        MSM_HIP_CHECK(hipMemcpyAsync(labels, P.labels, (size_t)n * sizeof(msm_idx_t), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(distances, P.dist, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    }
+    double s = 0.0;
+    if ((rc = sum_partials_host(dSum.as<double>(), nblk, &s))) return rc;  // synchronises
+    if (inertia) *inertia = s;
+    return MSM_OK;
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" {
+
+int msm_dist_f32(const float* X, const float* y, const char* metric, msm_idx_t n, msm_idx_t m,
+                 const msm_idx_t* X_indices, msm_idx_t n_X_indices, double* out, int on_device)
+{
+    return cdist_impl<float>(X, y, metric, n, 1, m, X_indices, n_X_indices, out, on_device);
+}
+
+int msm_dist_f64(const double* X, const double* y, const char* metric, msm_idx_t n, msm_idx_t m,
+                 const msm_idx_t* X_indices, msm_idx_t n_X_indices, double* out, int on_device)
+{
+    return cdist_impl<double>(X, y, metric, n, 1, m, X_indices, n_X_indices, out, on_device);
+}
+
+int msm_cdist_f32(const float* XA, const float* XB, const char* metric, msm_idx_t na, msm_idx_t nb,
+                  msm_idx_t m, double* out, int on_device)
+{
+    return cdist_impl<float>(XA, XB, metric, na, nb, m, nullptr, 0, out, on_device);
+}
+
+int msm_cdist_f64(const double* XA, const double* XB, const char* metric, msm_idx_t na,
+                  msm_idx_t nb, msm_idx_t m, double* out, int on_device)
+{
+    return cdist_impl<double>(XA, XB, metric, na, nb, m, nullptr, 0, out, on_device);
+}
+
+int msm_assign_nearest_f32(const float* X, const float* Y, const char* metric,
+                           const msm_idx_t* X_indices, msm_idx_t n_X, msm_idx_t n_Y,
+                           msm_idx_t n_features, msm_idx_t n_X_indices, msm_idx_t* assignments,
+                           double* min_dist, double* inertia, int on_device)
+{
+    return assign_nearest_impl<float>(X, Y, metric, X_indices, n_X, n_Y, n_features, n_X_indices,
+                                      assignments, min_dist, inertia, on_device);
+}
+
+int msm_assign_nearest_f64(const double* X, const double* Y, const char* metric,
+                           const msm_idx_t* X_indices, msm_idx_t n_X, msm_idx_t n_Y,
+                           msm_idx_t n_features, msm_idx_t n_X_indices, msm_idx_t* assignments,
+                           double* min_dist, double* inertia, int on_device)
+{
+    return assign_nearest_impl<double>(X, Y, metric, X_indices, n_X, n_Y, n_features, n_X_indices,
+                                       assignments, min_dist, inertia, on_device);
+}
+
+int msm_kcenters_fit_f32(const float* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters,
+                         const char* metric, msm_idx_t seed_index, msm_idx_t* ids,
+                         msm_idx_t* labels, double* distances, double* inertia, int on_device)
+{
+    return kcenters_impl<float>(X, n, m, n_clusters, metric, seed_index, ids, labels, distances, inertia, on_device);
+}
+
+int msm_kcenters_fit_f64(const double* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters,
+                         const char* metric, msm_idx_t seed_index, msm_idx_t* ids,
+                         msm_idx_t* labels, double* distances, double* inertia, int on_device)
+{
+    return kcenters_impl<double>(X, n, m, n_clusters, metric, seed_index, ids, labels, distances, inertia, on_device);
+}
+
+}  // extern "C"

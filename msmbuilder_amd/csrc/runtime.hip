@@ -1,0 +1,217 @@
+// runtime.hip -- device selection, stream, error state, memory helpers of libmsmhip.
+#include "common.h"
+
+#include <string>
+
+namespace msm {
+
+static thread_local char g_err[512] = "";
+static hipStream_t g_stream = nullptr;
+static int g_num_cus = 0;
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+hipStream_t stream() { return g_stream; }
+
+int num_cus()
+{
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return MSM_OK;
+    release();
+    size_t want = bytes + (bytes >> 3) + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(MSM_ERR_HIP, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return MSM_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+int metric_id(const char* name)
+{
+    if (!name) return -1;
+    static const char* names[M_COUNT] = {"euclidean", "sqeuclidean", "cityblock", "chebyshev",
+                                         "canberra",  "braycurtis",  "hamming",   "jaccard"};
+    for (int i = 0; i < M_COUNT; ++i)
+        if (strcmp(name, names[i]) == 0) return i;
+    return -1;
+}
+
+__global__ void gather_rows_kernel(const char* __restrict__ X, size_t row_bytes,
+                                   const msm_idx_t* __restrict__ rows, char* __restrict__ out)
+{
+    const msm_idx_t r = rows[blockIdx.x];
+    const char* src = X + (size_t)r * row_bytes;
+    char* dst = out + (size_t)blockIdx.x * row_bytes;
+    for (size_t b = threadIdx.x; b < row_bytes; b += blockDim.x) dst[b] = src[b];
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" {
+
+const char* msm_last_error(void) { return g_err; }
+
+const char* msm_version(void) { return "msmhip 0.1 (gfx950)"; }
+
+int msm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n < 0 ? 0 : n;
+}
+
+int msm_init(int device)
+{
+    int n = msm_device_count();
+    if (n == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(MSM_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    MSM_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MSM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MSM_ERR_NODEVICE, "device %d is %s; libmsmhip is built for gfx950 only", device,
+                    prop.gcnArchName);
+    g_num_cus = prop.multiProcessorCount;
+    return MSM_OK;
+}
+
+int msm_set_stream(void* hip_stream)
+{
+    g_stream = static_cast<hipStream_t>(hip_stream);
+    return MSM_OK;
+}
+
+int msm_synchronize(void)
+{
+    MSM_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return MSM_OK;
+}
+
+int msm_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes)
+{
+    int dev = 0;
+    MSM_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    MSM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return MSM_OK;
+}
+
+int msm_malloc(void** dptr, size_t bytes)
+{
+    if (!dptr) return fail(MSM_ERR_INVALID, "msm_malloc: null output pointer");
+    MSM_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 1));
+    return MSM_OK;
+}
+
+int msm_free(void* dptr)
+{
+    if (dptr) MSM_HIP_CHECK(hipFree(dptr));
+    return MSM_OK;
+}
+
+int msm_memcpy_h2d(void* dst, const void* src, size_t bytes)
+{
+    MSM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
+    MSM_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return MSM_OK;
+}
+
+int msm_memcpy_d2h(void* dst, const void* src, size_t bytes)
+{
+    MSM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+    MSM_HIP_CHECK(hipStreamSynchronize(g_stream));
+    return MSM_OK;
+}
+
+int msm_memcpy_d2d(void* dst, const void* src, size_t bytes)
+{
+    MSM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return MSM_OK;
+}
+
+int msm_gather_rows(const void* X, int elem_size, msm_idx_t n_features, const msm_idx_t* rows,
+                    msm_idx_t n_rows, void* out, int on_device)
+{
+    if (!X || !rows || !out || elem_size <= 0 || n_features <= 0 || n_rows < 0)
+        return fail(MSM_ERR_INVALID, "msm_gather_rows: bad argument");
+    const size_t row_bytes = (size_t)elem_size * n_features;
+    if (n_rows == 0) return MSM_OK;
+    if (!on_device) {
+        for (msm_idx_t i = 0; i < n_rows; ++i)
+            memcpy((char*)out + i * row_bytes, (const char*)X + rows[i] * row_bytes, row_bytes);
+        return MSM_OK;
+    }
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, g_stream,
+                       (const char*)X, row_bytes, rows, (char*)out);
+    MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
+int msm_event_create(void** ev)
+{
+    hipEvent_t e;
+    MSM_HIP_CHECK(hipEventCreate(&e));
+    *ev = e;
+    return MSM_OK;
+}
+
+int msm_event_record(void* ev)
+{
+    MSM_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev), g_stream));
+    return MSM_OK;
+}
+
+int msm_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    MSM_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+    MSM_HIP_CHECK(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return MSM_OK;
+}
+
+int msm_event_destroy(void* ev)
+{
+    MSM_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(ev)));
+    return MSM_OK;
+}
+
+}  // extern "C"

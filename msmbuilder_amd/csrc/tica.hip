@@ -1,0 +1,912 @@
+// tica.hip -- time-lagged second-moment accumulation for tICA on gfx950.
+//
+// Replaces the body of tICA._fit (/root/reference/msmbuilder/decomposition/tica.py:401-424):
+//   C  += X[:-tau].T @ X[tau:]                                  (:417)
+//   G  += X[:-tau].T @ X[:-tau] + X[tau:].T @ X[tau:]           (:421-422; only the sum is read, :245)
+//   s0 += X[:-tau].sum(0),  stau += X[tau:].sum(0)              (:418-419)
+// The reference does three float64 dgemm per trajectory; here C and G are ONE
+// MFMA kernel over frame-major X (X is read as both operands: A = X^T needs no
+// transpose because the MFMA A and B fragments are both k-major):
+//   * C tile (I,J):  sum_t  a(t) * X[t, I]^T X[t+tau, J],  a(t) = [t < len-tau]
+//   * G tile (I<=J): sum_t  w(t) * X[t, I]^T X[t, J],      w(t) = [t < len-tau] + [t >= tau]
+//     (w in {0,1,2} is exact in fp32, so S0+Stau needs no head/tail correction pass;
+//      the lower triangle is mirrored at export).
+// Decomposition: a persistent grid of S cohorts x ntiles workgroups (<= resident
+// slots, one round, no tail).  Every workgroup owns ONE 128x128 output tile for
+// its whole life and walks the frame chunks c = cohort, cohort+S, ...; a chunk is
+// <= 4096 frames of one trajectory, accumulated in fp32 MFMA registers and then
+// merged in fp64 into the workgroup's private slab (no atomics, deterministic).
+// The cohort's workgroups read the same frames at the same time and are placed on
+// one XCD where possible, so the 13x panel re-read (F=512) is L2 traffic, not HBM.
+#include "common.h"
+
+#include <vector>
+
+namespace msm {
+
+constexpr int TM = 128;     // output tile is TM x TM features
+constexpr int NT = 256;     // threads per workgroup: 4 waves as 2x2, 64x64 outputs per wave
+constexpr int BK32 = 32;    // frames per K-step, fp32 kernel
+constexpr int BK64 = 16;    // frames per K-step, fp64 kernel
+constexpr int KCMAX = 4096; // max frames accumulated in fp32 before an fp64 merge
+constexpr int NCB = 512;    // column-sum partial slots
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct TicaChunk {
+    const void* base;  // row 0 of the trajectory
+    long long row0;    // first row of this chunk inside the trajectory
+    long long len;     // trajectory length
+    int n;             // rows in this chunk
+    int pad;
+};
+
+struct TicaArgs {
+    const TicaChunk* chunks;  // device table, or nullptr -> `single` split arithmetically by kc
+    TicaChunk single;
+    long long nchunks;
+    long long ld;
+    int kc;
+    int F, lag, T, ntiles, S;
+    double* slabs;    // [S*ntiles][TM*TM] fp64, owned per workgroup
+    double* colpart;  // [NCB][2][F] fp64 partial column sums (temporary buffer)
+    int* flag;        // sticky non-finite flag
+};
+
+__device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
+{
+    if (P.chunks) return P.chunks[c];
+    TicaChunk ch = P.single;
+    ch.row0 = c * (long long)P.kc;
+    long long rem = ch.len - ch.row0;
+    ch.n = (int)(rem < P.kc ? rem : P.kc);
+    return ch;
+}
+
+// persistent block id -> (cohort, tile); blocks land on XCD (blockIdx % 8), so remap to
+// make consecutive p (= one cohort's tiles) share an XCD's L2.  Bijective for any grid.
+__device__ __forceinline__ int xcd_linear_id()
+{
+    const int G = gridDim.x, b = blockIdx.x;
+    const int q = G / 8, r = G % 8, xcd = b % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+}
+
+__device__ __forceinline__ void decode_tile(int tile, int T, int& I, int& J, int& isG)
+{
+    if (tile < T * T) {
+        isG = 0;
+        I = tile / T;
+        J = tile % T;
+    } else {
+        isG = 1;
+        int u = tile - T * T;
+        I = 0;
+        while (u >= T - I) {
+            u -= T - I;
+            ++I;
+        }
+        J = I + u;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fp32 kernel: v_mfma_f32_32x32x2_f32.  LDS panels are frame-major [BK][128]
+// exactly like X in HBM (coalesced 512-B row segments in, conflict-free
+// ds_read_b32 fragment reads out: lanes 0-31 read 32 consecutive floats of
+// frame k, lanes 32-63 of frame k+1).
+// ---------------------------------------------------------------------------
+template <bool VEC4>
+struct Stage32 {
+    float4 a[4], b[4];
+};
+
+template <bool VEC4>
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ p, int col, int F)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VEC4) {
+        if (col < F) v = *reinterpret_cast<const float4*>(p);
+    } else {
+        if (col + 0 < F) v.x = p[0];
+        if (col + 1 < F) v.y = p[1];
+        if (col + 2 < F) v.z = p[2];
+        if (col + 3 < F) v.w = p[3];
+    }
+    return v;
+}
+
+template <bool VEC4>
+__device__ __forceinline__ void stage_load32(Stage32<VEC4>& st, const TicaArgs& P,
+                                             const TicaChunk& ch, int k0, int isG, int tauB,
+                                             int I0, int J0, int tid)
+{
+    const int c4 = (tid & 31) * 4;
+    const int rr0 = tid >> 5;
+    const float* X = static_cast<const float*>(ch.base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kr = k0 + rr0 + 8 * j;
+        const long long r = ch.row0 + kr;
+        float sc = 0.f;
+        if (kr < ch.n) {
+            sc = (r < ch.len - P.lag) ? 1.f : 0.f;
+            if (isG) sc += (r >= P.lag) ? 1.f : 0.f;
+        }
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (sc != 0.f) {
+            va = load_row4<VEC4>(X + r * P.ld + I0 + c4, I0 + c4, P.F);
+            va.x *= sc; va.y *= sc; va.z *= sc; va.w *= sc;
+            if (r + tauB < ch.len) vb = load_row4<VEC4>(X + (r + tauB) * P.ld + J0 + c4, J0 + c4, P.F);
+        }
+        st.a[j] = va;
+        st.b[j] = vb;
+    }
+}
+
+template <bool VEC4>
+__device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As, float* Bs, int tid)
+{
+    const int c4 = (tid & 31) * 4;
+    const int rr0 = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = rr0 + 8 * j;
+        *reinterpret_cast<float4*>(As + rr * TM + c4) = st.a[j];
+        *reinterpret_cast<float4*>(Bs + rr * TM + c4) = st.b[j];
+    }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);  // [2][BK32][TM]
+    float* Bs = As + 2 * BK32 * TM;              // [2][BK32][TM]
+
+    const int tid = threadIdx.x;
+    const int p = xcd_linear_id();
+    const int cohort = p / P.ntiles, tile = p % P.ntiles;
+    int I, J, isG;
+    decode_tile(tile, P.T, I, J, isG);
+    const int I0 = I * TM, J0 = J * TM;
+    const int tauB = isG ? 0 : P.lag;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kl = lane >> 5, cl = lane & 31;
+    double* slab = P.slabs + (size_t)p * (TM * TM);
+
+    for (long long c = cohort; c < P.nchunks; c += P.S) {
+        const TicaChunk ch = get_chunk(P, c);
+        const int nsteps = (ch.n + BK32 - 1) / BK32;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+
+        Stage32<VEC4> st;
+        stage_load32<VEC4>(st, P, ch, 0, isG, tauB, I0, J0, tid);
+        stage_store32<VEC4>(st, As, Bs, tid);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nsteps) stage_load32<VEC4>(st, P, ch, (s + 1) * BK32, isG, tauB, I0, J0, tid);
+            const float* Ab = As + buf * (BK32 * TM) + kl * TM + wr * 64 + cl;
+            const float* Bb = Bs + buf * (BK32 * TM) + kl * TM + wc * 64 + cl;
+#pragma unroll 4
+            for (int kk = 0; kk < BK32 / 2; ++kk) {
+                const float a0 = Ab[kk * 2 * TM], a1 = Ab[kk * 2 * TM + 32];
+                const float b0 = Bb[kk * 2 * TM], b1 = Bb[kk * 2 * TM + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (s + 1 < nsteps)
+                stage_store32<VEC4>(st, As + (buf ^ 1) * (BK32 * TM), Bs + (buf ^ 1) * (BK32 * TM), tid);
+            __syncthreads();
+        }
+        // fp64 merge of this chunk's fp32 partial into the workgroup's private slab
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    double* q = slab + (wr * 64 + bi * 32 + row) * TM + wc * 64 + bj * 32 + cl;
+                    *q += (double)acc[bi][bj][r];
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fp64 kernel: v_mfma_f64_16x16x4_f64 on inputs widened to fp64 while staging.
+// fp32 x fp32 products are exact in fp64, so this is the reference's float64
+// arithmetic up to summation order.  Accumulators stay in registers for the
+// workgroup's whole life (one slab merge at the end).
+// ---------------------------------------------------------------------------
+template <typename TIn>
+__global__ __launch_bounds__(NT, 1) void tica_mfma_f64_kernel(TicaArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* As = reinterpret_cast<double*>(smem);  // [BK64][TM]
+    double* Bs = As + BK64 * TM;                   // [BK64][TM]
+
+    const int tid = threadIdx.x;
+    const int p = xcd_linear_id();
+    const int cohort = p / P.ntiles, tile = p % P.ntiles;
+    int I, J, isG;
+    decode_tile(tile, P.T, I, J, isG);
+    const int I0 = I * TM, J0 = J * TM;
+    const int tauB = isG ? 0 : P.lag;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kl = lane >> 4, cl = lane & 15;  // A[i=cl][k=kl], B[k=kl][j=cl]
+    double* slab = P.slabs + (size_t)p * (TM * TM);
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[bi][bj][r] = 0.0;
+
+    // staging map: 16 rows x 128 cols per panel = 2048 elements / 256 threads = 8 each:
+    // thread -> row (tid>>4), cols (tid&15)*8 .. +7
+    const int srow = tid >> 4, scol = (tid & 15) * 8;
+
+    for (long long c = cohort; c < P.nchunks; c += P.S) {
+        const TicaChunk ch = get_chunk(P, c);
+        const TIn* X = static_cast<const TIn*>(ch.base);
+        const int nsteps = (ch.n + BK64 - 1) / BK64;
+        for (int s = 0; s < nsteps; ++s) {
+            const int kr = s * BK64 + srow;
+            const long long r = ch.row0 + kr;
+            double sc = 0.0;
+            if (kr < ch.n) {
+                sc = (r < ch.len - P.lag) ? 1.0 : 0.0;
+                if (isG) sc += (r >= P.lag) ? 1.0 : 0.0;
+            }
+            double va[8], vb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                va[e] = 0.0;
+                vb[e] = 0.0;
+            }
+            if (sc != 0.0) {
+                const TIn* pa = X + r * P.ld + I0 + scol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (I0 + scol + e < P.F) va[e] = sc * (double)pa[e];
+                if (r + tauB < ch.len) {
+                    const TIn* pb = X + (r + tauB) * P.ld + J0 + scol;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (J0 + scol + e < P.F) vb[e] = (double)pb[e];
+                }
+            }
+            __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                As[srow * TM + scol + e] = va[e];
+                Bs[srow * TM + scol + e] = vb[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < BK64 / 4; ++kk) {
+                double a[4], b[4];
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi) a[bi] = As[(kk * 4 + kl) * TM + wr * 64 + bi * 16 + cl];
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj) b[bj] = Bs[(kk * 4 + kl) * TM + wc * 64 + bj * 16 + cl];
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+                    for (int bj = 0; bj < 4; ++bj)
+                        acc[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], b[bj], acc[bi][bj], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of the f64 16x16x4 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kl + 4 * r;
+                double* q = slab + (wr * 64 + bi * 16 + row) * TM + wc * 64 + bj * 16 + cl;
+                *q += acc[bi][bj][r];
+            }
+}
+
+// ---------------------------------------------------------------------------
+// Column sums s0 / stau (tica.py:418-419) + the finite check of
+// utils/validation.py:68-74, one streaming pass, fp64 accumulation.
+// Block b owns partial slot b and walks chunks b, b+grid, ...
+// ---------------------------------------------------------------------------
+template <typename TIn>
+__global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
+{
+    __shared__ double red[2][NT];
+    const int tid = threadIdx.x;
+    int cpb = 1;
+    while (cpb < P.F && cpb < NT) cpb <<= 1;  // columns per pass (power of two <= 256)
+    const int rl = NT / cpb;                  // row lanes
+    const int tc = tid % cpb, tr = tid / cpb;
+    double* part = P.colpart + (size_t)blockIdx.x * 2 * P.F;
+    int bad = 0;
+    for (int c0 = 0; c0 < P.F; c0 += cpb) {
+        const int col = c0 + tc;
+        double s0 = 0.0, st = 0.0;
+        if (col < P.F) {
+            for (long long c = blockIdx.x; c < P.nchunks; c += gridDim.x) {
+                const TicaChunk ch = get_chunk(P, c);
+                const TIn* X = static_cast<const TIn*>(ch.base);
+                for (int kr = tr; kr < ch.n; kr += rl) {
+                    const long long r = ch.row0 + kr;
+                    const double x = (double)X[r * P.ld + col];
+                    bad |= !isfinite(x);
+                    if (r < ch.len - P.lag) s0 += x;
+                    if (r >= P.lag) st += x;
+                }
+            }
+        }
+        red[0][tid] = s0;
+        red[1][tid] = st;
+        __syncthreads();
+        if (tr == 0 && col < P.F) {
+            for (int k = 1; k < rl; ++k) {
+                s0 += red[0][k * cpb + tc];
+                st += red[1][k * cpb + tc];
+            }
+            part[col] += s0;
+            part[P.F + col] += st;
+        }
+        __syncthreads();
+    }
+    if (bad) atomicOr(P.flag, 1);
+}
+
+// colpart (persistent) += coltmp, then coltmp = 0
+__global__ void tica_colmerge_kernel(double* __restrict__ dst, double* __restrict__ tmp, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dst[i] += tmp[i];
+        tmp[i] = 0.0;
+    }
+}
+
+// packed[C | G | s0 | stau | n_obs | n_seq] = base + sum over slabs / column partials
+__global__ void tica_export_kernel(const double* __restrict__ slabs, const double* __restrict__ colpart,
+                                   const double* __restrict__ base, double* __restrict__ out, int F,
+                                   int T, int ntiles, int S)
+{
+    const size_t FF = (size_t)F * F;
+    const size_t total = 2 * FF + 2 * (size_t)F;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    double v = base[idx];
+    if (idx < 2 * FF) {
+        const int type = idx >= FF;
+        const size_t e = idx - (type ? FF : 0);
+        int i = (int)(e / F), j = (int)(e % F);
+        int ti = i / TM, tj = j / TM;
+        int tile;
+        if (type == 0) {
+            tile = ti * T + tj;
+        } else {
+            if (ti > tj) {  // lower triangle: mirror of the computed upper tile
+                int t = i; i = j; j = t;
+                t = ti; ti = tj; tj = t;
+            }
+            // upper-triangle tiles are enumerated row by row: (0,0..T-1), (1,1..T-1), ...
+            tile = T * T + ti * T - ti * (ti - 1) / 2 + (tj - ti);
+        }
+        const size_t off = (size_t)(i % TM) * TM + (j % TM);
+        for (int s = 0; s < S; ++s) v += slabs[((size_t)s * ntiles + tile) * (TM * TM) + off];
+    } else {
+        const size_t e = idx - 2 * FF;  // [s0 | stau]
+        for (int b = 0; b < NCB; ++b) v += colpart[(size_t)b * 2 * F + e];
+    }
+    out[idx] = v;
+}
+
+// out[n,k] = (X - mean) @ comps^T in fp64; wave = component lane, lane = row.
+template <typename TIn>
+__global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict__ X, long long n,
+                                                          int F, long long ld,
+                                                          const double* __restrict__ mean,
+                                                          const double* __restrict__ comps, int k,
+                                                          double* __restrict__ out, int* flag)
+{
+    constexpr int FC = 32, KT = 32;  // feature chunk, component tile (8 per wave)
+    __shared__ double Xs[64][FC + 1];
+    __shared__ double Vs[KT][FC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long row0 = (long long)blockIdx.x * 64;
+    int bad = 0;
+    for (int k0 = 0; k0 < k; k0 += KT) {
+        double acc[KT / 4];
+#pragma unroll
+        for (int a = 0; a < KT / 4; ++a) acc[a] = 0.0;
+        for (int f0 = 0; f0 < F; f0 += FC) {
+            __syncthreads();
+            for (int e = tid; e < 64 * FC; e += NT) {
+                const int rr = e / FC, ff = e % FC;
+                const long long r = row0 + rr;
+                double v = 0.0;
+                if (r < n && f0 + ff < F) {
+                    const double x = (double)X[r * ld + f0 + ff];
+                    bad |= !isfinite(x);
+                    v = x - mean[f0 + ff];
+                }
+                Xs[rr][ff] = v;
+            }
+            for (int e = tid; e < KT * FC; e += NT) {
+                const int kk = e / FC, ff = e % FC;
+                Vs[kk][ff] = (k0 + kk < k && f0 + ff < F) ? comps[(size_t)(k0 + kk) * F + f0 + ff] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int ff = 0; ff < FC; ++ff) {
+                const double x = Xs[lane][ff];
+#pragma unroll
+                for (int a = 0; a < KT / 4; ++a) acc[a] = fma(x, Vs[wave * (KT / 4) + a][ff], acc[a]);
+            }
+        }
+        const long long r = row0 + lane;
+        if (r < n) {
+#pragma unroll
+            for (int a = 0; a < KT / 4; ++a) {
+                const int kk = k0 + wave * (KT / 4) + a;
+                if (kk < k) out[r * k + kk] = acc[a];
+            }
+        }
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+struct msm_tica {
+    int F = 0, lag = 0, mode = 0, T = 0, ntiles = 0, S = 0, G = 0;
+    double* slabs = nullptr;    // [G][TM*TM]
+    double* base = nullptr;     // packed [2FF+2F] imported state
+    double* colpart = nullptr;  // [NCB][2][F]
+    double* coltmp = nullptr;   // [NCB][2][F]
+    double* packed = nullptr;   // [2FF+2F+2] export scratch
+    int* flag = nullptr;        // [2]: [0] sticky, [1] per-call
+    long long n_obs = 0, n_seq = 0;
+    DevBuf table, staging;
+    size_t packed_len() const { return 2 * (size_t)F * F + 2 * (size_t)F + 2; }
+};
+
+namespace {
+
+template <typename K>
+int query_slots(K kernel, size_t lds, int* slots)
+{
+    int occ = 0;
+    MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, NT, lds));
+    if (occ < 1) occ = 1;
+    *slots = occ * num_cus();
+    return MSM_OK;
+}
+
+constexpr size_t LDS32 = 2 * 2 * BK32 * TM * sizeof(float);  // 64 KiB
+constexpr size_t LDS64 = 2 * BK64 * TM * sizeof(double);     // 32 KiB (single-buffered)
+
+int tica_zero(msm_tica* h)
+{
+    const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
+    MSM_HIP_CHECK(hipMemsetAsync(h->slabs, 0, (size_t)h->G * TM * TM * sizeof(double), stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->base, 0, FF2 * sizeof(double), stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->colpart, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, 2 * sizeof(int), stream()));
+    h->n_obs = 0;
+    h->n_seq = 0;
+    return MSM_OK;
+}
+
+// device-resident trajectories only
+int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t* n_rows,
+                           msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int check_finite,
+                           msm_idx_t* n_skipped)
+{
+    long long total = 0, nvalid = 0, skipped = 0;
+    bool aligned = (h->F % 4 == 0) && (ld % 4 == 0);
+    for (msm_idx_t s = 0; s < n_seq; ++s) {
+        if (n_rows[s] > h->lag) {
+            total += n_rows[s];
+            ++nvalid;
+            if (((uintptr_t)ptrs[s]) & 15) aligned = false;
+        } else {
+            ++skipped;
+        }
+    }
+    if (n_skipped) *n_skipped = skipped;
+    if (nvalid == 0) return MSM_OK;
+
+    // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
+    const int bk = (h->mode == MSM_TICA_F32 && dtype_bytes == 4) ? BK32 : BK64;
+    long long kc = ceil_div(total, h->S);
+    kc = ceil_div(kc, bk) * bk;
+    if (kc > KCMAX) kc = KCMAX;
+    if (kc < bk) kc = bk;
+
+    TicaArgs P;
+    memset(&P, 0, sizeof(P));
+    P.ld = ld;
+    P.kc = (int)kc;
+    P.F = h->F;
+    P.lag = h->lag;
+    P.T = h->T;
+    P.ntiles = h->ntiles;
+    P.S = h->S;
+    P.slabs = h->slabs;
+    P.colpart = h->coltmp;
+    P.flag = h->flag;
+
+    if (nvalid == 1 && n_seq == 1) {
+        P.chunks = nullptr;
+        P.single.base = ptrs[0];
+        P.single.row0 = 0;
+        P.single.len = n_rows[0];
+        P.single.n = 0;
+        P.nchunks = ceil_div(n_rows[0], kc);
+    } else {
+        std::vector<TicaChunk> tab;
+        tab.reserve((size_t)(total / kc + nvalid + 1));
+        for (msm_idx_t s = 0; s < n_seq; ++s) {
+            const long long len = n_rows[s];
+            if (len <= h->lag) continue;
+            const long long nch = ceil_div(len, kc);
+            long long piece = ceil_div(ceil_div(len, nch), bk) * bk;
+            for (long long r0 = 0; r0 < len; r0 += piece) {
+                TicaChunk ch;
+                ch.base = ptrs[s];
+                ch.row0 = r0;
+                ch.len = len;
+                ch.n = (int)((len - r0) < piece ? (len - r0) : piece);
+                ch.pad = 0;
+                tab.push_back(ch);
+            }
+        }
+        int rc = h->table.reserve(tab.size() * sizeof(TicaChunk));
+        if (rc) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->table.p, tab.data(), tab.size() * sizeof(TicaChunk),
+                                     hipMemcpyHostToDevice, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // `tab` is pageable host memory
+        P.chunks = h->table.as<TicaChunk>();
+        P.nchunks = (long long)tab.size();
+    }
+
+    // 1) column sums + finite check into the temporary partials
+    if (dtype_bytes == 4)
+        hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), P);
+    else
+        hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), P);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (check_finite) {
+        int f[2] = {0, 0};
+        MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        if (f[0]) {
+            MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
+            MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, sizeof(int), stream()));
+            return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
+        }
+    }
+    {
+        const size_t n = (size_t)NCB * 2 * h->F;
+        hipLaunchKernelGGL(tica_colmerge_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
+                           h->colpart, h->coltmp, n);
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    // 2) the MFMA pass
+    if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
+        if (aligned)
+            hipLaunchKernelGGL(tica_mfma_f32_kernel<true>, dim3(h->G), dim3(NT), LDS32, stream(), P);
+        else
+            hipLaunchKernelGGL(tica_mfma_f32_kernel<false>, dim3(h->G), dim3(NT), LDS32, stream(), P);
+    } else if (dtype_bytes == 4) {
+        hipLaunchKernelGGL(tica_mfma_f64_kernel<float>, dim3(h->G), dim3(NT), LDS64, stream(), P);
+    } else {
+        hipLaunchKernelGGL(tica_mfma_f64_kernel<double>, dim3(h->G), dim3(NT), LDS64, stream(), P);
+    }
+    MSM_HIP_CHECK(hipGetLastError());
+    for (msm_idx_t s = 0; s < n_seq; ++s)
+        if (n_rows[s] > h->lag) {
+            h->n_obs += n_rows[s];
+            h->n_seq += 1;
+        }
+    return MSM_OK;
+}
+
+int tica_export_device(msm_tica* h)
+{
+    const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
+    hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
+                       h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
+    MSM_HIP_CHECK(hipGetLastError());
+    const double cnt[2] = {(double)h->n_obs, (double)h->n_seq};
+    MSM_HIP_CHECK(hipMemcpyAsync(h->packed + total, cnt, sizeof(cnt), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, int mode)
+{
+    if (!out) return fail(MSM_ERR_INVALID, "msm_tica_create: null handle pointer");
+    if (n_features < 1 || n_features > (1 << 15)) return fail(MSM_ERR_INVALID, "n_features=%lld out of range", (long long)n_features);
+    if (lag_time < 1) return fail(MSM_ERR_INVALID, "lag_time must be >= 1");
+    if (mode != MSM_TICA_F32 && mode != MSM_TICA_F64) return fail(MSM_ERR_INVALID, "unknown tica mode %d", mode);
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    msm_tica* h = new msm_tica();
+    h->F = (int)n_features;
+    h->lag = (int)lag_time;
+    h->mode = mode;
+    h->T = (int)ceil_div(n_features, TM);
+    h->ntiles = h->T * h->T + h->T * (h->T + 1) / 2;
+    int slots32 = 0, slots64 = 0, rc;
+    MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_f32_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
+    MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_f32_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
+    if ((rc = query_slots(tica_mfma_f32_kernel<true>, LDS32, &slots32))) { delete h; return rc; }
+    if ((rc = query_slots(tica_mfma_f64_kernel<float>, LDS64, &slots64))) { delete h; return rc; }
+    // one resident round: S cohorts of ntiles workgroups (both kernels must fit)
+    int slots = slots32 < slots64 ? slots32 : slots64;
+    if (mode == MSM_TICA_F32) {
+        // f64 inputs in f32 mode still go through the f64 kernel; keep the smaller figure
+    }
+    h->S = slots / h->ntiles;
+    if (h->S < 1) h->S = 1;
+    h->G = h->S * h->ntiles;
+    const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void**)&h->slabs, (size_t)h->G * TM * TM * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->base, FF2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->colpart, (size_t)NCB * 2 * h->F * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->coltmp, (size_t)NCB * 2 * h->F * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->packed, (FF2 + 2) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->flag, 2 * sizeof(int));
+    if (e != hipSuccess) {
+        msm_tica_destroy(h);
+        return fail(MSM_ERR_HIP, "msm_tica_create: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    rc = tica_zero(h);
+    if (rc) {
+        msm_tica_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return MSM_OK;
+}
+
+int msm_tica_destroy(msm_tica_t* h)
+{
+    if (!h) return MSM_OK;
+    (void)hipStreamSynchronize(stream());
+    if (h->slabs) (void)hipFree(h->slabs);
+    if (h->base) (void)hipFree(h->base);
+    if (h->colpart) (void)hipFree(h->colpart);
+    if (h->coltmp) (void)hipFree(h->coltmp);
+    if (h->packed) (void)hipFree(h->packed);
+    if (h->flag) (void)hipFree(h->flag);
+    delete h;
+    return MSM_OK;
+}
+
+int msm_tica_reset(msm_tica_t* h)
+{
+    if (!h) return fail(MSM_ERR_STATE, "null tica handle");
+    return tica_zero(h);
+}
+
+int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
+                              msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int on_device,
+                              int check_finite, msm_idx_t* n_skipped)
+{
+    if (!h) return fail(MSM_ERR_STATE, "null tica handle");
+    if (n_seq < 0 || (n_seq > 0 && (!X_ptrs || !n_rows))) return fail(MSM_ERR_INVALID, "bad sequence table");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (ld < h->F) return fail(MSM_ERR_INVALID, "ld=%lld < n_features=%d", (long long)ld, h->F);
+    for (msm_idx_t s = 0; s < n_seq; ++s)
+        if (n_rows[s] < 0 || (n_rows[s] > 0 && !X_ptrs[s])) return fail(MSM_ERR_INVALID, "bad sequence %lld", (long long)s);
+    if (n_skipped) *n_skipped = 0;
+    if (n_seq == 0) return MSM_OK;
+    if (on_device) return tica_accumulate_device(h, X_ptrs, n_rows, n_seq, dtype_bytes, ld, check_finite, n_skipped);
+
+    // host trajectories: stage groups of them (compacted to ld = F) through a device buffer
+    const size_t row_bytes = (size_t)h->F * dtype_bytes;
+    const size_t budget = (size_t)1 << 30;
+    msm_idx_t skipped_total = 0;
+    msm_idx_t s = 0;
+    while (s < n_seq) {
+        size_t bytes = 0;
+        msm_idx_t e = s;
+        while (e < n_seq && (e == s || bytes + (size_t)n_rows[e] * row_bytes <= budget)) {
+            bytes += ((size_t)n_rows[e] * row_bytes + 255) & ~(size_t)255;
+            ++e;
+        }
+        int rc = h->staging.reserve(bytes ? bytes : 256);
+        if (rc) return rc;
+        std::vector<const void*> dptrs((size_t)(e - s));
+        size_t off = 0;
+        for (msm_idx_t i = s; i < e; ++i) {
+            char* d = h->staging.as<char>() + off;
+            dptrs[(size_t)(i - s)] = d;
+            if (n_rows[i] > 0) {
+                if (ld == h->F) {
+                    MSM_HIP_CHECK(hipMemcpyAsync(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes, hipMemcpyHostToDevice, stream()));
+                } else {
+                    MSM_HIP_CHECK(hipMemcpy2DAsync(d, row_bytes, X_ptrs[i], (size_t)ld * dtype_bytes, row_bytes,
+                                                   (size_t)n_rows[i], hipMemcpyHostToDevice, stream()));
+                }
+            }
+            off += ((size_t)n_rows[i] * row_bytes + 255) & ~(size_t)255;
+        }
+        msm_idx_t sk = 0;
+        rc = tica_accumulate_device(h, dptrs.data(), n_rows + s, e - s, dtype_bytes, h->F, check_finite, &sk);
+        if (rc) return rc;
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // staging buffer is reused by the next group
+        skipped_total += sk;
+        s = e;
+    }
+    if (n_skipped) *n_skipped = skipped_total;
+    return MSM_OK;
+}
+
+int msm_tica_accumulate(msm_tica_t* h, const void* X, int dtype_bytes, msm_idx_t n_rows,
+                        msm_idx_t ld, int on_device, int check_finite, int* skipped)
+{
+    msm_idx_t sk = 0;
+    const void* ptrs[1] = {X};
+    int rc = msm_tica_accumulate_batch(h, ptrs, &n_rows, 1, dtype_bytes, ld, on_device, check_finite, &sk);
+    if (skipped) *skipped = (int)sk;
+    return rc;
+}
+
+int msm_tica_nonfinite(msm_tica_t* h, int* flag)
+{
+    if (!h || !flag) return fail(MSM_ERR_STATE, "null argument");
+    int f[2];
+    MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    *flag = f[0];
+    return MSM_OK;
+}
+
+msm_idx_t msm_tica_packed_size(msm_tica_t* h) { return h ? (msm_idx_t)h->packed_len() : 0; }
+
+int msm_tica_export_packed(msm_tica_t* h, double* buf, int on_device)
+{
+    if (!h || !buf) return fail(MSM_ERR_STATE, "null argument");
+    int rc = tica_export_device(h);
+    if (rc) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(buf, h->packed, h->packed_len() * sizeof(double),
+                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_tica_import_packed(msm_tica_t* h, const double* buf, int on_device)
+{
+    if (!h || !buf) return fail(MSM_ERR_STATE, "null argument");
+    const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
+    long long keep_flag = 0;
+    (void)keep_flag;
+    int rc = tica_zero(h);
+    if (rc) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(h->base, buf, FF2 * sizeof(double),
+                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream()));
+    double cnt[2];
+    MSM_HIP_CHECK(hipMemcpyAsync(cnt, buf + FF2, sizeof(cnt),
+                                 on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    h->n_obs = (long long)(cnt[0] + 0.5);
+    h->n_seq = (long long)(cnt[1] + 0.5);
+    return MSM_OK;
+}
+
+int msm_tica_export(msm_tica_t* h, double* C, double* G, double* s0, double* stau,
+                    msm_idx_t* n_observations, msm_idx_t* n_sequences)
+{
+    if (!h) return fail(MSM_ERR_STATE, "null tica handle");
+    int rc = tica_export_device(h);
+    if (rc) return rc;
+    const size_t FF = (size_t)h->F * h->F;
+    if (C) MSM_HIP_CHECK(hipMemcpyAsync(C, h->packed, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (G) MSM_HIP_CHECK(hipMemcpyAsync(G, h->packed + FF, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (s0) MSM_HIP_CHECK(hipMemcpyAsync(s0, h->packed + 2 * FF, h->F * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (stau) MSM_HIP_CHECK(hipMemcpyAsync(stau, h->packed + 2 * FF + h->F, h->F * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    if (n_observations) *n_observations = h->n_obs;
+    if (n_sequences) *n_sequences = h->n_seq;
+    return MSM_OK;
+}
+
+int msm_tica_import(msm_tica_t* h, const double* C, const double* G, const double* s0,
+                    const double* stau, msm_idx_t n_observations, msm_idx_t n_sequences)
+{
+    if (!h || !C || !G || !s0 || !stau) return fail(MSM_ERR_STATE, "null argument");
+    int rc = tica_zero(h);
+    if (rc) return rc;
+    const size_t FF = (size_t)h->F * h->F;
+    MSM_HIP_CHECK(hipMemcpyAsync(h->base, C, FF * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(h->base + FF, G, FF * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(h->base + 2 * FF, s0, h->F * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(h->base + 2 * FF + h->F, stau, h->F * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    h->n_obs = n_observations;
+    h->n_seq = n_sequences;
+    return MSM_OK;
+}
+
+int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features,
+                     msm_idx_t ld, const double* mean, const double* comps, msm_idx_t k,
+                     double* out, int on_device, int check_finite)
+{
+    if (!X || !mean || !comps || !out) return fail(MSM_ERR_INVALID, "msm_tica_project: null pointer");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (n_rows < 0 || n_features < 1 || k < 1 || ld < n_features) return fail(MSM_ERR_INVALID, "bad shape");
+    if (n_rows == 0) return MSM_OK;
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    DevBuf dX, dOut, dPar;
+    int rc;
+    const size_t par_n = (size_t)n_features + (size_t)k * n_features;
+    if ((rc = dPar.reserve(par_n * sizeof(double) + 16))) return rc;
+    double* dmean = dPar.as<double>();
+    double* dcomps = dmean + n_features;
+    int* dflag = reinterpret_cast<int*>(dcomps + (size_t)k * n_features);
+    MSM_HIP_CHECK(hipMemcpyAsync(dmean, mean, n_features * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(dcomps, comps, (size_t)k * n_features * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
+    const void* Xd = X;
+    double* outd = out;
+    msm_idx_t ldd = ld;
+    if (!on_device) {
+        if ((rc = dX.reserve((size_t)n_rows * n_features * dtype_bytes))) return rc;
+        if ((rc = dOut.reserve((size_t)n_rows * k * sizeof(double)))) return rc;
+        MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, (size_t)n_features * dtype_bytes, X, (size_t)ld * dtype_bytes,
+                                       (size_t)n_features * dtype_bytes, (size_t)n_rows, hipMemcpyHostToDevice, stream()));
+        Xd = dX.p;
+        outd = dOut.as<double>();
+        ldd = n_features;
+    }
+    const unsigned grid = (unsigned)ceil_div(n_rows, 64);
+    if (dtype_bytes == 4)
+        hipLaunchKernelGGL(tica_project_kernel<float>, dim3(grid), dim3(NT), 0, stream(), (const float*)Xd,
+                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag);
+    else
+        hipLaunchKernelGGL(tica_project_kernel<double>, dim3(grid), dim3(NT), 0, stream(), (const double*)Xd,
+                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (!on_device)
+        MSM_HIP_CHECK(hipMemcpyAsync(out, outd, (size_t)n_rows * k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    int f = 0;
+    if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // scratch buffers die with this frame
+    if (check_finite && f) return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
+    return MSM_OK;
+}
+
+}  // extern "C"

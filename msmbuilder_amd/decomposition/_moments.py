@@ -1,0 +1,74 @@
+"""Host-side finalisation of the tICA accumulators (float64 numpy, O(F^2) / O(F^3)).
+
+The device hands back four sums over all lagged pairs (t, t+tau) of all trajectories:
+
+    C    = sum x_t x_{t+tau}^T                     (lagged second moment)
+    G    = sum x_t x_t^T + x_{t+tau} x_{t+tau}^T   (instantaneous, both ends)
+    s0   = sum x_t,   stau = sum x_{t+tau}
+    n_pairs = n_observations - tau * n_sequences
+
+from which the symmetrised estimators of the reference are formed
+(/root/reference/msmbuilder/decomposition/tica.py:228-259):
+
+    mu = (s0 + stau) / (2 n_pairs)
+    offset_correlation = (C + C^T) / (2 n_pairs) - mu mu^T
+    S                  =  G        / (2 n_pairs) - mu mu^T
+    covariance         = (1 - rho) S + rho (tr S / p) I
+
+with rho either given or the Rao-Blackwellised Ledoit-Wolf estimate
+(tica.py:492-524, Chen/Wiesel/Hero ICASSP 2009) evaluated with n = n_observations.
+"""
+import numpy as np
+import scipy.linalg
+
+
+def pair_count(n_observations, n_sequences, lag_time):
+    return n_observations - lag_time * n_sequences
+
+
+def mean_vector(s0, stau, n_pairs):
+    return (s0 + stau) / float(2 * n_pairs)
+
+
+def offset_correlation(C, mu, n_pairs):
+    return (C + C.T) / (2 * n_pairs) - np.outer(mu, mu)
+
+
+def sample_covariance(G, mu, n_pairs):
+    return G / (2 * n_pairs) - np.outer(mu, mu)
+
+
+def rblw_shrinkage(S, n):
+    """Rao-Blackwell Ledoit-Wolf intensity rho in [0, 1] for a p x p sample covariance."""
+    p = S.shape[0]
+    tr = np.trace(S)
+    alpha = (n - 2) / (n * (n + 2))
+    beta = ((p + 1) * n - 2) / (n * (n + 2))
+    U = p * np.sum(S * S) / tr ** 2 - 1
+    return min(alpha + beta / U, 1)
+
+
+def shrink(S, rho):
+    """(1 - rho) S + rho * (tr S / p) * I"""
+    p = S.shape[0]
+    out = (1 - rho) * S
+    out[np.diag_indices(p)] += rho * np.trace(S) / p
+    return out
+
+
+def rao_blackwell_ledoit_wolf(S, n):
+    """Same call signature and return value as the reference's helper: (sigma, shrinkage)."""
+    p = len(S)
+    assert S.shape == (p, p)
+    rho = rblw_shrinkage(S, n)
+    F = (np.trace(S) / p) * np.eye(p)
+    return (1 - rho) * S + rho * F, rho
+
+
+def top_generalized_eigenpairs(lhs, rhs, k):
+    """k largest solutions of lhs v = lambda rhs v, eigenvalues descending
+    (LAPACK dsygvx through scipy, as tica.py:188-194)."""
+    F = lhs.shape[0]
+    vals, vecs = scipy.linalg.eigh(lhs, b=rhs, subset_by_index=[F - k, F - 1])
+    order = np.argsort(vals)[::-1]
+    return vals[order], vecs[:, order]

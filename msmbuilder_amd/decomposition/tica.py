@@ -1,0 +1,483 @@
+"""tICA on MI355X: drop-in for ``msmbuilder.decomposition.tICA``.
+
+Same constructor, methods, learned attributes, warnings and exceptions as
+/root/reference/msmbuilder/decomposition/tica.py:26-489.  What differs is where
+the work happens: ``_fit`` (tica.py:401-424 -- the float64 up-cast and the three
+dgemm per trajectory) is replaced by libmsmhip's MFMA accumulation kernel
+(msmbuilder_amd/csrc/tica.hip) and the accumulators live in HBM; ``transform``
+(tica.py:329-352) is the fused projection kernel.  The O(F^2)/O(F^3)
+finalisation (means, shrinkage, generalized eigensolve: tica.py:167-259,492-524)
+is unchanged numpy/scipy on the host, fed by one export of the accumulators.
+
+Inputs may be numpy arrays (host; staged over PCIe) or 2-D torch CUDA tensors
+(device-resident: nothing crosses PCIe, ``transform`` returns CUDA tensors).
+
+Precision: ``MSMBUILDER_AMD_TICA_MODE=f32`` (default) accumulates float32 inputs
+with exact-fp32 MFMA in <=4096-frame chunks merged in fp64 (eigenvalues agree
+with the float64 reference to rtol 1e-5, typically 1e-7); ``f64`` uses the fp64
+MFMA on widened inputs and reproduces the reference's float64 arithmetic up to
+summation order (rtol 1e-10).  float64 inputs always take the fp64 kernel.
+
+Multi-GPU: every rank fits its own shard of trajectories, then
+``allreduce()`` sums the packed accumulators with one RCCL all-reduce
+(torch.distributed); see msmbuilder_amd/parallel.py.
+"""
+from __future__ import print_function, division, absolute_import
+
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+from sklearn.base import TransformerMixin
+
+from .. import _lib
+from .._lib import Arr, check, is_device_array
+from ..base import BaseEstimator
+from ..utils import check_iter_of_sequences, array2d
+from . import _moments
+from ._moments import rao_blackwell_ledoit_wolf  # noqa: F401  (public name in the reference module)
+
+__all__ = ['tICA']
+
+_BATCH_BYTES = 1 << 30  # host trajectories are shipped in groups of about this size
+
+
+def _mode_from_env():
+    m = os.environ.get("MSMBUILDER_AMD_TICA_MODE", "f32").lower()
+    if m not in ("f32", "f64"):
+        raise ValueError("MSMBUILDER_AMD_TICA_MODE must be 'f32' or 'f64'")
+    return _lib.TICA_F64 if m == "f64" else _lib.TICA_F32
+
+
+class tICA(BaseEstimator, TransformerMixin):
+    """Time-structure Independent Component Analysis (tICA)
+
+    Linear dimensionality reduction using an eigendecomposition of the
+    time-lag correlation matrix and covariance matrix of the data, keeping
+    only the vectors which decorrelate slowest to project the data into a
+    lower dimensional space.
+
+    Parameters
+    ----------
+    n_components : int, None
+        Number of components to keep.
+    lag_time : int
+        Delay time forward or backward in the input data. The time-lagged
+        correlations is computed between datas X[t] and X[t+lag_time].
+    shrinkage : float, default=None
+        The covariance shrinkage intensity (range 0-1). If shrinkage is not
+        specified (the default) it is estimated using an analytic formula
+        (the Rao-Blackwellized Ledoit-Wolf estimator).
+    kinetic_mapping : bool, default=False
+        If True, weigh the projections by the tICA eigenvalues.
+    commute_mapping : bool, default=False
+        If True, scale by the regularized timescales (commute map).
+
+    Attributes
+    ----------
+    components_, offset_correlation_, eigenvalues_, eigenvectors_, means_,
+    n_observations_, n_sequences_, timescales_, covariance_, shrinkage_, score_
+        exactly as in the reference (tica.py:52-82).
+    """
+
+    def __init__(self, n_components=None, lag_time=1, shrinkage=None,
+                 kinetic_mapping=False, commute_mapping=False):
+        self.n_components = n_components
+        self.lag_time = lag_time
+        self.shrinkage = shrinkage
+        self.shrinkage_ = None
+        self.kinetic_mapping = kinetic_mapping
+        self.commute_mapping = commute_mapping
+        if self.kinetic_mapping and self.commute_mapping:
+            raise ValueError("Can't have both kinetic mapping and "
+                             "commute mapping. Please only use one.")
+        self.n_features = None
+        self.n_observations_ = None
+        self.n_sequences_ = None
+
+        self._initialized = False
+
+        # device side: opaque msm_tica_t* holding the accumulators in HBM
+        self._handle = None
+        # host mirrors, refreshed from the device when stale
+        # X[:-lag].T @ X[lag:]
+        self._outer_0_to_T_lagged = None
+        # X[:-lag].sum(0) and X[lag:].sum(0)
+        self._sum_0_to_TminusTau = None
+        self._sum_tau_to_T = None
+        # X[:-lag].T @ X[:-lag] + X[lag:].T @ X[lag:]  (the reference keeps the two terms
+        # apart but only ever reads their sum, tica.py:245)
+        self._outer_gram_sum = None
+        self._host_stale = False
+
+        # Cached results of the eigendecompsition
+        self._components_ = None
+        self._eigenvectors_ = None
+        self._eigenvalues_ = None
+
+        # are our current tICs dirty? set by _fit
+        self._is_dirty = True
+
+    # ------------------------------------------------------------------ device state
+    def _initialize(self, n_features):
+        if self._initialized:
+            return
+        if self.n_components is None:
+            self.n_components = n_features
+        self.n_features = n_features
+        self.n_observations_ = 0
+        self.n_sequences_ = 0
+        self._release()
+        _lib.ensure_device()
+        h = C.c_void_p()
+        check(_lib.lib().msm_tica_create(C.byref(h), int(n_features), int(self.lag_time), _mode_from_env()))
+        self._handle = h
+        self._outer_0_to_T_lagged = np.zeros((n_features, n_features))
+        self._sum_0_to_TminusTau = np.zeros(n_features)
+        self._sum_tau_to_T = np.zeros(n_features)
+        self._outer_gram_sum = np.zeros((n_features, n_features))
+        self._host_stale = False
+        self._initialized = True
+
+    def _release(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            try:
+                _lib.lib().msm_tica_destroy(h)
+            except Exception:
+                pass
+        self._handle = None
+
+    def __del__(self):
+        self._release()
+
+    def _ensure_handle(self):
+        """(Re)create the device handle from the host mirrors (after unpickling)."""
+        if self._handle is None and self._initialized:
+            _lib.ensure_device()
+            h = C.c_void_p()
+            check(_lib.lib().msm_tica_create(C.byref(h), int(self.n_features), int(self.lag_time),
+                                             _mode_from_env()))
+            self._handle = h
+            c = np.ascontiguousarray(self._outer_0_to_T_lagged, dtype=np.float64)
+            g = np.ascontiguousarray(self._outer_gram_sum, dtype=np.float64)
+            s0 = np.ascontiguousarray(self._sum_0_to_TminusTau, dtype=np.float64)
+            st = np.ascontiguousarray(self._sum_tau_to_T, dtype=np.float64)
+            check(_lib.lib().msm_tica_import(h, c.ctypes.data, g.ctypes.data, s0.ctypes.data,
+                                             st.ctypes.data, int(self.n_observations_),
+                                             int(self.n_sequences_)))
+
+    def _pull(self):
+        """Refresh the host mirrors of the accumulators (one D2H of 2F^2+2F doubles)."""
+        if not self._host_stale:
+            return
+        F = self.n_features
+        c = np.empty((F, F))
+        g = np.empty((F, F))
+        s0 = np.empty(F)
+        st = np.empty(F)
+        nobs, nseq = C.c_int64(0), C.c_int64(0)
+        check(_lib.lib().msm_tica_export(self._handle, c.ctypes.data, g.ctypes.data, s0.ctypes.data,
+                                         st.ctypes.data, C.byref(nobs), C.byref(nseq)))
+        self._outer_0_to_T_lagged, self._outer_gram_sum = c, g
+        self._sum_0_to_TminusTau, self._sum_tau_to_T = s0, st
+        self._host_stale = False
+
+    def __getstate__(self):
+        if self._initialized and self._handle is not None:
+            self._pull()
+        d = dict(self.__dict__)
+        d["_handle"] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._handle = None
+
+    # --------------------------------------------------------------------- solve
+    def _solve(self):
+        if not self._is_dirty:
+            # someone might have changed n_components
+            if len(self._eigenvalues_) >= self.n_components:
+                return
+
+        # just check to make sure we've actually seen some data
+        if not self.n_observations_:
+            raise RuntimeError('The model must be fit() before use.')
+
+        lhs = self.offset_correlation_
+        rhs = self.covariance_
+
+        if not np.allclose(lhs, lhs.T):
+            raise RuntimeError('offset correlation matrix is not symmetric')
+        if not np.allclose(rhs, rhs.T):
+            raise RuntimeError('correlation matrix is not symmetric')
+
+        vals, vecs = _moments.top_generalized_eigenpairs(lhs, rhs, self.n_components)
+
+        self._eigenvalues_ = vals
+        self._eigenvectors_ = vecs
+
+        self._is_dirty = False
+
+    @property
+    def score_(self):
+        """Training score: the sum of the first `n_components` eigenvalues"""
+        self._solve()
+        return self._eigenvalues_[:self.n_components].sum()
+
+    @property
+    def eigenvectors_(self):
+        self._solve()
+        return self._eigenvectors_[:, :self.n_components]
+
+    @property
+    def eigenvalues_(self):
+        self._solve()
+        return self._eigenvalues_[:self.n_components]
+
+    @property
+    def timescales_(self):
+        self._solve()
+        return -1. * self.lag_time / np.log(self._eigenvalues_[:self.n_components])
+
+    @property
+    def components_(self):
+        return self.eigenvectors_[:, 0:self.n_components].T
+
+    @property
+    def _n_pairs(self):
+        return _moments.pair_count(self.n_observations_, self.n_sequences_, self.lag_time)
+
+    @property
+    def means_(self):
+        self._pull()
+        return _moments.mean_vector(self._sum_0_to_TminusTau, self._sum_tau_to_T, self._n_pairs)
+
+    @property
+    def offset_correlation_(self):
+        self._pull()
+        return _moments.offset_correlation(self._outer_0_to_T_lagged, self.means_, self._n_pairs)
+
+    @property
+    def covariance_(self):
+        """Shrunk covariance; reading it also sets ``shrinkage_`` (as in the reference)."""
+        self._pull()
+        S = _moments.sample_covariance(self._outer_gram_sum, self.means_, self._n_pairs)
+        if self.shrinkage is None:
+            self.shrinkage_ = _moments.rblw_shrinkage(S, n=self.n_observations_)
+        else:
+            self.shrinkage_ = self.shrinkage
+        return _moments.shrink(S, self.shrinkage_)
+
+    # ----------------------------------------------------------------------- fit
+    def fit(self, sequences, y=None):
+        """Fit the model with a collection of sequences.
+
+        This method is not online.  Any state accumulated from previous calls to
+        fit() or partial_fit() will be cleared. For online learning, use
+        `partial_fit`.
+
+        Parameters
+        ----------
+        sequences: list of array-like, each of shape (n_samples_i, n_features)
+        y : None
+            Ignored
+
+        Returns
+        -------
+        self
+        """
+        self._initialized = False
+        check_iter_of_sequences(sequences, max_iter=3)  # we might be lazy-loading
+        group, group_bytes = [], 0
+        for X in sequences:
+            group.append(X)
+            group_bytes += int(np.prod(X.shape)) * 8
+            if group_bytes >= _BATCH_BYTES:
+                self._fit_many(group)
+                group, group_bytes = [], 0
+        if group:
+            self._fit_many(group)
+
+        if not self.n_sequences_:
+            raise ValueError('All sequences were shorter than '
+                             'the lag time, %d' % self.lag_time)
+
+        return self
+
+    def partial_fit(self, X):
+        """Fit the model with X (online; the state is updated with the new data)."""
+        self._fit(X)
+        return self
+
+    def _prepare(self, X):
+        """array2d + dtype rule: float32/float64 are consumed natively, anything else is
+        up-cast to float64 exactly like tica.py:402."""
+        X = array2d(X)
+        if is_device_array(X):
+            import torch
+            if X.dtype not in (torch.float32, torch.float64):
+                X = X.to(torch.float64)
+            return X.contiguous()
+        if X.dtype not in (np.float32, np.float64):
+            X = np.asarray(X, dtype=np.float64)
+        return np.ascontiguousarray(X)
+
+    def _fit(self, X):
+        self._fit_many([X])
+
+    def _fit_many(self, Xs):
+        """One launch for a group of trajectories (tica.py:401-424 per trajectory)."""
+        prepared = []
+        for X in Xs:
+            X = self._prepare(X)
+            if X.shape[1] > X.shape[0]:
+                warnings.warn("The number of features (%d) is greater than the length of the data (%d). "
+                              "The covariance matrix is not guaranteed to be positive definite."
+                              % (X.shape[1], X.shape[0]))
+            self._initialize(X.shape[1])
+            if X.shape[1] != self.n_features:
+                raise ValueError("shapes (%d,%d) and (%d,%d) not aligned" % (
+                    self.n_features, self.n_features, X.shape[1], X.shape[0]))
+            # We don't need to scream and shout here. Just ignore this data.
+            if not len(X) > self.lag_time:
+                warnings.warn("length of data (%d) is too short for the lag time (%d)"
+                              % (len(X), self.lag_time))
+                continue
+            prepared.append(X)
+        if not prepared:
+            return
+        self._ensure_handle()
+        # one launch per (placement, dtype) class, preserving the reference's skip semantics
+        classes = {}
+        for X in prepared:
+            key = (is_device_array(X), 8 if str(X.dtype).endswith("64") else 4)
+            classes.setdefault(key, []).append(X)
+        L = _lib.lib()
+        for (on_dev, nbytes), arrs in classes.items():
+            views = [Arr(a) for a in arrs]
+            n = len(views)
+            ptrs = (C.c_void_p * n)(*[v.ptr for v in views])
+            rows = (C.c_int64 * n)(*[v.shape[0] for v in views])
+            skipped = C.c_int64(0)
+            check(L.msm_tica_accumulate_batch(self._handle, ptrs, rows, n, nbytes,
+                                              int(self.n_features), int(on_dev), 1, C.byref(skipped)))
+            for v in views:
+                self.n_observations_ += v.shape[0]
+                self.n_sequences_ += 1
+        self._host_stale = True
+        self._is_dirty = True
+
+    # ------------------------------------------------------------------ multi-GPU
+    def allreduce(self, group=None):
+        """Sum the accumulators over all ranks of ``torch.distributed`` (RCCL over xGMI
+        with the ``nccl`` backend; ``gloo`` on CPU-only test runs): one all-reduce of the
+        packed [C | G | s0 | stau | n_obs | n_seq] buffer.  Every rank ends with the
+        global model.  Call after the local ``fit``/``partial_fit`` calls."""
+        from ..parallel import allreduce_tica
+        allreduce_tica(self, group=group)
+        return self
+
+    # ------------------------------------------------------------------ transform
+    def _projection(self):
+        """(mean, k x F matrix) with the kinetic / commute column scaling folded in
+        (tica.py:335-351)."""
+        comps = np.array(self.components_, dtype=np.float64)
+        if self.kinetic_mapping:
+            comps = comps * self.eigenvalues_[:, None]
+        if self.commute_mapping:
+            with np.errstate(all="ignore"):
+                regularized_timescales = 0.5 * self.timescales_ * \
+                    np.tanh(np.pi * ((self.timescales_ - self.lag_time) / self.lag_time) + 1)
+                scale = np.sqrt(regularized_timescales / 2)
+            # the reference multiplies and then nan_to_num()s the result: a NaN scale
+            # (negative eigenvalue / timescale below the lag) zeroes the column
+            scale = np.where(np.isnan(scale), 0.0, scale)
+            comps = comps * scale[:, None]
+        return np.ascontiguousarray(self.means_, dtype=np.float64), np.ascontiguousarray(comps)
+
+    def transform(self, sequences):
+        """Apply the dimensionality reduction on X.
+
+        Parameters
+        ----------
+        sequences: list of array-like, each of shape (n_samples_i, n_features)
+
+        Returns
+        -------
+        sequence_new : list of array-like, each of shape (n_samples_i, n_components)
+        """
+        check_iter_of_sequences(sequences, max_iter=3)  # we might be lazy-loading
+        sequences_new = []
+        mean, comps = None, None
+        L = _lib.lib()
+        for X in sequences:
+            X = self._prepare(X)
+            if mean is None:
+                mean, comps = self._projection()
+            if X.shape[1] != comps.shape[1]:
+                raise ValueError("shapes (%d,%d) and (%d,%d) not aligned" % (
+                    X.shape[0], X.shape[1], comps.shape[1], comps.shape[0]))
+            ax = Arr(X)
+            k = comps.shape[0]
+            out = _lib.empty_like_placement(ax, (ax.shape[0], k), np.float64)
+            aout = Arr(out, np.float64)
+            if ax.shape[0] > 0:
+                check(L.msm_tica_project(ax.vp, ax.dtype.itemsize, ax.shape[0], ax.shape[1], ax.shape[1],
+                                         mean.ctypes.data, comps.ctypes.data, k, aout.vp, ax.on_device, 1))
+            sequences_new.append(out)
+        return sequences_new
+
+    def partial_transform(self, features):
+        """Apply the dimensionality reduction on a single featurized trajectory."""
+        sequences = [features]
+        return self.transform(sequences)[0]
+
+    def fit_transform(self, sequences, y=None):
+        """Fit the model with X and apply the dimensionality reduction on X."""
+        self.fit(sequences)
+        return self.transform(sequences)
+
+    # ---------------------------------------------------------------------- score
+    def score(self, sequences, y=None):
+        """Score the model on new data using the generalized matrix Rayleigh quotient
+        (tica.py:426-467)."""
+        assert self._initialized
+        V = self.eigenvectors_
+
+        m2 = self.__class__(shrinkage=self.shrinkage, n_components=self.n_components,
+                            lag_time=self.lag_time)
+        for X in sequences:
+            m2.partial_fit(X)
+
+        numerator = V.T.dot(m2.offset_correlation_).dot(V)
+        denominator = V.T.dot(m2.covariance_).dot(V)
+
+        try:
+            trace = np.trace(numerator.dot(np.linalg.inv(denominator)))
+        except np.linalg.LinAlgError:
+            trace = np.nan
+        return trace
+
+    def summarize(self):
+        """Some summary information."""
+        # force shrinkage to be calculated
+        self.covariance_
+
+        return """time-structure based Independent Components Analysis (tICA)
+-----------------------------------------------------------
+n_components        : {n_components}
+shrinkage           : {shrinkage}
+lag_time            : {lag_time}
+kinetic_mapping     : {kinetic_mapping}
+
+Top 5 timescales :
+{timescales}
+
+Top 5 eigenvalues :
+{eigenvalues}
+""".format(n_components=self.n_components, lag_time=self.lag_time,
+           shrinkage=self.shrinkage_, kinetic_mapping=self.kinetic_mapping,
+           timescales=self.timescales_[:5], eigenvalues=self.eigenvalues_[:5])

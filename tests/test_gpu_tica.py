@@ -1,0 +1,228 @@
+"""GPU parity of msmbuilder_amd.tICA (through the C ABI) against the oracle and the
+golden vectors produced by the real reference (tests/golden/make_golden.py)."""
+import os
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = {"f32": 1e-5, "f64": 1e-10}   # stated eigenvalue tolerances
+
+
+def _ar1(seed, n_seq, n_frames, n_features, offset=3.0):
+    rs = np.random.RandomState(seed)
+    k = 6
+    M = rs.randn(k, n_features)
+    b = rs.uniform(-offset, offset, size=n_features)
+    a = np.exp(-1.0 / (5.0 * (1 + np.arange(k))))
+    out = []
+    for _ in range(n_seq):
+        eps = rs.randn(n_frames, k)
+        z = np.zeros((n_frames, k))
+        z[0] = eps[0]
+        for t in range(1, n_frames):
+            z[t] = a * z[t - 1] + np.sqrt(1 - a * a) * eps[t]
+        out.append((z.dot(M) + 0.5 * rs.randn(n_frames, n_features) + b).astype(np.float32))
+    return out
+
+
+def _fit_pair(seqs, mode, monkeypatch, **kw):
+    from msmbuilder_amd import tICA
+    from oracle.tica_oracle import TicaOracle
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = tICA(**kw).fit(seqs)
+        o = TicaOracle(**kw).fit(seqs)
+    return m, o
+
+
+def _vec_match(V, Vref, Sigma, tol=1e-4):
+    """eigenvectors up to sign: |v^T Sigma v_ref| >= 1 - tol (both Sigma-orthonormal)."""
+    ov = np.abs(np.einsum("ik,ij,jk->k", V, Sigma, Vref))
+    assert np.all(ov >= 1 - tol), ov
+
+
+@pytest.mark.parametrize("mode", ["f32", "f64"])
+@pytest.mark.parametrize("F,lag,nf", [(12, 7, 400), (128, 10, 1500), (171, 1, 900), (260, 25, 700)])
+def test_accumulators_and_eigs_vs_oracle(gpu, monkeypatch, mode, F, lag, nf):
+    seqs = _ar1(F + lag, 4, nf, F)
+    seqs[1] = seqs[1][: nf // 3]        # ragged
+    seqs.append(seqs[0][:lag])          # == lag: skipped (tica.py:410-412)
+    seqs.append(seqs[2][: lag + 1])     # one lagged pair
+    m, o = _fit_pair(seqs, mode, monkeypatch, n_components=5, lag_time=lag)
+    assert m.n_observations_ == o.n_observations_ and m.n_sequences_ == o.n_sequences_
+    m._pull()
+    tol = dict(rtol=2e-6, atol=2e-4) if mode == "f32" else dict(rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(m._outer_0_to_T_lagged, o.C, **tol)
+    np.testing.assert_allclose(m._outer_gram_sum, o.S0 + o.Stau, **tol)
+    np.testing.assert_allclose(m._sum_0_to_TminusTau, o.s0, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(m._sum_tau_to_T, o.stau, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(m._outer_gram_sum, m._outer_gram_sum.T)
+    np.testing.assert_allclose(m.eigenvalues_, o.eigenvalues_, rtol=RTOL[mode])
+    np.testing.assert_allclose(m.means_, o.means_, rtol=1e-10, atol=1e-12)
+    assert abs(m.shrinkage_ - o.shrinkage_) <= 1e-6 * max(1e-12, abs(o.shrinkage_)) + 1e-12
+    _vec_match(m.eigenvectors_, o.eigenvectors_, o.covariance_)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f64"])
+def test_golden_known_answers(gpu, monkeypatch, golden_dir, mode):
+    """Outputs of the REAL reference tica.py (fixtures) incl. SURVEY.md's known answers."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    g = np.load(os.path.join(golden_dir, "tica_golden.npz"))
+    rs = np.random.RandomState(0)
+    seqs = [rs.randn(1000, 6).astype(np.float32) for _ in range(3)] + [rs.randn(2, 6).astype(np.float32)]
+    for tag, shr in (("A0", 0), ("An", None)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=3, lag_time=2, shrinkage=shr).fit(seqs)
+        assert [m.n_observations_, m.n_sequences_] == list(g[tag + "_n_obs_seq"])
+        np.testing.assert_allclose(m.eigenvalues_, g[tag + "_eigenvalues"], rtol=RTOL[mode] * 10)
+        np.testing.assert_allclose(m.timescales_, g[tag + "_timescales"], rtol=1e-4)
+        np.testing.assert_allclose(m.means_, g[tag + "_means"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(m.offset_correlation_, g[tag + "_offset_correlation"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(m.covariance_, g[tag + "_covariance"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(m.shrinkage_, g[tag + "_shrinkage_"], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(m.score_, g[tag + "_score_"], rtol=1e-5)
+        Y = m.transform(seqs[:1])[0]
+        Yg = g[tag + "_transform0"]
+        assert Y.dtype == np.float64 and Y.shape == Yg.shape
+        sign = np.sign((Y * Yg).sum(0))
+        np.testing.assert_allclose(Y * sign, Yg, rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(m.score(seqs[1:3]), g[tag + "_score_test"], rtol=1e-4)
+    # SURVEY.md section 8(c) constants
+    np.testing.assert_allclose(g["A0_eigenvalues"], [0.030889057382, 0.024348710243, 0.010004331246], rtol=1e-9)
+
+
+def test_golden_ragged_mappings(gpu, monkeypatch, golden_dir):
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    g = np.load(os.path.join(golden_dir, "tica_golden.npz"))
+    seqs = [g["B_seq%d" % i] for i in range(5)]
+    for tag, kw in (("B", {}), ("Bk", dict(kinetic_mapping=True)), ("Bc", dict(commute_mapping=True))):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=4, lag_time=7, **kw).fit(seqs)
+        np.testing.assert_allclose(m.eigenvalues_, g[tag + "_eigenvalues"], rtol=1e-9)
+        np.testing.assert_allclose(m.timescales_, g[tag + "_timescales"], rtol=1e-7)
+        Y, Yg = m.transform(seqs[1:2])[0], g[tag + "_transform1"]
+        sign = np.sign((Y * Yg).sum(0))
+        sign[sign == 0] = 1
+        np.testing.assert_allclose(Y * sign, Yg, rtol=1e-6, atol=1e-8)
+        if tag == "B":
+            m._pull()
+            np.testing.assert_allclose(m._outer_0_to_T_lagged, g["B_C"], rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(m._outer_gram_sum, g["B_S0"] + g["B_Stau"], rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(m._sum_0_to_TminusTau, g["B_s0"], rtol=1e-12, atol=1e-9)
+            assert [m.n_observations_, m.n_sequences_] == list(g["B_n_obs_seq"])
+            assert m.summarize().splitlines()[:7] == str(g["B_summarize"]).splitlines()[:7]
+
+
+def test_reference_identities(gpu, monkeypatch):
+    """Restated from the reference's own tests (tests/test_decomposition.py:59-110,
+    tests/test_utils.py:59-79)."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    rs = np.random.RandomState(42)
+    X = rs.randn(100, 5)
+    for n in range(1, 5):
+        t = tICA(n_components=n, shrinkage=0).fit([X])
+        np.testing.assert_approx_equal(t.score([X]), t.eigenvalues_.sum())
+        np.testing.assert_approx_equal(t.score([X]), t.score_)
+    # changing n_components after the fit
+    t = tICA(n_components=1, shrinkage=0).fit([X])
+    Y1 = t.transform([X])[0]
+    t.n_components = 4
+    Y4 = t.transform([X])[0]
+    t.n_components = 3
+    Y3 = t.transform([X])[0]
+    assert Y1.shape == (100, 1) and Y4.shape == (100, 4) and Y3.shape == (100, 3)
+    np.testing.assert_allclose(Y1.flatten(), Y3[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(Y3, Y4[:, :3], rtol=1e-9)
+    # kinetic mapping
+    X = rs.randn(10, 3)
+    y1 = tICA(n_components=2, lag_time=1).fit_transform([np.copy(X)])[0]
+    t2 = tICA(n_components=2, lag_time=1, kinetic_mapping=True)
+    y2 = t2.fit_transform([np.copy(X)])[0]
+    np.testing.assert_allclose(y2, y1 * t2.eigenvalues_, rtol=1e-9)
+    # singular input keeps float64 outputs (test_decomposition.py:28-49)
+    Xs = rs.randn(100, 2)
+    Xs = np.hstack((Xs, Xs[:, 0, np.newaxis]))
+    t = tICA(n_components=1).fit([Xs])
+    assert t.components_.dtype == np.float64 and t.eigenvalues_.dtype == np.float64
+    # shapes
+    model = tICA(n_components=3).fit([rs.randn(100, 10)])
+    assert model.eigenvalues_.shape == (3,) and model.eigenvectors_.shape == (10, 3)
+    assert model.components_.shape == (3, 10)
+
+
+def test_errors_and_warnings(gpu):
+    from msmbuilder_amd import tICA
+    with pytest.raises(ValueError):
+        tICA(kinetic_mapping=True, commute_mapping=True)
+    with pytest.raises(ValueError):
+        tICA().fit([np.zeros(5)])  # not 2-D
+    with pytest.raises(ValueError, match="shorter"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tICA(lag_time=10).fit([np.random.randn(10, 3), np.random.randn(4, 3)])
+    with pytest.warns(UserWarning, match="too short"):
+        tICA(lag_time=10).partial_fit(np.random.randn(5, 3))
+    with pytest.raises(RuntimeError):
+        tICA().eigenvalues_
+    X = np.random.randn(50, 3).astype(np.float32)
+    X[7, 1] = np.nan
+    t = tICA(lag_time=2).fit([np.random.randn(50, 3).astype(np.float32)])
+    before = t.eigenvalues_.copy()
+    with pytest.raises(ValueError, match="NaN"):
+        t.partial_fit(X)
+    t._is_dirty = True
+    np.testing.assert_array_equal(t.eigenvalues_, before)   # state untouched by the rejected input
+
+
+def test_partial_fit_pickle_and_order(gpu, monkeypatch):
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    seqs = _ar1(5, 6, 300, 20)
+    a = tICA(n_components=3, lag_time=4).fit(seqs)
+    b = tICA(n_components=3, lag_time=4)
+    for s in seqs[:3]:
+        b.partial_fit(s)
+    b = pickle.loads(pickle.dumps(b))     # resumable after unpickling (plain-pickle models)
+    for s in seqs[3:]:
+        b.partial_fit(s)
+    np.testing.assert_allclose(a.eigenvalues_, b.eigenvalues_, rtol=1e-11)
+    assert a.n_observations_ == b.n_observations_ and a.n_sequences_ == b.n_sequences_
+    c = pickle.loads(pickle.dumps(a))
+    np.testing.assert_array_equal(a.eigenvalues_, c.eigenvalues_)
+
+
+def test_device_resident_inputs(gpu, monkeypatch):
+    torch = pytest.importorskip("torch")
+    from msmbuilder_amd import tICA
+    seqs = _ar1(9, 3, 500, 64)
+    host = tICA(n_components=4, lag_time=3).fit(seqs)
+    dev = tICA(n_components=4, lag_time=3).fit([torch.from_numpy(s).cuda() for s in seqs])
+    np.testing.assert_array_equal(host.eigenvalues_, dev.eigenvalues_)
+    Yd = dev.transform([torch.from_numpy(seqs[0]).cuda()])[0]
+    assert Yd.is_cuda and Yd.dtype == torch.float64
+    np.testing.assert_array_equal(Yd.cpu().numpy(), host.transform(seqs[:1])[0])
+
+
+def test_f64_mfma_layout_asymmetric(gpu, monkeypatch):
+    """Transpose-detecting check of both MFMA output maps: C must equal X0^T X1, not its transpose."""
+    from msmbuilder_amd import tICA
+    rs = np.random.RandomState(3)
+    X = rs.randn(257, 130).astype(np.float32)
+    for mode in ("f32", "f64"):
+        monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+        m = tICA(lag_time=3).fit([X])
+        m._pull()
+        Xd = X.astype(np.float64)
+        C = Xd[:-3].T @ Xd[3:]
+        assert np.abs(C - C.T).max() > 1.0
+        np.testing.assert_allclose(m._outer_0_to_T_lagged, C, rtol=1e-5, atol=1e-3)
