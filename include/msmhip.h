@@ -103,6 +103,9 @@ int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const ms
                               msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int on_device,
                               int check_finite, msm_idx_t* n_skipped);
 int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until reset */
+/* HIP-event duration (ms) of the most recent MFMA accumulation launch of this handle,
+ * measured on the stream it ran on (bench.py's roofline leg); synchronises on it. */
+int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
 
 /* Accumulators as the reference defines them (float64, row-major F x F / F):
  *   C    = sum_traj X[:-tau].T @ X[tau:]                    (tica.py:417)

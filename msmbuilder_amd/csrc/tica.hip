@@ -489,6 +489,8 @@ struct msm_tica {
     double* packed = nullptr;   // [2FF+2F+2] export scratch
     int* flag = nullptr;        // [2]: [0] sticky, [1] per-call
     long long n_obs = 0, n_seq = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
+    bool timed = false;
     DevBuf table, staging;
     size_t packed_len() const { return 2 * (size_t)F * F + 2 * (size_t)F + 2; }
 };
@@ -617,6 +619,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipGetLastError());
     }
     // 2) the MFMA pass
+    if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
     if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
         if (aligned)
             hipLaunchKernelGGL(tica_mfma_f32_kernel<true>, dim3(h->G), dim3(NT), LDS32, stream(), P);
@@ -628,6 +631,10 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         hipLaunchKernelGGL(tica_mfma_f64_kernel<double>, dim3(h->G), dim3(NT), LDS64, stream(), P);
     }
     MSM_HIP_CHECK(hipGetLastError());
+    if (h->ev1) {
+        MSM_HIP_CHECK(hipEventRecord(h->ev1, stream()));
+        h->timed = true;
+    }
     for (msm_idx_t s = 0; s < n_seq; ++s)
         if (n_rows[s] > h->lag) {
             h->n_obs += n_rows[s];
@@ -688,6 +695,8 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->coltmp, (size_t)NCB * 2 * h->F * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->packed, (FF2 + 2) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->flag, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
         msm_tica_destroy(h);
         return fail(MSM_ERR_HIP, "msm_tica_create: hipMalloc failed: %s", hipGetErrorString(e));
@@ -711,6 +720,8 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->coltmp) (void)hipFree(h->coltmp);
     if (h->packed) (void)hipFree(h->packed);
     if (h->flag) (void)hipFree(h->flag);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
     return MSM_OK;
 }
@@ -792,6 +803,15 @@ int msm_tica_nonfinite(msm_tica_t* h, int* flag)
     MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     *flag = f[0];
+    return MSM_OK;
+}
+
+int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms)
+{
+    if (!h || !ms) return fail(MSM_ERR_STATE, "null argument");
+    if (!h->timed) return fail(MSM_ERR_STATE, "no accumulation launch recorded yet");
+    MSM_HIP_CHECK(hipEventSynchronize(h->ev1));
+    MSM_HIP_CHECK(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return MSM_OK;
 }
 

@@ -291,11 +291,14 @@ class tICA(BaseEstimator, TransformerMixin):
         """
         self._initialized = False
         check_iter_of_sequences(sequences, max_iter=3)  # we might be lazy-loading
+        # host trajectories are shipped over PCIe in groups of ~1 GiB; device-resident ones
+        # need no staging, so up to 4096 of them share one launch
         group, group_bytes = [], 0
         for X in sequences:
             group.append(X)
-            group_bytes += int(np.prod(X.shape)) * 8
-            if group_bytes >= _BATCH_BYTES:
+            if not is_device_array(X):
+                group_bytes += int(np.prod(X.shape)) * 8
+            if group_bytes >= _BATCH_BYTES or len(group) >= 4096:
                 self._fit_many(group)
                 group, group_bytes = [], 0
         if group:
