@@ -147,7 +147,7 @@ def main():
             warnings.simplefilter("ignore")
             tica = tICA(n_components=args.components, lag_time=args.lag)
             tica.fit(seqs)
-            if record:
+            if record is not None:
                 ms = C.c_float(0.0)
                 _lib.check(_lib.lib().msm_tica_last_kernel_ms(tica._handle, C.byref(ms)))
                 record.setdefault("mfma_ms", []).append(ms.value)
@@ -158,13 +158,13 @@ def main():
             ev = tica.eigenvalues_          # finalise + eigensolve (host)
             t1 = time.perf_counter()
             Y = tica.transform([X])[0]      # [frames, k] float64, device resident
-            if record:
+            if record is not None:
                 torch.cuda.synchronize()
                 record.setdefault("transform", []).append(time.perf_counter() - t1)
             t2 = time.perf_counter()
             kc = KCenters(n_clusters=args.clusters, random_state=0).fit([Y])
             labels = kc.predict([Y])[0]
-            if record:
+            if record is not None:
                 torch.cuda.synchronize()
                 record.setdefault("cluster", []).append(time.perf_counter() - t2)
         return ev, labels, kc

@@ -481,7 +481,8 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
 using namespace msm;
 
 struct msm_tica {
-    int F = 0, lag = 0, mode = 0, T = 0, ntiles = 0, S = 0, G = 0;
+    int F = 0, lag = 0, mode = 0, T = 0, ntiles = 0;
+    int S32 = 0, S64 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
     double* slabs = nullptr;    // [G][TM*TM]
     double* base = nullptr;     // packed [2FF+2F] imported state
     double* colpart = nullptr;  // [NCB][2][F]
@@ -543,8 +544,11 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     if (nvalid == 0) return MSM_OK;
 
     // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
-    const int bk = (h->mode == MSM_TICA_F32 && dtype_bytes == 4) ? BK32 : BK64;
-    long long kc = ceil_div(total, h->S);
+    const bool use32 = (h->mode == MSM_TICA_F32 && dtype_bytes == 4);
+    const int bk = use32 ? BK32 : BK64;
+    const int S = use32 ? h->S32 : h->S64;  // one resident round of S cohorts x ntiles workgroups
+    const int G = S * h->ntiles;
+    long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
     if (kc < bk) kc = bk;
@@ -557,7 +561,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     P.lag = h->lag;
     P.T = h->T;
     P.ntiles = h->ntiles;
-    P.S = h->S;
+    P.S = S;
     P.slabs = h->slabs;
     P.colpart = h->coltmp;
     P.flag = h->flag;
@@ -622,13 +626,13 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
     if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
         if (aligned)
-            hipLaunchKernelGGL(tica_mfma_f32_kernel<true>, dim3(h->G), dim3(NT), LDS32, stream(), P);
+            hipLaunchKernelGGL(tica_mfma_f32_kernel<true>, dim3(G), dim3(NT), LDS32, stream(), P);
         else
-            hipLaunchKernelGGL(tica_mfma_f32_kernel<false>, dim3(h->G), dim3(NT), LDS32, stream(), P);
+            hipLaunchKernelGGL(tica_mfma_f32_kernel<false>, dim3(G), dim3(NT), LDS32, stream(), P);
     } else if (dtype_bytes == 4) {
-        hipLaunchKernelGGL(tica_mfma_f64_kernel<float>, dim3(h->G), dim3(NT), LDS64, stream(), P);
+        hipLaunchKernelGGL(tica_mfma_f64_kernel<float>, dim3(G), dim3(NT), LDS64, stream(), P);
     } else {
-        hipLaunchKernelGGL(tica_mfma_f64_kernel<double>, dim3(h->G), dim3(NT), LDS64, stream(), P);
+        hipLaunchKernelGGL(tica_mfma_f64_kernel<double>, dim3(G), dim3(NT), LDS64, stream(), P);
     }
     MSM_HIP_CHECK(hipGetLastError());
     if (h->ev1) {
@@ -679,13 +683,12 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
     if ((rc = query_slots(tica_mfma_f32_kernel<true>, LDS32, &slots32))) { delete h; return rc; }
     if ((rc = query_slots(tica_mfma_f64_kernel<float>, LDS64, &slots64))) { delete h; return rc; }
-    // one resident round: S cohorts of ntiles workgroups (both kernels must fit)
-    int slots = slots32 < slots64 ? slots32 : slots64;
-    if (mode == MSM_TICA_F32) {
-        // f64 inputs in f32 mode still go through the f64 kernel; keep the smaller figure
-    }
-    h->S = slots / h->ntiles;
-    if (h->S < 1) h->S = 1;
+    // one resident round per launch: S cohorts of ntiles workgroups, per kernel flavour
+    h->S32 = slots32 / h->ntiles;
+    h->S64 = slots64 / h->ntiles;
+    if (h->S32 < 1) h->S32 = 1;
+    if (h->S64 < 1) h->S64 = 1;
+    h->S = h->S32 > h->S64 ? h->S32 : h->S64;  // slabs exist for the larger; unused ones stay zero
     h->G = h->S * h->ntiles;
     const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipError_t e = hipSuccess;
