@@ -29,7 +29,7 @@ constexpr int NT = 256;     // threads per workgroup: 4 waves as 2x2, 64x64 outp
 constexpr int BK32 = 32;    // frames per K-step, fp32 kernel
 constexpr int BK64 = 16;    // frames per K-step, fp64 kernel
 constexpr int KCMAX = 4096; // max frames accumulated in fp32 before an fp64 merge
-constexpr int NCB = 512;    // column-sum partial slots
+constexpr int NCB = 1024;   // column-sum partial slots (4 blocks per CU)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -100,21 +100,27 @@ __device__ __forceinline__ void decode_tile(int tile, int T, int& I, int& J, int
 template <bool VEC4>
 struct Stage32 {
     float4 a[4], b[4];
+    float sc[4];  // per-row weight applied when the stage is written to LDS (NOT at load time:
+                  // touching a loaded value early would park the wave on vmcnt before the MFMA loop)
 };
 
+// Unconditional loads: rows are clamped into the trajectory and columns into [0, F) so every
+// address is valid; validity is carried by the A-side weight (0 kills the whole rank-1 term,
+// B only has to be finite) and by the per-thread column masks applied at LDS-store time.
 template <bool VEC4>
-__device__ __forceinline__ float4 load_row4(const float* __restrict__ p, int col, int F)
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ rowp, int col, int F)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (VEC4) {
-        if (col < F) v = *reinterpret_cast<const float4*>(p);
+        const int c = col < F ? col : F - 4;
+        return *reinterpret_cast<const float4*>(rowp + c);
     } else {
-        if (col + 0 < F) v.x = p[0];
-        if (col + 1 < F) v.y = p[1];
-        if (col + 2 < F) v.z = p[2];
-        if (col + 3 < F) v.w = p[3];
+        float4 v;
+        v.x = rowp[col + 0 < F ? col + 0 : F - 1];
+        v.y = rowp[col + 1 < F ? col + 1 : F - 1];
+        v.z = rowp[col + 2 < F ? col + 2 : F - 1];
+        v.w = rowp[col + 3 < F ? col + 3 : F - 1];
+        return v;
     }
-    return v;
 }
 
 template <bool VEC4>
@@ -125,6 +131,7 @@ __device__ __forceinline__ void stage_load32(Stage32<VEC4>& st, const TicaArgs& 
     const int c4 = (tid & 31) * 4;
     const int rr0 = tid >> 5;
     const float* X = static_cast<const float*>(ch.base);
+    const long long last = ch.len - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int kr = k0 + rr0 + 8 * j;
@@ -134,27 +141,29 @@ __device__ __forceinline__ void stage_load32(Stage32<VEC4>& st, const TicaArgs& 
             sc = (r < ch.len - P.lag) ? 1.f : 0.f;
             if (isG) sc += (r >= P.lag) ? 1.f : 0.f;
         }
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-        if (sc != 0.f) {
-            va = load_row4<VEC4>(X + r * P.ld + I0 + c4, I0 + c4, P.F);
-            va.x *= sc; va.y *= sc; va.z *= sc; va.w *= sc;
-            if (r + tauB < ch.len) vb = load_row4<VEC4>(X + (r + tauB) * P.ld + J0 + c4, J0 + c4, P.F);
-        }
-        st.a[j] = va;
-        st.b[j] = vb;
+        const long long ra = r < last ? r : last;
+        const long long rb = (r + tauB) < last ? (r + tauB) : last;
+        st.a[j] = load_row4<VEC4>(X + ra * P.ld, I0 + c4, P.F);
+        st.b[j] = load_row4<VEC4>(X + rb * P.ld, J0 + c4, P.F);
+        st.sc[j] = sc;
     }
 }
 
 template <bool VEC4>
-__device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As, float* Bs, int tid)
+__device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As, float* Bs, int tid,
+                                              float4 ma, float4 mb)
 {
     const int c4 = (tid & 31) * 4;
     const int rr0 = tid >> 5;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int rr = rr0 + 8 * j;
-        *reinterpret_cast<float4*>(As + rr * TM + c4) = st.a[j];
-        *reinterpret_cast<float4*>(Bs + rr * TM + c4) = st.b[j];
+        const float sc = st.sc[j];
+        *reinterpret_cast<float4*>(As + rr * TM + c4) =
+            make_float4(st.a[j].x * (sc * ma.x), st.a[j].y * (sc * ma.y), st.a[j].z * (sc * ma.z),
+                        st.a[j].w * (sc * ma.w));
+        *reinterpret_cast<float4*>(Bs + rr * TM + c4) =
+            make_float4(st.b[j].x * mb.x, st.b[j].y * mb.y, st.b[j].z * mb.z, st.b[j].w * mb.w);
     }
 }
 
@@ -178,6 +187,13 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
     const int kl = lane >> 5, cl = lane & 31;
     double* slab = P.slabs + (size_t)p * (TM * TM);
 
+    // column masks of this thread's staging float4 (only partial tiles of F % 128 != 0 have zeros)
+    const int c4 = (tid & 31) * 4;
+    const float4 ma = make_float4(I0 + c4 + 0 < P.F ? 1.f : 0.f, I0 + c4 + 1 < P.F ? 1.f : 0.f,
+                                  I0 + c4 + 2 < P.F ? 1.f : 0.f, I0 + c4 + 3 < P.F ? 1.f : 0.f);
+    const float4 mb = make_float4(J0 + c4 + 0 < P.F ? 1.f : 0.f, J0 + c4 + 1 < P.F ? 1.f : 0.f,
+                                  J0 + c4 + 2 < P.F ? 1.f : 0.f, J0 + c4 + 3 < P.F ? 1.f : 0.f);
+
     for (long long c = cohort; c < P.nchunks; c += P.S) {
         const TicaChunk ch = get_chunk(P, c);
         const int nsteps = (ch.n + BK32 - 1) / BK32;
@@ -191,37 +207,54 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 
         Stage32<VEC4> st;
         stage_load32<VEC4>(st, P, ch, 0, isG, tauB, I0, J0, tid);
-        stage_store32<VEC4>(st, As, Bs, tid);
+        stage_store32<VEC4>(st, As, Bs, tid, ma, mb);
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
             const int buf = s & 1;
             if (s + 1 < nsteps) stage_load32<VEC4>(st, P, ch, (s + 1) * BK32, isG, tauB, I0, J0, tid);
             const float* Ab = As + buf * (BK32 * TM) + kl * TM + wr * 64 + cl;
             const float* Bb = Bs + buf * (BK32 * TM) + kl * TM + wc * 64 + cl;
+            // fragment reads run one k-pair ahead of the MFMAs that consume them
+            float a0 = Ab[0], a1 = Ab[32], b0 = Bb[0], b1 = Bb[32];
 #pragma unroll 4
             for (int kk = 0; kk < BK32 / 2; ++kk) {
-                const float a0 = Ab[kk * 2 * TM], a1 = Ab[kk * 2 * TM + 32];
-                const float b0 = Bb[kk * 2 * TM], b1 = Bb[kk * 2 * TM + 32];
+                const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;
+                const float na0 = Ab[kn * 2 * TM], na1 = Ab[kn * 2 * TM + 32];
+                const float nb0 = Bb[kn * 2 * TM], nb1 = Bb[kn * 2 * TM + 32];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
             }
             if (s + 1 < nsteps)
-                stage_store32<VEC4>(st, As + (buf ^ 1) * (BK32 * TM), Bs + (buf ^ 1) * (BK32 * TM), tid);
+                stage_store32<VEC4>(st, As + (buf ^ 1) * (BK32 * TM), Bs + (buf ^ 1) * (BK32 * TM), tid, ma, mb);
             __syncthreads();
         }
-        // fp64 merge of this chunk's fp32 partial into the workgroup's private slab
+        // fp64 merge of this chunk's fp32 partial into the workgroup's private slab.  Per 32x32
+        // block all 16 loads are issued before the first add/store (a plain `*q += x` loop
+        // compiles to 64 dependent round trips); addresses are a wave-uniform base plus ONE
+        // 32-bit per-lane offset so they cost no VGPR pairs.
+        unsigned toff = (unsigned)((wr * 64 + 4 * kl) * TM + wc * 64 + cl);
+        // opaque to the optimiser: otherwise the 64 slab addresses are hoisted out of the chunk
+        // loop as loop invariants (128 VGPRs -> scratch spills in the MFMA loop)
+        asm volatile("" : "+v"(toff));
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-            for (int bj = 0; bj < 2; ++bj)
+            for (int bj = 0; bj < 2; ++bj) {
+                double old[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kl;
-                    double* q = slab + (wr * 64 + bi * 32 + row) * TM + wc * 64 + bj * 32 + cl;
-                    *q += (double)acc[bi][bj][r];
+                    const double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
+                    old[r] = q[toff];
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
+                    q[toff] = old[r] + (double)acc[bi][bj][r];
+                }
+            }
     }
 }
 
@@ -336,40 +369,85 @@ __global__ __launch_bounds__(NT, 1) void tica_mfma_f64_kernel(TicaArgs P)
 template <typename TIn>
 __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
 {
-    __shared__ double red[2][NT];
+    // thread -> a group of CW consecutive columns (one 16-byte load per row when aligned) and a
+    // row lane; RU rows are kept in flight per thread so the pass is HBM-bound, not latency-bound
+    constexpr int CW = 16 / sizeof(TIn);
+    constexpr int RU = 8;
+    __shared__ double red[2][NT][CW];
     const int tid = threadIdx.x;
+    const int ngroups = (P.F + CW - 1) / CW;
     int cpb = 1;
-    while (cpb < P.F && cpb < NT) cpb <<= 1;  // columns per pass (power of two <= 256)
-    const int rl = NT / cpb;                  // row lanes
+    while (cpb < ngroups && cpb < NT) cpb <<= 1;  // column groups per pass (power of two <= 256)
+    const int rl = NT / cpb;                      // row lanes
     const int tc = tid % cpb, tr = tid / cpb;
+    const bool vec = (P.F % CW == 0) && (P.ld % CW == 0);
     double* part = P.colpart + (size_t)blockIdx.x * 2 * P.F;
     int bad = 0;
-    for (int c0 = 0; c0 < P.F; c0 += cpb) {
-        const int col = c0 + tc;
-        double s0 = 0.0, st = 0.0;
+    for (int g0 = 0; g0 < ngroups; g0 += cpb) {
+        const int col = (g0 + tc) * CW;
+        double s0[CW], st[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) s0[e] = st[e] = 0.0;
         if (col < P.F) {
             for (long long c = blockIdx.x; c < P.nchunks; c += gridDim.x) {
                 const TicaChunk ch = get_chunk(P, c);
                 const TIn* X = static_cast<const TIn*>(ch.base);
-                for (int kr = tr; kr < ch.n; kr += rl) {
-                    const long long r = ch.row0 + kr;
-                    const double x = (double)X[r * P.ld + col];
-                    bad |= !isfinite(x);
-                    if (r < ch.len - P.lag) s0 += x;
-                    if (r >= P.lag) st += x;
+                const bool al = vec && ((((uintptr_t)X) & 15) == 0);
+                for (int k0 = tr; k0 < ch.n; k0 += rl * RU) {
+                    TIn v[RU][CW];
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const int kr = k0 + u * rl;
+                        const long long r = ch.row0 + kr;
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[u][e] = (TIn)0;
+                        if (kr < ch.n) {
+                            const TIn* p = X + r * P.ld + col;
+                            if (al) {
+                                *reinterpret_cast<float4*>(&v[u][0]) = *reinterpret_cast<const float4*>(p);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < CW; ++e)
+                                    if (col + e < P.F) v[u][e] = p[e];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const int kr = k0 + u * rl;
+                        const long long r = ch.row0 + kr;
+                        const bool in0 = (kr < ch.n) && (r < ch.len - P.lag);
+                        const bool in1 = (kr < ch.n) && (r >= P.lag);
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) {
+                            const double x = (double)v[u][e];
+                            bad |= !isfinite(x);
+                            if (in0) s0[e] += x;
+                            if (in1) st[e] += x;
+                        }
+                    }
                 }
             }
         }
-        red[0][tid] = s0;
-        red[1][tid] = st;
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+            red[0][tid][e] = s0[e];
+            red[1][tid][e] = st[e];
+        }
         __syncthreads();
         if (tr == 0 && col < P.F) {
-            for (int k = 1; k < rl; ++k) {
-                s0 += red[0][k * cpb + tc];
-                st += red[1][k * cpb + tc];
-            }
-            part[col] += s0;
-            part[P.F + col] += st;
+            for (int k = 1; k < rl; ++k)
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    s0[e] += red[0][k * cpb + tc][e];
+                    st[e] += red[1][k * cpb + tc][e];
+                }
+#pragma unroll
+            for (int e = 0; e < CW; ++e)
+                if (col + e < P.F) {
+                    part[col + e] += s0[e];
+                    part[P.F + col + e] += st[e];
+                }
         }
         __syncthreads();
     }
