@@ -1,0 +1,100 @@
+"""GPU parity of the k-means labelling kernel and MiniBatchKMeans against scikit-learn
+(the third-party arithmetic behind msmbuilder.cluster.MiniBatchKMeans; parity definition in
+DESIGN.md: centres/inertia rtol 1e-4, labels equal except fp32 near-ties)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _brute(X, C):
+    d = ((X[:, None, :].astype(np.float64) - C[None].astype(np.float64)) ** 2).sum(-1)
+    return d.argmin(1), d
+
+
+def _labels_agree(lab, X, C, rtol=1e-5):
+    ref, d = _brute(X, C)
+    bad = np.nonzero(lab != ref)[0]
+    for i in bad:   # a different label is only acceptable for an fp32 near-tie
+        assert abs(d[i, lab[i]] - d[i, ref[i]]) <= rtol * max(d[i, ref[i]], 1e-12) + 1e-4, (i, d[i, lab[i]], d[i, ref[i]])
+    return len(bad)
+
+
+@pytest.mark.parametrize("n,f,k", [(1, 3, 1), (1000, 8, 6), (5000, 512, 1000), (3001, 130, 257), (777, 31, 129)])
+def test_label_kernel(gpu, n, f, k):
+    from msmbuilder_amd.cluster.minibatchkmeans import label_inertia
+    rs = np.random.RandomState(n + k)
+    C = (rs.randn(k, f) * 3).astype(np.float32)
+    X = (C[rs.randint(0, k, n)] + rs.randn(n, f)).astype(np.float32)
+    lab, inertia = label_inertia(X, C)
+    assert lab.dtype == np.int32 and lab.shape == (n,)
+    nbad = _labels_agree(lab, X, C)
+    assert nbad <= max(1, n // 200)
+    ref_inertia = ((X.astype(np.float64) - C[lab].astype(np.float64)) ** 2).sum()
+    np.testing.assert_allclose(inertia, ref_inertia, rtol=1e-5)
+
+
+def test_label_ties_lowest_index(gpu):
+    from msmbuilder_amd.cluster.minibatchkmeans import label_inertia
+    X = np.zeros((300, 16), dtype=np.float32)
+    C = np.ones((200, 16), dtype=np.float32)      # all centres identical -> label 0 everywhere
+    lab, _ = label_inertia(X, C)
+    assert np.all(lab == 0)
+    C[150] = 0                                     # unique best
+    lab, inertia = label_inertia(X, C)
+    assert np.all(lab == 150) and inertia == 0.0
+
+
+def test_minibatch_golden_sklearn(gpu, golden_dir):
+    from msmbuilder_amd import MiniBatchKMeans
+    g = np.load(os.path.join(golden_dir, "mbkm_golden.npz"))
+    X, init = g["X"], g["init"]
+    m = MiniBatchKMeans(n_clusters=6, init=init, n_init=1, batch_size=256, max_iter=5, random_state=0,
+                        max_no_improvement=None, reassignment_ratio=0.0, tol=0.0).fit([X[:1000], X[1000:]])
+    assert m.n_steps_ == int(g["n_steps"])
+    np.testing.assert_allclose(m.cluster_centers_, g["centers"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m._counts, g["counts"], rtol=1e-6)
+    np.testing.assert_allclose(m.inertia_, float(g["inertia"]), rtol=1e-4)
+    labels = np.concatenate(m.labels_)
+    assert labels.dtype == np.int32 and len(m.labels_) == 2 and len(m.labels_[0]) == 1000
+    assert (labels != g["labels"]).mean() < 1e-3
+
+
+def test_minibatch_vs_sklearn_live(gpu):
+    sk = pytest.importorskip("sklearn.cluster")
+    from msmbuilder_amd import MiniBatchKMeans
+    rs = np.random.RandomState(3)
+    cent = rs.randn(20, 32) * 5
+    X = (cent[rs.randint(0, 20, 20000)] + rs.randn(20000, 32)).astype(np.float32)
+    init = X[rs.choice(20000, 20, replace=False)].copy()
+    kw = dict(n_clusters=20, init=init, n_init=1, batch_size=512, max_iter=3, random_state=5)
+    ref = sk.MiniBatchKMeans(**kw).fit(X)
+    mine = MiniBatchKMeans(**kw).fit([X])
+    assert mine.n_steps_ == ref.n_steps_          # same minibatch stream, same early-stopping decisions
+    np.testing.assert_allclose(mine.cluster_centers_, ref.cluster_centers_, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(mine.inertia_, ref.inertia_, rtol=1e-4)
+    assert (mine.labels_[0] != ref.labels_).mean() < 1e-3
+    assert np.array_equal(mine.predict([X[:100]])[0], mine.labels_[0][:100])
+    # k-means++ seeding: same RNG call order, so the same seeds are drawn (host fp32 arithmetic may
+    # differ in the last bit; compare the resulting objective, not the centres)
+    a = sk.MiniBatchKMeans(n_clusters=20, random_state=1, n_init=1).fit(X)
+    b = MiniBatchKMeans(n_clusters=20, random_state=1, n_init=1).fit([X])
+    assert abs(b.inertia_ - a.inertia_) / a.inertia_ < 0.05
+    assert "MiniBatchKMeans" in b.summarize()
+
+
+def test_minibatch_device_resident(gpu):
+    torch = pytest.importorskip("torch")
+    from msmbuilder_amd import MiniBatchKMeans
+    rs = np.random.RandomState(8)
+    cent = rs.randn(8, 16) * 5
+    X = (cent[rs.randint(0, 8, 6000)] + rs.randn(6000, 16)).astype(np.float32)
+    init = X[:8].copy()
+    kw = dict(n_clusters=8, init=init, n_init=1, batch_size=300, max_iter=2, random_state=2)
+    host = MiniBatchKMeans(**kw).fit([X])
+    dev = MiniBatchKMeans(**kw).fit([torch.from_numpy(X).cuda()])
+    np.testing.assert_array_equal(host.cluster_centers_, dev.cluster_centers_)
+    assert dev.labels_[0].is_cuda
+    np.testing.assert_array_equal(host.labels_[0], dev.labels_[0].cpu().numpy())

@@ -1,0 +1,185 @@
+"""CPU tier: the C ABI (library loads, exports every declared symbol, fails loudly without a
+GPU), host-side logic (validation, finalisation math, sharding) and the world_size-2 gloo
+path of the multi-GPU reductions."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = []
+    for hdr in ("msmhip.h", "msmhip_libdistance.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names += re.findall(r"\b((?:msm_|assign_nearest_|dist_|cdist_)\w+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from msmbuilder_amd import _lib
+    L = _lib.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 45
+    for s in syms:
+        assert hasattr(L, s), "libmsmhip.so does not export %s" % s
+    assert b"gfx950" in L.msm_version()
+
+
+def test_built_for_gfx950_only():
+    so = os.path.join(ROOT, "msmbuilder_amd", "libmsmhip.so")
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", so], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("llvm-objdump --offloading unavailable")
+    archs = set(re.findall(r"gfx[0-9a-f]+", out.stdout))
+    assert archs == {"gfx950"}, archs
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    from msmbuilder_amd import _lib, tICA, KCenters, libdistance
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.NoDeviceError):
+        tICA().fit([np.random.randn(50, 3)])
+    with pytest.raises(_lib.NoDeviceError):
+        KCenters(n_clusters=2).fit([np.random.randn(50, 3)])
+    with pytest.raises(_lib.NoDeviceError):
+        libdistance.assign_nearest(np.zeros((4, 2)), np.zeros((2, 2)), "euclidean")
+    # argument validation still happens before any device work, with the reference's error types
+    with pytest.raises(ValueError):
+        libdistance.assign_nearest(np.zeros((4, 2)), np.zeros((2, 2)), "rmsd")
+    with pytest.raises(TypeError):
+        libdistance.cdist(np.zeros((4, 2), np.float32), np.zeros((2, 2)), "euclidean")
+    with pytest.raises(ValueError):
+        tICA(kinetic_mapping=True, commute_mapping=True)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "msmbuilder_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().lower().replace("# oracle", ""), f
+
+
+def test_validation_semantics():
+    from msmbuilder_amd.utils import array2d, check_iter_of_sequences
+    check_iter_of_sequences([np.zeros((3, 2)), np.zeros((1, 2))])
+    with pytest.raises(ValueError, match="list of sequences"):
+        check_iter_of_sequences([np.zeros(3)])
+    with pytest.raises(ValueError, match="list of sequences"):
+        check_iter_of_sequences([np.zeros((3, 2)), [[1, 2]]])
+    check_iter_of_sequences(iter([np.zeros((3, 2))] * 10), max_iter=3)
+    assert array2d([1.0, 2.0]).shape == (1, 2)
+    with pytest.raises(ValueError, match="NaN"):
+        array2d(np.array([[1.0, np.nan]]))
+    big = np.full((2, 2), 1e308)   # the sum overflows but every element is finite: accepted
+    assert array2d(big) is big
+
+
+def test_moments_match_oracle_formulas():
+    from msmbuilder_amd.decomposition import _moments
+    from oracle.tica_oracle import TicaOracle, rao_blackwell_ledoit_wolf
+    rs = np.random.RandomState(4)
+    seqs = [rs.randn(200, 7) + 2 for _ in range(3)]
+    for shr in (None, 0.0, 0.3):
+        o = TicaOracle(n_components=3, lag_time=5, shrinkage=shr).fit(seqs)
+        npairs = _moments.pair_count(o.n_observations_, o.n_sequences_, 5)
+        mu = _moments.mean_vector(o.s0, o.stau, npairs)
+        np.testing.assert_array_equal(mu, o.means_)
+        np.testing.assert_array_equal(_moments.offset_correlation(o.C, mu, npairs), o.offset_correlation_)
+        S = _moments.sample_covariance(o.S0 + o.Stau, mu, npairs)
+        rho = _moments.rblw_shrinkage(S, o.n_observations_) if shr is None else shr
+        np.testing.assert_allclose(_moments.shrink(S, rho), o.covariance_, rtol=1e-14, atol=1e-16)
+        sig, r2 = _moments.rao_blackwell_ledoit_wolf(S, o.n_observations_)
+        sig_o, r_o = rao_blackwell_ledoit_wolf(S, o.n_observations_)
+        assert r2 == r_o and np.array_equal(sig, sig_o)
+        vals, vecs = _moments.top_generalized_eigenpairs(o.offset_correlation_, o.covariance_, 3)
+        np.testing.assert_allclose(vals, o.eigenvalues_, rtol=1e-12)
+
+
+def test_shard_sequences_balanced_and_complete():
+    from msmbuilder_amd.parallel import shard_sequences
+    rs = np.random.RandomState(0)
+    seqs = [np.zeros((int(n), 1)) for n in rs.randint(10, 5000, size=57)]
+    for world in (1, 2, 4, 8):
+        owned = [shard_sequences(seqs, r, world) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(57))
+        loads = [sum(len(seqs[i]) for i in o) for o in owned]
+        assert max(loads) - min(loads) <= 5000
+
+
+def test_sharded_sum_equals_unsharded_oracle():
+    """Single-process simulation of the multi-rank tICA: per-rank partial accumulators summed
+    == one pass over everything (lagged pairs never cross a trajectory, reference tica.py:417)."""
+    from msmbuilder_amd.parallel import shard_sequences
+    from oracle.tica_oracle import TicaOracle
+    rs = np.random.RandomState(1)
+    seqs = [rs.randn(int(n), 5) for n in rs.randint(3, 400, size=23)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = TicaOracle(lag_time=4).fit(seqs)
+        parts = []
+        for r in range(4):
+            o = TicaOracle(lag_time=4)
+            for i in shard_sequences(seqs, r, 4):
+                o.partial_fit(seqs[i])
+            parts.append(o)
+    for name in ("C", "S0", "Stau", "s0", "stau"):
+        np.testing.assert_allclose(sum(getattr(p, name) for p in parts), getattr(full, name), rtol=1e-12, atol=1e-10)
+    assert sum(p.n_observations_ for p in parts) == full.n_observations_
+    assert sum(p.n_sequences_ for p in parts) == full.n_sequences_
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from msmbuilder_amd import parallel
+rank, world, local = parallel.init_from_env(backend="gloo")
+assert parallel.active() and parallel.world_size() == 2
+# 1) packed-accumulator all-reduce (the tICA exchange step) on oracle partials
+from oracle.tica_oracle import TicaOracle
+rs = np.random.RandomState(7)
+seqs = [rs.randn(int(n), 4) for n in rs.randint(20, 300, size=9)]
+mine = parallel.shard_sequences(seqs)
+o = TicaOracle(lag_time=3)
+for i in mine:
+    o.partial_fit(seqs[i])
+packed = np.concatenate([o.C.ravel(), (o.S0 + o.Stau).ravel(), o.s0, o.stau, [o.n_observations_, o.n_sequences_]])
+tot = parallel.allreduce_array(packed)
+full = TicaOracle(lag_time=3).fit(seqs)
+ref = np.concatenate([full.C.ravel(), (full.S0 + full.Stau).ravel(), full.s0, full.stau,
+                      [full.n_observations_, full.n_sequences_]])
+assert np.allclose(tot, ref, rtol=1e-12, atol=1e-10), np.abs(tot - ref).max()
+# 2) row sharding bookkeeping + distributed row gather (MiniBatchKMeans batches)
+X = np.arange(40, dtype=np.float32).reshape(10, 4) + 100 * rank
+shard = parallel.RowShard(10)
+assert shard.n_total == 20 and shard.offset == 10 * rank
+idx = np.array([0, 19, 10, 9, 3])
+rows = shard.gather_rows(lambda loc: X[loc], idx, 4)
+expect = np.stack([(np.arange(40, dtype=np.float32).reshape(10, 4) + 100 * (i // 10))[i % 10] for i in idx])
+assert np.array_equal(rows, expect)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_gloo_world2_reductions(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o
