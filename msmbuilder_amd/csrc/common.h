@@ -36,6 +36,12 @@ struct DevBuf {
     template <typename T> T* as() { return static_cast<T*>(p); }
 };
 
+// Process-lifetime scratch slots (grow-only, never freed: hipFree synchronises the device and
+// a per-call malloc/free pair costs more than the small kernels it serves).  Every entry point
+// that uses them synchronises the stream before returning, so slots can be shared.
+DevBuf& pool(int slot);
+enum PoolSlot { PS_X = 0, PS_Y, PS_IDX, PS_LAB, PS_MIN, PS_PART, PS_OUT, PS_IDS, PS_SUM, PS_PAR, PS_W, PS_S, PS_COUNT };
+
 // metric ids shared by host dispatch and device kernels
 enum Metric : int {
     M_EUCLIDEAN = 0,

@@ -94,6 +94,42 @@ __device__ __forceinline__ void stage_rows(T* Xs, const T* __restrict__ X,
     }
 }
 
+// Small-m fast path (m <= FC, e.g. clustering in tICA space): each lane keeps its whole row
+// in registers, fetched with the widest aligned vector loads the row size allows; a wave's 64
+// rows are contiguous in memory, so HBM still sees a linear stream.  No LDS round trip.
+template <typename T>
+__device__ __forceinline__ void load_row_regs(T (&x)[FeatChunk<T>::FC], const T* __restrict__ p, int m, int vecw)
+{
+    constexpr int FC = FeatChunk<T>::FC;
+#pragma unroll
+    for (int f = 0; f < FC; ++f) x[f] = (T)0;
+    if (vecw == 16) {
+        constexpr int E = 16 / sizeof(T);
+#pragma unroll
+        for (int v = 0; v < FC / E; ++v)
+            if (v * E < m) {
+                const float4 q = *reinterpret_cast<const float4*>(p + v * E);
+                const T* qe = reinterpret_cast<const T*>(&q);
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[v * E + e] = qe[e];
+            }
+    } else if (vecw == 8) {
+        constexpr int E = 8 / sizeof(T);
+#pragma unroll
+        for (int v = 0; v < FC / E; ++v)
+            if (v * E < m) {
+                const float2 q = *reinterpret_cast<const float2*>(p + v * E);
+                const T* qe = reinterpret_cast<const T*>(&q);
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[v * E + e] = qe[e];
+            }
+    } else {
+#pragma unroll
+        for (int f = 0; f < FC; ++f)
+            if (f < m) x[f] = p[f];
+    }
+}
+
 struct PairArgs {
     const void* X;
     const msm_idx_t* X_indices;
@@ -103,6 +139,7 @@ struct PairArgs {
     double* min_dist;     // assign (nullable)
     double* partial;      // assign: per-block inertia partials
     double* out;          // cdist / dist
+    int vecw;             // fast path: vector width in bytes of the per-lane row loads (0 = LDS path)
 };
 
 // MODE 0: assign_nearest (assign.hpp:6-91), MODE 1: cdist (cdist.hpp) / dist (K == 1)
@@ -182,6 +219,68 @@ __global__ __launch_bounds__(DT) void pair_kernel(PairArgs P)
     }
 }
 
+// Same contract as pair_kernel for m <= FC and contiguous rows (no X_indices): rows in registers.
+template <typename T, int M, int MODE>
+__global__ __launch_bounds__(DT) void pair_small_kernel(PairArgs P)
+{
+    constexpr int FC = FeatChunk<T>::FC;
+    __shared__ T Ys[CJ * FC];
+    __shared__ double red[DT];
+    const T* X = static_cast<const T*>(P.X);
+    const T* Y = static_cast<const T*>(P.Y);
+    const int tid = threadIdx.x;
+    const int m = (int)P.m;
+    double inertia = 0.0;
+    const long long ntile = (P.n + DT - 1) / DT;
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long long i = t * DT + tid;
+        T x[FC];
+        load_row_regs<T>(x, X + (i < P.n ? i : P.n - 1) * P.m, m, P.vecw);
+        double min_d = 1.7976931348623157e308;
+        long long lab = 0;
+        for (long long j0 = 0; j0 < P.K; j0 += CJ) {
+            __syncthreads();
+            for (int e = tid; e < CJ * FC; e += DT) {
+                const int c = e / FC, ff = e % FC;
+                Ys[e] = (j0 + c < P.K && ff < m) ? Y[(j0 + c) * P.m + ff] : (T)0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CJ; ++c) {
+                if (j0 + c < P.K) {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int ff = 0; ff < FC; ++ff)
+                        if (ff < m) m_update<T, M>(a, b, x[ff], Ys[c * FC + ff]);
+                    const double d = m_final<M>(a, b, P.m);
+                    if (MODE == 0) {
+                        if (d < min_d) {
+                            min_d = d;
+                            lab = j0 + c;
+                        }
+                    } else if (i < P.n) {
+                        P.out[i * P.K + j0 + c] = d;
+                    }
+                }
+            }
+        }
+        if (MODE == 0 && i < P.n) {
+            P.labels[i] = lab;
+            if (P.min_dist) P.min_dist[i] = min_d;
+            inertia += min_d;
+        }
+    }
+    if (MODE == 0) {
+        red[tid] = inertia;
+        __syncthreads();
+        for (int s = DT / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) P.partial[blockIdx.x] = red[0];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // One k-centers pass (kcenters.py:91-97), fused: (prologue) global argmax of the
 // previous pass's per-block partials -> new centre index c; d = metric(X, X[c]);
@@ -205,6 +304,7 @@ struct KcArgs {
     double* dist;
     msm_idx_t* labels;
     msm_idx_t* ids;         // device [K]
+    int vecw;               // > 0: rows in registers (m <= FC), vector width in bytes
 };
 
 __device__ __forceinline__ bool kc_better(double v, long long i, double bv, long long bi)
@@ -257,10 +357,22 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
     double bv = -1.0;
     long long bi = -1;
     const long long ntile = (P.n + DT - 1) / DT;
+    if (P.vecw > 0) {  // centre row once per block, broadcast from LDS
+        __syncthreads();
+        if (tid < FC) ys[tid] = tid < P.m ? y[tid] : (T)0;
+        __syncthreads();
+    }
     for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
         const long long row0 = t * DT;
         const long long i = row0 + tid;
         double a = 0.0, b = 0.0;
+        if (P.vecw > 0) {
+            T x[FC];
+            load_row_regs<T>(x, X + (i < P.n ? i : P.n - 1) * P.m, (int)P.m, P.vecw);
+#pragma unroll
+            for (int ff = 0; ff < FC; ++ff)
+                if (ff < P.m) m_update<T, M>(a, b, x[ff], ys[ff]);
+        } else
         for (int f0 = 0; f0 < P.m; f0 += FC) {
             const int fw = (int)((P.m - f0) < FC ? (P.m - f0) : FC);
             __syncthreads();
@@ -323,12 +435,27 @@ __global__ __launch_bounds__(DT) void sum_partial_kernel(const double* __restric
 }
 
 // ---- host-side dispatch ----------------------------------------------------
+// widest aligned per-lane vector load for a [*, m] row-major array, 0 if the fast path does not apply
+template <typename T>
+static int row_vecw(const void* X, long long m, bool has_indices)
+{
+    if (has_indices || m > FeatChunk<T>::FC) return 0;
+    const size_t rb = (size_t)m * sizeof(T);
+    const uintptr_t a = (uintptr_t)X;
+    if (a % 16 == 0 && rb % 16 == 0) return 16;
+    if (a % 8 == 0 && rb % 8 == 0) return 8;
+    return (a % sizeof(T) == 0) ? (int)sizeof(T) : 0;
+}
+
 template <typename T, int MODE>
 void launch_pair(int metric, int grid, const PairArgs& P)
 {
 #define MSM_CASE(MM)                                                                              \
     case MM:                                                                                      \
-        hipLaunchKernelGGL((pair_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P);     \
+        if (P.vecw > 0)                                                                           \
+            hipLaunchKernelGGL((pair_small_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P); \
+        else                                                                                      \
+            hipLaunchKernelGGL((pair_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P); \
         break;
     switch (metric) {
         MSM_CASE(M_EUCLIDEAN)
@@ -388,7 +515,8 @@ int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_id
     if (n == 0) return MSM_OK;
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     int rc;
-    DevBuf dX, dY, dIdx, dLab, dMin, dPart;
+    DevBuf &dX = pool(PS_X), &dY = pool(PS_Y), &dIdx = pool(PS_IDX), &dLab = pool(PS_LAB), &dMin = pool(PS_MIN),
+           &dPart = pool(PS_PART);
     const int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
     if ((rc = dY.reserve((size_t)(n_Y ? n_Y : 1) * m * sizeof(T)))) return rc;
     if (n_Y) MSM_HIP_CHECK(hipMemcpyAsync(dY.p, Y, (size_t)n_Y * m * sizeof(T), hipMemcpyHostToDevice, stream()));
@@ -421,6 +549,7 @@ int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_id
             P.min_dist = dMin.as<double>();
         }
     }
+    P.vecw = row_vecw<T>(P.X, m, P.X_indices != nullptr);
     launch_pair<T, 0>(mid, grid, P);
     MSM_HIP_CHECK(hipGetLastError());
     if (!on_device) {
@@ -446,7 +575,7 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
     if (n == 0 || nb == 0) return MSM_OK;
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     int rc;
-    DevBuf dX, dY, dIdx, dOut;
+    DevBuf &dX = pool(PS_X), &dY = pool(PS_Y), &dIdx = pool(PS_IDX), &dOut = pool(PS_OUT);
     const int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
     if ((rc = dY.reserve((size_t)nb * m * sizeof(T)))) return rc;
     MSM_HIP_CHECK(hipMemcpyAsync(dY.p, XB, (size_t)nb * m * sizeof(T), hipMemcpyHostToDevice, stream()));
@@ -472,6 +601,7 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
         if ((rc = dOut.reserve((size_t)n * nb * sizeof(double)))) return rc;
         P.out = dOut.as<double>();
     }
+    P.vecw = row_vecw<T>(P.X, m, P.X_indices != nullptr);
     launch_pair<T, 1>(mid, grid, P);
     MSM_HIP_CHECK(hipGetLastError());
     if (!on_device)
@@ -492,7 +622,8 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     if (seed < 0 || seed >= n) return fail(MSM_ERR_INVALID, "kcenters_fit: seed_index out of range");
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     int rc;
-    DevBuf dX, dLab, dDist, dPart, dIds, dSum;
+    DevBuf &dX = pool(PS_X), &dLab = pool(PS_LAB), &dDist = pool(PS_MIN), &dPart = pool(PS_PART), &dIds = pool(PS_IDS),
+           &dSum = pool(PS_SUM);
     const int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
     if ((rc = dPart.reserve((size_t)2 * nblk * sizeof(KcPartial)))) return rc;
     if ((rc = dIds.reserve((size_t)K * sizeof(msm_idx_t)))) return rc;
@@ -517,6 +648,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         P.labels = dLab.as<msm_idx_t>();
         P.dist = dDist.as<double>();
     }
+    P.vecw = row_vecw<T>(P.X, m, false);
     KcPartial* part = dPart.as<KcPartial>();
     for (msm_idx_t it = 0; it < K; ++it) {
         P.it = (int)it;

@@ -303,7 +303,7 @@ static int km_label_and_inertia(KmArgs& P, double* inertia)
     MSM_HIP_CHECK(hipGetLastError());
     if (inertia) {
         const int nb = (int)std::min<long long>(ceil_div(P.n, 4), 1024);
-        DevBuf dPart;
+        DevBuf& dPart = pool(PS_PART);
         int rc = dPart.reserve((size_t)nb * sizeof(double));
         if (rc) return rc;
         hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, dPart.as<double>());
@@ -332,7 +332,7 @@ int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* 
     if (inertia) *inertia = 0.0;
     if (n == 0) return MSM_OK;
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
-    DevBuf dC, dX, dL;
+    DevBuf &dC = pool(PS_Y), &dX = pool(PS_X), &dL = pool(PS_LAB);
     float *dCent, *dNorm;
     int rc = km_prepare(centers, K, m, dC, &dCent, &dNorm);
     if (rc) return rc;
@@ -370,7 +370,7 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
     for (msm_idx_t b = 0; b < B; ++b)
         if (batch_idx[b] < 0 || batch_idx[b] >= n) return fail(MSM_ERR_INVALID, "mbk_step: batch index out of range");
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
-    DevBuf dC, dXb, dIdx, dL, dW, dS;
+    DevBuf &dC = pool(PS_Y), &dXb = pool(PS_X), &dIdx = pool(PS_IDX), &dL = pool(PS_LAB), &dW = pool(PS_W), &dS = pool(PS_S);
     float *dCent, *dNorm;
     int rc = km_prepare(centers, K, m, dC, &dCent, &dNorm);
     if (rc) return rc;

@@ -61,6 +61,12 @@ void DevBuf::release()
     cap = 0;
 }
 
+DevBuf& pool(int slot)
+{
+    static DevBuf* slots = new DevBuf[PS_COUNT];  // intentionally leaked (outlives HIP teardown)
+    return slots[slot];
+}
+
 int metric_id(const char* name)
 {
     if (!name) return -1;

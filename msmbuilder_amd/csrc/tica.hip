@@ -499,55 +499,83 @@ __global__ void tica_export_kernel(const double* __restrict__ slabs, const doubl
     out[idx] = v;
 }
 
-// out[n,k] = (X - mean) @ comps^T in fp64; wave = component lane, lane = row.
+// out[n,k] = (X - mean) @ comps^T in fp64 (tica.py:329-333).  HBM-bound: reads F*sizeof(T) and
+// writes 8k bytes per frame.  A workgroup owns 64 rows; X tiles [64][FC] arrive as 16-byte
+// loads (256-byte row segments), are centred and widened while being written to LDS (pitch
+// FC+1 doubles: conflict-free lane-per-row ds_read_b64); wave w accumulates the components
+// w*npw .. w*npw+npw-1 of the current tile of <= 32 components, lane = row, one fp64 FMA
+// chain per output in feature order (deterministic).
 template <typename TIn>
 __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict__ X, long long n,
                                                           int F, long long ld,
                                                           const double* __restrict__ mean,
                                                           const double* __restrict__ comps, int k,
-                                                          double* __restrict__ out, int* flag)
+                                                          double* __restrict__ out, int* flag, int vec)
 {
-    constexpr int FC = 32, KT = 32;  // feature chunk, component tile (8 per wave)
+    constexpr int FC = 64, KT = 32, CW = 16 / sizeof(TIn);
     __shared__ double Xs[64][FC + 1];
     __shared__ double Vs[KT][FC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long row0 = (long long)blockIdx.x * 64;
     int bad = 0;
     for (int k0 = 0; k0 < k; k0 += KT) {
+        const int kt = (k - k0) < KT ? (k - k0) : KT;
+        const int npw = (kt + 3) / 4;  // components per wave in this tile (<= 8)
         double acc[KT / 4];
 #pragma unroll
         for (int a = 0; a < KT / 4; ++a) acc[a] = 0.0;
         for (int f0 = 0; f0 < F; f0 += FC) {
             __syncthreads();
-            for (int e = tid; e < 64 * FC; e += NT) {
-                const int rr = e / FC, ff = e % FC;
-                const long long r = row0 + rr;
-                double v = 0.0;
-                if (r < n && f0 + ff < F) {
-                    const double x = (double)X[r * ld + f0 + ff];
-                    bad |= !isfinite(x);
-                    v = x - mean[f0 + ff];
+            if (vec) {
+                // 64 rows x (FC / CW) vectors, CW elements each
+                constexpr int VPR = FC / CW;
+                for (int e = tid; e < 64 * VPR; e += NT) {
+                    const int rr = e / VPR, cc = (e % VPR) * CW;
+                    const long long r = row0 + rr;
+                    TIn v[CW];
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) v[q] = (TIn)0;
+                    if (r < n && f0 + cc < F)
+                        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(X + r * ld + f0 + cc);
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) {
+                        const double x = (double)v[q];
+                        bad |= !isfinite(x);
+                        Xs[rr][cc + q] = (f0 + cc + q < F) ? x - mean[f0 + cc + q] : 0.0;
+                    }
                 }
-                Xs[rr][ff] = v;
+            } else {
+                for (int e = tid; e < 64 * FC; e += NT) {
+                    const int rr = e / FC, ff = e % FC;
+                    const long long r = row0 + rr;
+                    double v = 0.0;
+                    if (r < n && f0 + ff < F) {
+                        const double x = (double)X[r * ld + f0 + ff];
+                        bad |= !isfinite(x);
+                        v = x - mean[f0 + ff];
+                    }
+                    Xs[rr][ff] = v;
+                }
             }
             for (int e = tid; e < KT * FC; e += NT) {
                 const int kk = e / FC, ff = e % FC;
-                Vs[kk][ff] = (k0 + kk < k && f0 + ff < F) ? comps[(size_t)(k0 + kk) * F + f0 + ff] : 0.0;
+                Vs[kk][ff] = (kk < kt && f0 + ff < F) ? comps[(size_t)(k0 + kk) * F + f0 + ff] : 0.0;
             }
             __syncthreads();
-#pragma unroll 4
-            for (int ff = 0; ff < FC; ++ff) {
+            const int fw = (F - f0) < FC ? (F - f0) : FC;
+            for (int ff = 0; ff < fw; ++ff) {
                 const double x = Xs[lane][ff];
 #pragma unroll
-                for (int a = 0; a < KT / 4; ++a) acc[a] = fma(x, Vs[wave * (KT / 4) + a][ff], acc[a]);
+                for (int a = 0; a < KT / 4; ++a)
+                    if (a < npw) acc[a] = fma(x, Vs[wave * npw + a][ff], acc[a]);
             }
         }
         const long long r = row0 + lane;
         if (r < n) {
 #pragma unroll
             for (int a = 0; a < KT / 4; ++a) {
-                const int kk = k0 + wave * (KT / 4) + a;
-                if (kk < k) out[r * k + kk] = acc[a];
+                const int kk = wave * npw + a;
+                if (a < npw && kk < kt) out[r * k + k0 + kk] = acc[a];
             }
         }
     }
@@ -971,7 +999,7 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     if (n_rows < 0 || n_features < 1 || k < 1 || ld < n_features) return fail(MSM_ERR_INVALID, "bad shape");
     if (n_rows == 0) return MSM_OK;
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
-    DevBuf dX, dOut, dPar;
+    DevBuf &dX = pool(PS_X), &dOut = pool(PS_OUT), &dPar = pool(PS_PAR);
     int rc;
     const size_t par_n = (size_t)n_features + (size_t)k * n_features;
     if ((rc = dPar.reserve(par_n * sizeof(double) + 16))) return rc;
@@ -994,12 +1022,14 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
         ldd = n_features;
     }
     const unsigned grid = (unsigned)ceil_div(n_rows, 64);
+    const int cw = 16 / dtype_bytes;
+    const int vec = (((uintptr_t)Xd) % 16 == 0) && (ldd % cw == 0) && (n_features % cw == 0);
     if (dtype_bytes == 4)
         hipLaunchKernelGGL(tica_project_kernel<float>, dim3(grid), dim3(NT), 0, stream(), (const float*)Xd,
-                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag);
+                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag, vec);
     else
         hipLaunchKernelGGL(tica_project_kernel<double>, dim3(grid), dim3(NT), 0, stream(), (const double*)Xd,
-                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag);
+                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag, vec);
     MSM_HIP_CHECK(hipGetLastError());
     if (!on_device)
         MSM_HIP_CHECK(hipMemcpyAsync(out, outd, (size_t)n_rows * k * sizeof(double), hipMemcpyDeviceToHost, stream()));
