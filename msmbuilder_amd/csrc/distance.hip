@@ -249,9 +249,14 @@ __global__ __launch_bounds__(DT) void pair_small_kernel(PairArgs P)
             for (int c = 0; c < CJ; ++c) {
                 if (j0 + c < P.K) {
                     double a = 0.0, b = 0.0;
+                    // zero padding is exact for every metric (a 0/0 pair adds nothing), so the
+                    // feature loop is predicated per group of 4, not per element
 #pragma unroll
-                    for (int ff = 0; ff < FC; ++ff)
-                        if (ff < m) m_update<T, M>(a, b, x[ff], Ys[c * FC + ff]);
+                    for (int g = 0; g < FC / 4; ++g)
+                        if (g * 4 < m) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) m_update<T, M>(a, b, x[g * 4 + q], Ys[c * FC + g * 4 + q]);
+                        }
                     const double d = m_final<M>(a, b, P.m);
                     if (MODE == 0) {
                         if (d < min_d) {
@@ -370,8 +375,11 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
             T x[FC];
             load_row_regs<T>(x, X + (i < P.n ? i : P.n - 1) * P.m, (int)P.m, P.vecw);
 #pragma unroll
-            for (int ff = 0; ff < FC; ++ff)
-                if (ff < P.m) m_update<T, M>(a, b, x[ff], ys[ff]);
+            for (int g = 0; g < FC / 4; ++g)
+                if (g * 4 < P.m) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) m_update<T, M>(a, b, x[g * 4 + q], ys[g * 4 + q]);
+                }
         } else
         for (int f0 = 0; f0 < P.m; f0 += FC) {
             const int fw = (int)((P.m - f0) < FC ? (P.m - f0) : FC);

@@ -20,6 +20,7 @@
 // one XCD where possible, so the 13x panel re-read (F=512) is L2 traffic, not HBM.
 #include "common.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace msm {
@@ -505,14 +506,14 @@ __global__ void tica_export_kernel(const double* __restrict__ slabs, const doubl
 // FC+1 doubles: conflict-free lane-per-row ds_read_b64); wave w accumulates the components
 // w*npw .. w*npw+npw-1 of the current tile of <= 32 components, lane = row, one fp64 FMA
 // chain per output in feature order (deterministic).
-template <typename TIn>
+template <typename TIn, int NPW>
 __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict__ X, long long n,
                                                           int F, long long ld,
                                                           const double* __restrict__ mean,
                                                           const double* __restrict__ comps, int k,
                                                           double* __restrict__ out, int* flag, int vec)
 {
-    constexpr int FC = 64, KT = 32, CW = 16 / sizeof(TIn);
+    constexpr int FC = 64, KT = 4 * NPW, CW = 16 / sizeof(TIn);  // NPW components per wave
     __shared__ double Xs[64][FC + 1];
     __shared__ double Vs[KT][FC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -520,10 +521,9 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
     int bad = 0;
     for (int k0 = 0; k0 < k; k0 += KT) {
         const int kt = (k - k0) < KT ? (k - k0) : KT;
-        const int npw = (kt + 3) / 4;  // components per wave in this tile (<= 8)
-        double acc[KT / 4];
+        double acc[NPW];
 #pragma unroll
-        for (int a = 0; a < KT / 4; ++a) acc[a] = 0.0;
+        for (int a = 0; a < NPW; ++a) acc[a] = 0.0;
         for (int f0 = 0; f0 < F; f0 += FC) {
             __syncthreads();
             if (vec) {
@@ -566,16 +566,15 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
             for (int ff = 0; ff < fw; ++ff) {
                 const double x = Xs[lane][ff];
 #pragma unroll
-                for (int a = 0; a < KT / 4; ++a)
-                    if (a < npw) acc[a] = fma(x, Vs[wave * npw + a][ff], acc[a]);
+                for (int a = 0; a < NPW; ++a) acc[a] = fma(x, Vs[wave * NPW + a][ff], acc[a]);
             }
         }
         const long long r = row0 + lane;
         if (r < n) {
 #pragma unroll
-            for (int a = 0; a < KT / 4; ++a) {
-                const int kk = wave * npw + a;
-                if (a < npw && kk < kt) out[r * k + k0 + kk] = acc[a];
+            for (int a = 0; a < NPW; ++a) {
+                const int kk = wave * NPW + a;
+                if (kk < kt) out[r * k + k0 + kk] = acc[a];
             }
         }
     }
@@ -1024,12 +1023,28 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     const unsigned grid = (unsigned)ceil_div(n_rows, 64);
     const int cw = 16 / dtype_bytes;
     const int vec = (((uintptr_t)Xd) % 16 == 0) && (ldd % cw == 0) && (n_features % cw == 0);
-    if (dtype_bytes == 4)
-        hipLaunchKernelGGL(tica_project_kernel<float>, dim3(grid), dim3(NT), 0, stream(), (const float*)Xd,
-                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag, vec);
-    else
-        hipLaunchKernelGGL(tica_project_kernel<double>, dim3(grid), dim3(NT), 0, stream(), (const double*)Xd,
-                           (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag, vec);
+    const int npw = (int)std::min<msm_idx_t>(8, ceil_div(k, 4));  // components per wave
+#define MSM_PROJ(TT, NN)                                                                              \
+    hipLaunchKernelGGL((tica_project_kernel<TT, NN>), dim3(grid), dim3(NT), 0, stream(), (const TT*)Xd, \
+                       (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag, vec)
+#define MSM_PROJ_T(TT)                                                                                \
+    switch (npw) {                                                                                    \
+    case 1: MSM_PROJ(TT, 1); break;                                                                   \
+    case 2: MSM_PROJ(TT, 2); break;                                                                   \
+    case 3: MSM_PROJ(TT, 3); break;                                                                   \
+    case 4: MSM_PROJ(TT, 4); break;                                                                   \
+    case 5: MSM_PROJ(TT, 5); break;                                                                   \
+    case 6: MSM_PROJ(TT, 6); break;                                                                   \
+    case 7: MSM_PROJ(TT, 7); break;                                                                   \
+    default: MSM_PROJ(TT, 8); break;                                                                  \
+    }
+    if (dtype_bytes == 4) {
+        MSM_PROJ_T(float)
+    } else {
+        MSM_PROJ_T(double)
+    }
+#undef MSM_PROJ_T
+#undef MSM_PROJ
     MSM_HIP_CHECK(hipGetLastError());
     if (!on_device)
         MSM_HIP_CHECK(hipMemcpyAsync(out, outd, (size_t)n_rows * k * sizeof(double), hipMemcpyDeviceToHost, stream()));
