@@ -106,6 +106,8 @@ int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until 
 /* HIP-event duration (ms) of the most recent MFMA accumulation launch of this handle,
  * measured on the stream it ran on (bench.py's roofline leg); synchronises on it. */
 int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
+/* profiling: {shader-clock start, end, 100 MHz wall-clock start, end} of workgroup 0 of that launch */
+int msm_tica_debug_clocks(msm_tica_t* h, long long* out4);
 
 /* Accumulators as the reference defines them (float64, row-major F x F / F):
  *   C    = sum_traj X[:-tau].T @ X[tau:]                    (tica.py:417)

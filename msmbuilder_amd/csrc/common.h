@@ -58,4 +58,22 @@ int metric_id(const char* name);  // -1 if unknown
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// A data pointer that was itself LOADED from memory (e.g. out of a descriptor table) is a
+// generic pointer to the compiler, which then emits flat_load: slower, and because FLAT counts on
+// both vmcnt and lgkmcnt every counted wait degenerates to vmcnt(0).  Re-type it as global.
+template <typename T>
+using global_ptr = const T __attribute__((address_space(1)))*;
+template <typename T>
+__device__ __forceinline__ global_ptr<T> as_global(const void* p)
+{
+    return (global_ptr<T>)(uintptr_t)p;
+}
+typedef float raw_f32x4 __attribute__((ext_vector_type(4)));  // 16-byte load unit (no class ctor)
+template <typename T>
+__device__ __forceinline__ float4 load16_global(global_ptr<T> p)
+{
+    const raw_f32x4 v = *(global_ptr<raw_f32x4>)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 }  // namespace msm

@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace msm {
@@ -29,7 +30,8 @@ constexpr int TM = 128;     // output tile is TM x TM features
 constexpr int NT = 256;     // threads per workgroup: 4 waves as 2x2, 64x64 outputs per wave
 constexpr int BK32 = 32;    // frames per K-step, fp32 kernel
 constexpr int BK64 = 16;    // frames per K-step, fp64 kernel
-constexpr int KCMAX = 4096; // max frames accumulated in fp32 before an fp64 merge
+constexpr int KCMAX = 4096; // max frames per chunk (load-balance granule)
+constexpr int KFLUSH = 8192; // max frames accumulated in fp32 registers before an fp64 merge
 constexpr int NCB = 1024;   // column-sum partial slots (4 blocks per CU)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,6 +55,8 @@ struct TicaArgs {
     double* slabs;    // [S*ntiles][TM*TM] fp64, owned per workgroup
     double* colpart;  // [NCB][2][F] fp64 partial column sums (temporary buffer)
     int* flag;        // sticky non-finite flag
+    long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
+    int ablate;       // profiling only (MSM_TICA_ABLATE): 1 skip global->LDS restaging, 2 skip barriers, 4 skip LDS fragment reads
 };
 
 __device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
@@ -105,52 +109,74 @@ struct Stage32 {
                   // touching a loaded value early would park the wave on vmcnt before the MFMA loop)
 };
 
-// Unconditional loads: rows are clamped into the trajectory and columns into [0, F) so every
-// address is valid; validity is carried by the A-side weight (0 kills the whole rank-1 term,
-// B only has to be finite) and by the per-thread column masks applied at LDS-store time.
+// Per-chunk, wave-uniform addressing context.  Everything per-lane is 32-bit and chunk
+// relative: rows are clamped into the trajectory and columns into [0, F) so every address is
+// valid; validity is carried by the A-side weight (0 kills the whole rank-1 term, B only has to
+// be finite) and, for partial tiles, by column masks applied at LDS-store time.  Loads become
+// `global_load_dwordx4 v, v_off32, s[base]`: no 64-bit VALU address math in the K loop.
+struct ChunkCtx {
+    global_ptr<char> base;  // &X[row0][0]
+    int n;                  // rows in the chunk
+    int lo;                 // kr >= lo  <=>  row >= lag           (second Gram term)
+    int hi;                 // kr <  hi  <=>  row <  len - lag, and kr < n
+    int nmax;               // kr <= nmax keeps the row inside the trajectory
+    unsigned ldb;           // row pitch in bytes
+};
+
+__device__ __forceinline__ int sat_i32(long long v)
+{
+    return v > 0x3fffffff ? 0x3fffffff : (v < -0x3fffffff ? -0x3fffffff : (int)v);
+}
+
+__device__ __forceinline__ ChunkCtx make_ctx(const TicaArgs& P, const TicaChunk& ch)
+{
+    ChunkCtx c;
+    c.base = as_global<char>(ch.base) + (size_t)ch.row0 * (size_t)P.ld * sizeof(float);
+    c.n = ch.n;
+    c.lo = sat_i32((long long)P.lag - ch.row0);
+    const int hi = sat_i32(ch.len - P.lag - ch.row0);
+    c.hi = hi < ch.n ? hi : ch.n;
+    c.nmax = sat_i32(ch.len - 1 - ch.row0);
+    c.ldb = (unsigned)(P.ld * sizeof(float));
+    return c;
+}
+
 template <bool VEC4>
-__device__ __forceinline__ float4 load_row4(const float* __restrict__ rowp, int col, int F)
+__device__ __forceinline__ float4 load_row4(global_ptr<char> base, unsigned rowoff, int col, int F)
 {
     if (VEC4) {
         const int c = col < F ? col : F - 4;
-        return *reinterpret_cast<const float4*>(rowp + c);
+        return load16_global<char>(base + (rowoff + (unsigned)c * 4u));
     } else {
         float4 v;
-        v.x = rowp[col + 0 < F ? col + 0 : F - 1];
-        v.y = rowp[col + 1 < F ? col + 1 : F - 1];
-        v.z = rowp[col + 2 < F ? col + 2 : F - 1];
-        v.w = rowp[col + 3 < F ? col + 3 : F - 1];
+        v.x = *(global_ptr<float>)(base + (rowoff + 4u * (unsigned)(col + 0 < F ? col + 0 : F - 1)));
+        v.y = *(global_ptr<float>)(base + (rowoff + 4u * (unsigned)(col + 1 < F ? col + 1 : F - 1)));
+        v.z = *(global_ptr<float>)(base + (rowoff + 4u * (unsigned)(col + 2 < F ? col + 2 : F - 1)));
+        v.w = *(global_ptr<float>)(base + (rowoff + 4u * (unsigned)(col + 3 < F ? col + 3 : F - 1)));
         return v;
     }
 }
 
 template <bool VEC4>
-__device__ __forceinline__ void stage_load32(Stage32<VEC4>& st, const TicaArgs& P,
-                                             const TicaChunk& ch, int k0, int isG, int tauB,
-                                             int I0, int J0, int tid)
+__device__ __forceinline__ void stage_load32(Stage32<VEC4>& st, const ChunkCtx& cx, int F, int k0,
+                                             int isG, int tauB, int I0, int J0, int tid)
 {
     const int c4 = (tid & 31) * 4;
     const int rr0 = tid >> 5;
-    const float* X = static_cast<const float*>(ch.base);
-    const long long last = ch.len - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int kr = k0 + rr0 + 8 * j;
-        const long long r = ch.row0 + kr;
-        float sc = 0.f;
-        if (kr < ch.n) {
-            sc = (r < ch.len - P.lag) ? 1.f : 0.f;
-            if (isG) sc += (r >= P.lag) ? 1.f : 0.f;
-        }
-        const long long ra = r < last ? r : last;
-        const long long rb = (r + tauB) < last ? (r + tauB) : last;
-        st.a[j] = load_row4<VEC4>(X + ra * P.ld, I0 + c4, P.F);
-        st.b[j] = load_row4<VEC4>(X + rb * P.ld, J0 + c4, P.F);
+        float sc = (kr < cx.hi) ? 1.f : 0.f;
+        if (isG) sc += (kr >= cx.lo && kr < cx.n) ? 1.f : 0.f;
+        const int ra = kr < cx.nmax ? kr : cx.nmax;
+        const int rb = (kr + tauB) < cx.nmax ? (kr + tauB) : cx.nmax;
+        st.a[j] = load_row4<VEC4>(cx.base, (unsigned)ra * cx.ldb, I0 + c4, F);
+        st.b[j] = load_row4<VEC4>(cx.base, (unsigned)rb * cx.ldb, J0 + c4, F);
         st.sc[j] = sc;
     }
 }
 
-template <bool VEC4>
+template <bool VEC4, bool PARTIAL>
 __device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As, float* Bs, int tid,
                                               float4 ma, float4 mb)
 {
@@ -160,15 +186,21 @@ __device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As
     for (int j = 0; j < 4; ++j) {
         const int rr = rr0 + 8 * j;
         const float sc = st.sc[j];
-        *reinterpret_cast<float4*>(As + rr * TM + c4) =
-            make_float4(st.a[j].x * (sc * ma.x), st.a[j].y * (sc * ma.y), st.a[j].z * (sc * ma.z),
-                        st.a[j].w * (sc * ma.w));
-        *reinterpret_cast<float4*>(Bs + rr * TM + c4) =
-            make_float4(st.b[j].x * mb.x, st.b[j].y * mb.y, st.b[j].z * mb.z, st.b[j].w * mb.w);
+        if (PARTIAL) {
+            *reinterpret_cast<float4*>(As + rr * TM + c4) =
+                make_float4(st.a[j].x * (sc * ma.x), st.a[j].y * (sc * ma.y), st.a[j].z * (sc * ma.z),
+                            st.a[j].w * (sc * ma.w));
+            *reinterpret_cast<float4*>(Bs + rr * TM + c4) =
+                make_float4(st.b[j].x * mb.x, st.b[j].y * mb.y, st.b[j].z * mb.z, st.b[j].w * mb.w);
+        } else {
+            *reinterpret_cast<float4*>(As + rr * TM + c4) =
+                make_float4(st.a[j].x * sc, st.a[j].y * sc, st.a[j].z * sc, st.a[j].w * sc);
+            *reinterpret_cast<float4*>(Bs + rr * TM + c4) = st.b[j];
+        }
     }
 }
 
-template <bool VEC4>
+template <bool VEC4, bool PARTIAL>
 __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -195,67 +227,103 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
     const float4 mb = make_float4(J0 + c4 + 0 < P.F ? 1.f : 0.f, J0 + c4 + 1 < P.F ? 1.f : 0.f,
                                   J0 + c4 + 2 < P.F ? 1.f : 0.f, J0 + c4 + 3 < P.F ? 1.f : 0.f);
 
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+    int rows_acc = 0;
+    if (P.dbg && blockIdx.x == 0 && tid == 0) {
+        P.dbg[0] = clock64();
+        P.dbg[2] = wall_clock64();
+    }
+
     for (long long c = cohort; c < P.nchunks; c += P.S) {
         const TicaChunk ch = get_chunk(P, c);
         const int nsteps = (ch.n + BK32 - 1) / BK32;
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-            for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
-
-        Stage32<VEC4> st;
-        stage_load32<VEC4>(st, P, ch, 0, isG, tauB, I0, J0, tid);
-        stage_store32<VEC4>(st, As, Bs, tid, ma, mb);
+        const ChunkCtx cx = make_ctx(P, ch);
+        // Register-staged software pipeline, TWO K-steps deep: while step s runs on the MFMA pipe
+        // the panel of step s+1 sits in one register set (written to LDS at the end of step s) and
+        // the loads of step s+2 are in flight into the other.  One step of lookahead is not enough:
+        // every step has first-touch L2 misses (the lagged panel), and an HBM round trip under load
+        // is about as long as one step, which stalled 16 % of the kernel on vmcnt.
+        Stage32<VEC4> st0, st1;
+        stage_load32<VEC4>(st0, cx, P.F, 0, isG, tauB, I0, J0, tid);
+        stage_store32<VEC4, PARTIAL>(st0, As, Bs, tid, ma, mb);
+        stage_load32<VEC4>(st0, cx, P.F, BK32, isG, tauB, I0, J0, tid);
         __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nsteps) stage_load32<VEC4>(st, P, ch, (s + 1) * BK32, isG, tauB, I0, J0, tid);
-            const float* Ab = As + buf * (BK32 * TM) + kl * TM + wr * 64 + cl;
-            const float* Bb = Bs + buf * (BK32 * TM) + kl * TM + wc * 64 + cl;
-            // fragment reads run one k-pair ahead of the MFMAs that consume them
-            float a0 = Ab[0], a1 = Ab[32], b0 = Bb[0], b1 = Bb[32];
-#pragma unroll 4
-            for (int kk = 0; kk < BK32 / 2; ++kk) {
-                const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;
-                const float na0 = Ab[kn * 2 * TM], na1 = Ab[kn * 2 * TM + 32];
-                const float nb0 = Bb[kn * 2 * TM], nb1 = Bb[kn * 2 * TM + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-            }
-            if (s + 1 < nsteps)
-                stage_store32<VEC4>(st, As + (buf ^ 1) * (BK32 * TM), Bs + (buf ^ 1) * (BK32 * TM), tid, ma, mb);
-            __syncthreads();
+#define MSM_TICA_STEP(SNEXT, SLOAD, BUF)                                                          \
+        {                                                                                         \
+            /* unconditional (rows past the chunk are clamped and weighted 0): a branch here makes */ \
+            /* the compiler wait vmcnt(0) instead of vmcnt(8) before the LDS store below          */ \
+            if (!(P.ablate & 8)) stage_load32<VEC4>(SLOAD, cx, P.F, (s + 2) * BK32, isG, tauB, I0, J0, tid); \
+            const float* Ab = As + (BUF) * (BK32 * TM) + kl * TM + wr * 64 + cl;                  \
+            const float* Bb = Bs + (BUF) * (BK32 * TM) + kl * TM + wc * 64 + cl;                  \
+            /* fragment reads run one k-pair ahead of the MFMAs that consume them */              \
+            float a0 = Ab[0], a1 = Ab[32], b0 = Bb[0], b1 = Bb[32];                               \
+            _Pragma("unroll 4") for (int kk = 0; kk < BK32 / 2; ++kk) {                           \
+                const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;                                 \
+                float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;                                     \
+                if (!(P.ablate & 4)) {                                                            \
+                    na0 = Ab[kn * 2 * TM]; na1 = Ab[kn * 2 * TM + 32];                            \
+                    nb0 = Bb[kn * 2 * TM]; nb1 = Bb[kn * 2 * TM + 32];                            \
+                }                                                                                 \
+                __builtin_amdgcn_sched_barrier(0); /* keep the reads ABOVE the MFMAs they do not feed */ \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);     \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);     \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);     \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);     \
+                __builtin_amdgcn_sched_barrier(0);                                                \
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                           \
+            }                                                                                     \
+            if (s + 1 < nsteps && !(P.ablate & 16))                                               \
+                stage_store32<VEC4, PARTIAL>(SNEXT, As + ((BUF) ^ 1) * (BK32 * TM), Bs + ((BUF) ^ 1) * (BK32 * TM), tid, ma, mb); \
+            if (!(P.ablate & 2)) __syncthreads();                                                 \
         }
-        // fp64 merge of this chunk's fp32 partial into the workgroup's private slab.  Per 32x32
-        // block all 16 loads are issued before the first add/store (a plain `*q += x` loop
-        // compiles to 64 dependent round trips); addresses are a wave-uniform base plus ONE
-        // 32-bit per-lane offset so they cost no VGPR pairs.
-        unsigned toff = (unsigned)((wr * 64 + 4 * kl) * TM + wc * 64 + cl);
-        // opaque to the optimiser: otherwise the 64 slab addresses are hoisted out of the chunk
-        // loop as loop invariants (128 VGPRs -> scratch spills in the MFMA loop)
-        asm volatile("" : "+v"(toff));
+        for (int s = 0; s < nsteps; s += 2) {
+            MSM_TICA_STEP(st0, st1, 0)
+            ++s;
+            if (s < nsteps) MSM_TICA_STEP(st1, st0, 1)
+            --s;
+        }
+#undef MSM_TICA_STEP
+        // fp64 merge of the fp32 partial into the workgroup's private slab, once <= KFLUSH frames
+        // are in the registers.  Per 64x32 half all 32 loads are issued before the first add/store
+        // (a plain `*q += x` loop compiles to 64 dependent round trips); addresses are a
+        // wave-uniform base plus ONE 32-bit per-lane offset so they cost no VGPR pairs.
+        rows_acc += ch.n;
+        if (rows_acc + P.kc > KFLUSH || c + P.S >= P.nchunks) {
+            rows_acc = 0;
+            unsigned toff = (unsigned)((wr * 64 + 4 * kl) * TM + wc * 64 + cl);
+            // opaque to the optimiser: otherwise the 64 slab addresses are hoisted out of the chunk
+            // loop as loop invariants (128 VGPRs -> scratch spills in the MFMA loop)
+            asm volatile("" : "+v"(toff));
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
+            for (int bi = 0; bi < 2; ++bi) {
+                double old[2][16];
 #pragma unroll
-            for (int bj = 0; bj < 2; ++bj) {
-                double old[16];
+                for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
-                    old[r] = q[toff];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
+                        old[bj][r] = q[toff];
+                    }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
-                    q[toff] = old[r] + (double)acc[bi][bj][r];
-                }
+                for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
+                        q[toff] = old[bj][r] + (double)acc[bi][bj][r];
+                        acc[bi][bj][r] = 0.f;
+                    }
             }
+        }
+    }
+    if (P.dbg && blockIdx.x == 0 && tid == 0) {
+        P.dbg[1] = clock64();
+        P.dbg[3] = wall_clock64();
     }
 }
 
@@ -299,7 +367,7 @@ __global__ __launch_bounds__(NT, 1) void tica_mfma_f64_kernel(TicaArgs P)
 
     for (long long c = cohort; c < P.nchunks; c += P.S) {
         const TicaChunk ch = get_chunk(P, c);
-        const TIn* X = static_cast<const TIn*>(ch.base);
+        const global_ptr<TIn> X = as_global<TIn>(ch.base);
         const int nsteps = (ch.n + BK64 - 1) / BK64;
         for (int s = 0; s < nsteps; ++s) {
             const int kr = s * BK64 + srow;
@@ -316,12 +384,12 @@ __global__ __launch_bounds__(NT, 1) void tica_mfma_f64_kernel(TicaArgs P)
                 vb[e] = 0.0;
             }
             if (sc != 0.0) {
-                const TIn* pa = X + r * P.ld + I0 + scol;
+                const global_ptr<TIn> pa = X + r * P.ld + I0 + scol;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (I0 + scol + e < P.F) va[e] = sc * (double)pa[e];
                 if (r + tauB < ch.len) {
-                    const TIn* pb = X + (r + tauB) * P.ld + J0 + scol;
+                    const global_ptr<TIn> pb = X + (r + tauB) * P.ld + J0 + scol;
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (J0 + scol + e < P.F) vb[e] = (double)pb[e];
@@ -392,8 +460,8 @@ __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
         if (col < P.F) {
             for (long long c = blockIdx.x; c < P.nchunks; c += gridDim.x) {
                 const TicaChunk ch = get_chunk(P, c);
-                const TIn* X = static_cast<const TIn*>(ch.base);
-                const bool al = vec && ((((uintptr_t)X) & 15) == 0);
+                const global_ptr<TIn> X = as_global<TIn>(ch.base);
+                const bool al = vec && ((((uintptr_t)ch.base) & 15) == 0);
                 for (int k0 = tr; k0 < ch.n; k0 += rl * RU) {
                     TIn v[RU][CW];
 #pragma unroll
@@ -403,9 +471,9 @@ __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
 #pragma unroll
                         for (int e = 0; e < CW; ++e) v[u][e] = (TIn)0;
                         if (kr < ch.n) {
-                            const TIn* p = X + r * P.ld + col;
+                            const global_ptr<TIn> p = X + r * P.ld + col;
                             if (al) {
-                                *reinterpret_cast<float4*>(&v[u][0]) = *reinterpret_cast<const float4*>(p);
+                                *reinterpret_cast<float4*>(&v[u][0]) = load16_global<TIn>(p);
                             } else {
 #pragma unroll
                                 for (int e = 0; e < CW; ++e)
@@ -500,36 +568,36 @@ __global__ void tica_export_kernel(const double* __restrict__ slabs, const doubl
     out[idx] = v;
 }
 
-// out[n,k] = (X - mean) @ comps^T in fp64 (tica.py:329-333).  HBM-bound: reads F*sizeof(T) and
-// writes 8k bytes per frame.  A workgroup owns 64 rows; X tiles [64][FC] arrive as 16-byte
-// loads (256-byte row segments), are centred and widened while being written to LDS (pitch
-// FC+1 doubles: conflict-free lane-per-row ds_read_b64); wave w accumulates the components
-// w*npw .. w*npw+npw-1 of the current tile of <= 32 components, lane = row, one fp64 FMA
-// chain per output in feature order (deterministic).
+// out[n,k] = (X - mean) @ comps^T in fp64 (tica.py:329-333), evaluated as X @ comps^T - (mean @ comps^T)
+// with the k constants mean @ comps^T precomputed on the host in fp64.  HBM-bound: reads
+// F*sizeof(T) and writes 8k bytes per frame.  A workgroup owns 128 rows; X tiles [128][FC] arrive
+// as 16-byte loads (256-byte row segments) and are written TRANSPOSED to LDS ([FC][128+1], raw
+// element type) so that lane-per-row reads are consecutive words; wave w accumulates components
+// w*NPW .. w*NPW+NPW-1 of the current tile of 4*NPW components for rows lane and lane+64, one
+// fp64 FMA chain per output in feature order (deterministic).
 template <typename TIn, int NPW>
 __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict__ X, long long n,
                                                           int F, long long ld,
-                                                          const double* __restrict__ mean,
+                                                          const double* __restrict__ muV,
                                                           const double* __restrict__ comps, int k,
                                                           double* __restrict__ out, int* flag, int vec)
 {
-    constexpr int FC = 64, KT = 4 * NPW, CW = 16 / sizeof(TIn);  // NPW components per wave
-    __shared__ double Xs[64][FC + 1];
+    constexpr int FC = 64, KT = 4 * NPW, CW = 16 / sizeof(TIn), RW = 128, RP = RW + 1;
+    __shared__ TIn Xs[FC * RP];
     __shared__ double Vs[KT][FC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long row0 = (long long)blockIdx.x * 64;
+    const long long row0 = (long long)blockIdx.x * RW;
     int bad = 0;
     for (int k0 = 0; k0 < k; k0 += KT) {
         const int kt = (k - k0) < KT ? (k - k0) : KT;
-        double acc[NPW];
+        double acc[2][NPW];
 #pragma unroll
-        for (int a = 0; a < NPW; ++a) acc[a] = 0.0;
+        for (int a = 0; a < NPW; ++a) acc[0][a] = acc[1][a] = 0.0;
         for (int f0 = 0; f0 < F; f0 += FC) {
             __syncthreads();
             if (vec) {
-                // 64 rows x (FC / CW) vectors, CW elements each
-                constexpr int VPR = FC / CW;
-                for (int e = tid; e < 64 * VPR; e += NT) {
+                constexpr int VPR = FC / CW;  // 16-byte vectors per row segment
+                for (int e = tid; e < RW * VPR; e += NT) {
                     const int rr = e / VPR, cc = (e % VPR) * CW;
                     const long long r = row0 + rr;
                     TIn v[CW];
@@ -539,22 +607,18 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
                         *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(X + r * ld + f0 + cc);
 #pragma unroll
                     for (int q = 0; q < CW; ++q) {
-                        const double x = (double)v[q];
-                        bad |= !isfinite(x);
-                        Xs[rr][cc + q] = (f0 + cc + q < F) ? x - mean[f0 + cc + q] : 0.0;
+                        bad |= !isfinite(v[q]);
+                        Xs[(cc + q) * RP + rr] = v[q];
                     }
                 }
             } else {
-                for (int e = tid; e < 64 * FC; e += NT) {
+                for (int e = tid; e < RW * FC; e += NT) {
                     const int rr = e / FC, ff = e % FC;
                     const long long r = row0 + rr;
-                    double v = 0.0;
-                    if (r < n && f0 + ff < F) {
-                        const double x = (double)X[r * ld + f0 + ff];
-                        bad |= !isfinite(x);
-                        v = x - mean[f0 + ff];
-                    }
-                    Xs[rr][ff] = v;
+                    TIn v = (TIn)0;
+                    if (r < n && f0 + ff < F) v = X[r * ld + f0 + ff];
+                    bad |= !isfinite(v);
+                    Xs[ff * RP + rr] = v;
                 }
             }
             for (int e = tid; e < KT * FC; e += NT) {
@@ -563,18 +627,27 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
             }
             __syncthreads();
             const int fw = (F - f0) < FC ? (F - f0) : FC;
+#pragma unroll 4
             for (int ff = 0; ff < fw; ++ff) {
-                const double x = Xs[lane][ff];
+                const double x0 = (double)Xs[ff * RP + lane];
+                const double x1 = (double)Xs[ff * RP + lane + 64];
 #pragma unroll
-                for (int a = 0; a < NPW; ++a) acc[a] = fma(x, Vs[wave * NPW + a][ff], acc[a]);
+                for (int a = 0; a < NPW; ++a) {
+                    const double v = Vs[wave * NPW + a][ff];
+                    acc[0][a] = fma(x0, v, acc[0][a]);
+                    acc[1][a] = fma(x1, v, acc[1][a]);
+                }
             }
         }
-        const long long r = row0 + lane;
-        if (r < n) {
 #pragma unroll
-            for (int a = 0; a < NPW; ++a) {
-                const int kk = wave * NPW + a;
-                if (kk < kt) out[r * k + k0 + kk] = acc[a];
+        for (int h = 0; h < 2; ++h) {
+            const long long r = row0 + lane + 64 * h;
+            if (r < n) {
+#pragma unroll
+                for (int a = 0; a < NPW; ++a) {
+                    const int kk = wave * NPW + a;
+                    if (kk < kt) out[r * k + k0 + kk] = acc[h][a] - muV[k0 + kk];
+                }
             }
         }
     }
@@ -594,6 +667,7 @@ struct msm_tica {
     double* coltmp = nullptr;   // [NCB][2][F]
     double* packed = nullptr;   // [2FF+2F+2] export scratch
     int* flag = nullptr;        // [2]: [0] sticky, [1] per-call
+    long long* dbg = nullptr;   // [4] profiling clocks
     long long n_obs = 0, n_seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
     bool timed = false;
@@ -670,6 +744,8 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     P.slabs = h->slabs;
     P.colpart = h->coltmp;
     P.flag = h->flag;
+    P.dbg = h->dbg;
+    { const char* ab = getenv("MSM_TICA_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
 
     if (nvalid == 1 && n_seq == 1) {
         P.chunks = nullptr;
@@ -730,10 +806,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // 2) the MFMA pass
     if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
     if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
-        if (aligned)
-            hipLaunchKernelGGL(tica_mfma_f32_kernel<true>, dim3(G), dim3(NT), LDS32, stream(), P);
+        if (aligned && h->F % TM == 0)
+            hipLaunchKernelGGL((tica_mfma_f32_kernel<true, false>), dim3(G), dim3(NT), LDS32, stream(), P);
+        else if (aligned)
+            hipLaunchKernelGGL((tica_mfma_f32_kernel<true, true>), dim3(G), dim3(NT), LDS32, stream(), P);
         else
-            hipLaunchKernelGGL(tica_mfma_f32_kernel<false>, dim3(G), dim3(NT), LDS32, stream(), P);
+            hipLaunchKernelGGL((tica_mfma_f32_kernel<false, true>), dim3(G), dim3(NT), LDS32, stream(), P);
     } else if (dtype_bytes == 4) {
         hipLaunchKernelGGL(tica_mfma_f64_kernel<float>, dim3(G), dim3(NT), LDS64, stream(), P);
     } else {
@@ -782,11 +860,21 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     h->T = (int)ceil_div(n_features, TM);
     h->ntiles = h->T * h->T + h->T * (h->T + 1) / 2;
     int slots32 = 0, slots64 = 0, rc;
-    MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_f32_kernel<true>),
+    MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_f32_kernel<true, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
-    MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_f32_kernel<false>),
+    MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_f32_kernel<true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
-    if ((rc = query_slots(tica_mfma_f32_kernel<true>, LDS32, &slots32))) { delete h; return rc; }
+    MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_f32_kernel<false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
+    {
+        // all three flavours must be resident in one round: size the cohorts by the tightest
+        int sa = 0, sb = 0, sc = 0;
+        if ((rc = query_slots(tica_mfma_f32_kernel<true, false>, LDS32, &sa))) { delete h; return rc; }
+        if ((rc = query_slots(tica_mfma_f32_kernel<true, true>, LDS32, &sb))) { delete h; return rc; }
+        if ((rc = query_slots(tica_mfma_f32_kernel<false, true>, LDS32, &sc))) { delete h; return rc; }
+        slots32 = sa < sb ? sa : sb;
+        slots32 = slots32 < sc ? slots32 : sc;
+    }
     if ((rc = query_slots(tica_mfma_f64_kernel<float>, LDS64, &slots64))) { delete h; return rc; }
     // one resident round per launch: S cohorts of ntiles workgroups, per kernel flavour
     h->S32 = slots32 / h->ntiles;
@@ -803,6 +891,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->coltmp, (size_t)NCB * 2 * h->F * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->packed, (FF2 + 2) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->flag, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->dbg, 4 * sizeof(long long));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -828,6 +917,7 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->coltmp) (void)hipFree(h->coltmp);
     if (h->packed) (void)hipFree(h->packed);
     if (h->flag) (void)hipFree(h->flag);
+    if (h->dbg) (void)hipFree(h->dbg);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -923,6 +1013,14 @@ int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms)
     return MSM_OK;
 }
 
+int msm_tica_debug_clocks(msm_tica_t* h, long long* out4)
+{
+    if (!h || !out4) return fail(MSM_ERR_STATE, "null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(out4, h->dbg, 4 * sizeof(long long), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
 msm_idx_t msm_tica_packed_size(msm_tica_t* h) { return h ? (msm_idx_t)h->packed_len() : 0; }
 
 int msm_tica_export_packed(msm_tica_t* h, double* buf, int on_device)
@@ -1000,12 +1098,18 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     DevBuf &dX = pool(PS_X), &dOut = pool(PS_OUT), &dPar = pool(PS_PAR);
     int rc;
-    const size_t par_n = (size_t)n_features + (size_t)k * n_features;
+    const size_t par_n = (size_t)k + (size_t)k * n_features;
     if ((rc = dPar.reserve(par_n * sizeof(double) + 16))) return rc;
-    double* dmean = dPar.as<double>();
-    double* dcomps = dmean + n_features;
+    std::vector<double> muV((size_t)k);
+    for (msm_idx_t c = 0; c < k; ++c) {
+        double sacc = 0.0;
+        for (msm_idx_t f = 0; f < n_features; ++f) sacc += mean[f] * comps[c * n_features + f];
+        muV[(size_t)c] = sacc;
+    }
+    double* dmean = dPar.as<double>();  // holds mean @ comps^T (k values)
+    double* dcomps = dmean + k;
     int* dflag = reinterpret_cast<int*>(dcomps + (size_t)k * n_features);
-    MSM_HIP_CHECK(hipMemcpyAsync(dmean, mean, n_features * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(dmean, muV.data(), k * sizeof(double), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(dcomps, comps, (size_t)k * n_features * sizeof(double), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
     const void* Xd = X;
@@ -1020,7 +1124,7 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
         outd = dOut.as<double>();
         ldd = n_features;
     }
-    const unsigned grid = (unsigned)ceil_div(n_rows, 64);
+    const unsigned grid = (unsigned)ceil_div(n_rows, 128);
     const int cw = 16 / dtype_bytes;
     const int vec = (((uintptr_t)Xd) % 16 == 0) && (ldd % cw == 0) && (n_features % cw == 0);
     const int npw = (int)std::min<msm_idx_t>(8, ceil_div(k, 4));  // components per wave
