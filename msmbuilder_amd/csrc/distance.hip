@@ -29,7 +29,6 @@ namespace msm {
 constexpr int DT = 256;  // threads = rows per tile
 constexpr int CJ = 8;    // centres per register tile
 constexpr int KC_MAXBLK = 1024;
-constexpr int KC_PRUNE_MAX = 1024;  // centre-to-centre distances kept in LDS for triangle pruning
 
 template <typename T> struct FeatChunk;
 template <> struct FeatChunk<float> { static constexpr int FC = 32; };
@@ -312,7 +311,6 @@ struct KcArgs {
     msm_idx_t* labels;
     msm_idx_t* ids;         // device [K]
     int vecw;               // > 0: rows in registers (m <= FC), vector width in bytes
-    int prune;              // triangle-inequality pruning enabled (true metrics only)
 };
 
 __device__ __forceinline__ bool kc_better(double v, long long i, double bv, long long bi)
@@ -362,29 +360,6 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
     if (blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
     const T* y = X + cidx * P.m;
 
-    // Triangle-inequality pruning (exactness-preserving): for a true metric,
-    //   d(x, c_new) >= d(c_new, c_lab(x)) - d(x, c_lab(x)),
-    // so whenever d(c_new, c_lab) >= 2 d(x, c_lab) (with a margin far above the rounding error of
-    // the computed distances) the strict `d < distances_` test of kcenters.py:93 cannot succeed
-    // and the row need not be read at all: distances_ / labels_ / the argmax are unchanged, i.e.
-    // results stay bit-identical to the reference while late passes touch 16 instead of
-    // 16 + m*sizeof(T) bytes per row.
-    constexpr bool kMetricOK = (M == M_EUCLIDEAN || M == M_SQEUCLIDEAN || M == M_CITYBLOCK || M == M_CHEBYSHEV);
-    __shared__ double Dl[kMetricOK ? KC_PRUNE_MAX : 1];
-    const bool prune = kMetricOK && P.prune && P.it > 0 && P.it <= KC_PRUNE_MAX;
-    if (prune) {
-        for (int j = tid; j < P.it; j += DT) {
-            const T* cj = X + P.ids[j] * P.m;
-            double a = 0.0, b = 0.0;
-            for (long long f = 0; f < P.m; ++f) m_update<T, M>(a, b, y[f], cj[f]);
-            Dl[j] = m_final<M>(a, b, P.m);
-        }
-        __syncthreads();
-    }
-    // computed distances carry the rounding of the float subtraction (2^-24 relative) for f32 data
-    const double margin = (sizeof(T) == 4) ? (1.0 + 1e-6) : (1.0 + 1e-9);
-    const double pfac = (M == M_SQEUCLIDEAN ? 4.0 : 2.0) * margin;
-
     double bv = -1.0;
     long long bi = -1;
     const long long ntile = (P.n + DT - 1) / DT;
@@ -397,23 +372,15 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         const long long row0 = t * DT;
         const long long i = row0 + tid;
         double a = 0.0, b = 0.0;
-        double cur0 = INFINITY;
-        bool skip = false;
-        if (prune && i < P.n) {
-            cur0 = P.dist[i];
-            skip = Dl[P.labels[i]] >= pfac * cur0;
-        }
         if (P.vecw > 0) {
-            if (!skip) {
-                T x[FC];
-                load_row_regs<T>(x, X + (i < P.n ? i : P.n - 1) * P.m, (int)P.m, P.vecw);
+            T x[FC];
+            load_row_regs<T>(x, X + (i < P.n ? i : P.n - 1) * P.m, (int)P.m, P.vecw);
 #pragma unroll
-                for (int g = 0; g < FC / 4; ++g)
-                    if (g * 4 < P.m) {
+            for (int g = 0; g < FC / 4; ++g)
+                if (g * 4 < P.m) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) m_update<T, M>(a, b, x[g * 4 + q], ys[g * 4 + q]);
-                    }
-            }
+                    for (int q = 0; q < 4; ++q) m_update<T, M>(a, b, x[g * 4 + q], ys[g * 4 + q]);
+                }
         } else
         for (int f0 = 0; f0 < P.m; f0 += FC) {
             const int fw = (int)((P.m - f0) < FC ? (P.m - f0) : FC);
@@ -424,8 +391,8 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
             for (int ff = 0; ff < fw; ++ff) m_update<T, M>(a, b, Xs[tid * (FC + 1) + ff], ys[ff]);
         }
         if (i < P.n) {
-            const double d = skip ? INFINITY : m_final<M>(a, b, P.m);
-            double cur = (P.it == 0) ? INFINITY : (prune ? cur0 : P.dist[i]);  // distances_.fill(inf), kcenters.py:87-88
+            const double d = m_final<M>(a, b, P.m);
+            double cur = (P.it == 0) ? INFINITY : P.dist[i];  // distances_.fill(inf), kcenters.py:87-88
             const bool upd = d < cur;                          // strict, kcenters.py:93
             if (upd) cur = d;
             if (P.it == 0 || upd) {
@@ -691,10 +658,6 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         P.dist = dDist.as<double>();
     }
     P.vecw = row_vecw<T>(P.X, m, false);
-    {
-        const char* e = getenv("MSM_KCENTERS_PRUNE");  // A/B switch for profiling; default on
-        P.prune = e ? atoi(e) : 1;
-    }
     KcPartial* part = dPart.as<KcPartial>();
     for (msm_idx_t it = 0; it < K; ++it) {
         P.it = (int)it;
