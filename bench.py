@@ -193,6 +193,13 @@ def main():
         flops = 4.0 * F * F * frames                     # algorithmic: 2 dense F x F rank-1 updates per frame
         achieved = flops / (mfma_ms * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if args.mode == "f32" else PEAK_F64_MFMA_TFLOPS
+        traffic = None   # PMC counters need their own rocprofv3 pass: read the committed measurement
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["tica_mfma_%s_kernel" % args.mode]
+            if tj["workload"].startswith("%dx%d " % (frames, F)):
+                traffic = tj["bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "frames/sec tICA fit + KCenters assign, 10M x 512 feats",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,7 +212,9 @@ def main():
                        "n_components": args.components, "n_clusters": args.clusters,
                        "parallelism": "frames sharded x%d, 1 all-reduce" % world},
             "roofline": {"bound": "mfma", "kernel": "tica_mfma_%s_kernel" % args.mode, "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": "bytes/launch at the L2 fabric side (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC pass, "
+                                         "profiles/traffic.json); includes Infinity-Cache hits; algorithmic bytes/launch = %d" % (frames * F * 4),
                          "kernel_ms": mfma_ms, "algorithmic_flop_per_frame": 4 * F * F,
                          "tica_accumulate_frames_per_s": frames / (mfma_ms * 1e-3)},
             "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k != "mfma_ms"},
