@@ -55,6 +55,7 @@ struct TicaArgs {
     double* slabs;    // [S*ntiles][TM*TM] fp64, owned per workgroup
     double* colpart;  // [NCB][2][F] fp64 partial column sums (temporary buffer)
     int* flag;        // sticky non-finite flag
+    unsigned* cosync; // [S] per-cohort arrival counters (zeroed per launch): keeps a cohort's workgroups within one chunk of each other
     long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
     int ablate;       // profiling only (MSM_TICA_ABLATE): 1 skip global->LDS restaging, 2 skip barriers, 4 skip LDS fragment reads
 };
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
     int rows_acc = 0;
+    int chunks_done = 0;
     if (P.dbg && blockIdx.x == 0 && tid == 0) {
         P.dbg[0] = clock64();
         P.dbg[2] = wall_clock64();
@@ -253,6 +255,16 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         stage_load32<VEC4>(st0, cx, P.F, 0, isG, tauB, I0, J0, tid);
         stage_store32<VEC4, PARTIAL>(st0, As, Bs, tid, ma, mb);
         stage_load32<VEC4>(st0, cx, P.F, BK32, isG, tauB, I0, J0, tid);
+        if (P.cosync && !(P.ablate & 32) && chunks_done > 0) {
+            if (tid == 0) {
+                const unsigned target = (unsigned)P.ntiles * (unsigned)chunks_done;
+                const long long t0 = clock64();
+                while (__hip_atomic_load(P.cosync + cohort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    if (clock64() - t0 > 200000) break;  // ~90 us: give up, never hang
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
         __syncthreads();
 #define MSM_TICA_STEP(SNEXT, SLOAD, BUF)                                                          \
         {                                                                                         \
@@ -289,6 +301,17 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
             --s;
         }
 #undef MSM_TICA_STEP
+        // Cohort pacing.  The cohort's workgroups read the SAME frames; left alone they drift apart
+        // by more than the 4 MB L2 holds and every panel is re-fetched from the Infinity Cache
+        // (measured 10x the algorithmic bytes).  A relaxed arrival counter per cohort, waited on
+        // at chunk boundaries, keeps them within one chunk of each other.  No data is exchanged
+        // (no fences needed) and the wait is BOUNDED: if a member is not resident the others
+        // simply run on, so this can cost performance but never correctness or liveness.
+        if (P.cosync && !(P.ablate & 32)) {
+            ++chunks_done;  // arrive now, wait later (after the slab merge and the next chunk's prologue)
+            if (tid == 0)
+                __hip_atomic_fetch_add(P.cosync + cohort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // fp64 merge of the fp32 partial into the workgroup's private slab, once <= KFLUSH frames
         // are in the registers.  Per 64x32 half all 32 loads are issued before the first add/store
         // (a plain `*q += x` loop compiles to 64 dependent round trips); addresses are a
@@ -668,6 +691,7 @@ struct msm_tica {
     double* packed = nullptr;   // [2FF+2F+2] export scratch
     int* flag = nullptr;        // [2]: [0] sticky, [1] per-call
     long long* dbg = nullptr;   // [4] profiling clocks
+    unsigned* cosync = nullptr; // [S] cohort pacing counters
     long long n_obs = 0, n_seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
     bool timed = false;
@@ -745,6 +769,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     P.colpart = h->coltmp;
     P.flag = h->flag;
     P.dbg = h->dbg;
+    {
+        // measured (10M x 512): pacing cuts the L2 fabric-side fetch from 207 GB to 79-82 GB per launch but
+        // makes the kernel 4 % slower (78.4 -> 81.7 ms), so it is opt-in
+        const char* e = getenv("MSM_TICA_COHORT_PACING");
+        P.cosync = (e && atoi(e)) ? h->cosync : nullptr;
+    }
     { const char* ab = getenv("MSM_TICA_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
 
     if (nvalid == 1 && n_seq == 1) {
@@ -804,6 +834,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipGetLastError());
     }
     // 2) the MFMA pass
+    MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(h->S + 1) * sizeof(unsigned), stream()));
     if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
     if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
         if (aligned && h->F % TM == 0)
@@ -892,6 +923,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->packed, (FF2 + 2) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->flag, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->dbg, 4 * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->cosync, (size_t)(h->S + 1) * sizeof(unsigned));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -918,6 +950,7 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->packed) (void)hipFree(h->packed);
     if (h->flag) (void)hipFree(h->flag);
     if (h->dbg) (void)hipFree(h->dbg);
+    if (h->cosync) (void)hipFree(h->cosync);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
