@@ -91,12 +91,9 @@ int msm_tica_reset(msm_tica_t* h); /* zero all accumulators and counters */
 
 /* One trajectory X[n_rows, n_features] (row stride ld elements), dtype_bytes = 4 (f32) or 8 (f64).
  * Lagged pairs never span calls.  n_rows <= lag_time is a no-op with *skipped = 1
- * (tica.py:410-412).  check_finite == 1: the call synchronises and returns
+ * (tica.py:410-412).  check_finite != 0: the call synchronises and returns
  * MSM_ERR_NONFINITE, state unchanged, if X holds NaN/Inf; check_finite == 0: fully
- * asynchronous, a sticky flag is kept (msm_tica_nonfinite); check_finite == 2: deferred --
- * like 0, and for float32 data in MSM_TICA_F32 mode the column sums and the finite check are
- * fused into the MFMA kernel (no separate pass over X); the caller must query
- * msm_tica_nonfinite() afterwards and reset the handle if it is set (what tICA.fit does). */
+ * asynchronous, a sticky flag is kept (msm_tica_nonfinite). */
 int msm_tica_accumulate(msm_tica_t* h, const void* X, int dtype_bytes, msm_idx_t n_rows,
                         msm_idx_t ld, int on_device, int check_finite, int* skipped);
 /* Many trajectories in one launch: X_ptrs[s] -> n_rows[s] x n_features, common ld.

@@ -55,8 +55,6 @@ struct TicaArgs {
     double* slabs;    // [S*ntiles][TM*TM] fp64, owned per workgroup
     double* colpart;  // [NCB][2][F] fp64 partial column sums (temporary buffer)
     int* flag;        // sticky non-finite flag
-    int fuse;         // 1: diagonal Gram workgroups also produce the column sums and the finite check
-    int edges_only;   // colsum kernel: only the head/tail rows (s0 - stau), for the fused path
     unsigned* cosync; // [S] per-cohort arrival counters (zeroed per launch): keeps a cohort's workgroups within one chunk of each other
     long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
     int ablate;       // profiling only (MSM_TICA_ABLATE): 1 skip global->LDS restaging, 2 skip barriers, 4 skip LDS fragment reads
@@ -181,7 +179,7 @@ __device__ __forceinline__ void stage_load32(Stage32<VEC4>& st, const ChunkCtx& 
 
 template <bool VEC4, bool PARTIAL>
 __device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As, float* Bs, int tid,
-                                              float4 ma, float4 mb, bool check, int& bad)
+                                              float4 ma, float4 mb)
 {
     const int c4 = (tid & 31) * 4;
     const int rr0 = tid >> 5;
@@ -189,8 +187,6 @@ __device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As
     for (int j = 0; j < 4; ++j) {
         const int rr = rr0 + 8 * j;
         const float sc = st.sc[j];
-        if (check)  // validation.py:68-74, fused: the diagonal Gram workgroups see every element once
-            bad |= !(isfinite(st.a[j].x) && isfinite(st.a[j].y) && isfinite(st.a[j].z) && isfinite(st.a[j].w));
         if (PARTIAL) {
             *reinterpret_cast<float4*>(As + rr * TM + c4) =
                 make_float4(st.a[j].x * (sc * ma.x), st.a[j].y * (sc * ma.y), st.a[j].z * (sc * ma.z),
@@ -241,11 +237,6 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
             for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
     int rows_acc = 0;
     int chunks_done = 0;
-    // fused column sums: the diagonal Gram tile (I, I) stages w_t * X[t, I-panel] as its A panel, and
-    // sum_t w_t x_t = s0 + stau (tica.py:418-419).  fp64 accumulator per (column, half), whole kernel.
-    const bool diag = P.fuse && isG && I == J;
-    double cs = 0.0;
-    int bad = 0;
     if (P.dbg && blockIdx.x == 0 && tid == 0) {
         P.dbg[0] = clock64();
         P.dbg[2] = wall_clock64();
@@ -262,7 +253,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         // is about as long as one step, which stalled 16 % of the kernel on vmcnt.
         Stage32<VEC4> st0, st1;
         stage_load32<VEC4>(st0, cx, P.F, 0, isG, tauB, I0, J0, tid);
-        stage_store32<VEC4, PARTIAL>(st0, As, Bs, tid, ma, mb, diag, bad);
+        stage_store32<VEC4, PARTIAL>(st0, As, Bs, tid, ma, mb);
         stage_load32<VEC4>(st0, cx, P.F, BK32, isG, tauB, I0, J0, tid);
         if (P.cosync && !(P.ablate & 32) && chunks_done > 0) {
             if (tid == 0) {
@@ -282,10 +273,6 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
             if (!(P.ablate & 8)) stage_load32<VEC4>(SLOAD, cx, P.F, (s + 2) * BK32, isG, tauB, I0, J0, tid); \
             const float* Ab = As + (BUF) * (BK32 * TM) + kl * TM + wr * 64 + cl;                  \
             const float* Bb = Bs + (BUF) * (BK32 * TM) + kl * TM + wc * 64 + cl;                  \
-            if (diag) {                                                                           \
-                const float* cp = As + (BUF) * (BK32 * TM) + (tid >> 7) * 16 * TM + (tid & 127);  \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) cs += (double)cp[r * TM];          \
-            }                                                                                     \
             /* fragment reads run one k-pair ahead of the MFMAs that consume them */              \
             float a0 = Ab[0], a1 = Ab[32], b0 = Bb[0], b1 = Bb[32];                               \
             _Pragma("unroll 4") for (int kk = 0; kk < BK32 / 2; ++kk) {                           \
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
                 a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                           \
             }                                                                                     \
             if (s + 1 < nsteps && !(P.ablate & 16))                                               \
-                stage_store32<VEC4, PARTIAL>(SNEXT, As + ((BUF) ^ 1) * (BK32 * TM), Bs + ((BUF) ^ 1) * (BK32 * TM), tid, ma, mb, diag, bad); \
+                stage_store32<VEC4, PARTIAL>(SNEXT, As + ((BUF) ^ 1) * (BK32 * TM), Bs + ((BUF) ^ 1) * (BK32 * TM), tid, ma, mb); \
             if (!(P.ablate & 2)) __syncthreads();                                                 \
         }
         for (int s = 0; s < nsteps; s += 2) {
@@ -356,14 +343,6 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
                     }
             }
         }
-    }
-    if (diag) {
-        double* red = reinterpret_cast<double*>(smem);  // the panels are dead (last step ended on a barrier)
-        red[tid] = cs;
-        __syncthreads();
-        if (tid < TM && I0 + tid < P.F)
-            P.colpart[(size_t)cohort * 2 * P.F + I0 + tid] += red[tid] + red[tid + TM];
-        if (bad) atomicOr(P.flag, 1);
     }
     if (P.dbg && blockIdx.x == 0 && tid == 0) {
         P.dbg[1] = clock64();
@@ -506,18 +485,7 @@ __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
                 const TicaChunk ch = get_chunk(P, c);
                 const global_ptr<TIn> X = as_global<TIn>(ch.base);
                 const bool al = vec && ((((uintptr_t)ch.base) & 15) == 0);
-                // edges-only: rows [0, hcut) and [tcut, n) of the chunk are the only ones that matter
-                const long long hc = (P.lag < ch.len - P.lag ? P.lag : ch.len - P.lag) - ch.row0;
-                const long long tc0 = (P.lag > ch.len - P.lag ? P.lag : ch.len - P.lag) - ch.row0;
-                const int hcut = hc < 0 ? 0 : (hc > ch.n ? ch.n : (int)hc);
-                const int tcut = tc0 < 0 ? 0 : (tc0 > ch.n ? ch.n : (int)tc0);
                 for (int k0 = tr; k0 < ch.n; k0 += rl * RU) {
-                    if (P.edges_only && k0 >= hcut && k0 + rl * RU <= tcut) {
-                        // jump over the interior in one go (keep k0 congruent to tr modulo rl*RU)
-                        const int skip = (tcut - k0) / (rl * RU);
-                        if (skip > 0) k0 += (skip - 1) * rl * RU;
-                        continue;
-                    }
                     TIn v[RU][CW];
 #pragma unroll
                     for (int u = 0; u < RU; ++u) {
@@ -540,9 +508,8 @@ __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
                     for (int u = 0; u < RU; ++u) {
                         const int kr = k0 + u * rl;
                         const long long r = ch.row0 + kr;
-                        bool in0 = (kr < ch.n) && (r < ch.len - P.lag);
-                        bool in1 = (kr < ch.n) && (r >= P.lag);
-                        if (P.edges_only && in0 && in1) in0 = in1 = false;  // interior rows cancel in s0 - stau
+                        const bool in0 = (kr < ch.n) && (r < ch.len - P.lag);
+                        const bool in1 = (kr < ch.n) && (r >= P.lag);
 #pragma unroll
                         for (int e = 0; e < CW; ++e) {
                             const double x = (double)v[u][e];
@@ -570,9 +537,8 @@ __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
 #pragma unroll
             for (int e = 0; e < CW; ++e)
                 if (col + e < P.F) {
-                    // stored as (s0 + stau, s0 - stau): the fused MFMA path produces the sum directly
-                    if (!P.edges_only) part[col + e] += s0[e] + st[e];
-                    part[P.F + col + e] += s0[e] - st[e];
+                    part[col + e] += s0[e];
+                    part[P.F + col + e] += st[e];
                 }
         }
         __syncthreads();
@@ -619,14 +585,8 @@ __global__ void tica_export_kernel(const double* __restrict__ slabs, const doubl
         const size_t off = (size_t)(i % TM) * TM + (j % TM);
         for (int s = 0; s < S; ++s) v += slabs[((size_t)s * ntiles + tile) * (TM * TM) + off];
     } else {
-        const size_t e = idx - 2 * FF;  // [s0 | stau]; partials hold (s0 + stau | s0 - stau)
-        const size_t col = e < (size_t)F ? e : e - F;
-        double sum = 0.0, diff = 0.0;
-        for (int b = 0; b < NCB; ++b) {
-            sum += colpart[(size_t)b * 2 * F + col];
-            diff += colpart[(size_t)b * 2 * F + F + col];
-        }
-        v += 0.5 * (e < (size_t)F ? sum + diff : sum - diff);
+        const size_t e = idx - 2 * FF;  // [s0 | stau]
+        for (int b = 0; b < NCB; ++b) v += colpart[(size_t)b * 2 * F + e];
     }
     out[idx] = v;
 }
@@ -851,38 +811,23 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         P.nchunks = (long long)tab.size();
     }
 
-    const bool fused = (check_finite == 2) && use32;
-    P.fuse = fused ? 1 : 0;
-    if (fused) {
-        // deferred validation (fit(): the state was reset, a bad input resets it again): the MFMA
-        // kernel's diagonal Gram workgroups produce s0 + stau and the finite flag; only the 2*lag
-        // edge rows per trajectory are scanned here, for s0 - stau
-        TicaArgs E = P;
-        E.colpart = h->colpart;
-        E.edges_only = 1;
-        if (dtype_bytes == 4)
-            hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), E);
-        else
-            hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), E);
-        MSM_HIP_CHECK(hipGetLastError());
-        P.colpart = h->colpart;
-    } else {
-        // 1) column sums + finite check into the temporary partials
-        if (dtype_bytes == 4)
-            hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), P);
-        else
-            hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), P);
-        MSM_HIP_CHECK(hipGetLastError());
-        if (check_finite) {
-            int f[2] = {0, 0};
-            MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
-            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-            if (f[0]) {
-                MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
-                MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, sizeof(int), stream()));
-                return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
-            }
+    // 1) column sums + finite check into the temporary partials
+    if (dtype_bytes == 4)
+        hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), P);
+    else
+        hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), P);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (check_finite) {
+        int f[2] = {0, 0};
+        MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        if (f[0]) {
+            MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
+            MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, sizeof(int), stream()));
+            return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
         }
+    }
+    {
         const size_t n = (size_t)NCB * 2 * h->F;
         hipLaunchKernelGGL(tica_colmerge_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
                            h->colpart, h->coltmp, n);

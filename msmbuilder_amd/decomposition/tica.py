@@ -299,11 +299,10 @@ class tICA(BaseEstimator, TransformerMixin):
             if not is_device_array(X):
                 group_bytes += int(np.prod(X.shape)) * 8
             if group_bytes >= _BATCH_BYTES or len(group) >= 4096:
-                self._fit_many(group, deferred_check=True)
+                self._fit_many(group)
                 group, group_bytes = [], 0
         if group:
-            self._fit_many(group, deferred_check=True)
-        self._raise_if_nonfinite()
+            self._fit_many(group)
 
         if not self.n_sequences_:
             raise ValueError('All sequences were shorter than '
@@ -332,25 +331,8 @@ class tICA(BaseEstimator, TransformerMixin):
     def _fit(self, X):
         self._fit_many([X])
 
-    def _raise_if_nonfinite(self):
-        """fit() validates the input INSIDE the accumulation kernel (no extra pass over the data);
-        a NaN/Inf anywhere surfaces here as the reference's ValueError (validation.py:68-74) and the
-        half-built model is discarded (fit() had reset it anyway)."""
-        if self._handle is None:
-            return
-        flag = C.c_int(0)
-        check(_lib.lib().msm_tica_nonfinite(self._handle, C.byref(flag)))
-        if flag.value:
-            self._initialized = False
-            self._release()
-            self.n_observations_ = 0
-            self.n_sequences_ = 0
-            raise ValueError("Input contains NaN, infinity or a value too large for dtype('float32').")
-
-    def _fit_many(self, Xs, deferred_check=False):
-        """One launch for a group of trajectories (tica.py:401-424 per trajectory).
-        deferred_check: validate inside the kernel (fit); otherwise validate first and leave the
-        model untouched on failure (partial_fit)."""
+    def _fit_many(self, Xs):
+        """One launch for a group of trajectories (tica.py:401-424 per trajectory)."""
         prepared = []
         for X in Xs:
             X = self._prepare(X)
@@ -384,8 +366,7 @@ class tICA(BaseEstimator, TransformerMixin):
             rows = (C.c_int64 * n)(*[v.shape[0] for v in views])
             skipped = C.c_int64(0)
             check(L.msm_tica_accumulate_batch(self._handle, ptrs, rows, n, nbytes,
-                                              int(self.n_features), int(on_dev), 2 if deferred_check else 1,
-                                              C.byref(skipped)))
+                                              int(self.n_features), int(on_dev), 1, C.byref(skipped)))
             for v in views:
                 self.n_observations_ += v.shape[0]
                 self.n_sequences_ += 1
