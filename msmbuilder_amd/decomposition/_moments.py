@@ -71,6 +71,10 @@ def _blas_threads(F):
     spinning for tens of ms after the call, which starves the thread that is about to enqueue
     hundreds of small kernel launches (measured: the 200 k-centers launches went from 31 ms to
     48-90 ms right after a many-threaded solve)."""
+    import os
+    env = os.environ.get("MSMBUILDER_AMD_SOLVE_THREADS")
+    if env:
+        return max(1, int(env))
     return 1 if F <= 768 else 8
 
 
