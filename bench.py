@@ -127,6 +127,7 @@ def main():
 
     rank, world, local = parallel.init_from_env()
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (got WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
+    local = local % max(1, torch.cuda.device_count())  # identity on a real N-GPU node; lets 2 ranks share 1 GPU in smoke tests
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.ensure_device(local)
@@ -182,9 +183,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = float(parallel.allreduce_array(np.array([elapsed]), op="max")[0])
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps

@@ -56,10 +56,11 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("MSMBUILDER_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
+            local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=r, world_size=world,
                                     device_id=torch.device("cuda", local))
@@ -88,16 +89,16 @@ def _backend_is_nccl(group=None):
     return _dist().get_backend(group) == "nccl"
 
 
-def allreduce_array(a, group=None):
-    """Sum a host float64 numpy array over all ranks; returns the reduced copy."""
+def allreduce_array(a, group=None, op="sum"):
+    """Reduce (sum or max) a host float64 numpy array over all ranks; returns the reduced copy."""
     if not active():
         return a
     import torch
     dist = _dist()
-    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+    t = torch.from_numpy(np.array(a, dtype=np.float64, copy=True))
     if _backend_is_nccl(group):
         t = t.cuda()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
 
 
