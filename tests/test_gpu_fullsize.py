@@ -1,0 +1,187 @@
+"""Parity at BASELINE.json's full (single-GPU) sizes, through the C ABI: either against the
+oracle where it finishes in seconds, or through size-independent properties / an independent
+float64 contraction of the same data computed with torch on the device."""
+import ctypes as C
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _accumulators(m):
+    m._pull()
+    return m._outer_0_to_T_lagged, m._outer_gram_sum, m._sum_0_to_TminusTau, m._sum_tau_to_T
+
+
+@pytest.mark.parametrize("mode,rtol", [("f32", 2e-6), ("f64", 1e-12)])
+def test_config2_tica_1M_x_128_vs_fp64_contraction(gpu, monkeypatch, mode, rtol):
+    """configs[1]: 1M x 128 fp32, lag 100, one trajectory and the same data as 100 trajectories."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    N, F, lag = 1_000_000, 128, 100
+    z = torch.randn(N, 8, generator=g, device="cuda").cumsum(0) * 0.01
+    X = (z @ torch.randn(8, F, generator=g, device="cuda") + torch.randn(N, F, generator=g, device="cuda")
+         + torch.linspace(-2, 2, F, device="cuda")).float().contiguous()
+    Xd = X.double()
+    for n_seq in (1, 100):
+        T = N // n_seq
+        seqs = list(X.view(n_seq, T, F).unbind(0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=5, lag_time=lag).fit(seqs)
+        Cm, Gm, s0, st = _accumulators(m)
+        V = Xd.view(n_seq, T, F)
+        A, B = V[:, :-lag], V[:, lag:]
+        Cr = torch.einsum("sti,stj->ij", A, B).cpu().numpy()
+        Gr = (torch.einsum("sti,stj->ij", A, A) + torch.einsum("sti,stj->ij", B, B)).cpu().numpy()
+        scale = np.abs(Gr).max()
+        np.testing.assert_allclose(Cm, Cr, rtol=0, atol=rtol * scale)
+        np.testing.assert_allclose(Gm, Gr, rtol=0, atol=rtol * scale)
+        np.testing.assert_allclose(s0, A.sum((0, 1)).cpu().numpy(), rtol=1e-11)
+        np.testing.assert_allclose(st, B.sum((0, 1)).cpu().numpy(), rtol=1e-11)
+        assert m.n_observations_ == N and m.n_sequences_ == n_seq
+        assert np.array_equal(Gm, Gm.T)
+        assert np.all(np.diff(m.eigenvalues_) <= 0) and m.eigenvalues_[0] < 1.0 + 1e-9
+
+
+def test_tica_additivity_and_import_export(gpu, monkeypatch):
+    """sum of per-shard exports == one fit over everything (the multi-GPU exchange, single process);
+    import(export(x)) is the identity; shift invariance of the covariance."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    rs = np.random.RandomState(0)
+    seqs = [rs.randn(int(n), 40).astype(np.float32) + 1.5 for n in rs.randint(60, 4000, size=31)]
+    full = tICA(n_components=4, lag_time=50).fit(seqs)
+    parts = [tICA(n_components=4, lag_time=50).fit(seqs[i::4]) for i in range(4)]
+    for k in range(4):
+        ref = _accumulators(full)[k]
+        np.testing.assert_allclose(sum(_accumulators(p)[k] for p in parts), ref, rtol=1e-12, atol=1e-9 * np.abs(ref).max())
+    # merge the shards through the C ABI's packed import/export
+    L = gpu.lib()
+    n = int(L.msm_tica_packed_size(parts[0]._handle))
+    total = np.zeros(n)
+    for p in parts:
+        buf = np.empty(n)
+        gpu.check(L.msm_tica_export_packed(p._handle, C.c_void_p(buf.ctypes.data), 0))
+        total += buf
+    merged = parts[0]
+    gpu.check(L.msm_tica_import_packed(merged._handle, C.c_void_p(total.ctypes.data), 0))
+    merged.n_observations_, merged.n_sequences_ = int(total[-2]), int(total[-1])
+    merged._host_stale = merged._is_dirty = True
+    np.testing.assert_allclose(merged.eigenvalues_, full.eigenvalues_, rtol=1e-11)
+    assert merged.n_observations_ == full.n_observations_
+    # covariance / offset correlation are invariant under a constant shift of the data
+    shifted = tICA(n_components=4, lag_time=50).fit([s + np.float32(8.0) for s in seqs])
+    np.testing.assert_allclose(shifted.eigenvalues_, full.eigenvalues_, rtol=1e-6)
+    np.testing.assert_allclose(shifted.means_ - 8.0, full.means_, atol=1e-6)
+
+
+def test_config3_kcenters_280k_bit_exact(gpu):
+    """configs[2] shape: 280,000 x 10 (tICA space), K = 200: bit-exact against the C oracle."""
+    from msmbuilder_amd import KCenters
+    from oracle.libdistance_oracle import Oracle
+    o = Oracle()
+    rs = np.random.RandomState(3)
+    for dt in (np.float64, np.float32):
+        Y = (rs.randn(280_000, 10) * np.linspace(3, 0.3, 10)).astype(dt)
+        seqs = [Y[i * 10_000:(i + 1) * 10_000] for i in range(28)]
+        m = KCenters(n_clusters=200, random_state=0).fit(seqs)
+        ids, labels, dist = o.kcenters_fit(Y, 200, "euclidean", m.cluster_ids_[0])
+        assert m.cluster_ids_ == list(ids)
+        assert np.array_equal(np.concatenate(m.labels_), labels)
+        assert np.array_equal(np.concatenate(m.distances_), dist)
+        assert m.inertia_ == np.sum(dist)
+        pred = np.concatenate(m.predict(seqs))
+        assert np.array_equal(pred, o.assign_nearest(Y, np.ascontiguousarray(Y[ids]), "euclidean")[0])
+        # size-independent properties: every centre labels itself at distance 0; distances_ are the
+        # distances to the assigned centre; they never exceed the covering radius
+        assert np.array_equal(labels[ids], np.arange(200)) and np.all(dist[ids] == 0)
+        assert np.array_equal(pred, labels)
+
+
+def test_assign_nearest_1M_device_resident_properties(gpu):
+    from msmbuilder_amd import libdistance as ld
+    g = torch.Generator(device="cuda").manual_seed(1)
+    X = torch.randn(1_000_000, 10, generator=g, device="cuda", dtype=torch.float64)
+    Y = X[::5000].contiguous()                       # 200 centres that are data points
+    lab, inertia = ld.assign_nearest(X, Y, "euclidean")
+    d = ld.cdist(X[:50_000], Y, "euclidean")
+    assert torch.equal(lab[:50_000], d.argmin(1))
+    assert torch.equal(lab[::5000], torch.arange(200, device="cuda"))
+    dmin = ld.dist(X, Y[0], "euclidean")
+    assert float(dmin[0]) == 0.0
+    idx = torch.arange(0, 1_000_000, 7, device="cuda")
+    lab_i, _ = ld.assign_nearest(X, Y, "euclidean", idx)
+    assert torch.equal(lab_i, lab[::7])
+    # cityblock against a float64 torch evaluation (different summation order -> tolerance, labels may tie)
+    labc, _ = ld.assign_nearest(X[:50_000].contiguous(), Y, "cityblock")
+    ref = (X[:50_000, None, :] - Y[None]).abs().sum(-1)     # (torch.cdist(p=1) returns garbage here on ROCm)
+    pick = ref.gather(1, labc.view(-1, 1)).squeeze(1)
+    assert torch.all(pick <= ref.min(1).values * (1 + 1e-12))
+
+
+def test_config4_kmeans_label_1M_x_512_k1000(gpu):
+    from msmbuilder_amd.cluster.minibatchkmeans import label_inertia
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Cn = torch.randn(1000, 512, generator=g, device="cuda") * 2
+    X = Cn[torch.randint(0, 1000, (1_000_000,), generator=g, device="cuda")] + torch.randn(1_000_000, 512, generator=g, device="cuda")
+    lab, inertia = label_inertia(X, Cn.cpu().numpy())
+    d2 = torch.cdist(X[:100_000].double(), Cn.double()) ** 2
+    ref = d2.argmin(1)
+    mism = (lab[:100_000].long() != ref).nonzero().flatten()
+    picked = d2[mism, lab[:100_000].long()[mism]]
+    assert torch.all(picked <= d2[mism].min(1).values * (1 + 1e-4))      # only fp32 near-ties may differ
+    assert len(mism) < 100
+    ref_inertia = ((X.double() - Cn.double()[lab.long()]) ** 2).sum().item()
+    assert abs(inertia - ref_inertia) <= 1e-6 * ref_inertia
+
+
+def test_c_abi_direct_without_torch(gpu):
+    """The ABI on its own device buffers: ld > F, check_finite = 0 with the sticky flag, batch table."""
+    L = gpu.lib()
+    rs = np.random.RandomState(5)
+    F, ld, lag = 24, 32, 3
+    host = rs.randn(500, ld).astype(np.float32)
+    dptr = C.c_void_p()
+    gpu.check(L.msm_malloc(C.byref(dptr), host.nbytes))
+    gpu.check(L.msm_memcpy_h2d(dptr, C.c_void_p(host.ctypes.data), host.nbytes))
+    h = C.c_void_p()
+    gpu.check(L.msm_tica_create(C.byref(h), F, lag, gpu.TICA_F64))
+    # two trajectories inside one padded device array + one too-short one
+    ptrs = (C.c_void_p * 3)(dptr.value, dptr.value + 300 * ld * 4, dptr.value + 10 * ld * 4)
+    rows = (C.c_int64 * 3)(300, 200, 3)
+    skipped = C.c_int64(0)
+    gpu.check(L.msm_tica_accumulate_batch(h, ptrs, rows, 3, 4, ld, 1, 0, C.byref(skipped)))
+    assert skipped.value == 1
+    flag = C.c_int(-1)
+    gpu.check(L.msm_tica_nonfinite(h, C.byref(flag)))
+    assert flag.value == 0
+    Cm, Gm, s0, st = np.empty((F, F)), np.empty((F, F)), np.empty(F), np.empty(F)
+    nobs, nseq = C.c_int64(), C.c_int64()
+    gpu.check(L.msm_tica_export(h, Cm.ctypes.data, Gm.ctypes.data, s0.ctypes.data, st.ctypes.data,
+                                C.byref(nobs), C.byref(nseq)))
+    assert (nobs.value, nseq.value) == (500, 2)
+    X = host[:, :F].astype(np.float64)
+    ref = sum(a[:-lag].T @ a[lag:] for a in (X[:300], X[300:]))
+    np.testing.assert_allclose(Cm, ref, rtol=1e-12, atol=1e-10)
+    # non-finite input with check_finite = 1 is rejected and leaves the state alone
+    bad = host.copy()
+    bad[7, 3] = np.inf
+    gpu.check(L.msm_memcpy_h2d(dptr, C.c_void_p(bad.ctypes.data), bad.nbytes))
+    rc = L.msm_tica_accumulate(h, dptr, 4, 300, ld, 1, 1, None)
+    assert rc == gpu.MSM_ERR_NONFINITE and b"NaN" in L.msm_last_error()
+    C2 = np.empty((F, F))
+    gpu.check(L.msm_tica_export(h, C2.ctypes.data, None, None, None, None, None))
+    np.testing.assert_array_equal(C2, Cm)
+    # bad arguments
+    assert L.msm_tica_accumulate(h, dptr, 2, 300, ld, 1, 1, None) == gpu.MSM_ERR_INVALID
+    assert L.msm_tica_accumulate(h, dptr, 4, 300, F - 1, 1, 1, None) == gpu.MSM_ERR_INVALID
+    assert L.msm_tica_create(C.byref(C.c_void_p()), 0, 1, 0) == gpu.MSM_ERR_INVALID
+    out = np.zeros(4)
+    assert L.msm_dist_f32(dptr, dptr, b"manhattan", 4, 2, None, 0, C.c_void_p(out.ctypes.data), 0) == gpu.MSM_ERR_METRIC
+    gpu.check(L.msm_tica_destroy(h))
+    gpu.check(L.msm_free(dptr))
