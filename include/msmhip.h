@@ -167,6 +167,18 @@ int msm_kcenters_fit_f64(const double* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_
                          const char* metric, msm_idx_t seed_index, msm_idx_t* ids,
                          msm_idx_t* labels, double* distances, double* inertia, int on_device);
 
+/* One externally driven k-centers pass for row-sharded data (one process per GPU): the centre's
+ * coordinates y (host, m values; it may live on another rank) are supplied, distances_/labels_
+ * (device) get the strict running-min update with label `it`, and the shard-local
+ * (max distance, lowest local row attaining it, that row's m coordinates -- host, nullable)
+ * come back for the cross-rank argmax: one small D2H per pass. */
+int msm_kcenters_pass_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* y, msm_idx_t it,
+                          const char* metric, msm_idx_t* labels, double* distances, double* max_dist,
+                          msm_idx_t* argmax, float* argmax_row, int on_device);
+int msm_kcenters_pass_f64(const double* X, msm_idx_t n, msm_idx_t m, const double* y, msm_idx_t it,
+                          const char* metric, msm_idx_t* labels, double* distances, double* max_dist,
+                          msm_idx_t* argmax, double* argmax_row, int on_device);
+
 /* ---- k-means labelling / mini-batch step (fp32, GEMM form on MFMA) ---- */
 /* labels[i] = argmin_j ||X[i]-C[j]||^2 computed as ||c||^2 - 2 x.c (+||x||^2 for the
  * inertia), fp32 like scikit-learn's _labels_inertia; centers host [K, m].

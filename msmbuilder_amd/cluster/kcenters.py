@@ -68,12 +68,15 @@ class _KCenters(ClusterMixin, TransformerMixin):
 
     def fit(self, X, y=None):
         X = _as_float(X)
-        n_samples = len(X)
-        seed = check_random_state(self.random_state).randint(0, n_samples)
         metric = self.metric.decode() if isinstance(self.metric, bytes) else self.metric
         if metric not in libdistance.VECTOR_METRICS:
             raise ValueError('metric must be one of %s' %
                              ', '.join("'%s'" % s for s in libdistance.VECTOR_METRICS))
+        from .. import parallel
+        if parallel.active():
+            return self._fit_sharded(X, metric)
+        n_samples = len(X)
+        seed = check_random_state(self.random_state).randint(0, n_samples)
         ax = Arr(X)
         if len(ax.shape) != 2:
             raise ValueError("X must be 2-dimensional")
@@ -94,6 +97,61 @@ class _KCenters(ClusterMixin, TransformerMixin):
         # np.sum(distances_) as in kcenters.py:101 on the host; on the device the kernel's
         # fp64 tree sum of the same values
         self.inertia_ = np.sum(distances) if not ax.on_device else float(inertia.value)
+        return self
+
+    def _fit_sharded(self, X, metric):
+        """Row-sharded k-centers (one process per GPU): X is THIS rank's block of rows, ranks own
+        consecutive blocks of the global array.  Every pass runs locally on each rank; two tiny
+        all-reduces per centre exchange the (max distance, global row) candidates and the winner's
+        coordinates.  Results equal the single-process fit of the concatenated data bit for bit
+        (ties go to the lowest GLOBAL row, numpy's argmax).  labels_/distances_ stay sharded."""
+        from .. import parallel
+        import torch
+        if isinstance(X, np.ndarray):
+            X = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+        ax = Arr(X)
+        n_local, m = ax.shape
+        shard = parallel.RowShard(n_local)
+        kind = "f64" if ax.dtype == np.float64 else "f32"
+        K = int(self.n_clusters)
+        world, rank = parallel.world_size(), parallel.rank()
+        # rank 0's draw decides (random_state=None would differ per process)
+        seed = check_random_state(self.random_state).randint(0, shard.n_total)
+        seed = int(parallel.allreduce_array(np.array([float(seed) if rank == 0 else 0.0]))[0])
+        labels = empty_like_placement(ax, (n_local,), np.int64)
+        distances = empty_like_placement(ax, (n_local,), np.float64)
+        al, ad = Arr(labels, np.int64), Arr(distances, np.float64)
+        fn = getattr(_lib.lib(), "msm_kcenters_pass_" + kind)
+        fetch = lambda loc: ax.keep[torch.as_tensor(loc, device=ax.keep.device)].cpu().numpy()
+        ids, centers = [], []
+        c = seed
+        y = np.ascontiguousarray(shard.gather_rows(fetch, np.array([c]), m, dtype=ax.dtype)[0])
+        for it in range(K):
+            lmax, larg = C.c_double(-1.0), C.c_int64(-1)
+            lrow = np.zeros(m, dtype=ax.dtype)
+            if n_local > 0:
+                check(fn(ax.vp, n_local, m, y.ctypes.data, it, metric.encode(), al.vp, ad.vp,
+                         C.byref(lmax), C.byref(larg), lrow.ctypes.data, 1))
+            ids.append(int(c))
+            centers.append(y)
+            # ONE all-reduce per centre: every rank contributes (max, global row, that row's coordinates)
+            cand = np.zeros((world, 2 + m))
+            cand[rank, 0] = lmax.value if larg.value >= 0 else -1.0
+            cand[rank, 1] = float(shard.offset + larg.value) if larg.value >= 0 else -1.0
+            cand[rank, 2:] = lrow
+            cand = parallel.allreduce_array(cand.ravel()).reshape(world, 2 + m)
+            ok = cand[:, 1] >= 0
+            best = cand[ok, 0].max()
+            win = np.nonzero(ok & (cand[:, 0] == best))[0]
+            w = win[np.argmin(cand[win, 1])]                     # first occurrence of the maximum
+            c = int(cand[w, 1])
+            y = np.ascontiguousarray(cand[w, 2:].astype(ax.dtype))   # float32 coordinates are exact in float64
+        self.labels_ = labels
+        self.distances_ = distances
+        self.cluster_ids_ = ids
+        self.cluster_centers_ = np.stack(centers).astype(ax.dtype)
+        local_sum = float(distances.sum().item()) if n_local else 0.0
+        self.inertia_ = float(parallel.allreduce_array(np.array([local_sum]))[0])
         return self
 
     def predict(self, X):

@@ -311,6 +311,8 @@ struct KcArgs {
     msm_idx_t* labels;
     msm_idx_t* ids;         // device [K]
     int vecw;               // > 0: rows in registers (m <= FC), vector width in bytes
+    const void* ycenter;    // non-null: explicit centre coordinates (device, m values) instead of X[argmax];
+                            // used by the sharded driver, where the centre may live on another rank
 };
 
 __device__ __forceinline__ bool kc_better(double v, long long i, double bv, long long bi)
@@ -331,8 +333,10 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
     const int tid = threadIdx.x;
 
     // ---- prologue: centre of this pass ----
-    long long cidx;
-    if (P.it == 0) {
+    long long cidx = 0;
+    if (P.ycenter) {
+        // centre supplied by the host (multi-rank driver): nothing to reduce
+    } else if (P.it == 0) {
         cidx = P.seed;
     } else {
         double bv = -1.0;
@@ -357,8 +361,8 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         cidx = ri[0];
         __syncthreads();
     }
-    if (blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
-    const T* y = X + cidx * P.m;
+    if (!P.ycenter && blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
+    const T* y = P.ycenter ? static_cast<const T*>(P.ycenter) : X + cidx * P.m;
 
     double bv = -1.0;
     long long bi = -1;
@@ -425,6 +429,45 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         q.i = ri[0];
         P.next[blockIdx.x] = q;
     }
+}
+
+// sharded driver: reduce the per-block partials of one pass to (max, lowest row) and fetch that row
+template <typename T>
+__global__ __launch_bounds__(DT) void kc_finalize_kernel(const KcPartial* __restrict__ part, int nblk,
+                                                         const T* __restrict__ X, long long m,
+                                                         KcPartial* __restrict__ best, T* __restrict__ row)
+{
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    const int tid = threadIdx.x;
+    double bv = -1.0;
+    long long bi = -1;
+    for (int k = tid; k < nblk; k += DT) {
+        const KcPartial q = part[k];
+        if (q.i >= 0 && (bi < 0 || kc_better(q.v, q.i, bv, bi))) {
+            bv = q.v;
+            bi = q.i;
+        }
+    }
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int s = DT / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const long long oi = ri[tid + s];
+            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + s], oi, rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + s];
+                ri[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        best->v = rv[0];
+        best->i = ri[0];
+    }
+    if (ri[0] >= 0)
+        for (long long f = tid; f < m; f += DT) row[f] = X[ri[0] * m + f];
 }
 
 // deterministic per-block fp64 sums of a vector (inertia = np.sum(distances_))
@@ -679,11 +722,78 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     return MSM_OK;
 }
 
+// One externally driven pass (multi-rank k-centers): centre coordinates come from the host,
+// the local (max distance, lowest local row) comes back.
+template <typename T>
+int kcenters_pass_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y, msm_idx_t it, const char* metric,
+                       msm_idx_t* labels, double* distances, double* max_dist, msm_idx_t* argmax,
+                       T* argmax_row, int on_device)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!X || !y || !labels || !distances || !max_dist || !argmax) return fail(MSM_ERR_INVALID, "kcenters_pass: null pointer");
+    if (n < 1 || m < 1 || it < 0) return fail(MSM_ERR_INVALID, "kcenters_pass: bad shape");
+    if (!on_device) return fail(MSM_ERR_INVALID, "kcenters_pass: per-row arrays must be device resident");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    int rc;
+    DevBuf &dPart = pool(PS_PART), &dY = pool(PS_Y), &dIds = pool(PS_IDS);
+    const int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
+    if ((rc = dPart.reserve((size_t)nblk * sizeof(KcPartial)))) return rc;
+    if ((rc = dY.reserve((size_t)m * sizeof(T)))) return rc;
+    if ((rc = dIds.reserve(sizeof(msm_idx_t)))) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(dY.p, y, (size_t)m * sizeof(T), hipMemcpyHostToDevice, stream()));
+    KcArgs P;
+    memset(&P, 0, sizeof(P));
+    P.X = X;
+    P.n = n;
+    P.m = m;
+    P.it = (int)it;
+    P.nblk = nblk;
+    P.next = dPart.as<KcPartial>();
+    P.prev = nullptr;
+    P.dist = distances;
+    P.labels = labels;
+    P.ids = dIds.as<msm_idx_t>();
+    P.ycenter = dY.p;
+    P.vecw = row_vecw<T>(P.X, m, false);
+    launch_kc<T>(mid, nblk, P);
+    MSM_HIP_CHECK(hipGetLastError());
+    // device-side final reduce + fetch of the winning row: ONE small D2H per pass
+    DevBuf& dBest = pool(PS_SUM);
+    if ((rc = dBest.reserve(sizeof(KcPartial) + (size_t)m * sizeof(T)))) return rc;
+    KcPartial* dbest = dBest.as<KcPartial>();
+    T* drow = reinterpret_cast<T*>(dbest + 1);
+    hipLaunchKernelGGL((kc_finalize_kernel<T>), dim3(1), dim3(DT), 0, stream(), P.next, nblk, X, (long long)m, dbest, drow);
+    MSM_HIP_CHECK(hipGetLastError());
+    std::vector<char> hb(sizeof(KcPartial) + (size_t)m * sizeof(T));
+    MSM_HIP_CHECK(hipMemcpyAsync(hb.data(), dbest, hb.size(), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    const KcPartial* hp = reinterpret_cast<const KcPartial*>(hb.data());
+    *max_dist = hp->v;
+    *argmax = hp->i;
+    if (argmax_row && hp->i >= 0) memcpy(argmax_row, hb.data() + sizeof(KcPartial), (size_t)m * sizeof(T));
+    return MSM_OK;
+}
+
 }  // namespace msm
 
 using namespace msm;
 
 extern "C" {
+
+int msm_kcenters_pass_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* y, msm_idx_t it,
+                          const char* metric, msm_idx_t* labels, double* distances, double* max_dist,
+                          msm_idx_t* argmax, float* argmax_row, int on_device)
+{
+    return kcenters_pass_impl<float>(X, n, m, y, it, metric, labels, distances, max_dist, argmax, argmax_row, on_device);
+}
+
+int msm_kcenters_pass_f64(const double* X, msm_idx_t n, msm_idx_t m, const double* y, msm_idx_t it,
+                          const char* metric, msm_idx_t* labels, double* distances, double* max_dist,
+                          msm_idx_t* argmax, double* argmax_row, int on_device)
+{
+    return kcenters_pass_impl<double>(X, n, m, y, it, metric, labels, distances, max_dist, argmax, argmax_row, on_device);
+}
 
 int msm_dist_f32(const float* X, const float* y, const char* metric, msm_idx_t n, msm_idx_t m,
                  const msm_idx_t* X_indices, msm_idx_t n_X_indices, double* out, int on_device)
