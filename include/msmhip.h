@@ -24,6 +24,7 @@
  *   msm_dist_*        libdistance/src/dist.hpp:4-80     (via libdistance.pyx:229-270)
  *   msm_cdist_*       libdistance/src/cdist.hpp:4-49    (via libdistance.pyx:134-179)
  *   msm_assign_nearest_*  libdistance/src/assign.hpp:6-91 (via libdistance.pyx:82-131)
+ *   msm_pdist_* / msm_sumdist_*  libdistance/src/pdist.hpp:4-88, sumdist.hpp:4-44 (via libdistance.pyx:182-226, 273-310)
  *   msm_kcenters_fit_*    cluster/kcenters.py:79-102 (_KCenters.fit's k-pass loop)
  *   msm_kmeans_* / msm_mbk_*  sklearn MiniBatchKMeans arithmetic behind
  *                     cluster/__init__.py:67-69 (third-party)
@@ -145,6 +146,17 @@ int msm_cdist_f32(const float* XA, const float* XB, const char* metric, msm_idx_
                   msm_idx_t nb, msm_idx_t m, double* out, int on_device);
 int msm_cdist_f64(const double* XA, const double* XB, const char* metric, msm_idx_t na,
                   msm_idx_t nb, msm_idx_t m, double* out, int on_device);
+/* pdist.hpp:4-88: condensed upper triangle of the (indexed) rows, out has n(n-1)/2 entries;
+ * sumdist.hpp:4-44: sum over the listed pairs (pairs is [p][2], follows on_device; the reference
+ * sums sequentially, here an fp64 tree sum). */
+int msm_pdist_f32(const float* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* X_indices,
+                  msm_idx_t n_X_indices, double* out, int on_device);
+int msm_pdist_f64(const double* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* X_indices,
+                  msm_idx_t n_X_indices, double* out, int on_device);
+int msm_sumdist_f32(const float* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* pairs,
+                    msm_idx_t p, double* sum, int on_device);
+int msm_sumdist_f64(const double* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* pairs,
+                    msm_idx_t p, double* sum, int on_device);
 /* assignments[i] = argmin_j metric(X[i or X_indices[i]], Y[j]); min_dist nullable;
  * *inertia = sum_i min_dist[i] (fp64 tree sum; the reference sums sequentially). */
 int msm_assign_nearest_f32(const float* X, const float* Y, const char* metric,

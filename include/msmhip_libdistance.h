@@ -2,8 +2,8 @@
  * msmhip_libdistance.h -- the reference's own native seam, re-exported.
  *
  * These are, name for name and argument for argument, the functions that
- * /root/reference/msmbuilder/libdistance/libdistance.pyx:26-62 declares
- * `cdef extern ... nogil` from assign.hpp / dist.hpp / cdist.hpp.  A maintainer
+ * /root/reference/msmbuilder/libdistance/libdistance.pyx:26-67 declares
+ * `cdef extern ... nogil` from assign.hpp / dist.hpp / cdist.hpp / pdist.hpp / sumdist.hpp.  A maintainer
  * swaps the three `cdef extern from "....hpp"` blocks for
  * `cdef extern from "msmhip_libdistance.h"` and links libmsmhip.so (see
  * INTEGRATION.md); nothing else in libdistance.pyx changes.
@@ -56,6 +56,19 @@ void cdist_double(const double* XA, const double* XB, const char* metric, msm_np
                   msm_npy_intp nb, msm_npy_intp m, double* out);
 void cdist_float(const float* XA, const float* XB, const char* metric, msm_npy_intp na,
                  msm_npy_intp nb, msm_npy_intp m, double* out);
+
+/* pdist.hpp:4-88 */
+void pdist_double(const double* X, const char* metric, msm_npy_intp n, msm_npy_intp m, double* out);
+void pdist_float(const float* X, const char* metric, msm_npy_intp n, msm_npy_intp m, double* out);
+void pdist_double_X_indices(const double* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                            const msm_npy_intp* X_indices, msm_npy_intp n_X_indices, double* out);
+void pdist_float_X_indices(const float* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                           const msm_npy_intp* X_indices, msm_npy_intp n_X_indices, double* out);
+/* sumdist.hpp:4-44 (returns -1 for an unknown metric or any failure) */
+double sumdist_double(const double* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                      const msm_npy_intp* pairs, msm_npy_intp p);
+double sumdist_float(const float* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                     const msm_npy_intp* pairs, msm_npy_intp p);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,8 @@ def _declare(lib):
 
     for sfx in ("f32", "f64"):
         f("msm_dist_" + sfx, C.c_int, _p, _p, C.c_char_p, _i64, _i64, _p, _i64, _p, C.c_int)
+        f("msm_pdist_" + sfx, C.c_int, _p, C.c_char_p, _i64, _i64, _p, _i64, _p, C.c_int)
+        f("msm_sumdist_" + sfx, C.c_int, _p, C.c_char_p, _i64, _i64, _p, _i64, _f64p, C.c_int)
         f("msm_cdist_" + sfx, C.c_int, _p, _p, C.c_char_p, _i64, _i64, _i64, _p, C.c_int)
         f("msm_assign_nearest_" + sfx, C.c_int, _p, _p, C.c_char_p, _p, _i64, _i64, _i64, _i64, _p, _p,
           _f64p, C.c_int)

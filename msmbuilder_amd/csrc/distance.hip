@@ -470,6 +470,73 @@ __global__ __launch_bounds__(DT) void kc_finalize_kernel(const KcPartial* __rest
         for (long long f = tid; f < m; f += DT) row[f] = X[ri[0] * m + f];
 }
 
+// ---------------------------------------------------------------------------
+// pdist (pdist.hpp:4-88): condensed upper triangle, row i -> out[i*n - i(i+1)/2 + (j-i-1)], and
+// sumdist (sumdist.hpp:4-44): sum of metric over a pair list.  Same exact per-pair arithmetic:
+// one lane per pair, features in order, one fp64 accumulator.  Row i is staged in LDS (broadcast
+// reads); lane j walks its own row.
+// ---------------------------------------------------------------------------
+struct PdArgs {
+    const void* X;
+    const msm_idx_t* X_indices;  // nullable
+    long long n, m;              // n = number of (indexed) rows
+    double* out;
+    const msm_idx_t* pairs;      // sumdist: [p][2]
+    long long p;
+    double* partial;             // sumdist: per-block sums
+};
+
+template <typename T, int M>
+__global__ __launch_bounds__(DT) void pdist_kernel(PdArgs P)
+{
+    constexpr int UC = 1024;  // features of row i kept in LDS per sweep
+    __shared__ T us[UC];
+    const T* X = static_cast<const T*>(P.X);
+    const int tid = threadIdx.x;
+    for (long long ii = blockIdx.x; ii < P.n - 1; ii += gridDim.x) {
+        const long long i = P.X_indices ? P.X_indices[ii] : ii;
+        const long long base = ii * P.n - ii * (ii + 1) / 2 - ii - 1;  // + jj gives the condensed index
+        for (long long jj0 = ii + 1; jj0 < P.n; jj0 += DT) {
+            const long long jj = jj0 + tid;
+            const long long j = (jj < P.n) ? (P.X_indices ? P.X_indices[jj] : jj) : 0;
+            double a = 0.0, b = 0.0;
+            for (long long f0 = 0; f0 < P.m; f0 += UC) {
+                const int fw = (int)((P.m - f0) < UC ? (P.m - f0) : UC);
+                __syncthreads();
+                for (int f = tid; f < fw; f += DT) us[f] = X[i * P.m + f0 + f];
+                __syncthreads();
+                if (jj < P.n) {
+                    const T* v = X + j * P.m + f0;
+                    for (int f = 0; f < fw; ++f) m_update<T, M>(a, b, us[f], v[f]);
+                }
+            }
+            if (jj < P.n) P.out[base + jj] = m_final<M>(a, b, P.m);
+        }
+    }
+}
+
+template <typename T, int M>
+__global__ __launch_bounds__(DT) void sumdist_kernel(PdArgs P)
+{
+    __shared__ double red[DT];
+    const T* X = static_cast<const T*>(P.X);
+    double s = 0.0;
+    for (long long k = (long long)blockIdx.x * DT + threadIdx.x; k < P.p; k += (long long)gridDim.x * DT) {
+        const T* u = X + P.pairs[2 * k] * P.m;
+        const T* v = X + P.pairs[2 * k + 1] * P.m;
+        double a = 0.0, b = 0.0;
+        for (long long f = 0; f < P.m; ++f) m_update<T, M>(a, b, u[f], v[f]);
+        s += m_final<M>(a, b, P.m);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) P.partial[blockIdx.x] = red[0];
+}
+
 // deterministic per-block fp64 sums of a vector (inertia = np.sum(distances_))
 __global__ __launch_bounds__(DT) void sum_partial_kernel(const double* __restrict__ v, long long n,
                                                          double* __restrict__ partial)
@@ -528,6 +595,29 @@ void launch_kc(int metric, int grid, const KcArgs& P)
 #define MSM_CASE(MM)                                                                              \
     case MM:                                                                                      \
         hipLaunchKernelGGL((kcenters_pass_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P);  \
+        break;
+    switch (metric) {
+        MSM_CASE(M_EUCLIDEAN)
+        MSM_CASE(M_SQEUCLIDEAN)
+        MSM_CASE(M_CITYBLOCK)
+        MSM_CASE(M_CHEBYSHEV)
+        MSM_CASE(M_CANBERRA)
+        MSM_CASE(M_BRAYCURTIS)
+        MSM_CASE(M_HAMMING)
+        MSM_CASE(M_JACCARD)
+    }
+#undef MSM_CASE
+}
+
+template <typename T, int WHICH>
+void launch_pd(int metric, int grid, const PdArgs& P)
+{
+#define MSM_CASE(MM)                                                                              \
+    case MM:                                                                                      \
+        if (WHICH == 0)                                                                           \
+            hipLaunchKernelGGL((pdist_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P);      \
+        else                                                                                      \
+            hipLaunchKernelGGL((sumdist_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P);    \
         break;
     switch (metric) {
         MSM_CASE(M_EUCLIDEAN)
@@ -722,6 +812,84 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     return MSM_OK;
 }
 
+template <typename T>
+int pdist_impl(const T* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* X_indices,
+               msm_idx_t n_idx, double* out, int on_device)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!X || !out) return fail(MSM_ERR_INVALID, "pdist: null pointer");
+    if (n < 0 || m < 1) return fail(MSM_ERR_INVALID, "pdist: bad shape");
+    const long long nn = X_indices ? n_idx : n;
+    if (nn < 2) return MSM_OK;
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    int rc;
+    DevBuf &dX = pool(PS_X), &dIdx = pool(PS_IDX), &dOut = pool(PS_OUT);
+    const size_t npairs = (size_t)nn * (size_t)(nn - 1) / 2;
+    PdArgs P;
+    memset(&P, 0, sizeof(P));
+    P.n = nn;
+    P.m = m;
+    if (on_device) {
+        P.X = X;
+        P.X_indices = X_indices;
+        P.out = out;
+    } else {
+        if ((rc = dX.reserve((size_t)n * m * sizeof(T)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        P.X = dX.p;
+        if (X_indices) {
+            if ((rc = dIdx.reserve((size_t)nn * sizeof(msm_idx_t)))) return rc;
+            MSM_HIP_CHECK(hipMemcpyAsync(dIdx.p, X_indices, (size_t)nn * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+            P.X_indices = dIdx.as<msm_idx_t>();
+        }
+        if ((rc = dOut.reserve(npairs * sizeof(double)))) return rc;
+        P.out = dOut.as<double>();
+    }
+    launch_pd<T, 0>(mid, (int)std::min<long long>(nn - 1, 4096), P);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (!on_device) MSM_HIP_CHECK(hipMemcpyAsync(out, P.out, npairs * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+template <typename T>
+int sumdist_impl(const T* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* pairs,
+                 msm_idx_t p, double* sum, int on_device)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!X || !sum || (p > 0 && !pairs)) return fail(MSM_ERR_INVALID, "sumdist: null pointer");
+    if (n < 0 || m < 1 || p < 0) return fail(MSM_ERR_INVALID, "sumdist: bad shape");
+    *sum = 0.0;
+    if (p == 0) return MSM_OK;
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    int rc;
+    DevBuf &dX = pool(PS_X), &dIdx = pool(PS_IDX), &dPart = pool(PS_PART);
+    const int grid = (int)std::min<long long>(ceil_div(p, DT), 1024);
+    if ((rc = dPart.reserve((size_t)grid * sizeof(double)))) return rc;
+    PdArgs P;
+    memset(&P, 0, sizeof(P));
+    P.n = n;
+    P.m = m;
+    P.p = p;
+    P.partial = dPart.as<double>();
+    if (on_device) {
+        P.X = X;
+        P.pairs = pairs;
+    } else {
+        if ((rc = dX.reserve((size_t)n * m * sizeof(T)))) return rc;
+        if ((rc = dIdx.reserve((size_t)p * 2 * sizeof(msm_idx_t)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(dIdx.p, pairs, (size_t)p * 2 * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+        P.X = dX.p;
+        P.pairs = dIdx.as<msm_idx_t>();
+    }
+    launch_pd<T, 1>(mid, grid, P);
+    MSM_HIP_CHECK(hipGetLastError());
+    return sum_partials_host(P.partial, grid, sum);
+}
+
 // One externally driven pass (multi-rank k-centers): centre coordinates come from the host,
 // the local (max distance, lowest local row) comes back.
 template <typename T>
@@ -793,6 +961,30 @@ int msm_kcenters_pass_f64(const double* X, msm_idx_t n, msm_idx_t m, const doubl
                           msm_idx_t* argmax, double* argmax_row, int on_device)
 {
     return kcenters_pass_impl<double>(X, n, m, y, it, metric, labels, distances, max_dist, argmax, argmax_row, on_device);
+}
+
+int msm_pdist_f32(const float* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* X_indices,
+                  msm_idx_t n_X_indices, double* out, int on_device)
+{
+    return pdist_impl<float>(X, metric, n, m, X_indices, n_X_indices, out, on_device);
+}
+
+int msm_pdist_f64(const double* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* X_indices,
+                  msm_idx_t n_X_indices, double* out, int on_device)
+{
+    return pdist_impl<double>(X, metric, n, m, X_indices, n_X_indices, out, on_device);
+}
+
+int msm_sumdist_f32(const float* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* pairs,
+                    msm_idx_t p, double* sum, int on_device)
+{
+    return sumdist_impl<float>(X, metric, n, m, pairs, p, sum, on_device);
+}
+
+int msm_sumdist_f64(const double* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* pairs,
+                    msm_idx_t p, double* sum, int on_device)
+{
+    return sumdist_impl<double>(X, metric, n, m, pairs, p, sum, on_device);
 }
 
 int msm_dist_f32(const float* X, const float* y, const char* metric, msm_idx_t n, msm_idx_t m,

@@ -65,4 +65,40 @@ void cdist_float(const float* XA, const float* XB, const char* metric, msm_npy_i
     (void)msm_cdist_f32(XA, XB, metric, na, nb, m, out, 0);
 }
 
+void pdist_double(const double* X, const char* metric, msm_npy_intp n, msm_npy_intp m, double* out)
+{
+    (void)msm_pdist_f64(X, metric, n, m, nullptr, 0, out, 0);
+}
+
+void pdist_float(const float* X, const char* metric, msm_npy_intp n, msm_npy_intp m, double* out)
+{
+    (void)msm_pdist_f32(X, metric, n, m, nullptr, 0, out, 0);
+}
+
+void pdist_double_X_indices(const double* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                            const msm_npy_intp* X_indices, msm_npy_intp n_X_indices, double* out)
+{
+    (void)msm_pdist_f64(X, metric, n, m, (const msm_idx_t*)X_indices, n_X_indices, out, 0);
+}
+
+void pdist_float_X_indices(const float* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                           const msm_npy_intp* X_indices, msm_npy_intp n_X_indices, double* out)
+{
+    (void)msm_pdist_f32(X, metric, n, m, (const msm_idx_t*)X_indices, n_X_indices, out, 0);
+}
+
+double sumdist_double(const double* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                      const msm_npy_intp* pairs, msm_npy_intp p)
+{
+    double s = 0.0;
+    return msm_sumdist_f64(X, metric, n, m, (const msm_idx_t*)pairs, p, &s, 0) == MSM_OK ? s : -1.0;
+}
+
+double sumdist_float(const float* X, const char* metric, msm_npy_intp n, msm_npy_intp m,
+                     const msm_npy_intp* pairs, msm_npy_intp p)
+{
+    double s = 0.0;
+    return msm_sumdist_f32(X, metric, n, m, (const msm_idx_t*)pairs, p, &s, 0) == MSM_OK ? s : -1.0;
+}
+
 }  // extern "C"

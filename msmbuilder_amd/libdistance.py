@@ -2,7 +2,7 @@
 
 Same python-level signatures, dtype rules and error types as
 /root/reference/msmbuilder/libdistance/libdistance.pyx:82-270 (``assign_nearest``,
-``cdist``, ``dist``); the arithmetic runs in libmsmhip's exact HIP kernels
+``cdist``, ``dist``, ``pdist``, ``sumdist``); the arithmetic runs in libmsmhip's exact HIP kernels
 (msmbuilder_amd/csrc/distance.hip) and is bit-identical to the reference's
 scalar loops.  Extension: X / X_indices may be torch CUDA tensors, in which case
 the per-row outputs come back as CUDA tensors too (nothing crosses PCIe).
@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from ._lib import Arr, check, empty_like_placement, is_device_array
 
-__all__ = ['assign_nearest', 'cdist', 'dist']
+__all__ = ['assign_nearest', 'cdist', 'dist', 'pdist', 'sumdist']
 
 VECTOR_METRICS = ("euclidean", "sqeuclidean", "cityblock", "chebyshev",
                   "canberra", "braycurtis", "hamming", "jaccard",
@@ -138,3 +138,56 @@ def dist(X, y, metric, X_indices=None):
     check(fn(ax.vp, C.c_void_p(ay.ctypes.data), m, ax.shape[0], ax.shape[1],
              idx.vp if idx is not None else None, n, aout.vp, ax.on_device))
     return out
+
+
+def pdist(X, metric, X_indices=None):
+    """Condensed pairwise distances between the rows of X (or X[X_indices]):
+    libdistance.pyx:182-226 -> pdist.hpp:4-88.  float64 [n(n-1)/2]."""
+    if not _is_array(X):
+        raise TypeError()
+    m = _metric(metric)
+    dx = _dtype_of(X)
+    if dx == np.float64:
+        kind, dt = "f64", np.float64
+    elif dx == np.float32:
+        kind, dt = "f32", np.float32
+    else:
+        raise TypeError('X must be float32 or float64')
+    _require_c_contiguous(X)
+    ax = Arr(X, dt)
+    idx = None
+    n = ax.shape[0]
+    if X_indices is not None:
+        idx = Arr(X_indices, np.int64)
+        if idx.on_device != ax.on_device:
+            raise ValueError("X and X_indices must live on the same side (host or device)")
+        n = idx.shape[0]
+    out = empty_like_placement(ax, (n * (n - 1) // 2,), np.float64)
+    aout = Arr(out, np.float64)
+    fn = getattr(_lib.lib(), "msm_pdist_" + kind)
+    check(fn(ax.vp, m, ax.shape[0], ax.shape[1], idx.vp if idx is not None else None, n, aout.vp, ax.on_device))
+    return out
+
+
+def sumdist(X, metric, pair_indices):
+    """Sum of the distances between the listed pairs of rows: libdistance.pyx:273-310 ->
+    sumdist.hpp:4-44 (the reference adds sequentially; here an fp64 tree sum)."""
+    m = _metric(metric)
+    dx = _dtype_of(X)
+    if dx == np.float64:
+        kind, dt = "f64", np.float64
+    elif dx == np.float32:
+        kind, dt = "f32", np.float32
+    else:
+        raise TypeError('X must be both float32 or float64')
+    _require_c_contiguous(X)
+    ax = Arr(X, dt)
+    pairs = Arr(pair_indices, np.int64)
+    if len(pairs.shape) != 2 or pairs.shape[1] != 2:
+        raise ValueError('pair_indices must be of shape = (n_pairs, 2)')
+    if pairs.on_device != ax.on_device:
+        raise ValueError("X and pair_indices must live on the same side (host or device)")
+    s = C.c_double(0.0)
+    fn = getattr(_lib.lib(), "msm_sumdist_" + kind)
+    check(fn(ax.vp, m, ax.shape[0], ax.shape[1], pairs.vp, pairs.shape[0], C.byref(s), ax.on_device))
+    return float(s.value)

@@ -17,6 +17,8 @@
  *   dist / dist_X_indices src/dist.hpp:4-80
  *   cdist                 src/cdist.hpp:4-49
  *   assign_nearest        src/assign.hpp:6-91
+ *   pdist / _X_indices    src/pdist.hpp:4-88
+ *   sumdist               src/sumdist.hpp:4-44
  *
  * Arithmetic contract being pinned (this is what "bit-exact labels" means):
  *   - float inputs: `u[i] - v[i]` and `u[i] + v[i]` are evaluated in FLOAT
@@ -255,6 +257,58 @@ int oracle_cdist_f32(const float *XA, const float *XB, const char *metric, idx_t
     for (i = 0; i < na; i++)
         for (j = 0; j < nb; j++) out[k++] = metric_f32(id, XA + m * i, XB + m * j, m);
     return 0;
+}
+
+/* pdist.hpp: condensed upper triangle, row by row; rows are X_indices[ii] when given. */
+int oracle_pdist_f64(const double *X, const char *metric, idx_t n, idx_t m, const idx_t *X_indices,
+                     idx_t n_X_indices, double *out)
+{
+    int id = oracle_metric_id(metric);
+    idx_t ii, jj, k = 0, nn = X_indices == NULL ? n : n_X_indices;
+    if (id < 0) return -1;
+    for (ii = 0; ii < nn; ii++)
+        for (jj = ii + 1; jj < nn; jj++) {
+            idx_t i = X_indices == NULL ? ii : X_indices[ii], j = X_indices == NULL ? jj : X_indices[jj];
+            out[k++] = metric_f64(id, X + m * i, X + m * j, m);
+        }
+    return 0;
+}
+
+int oracle_pdist_f32(const float *X, const char *metric, idx_t n, idx_t m, const idx_t *X_indices,
+                     idx_t n_X_indices, double *out)
+{
+    int id = oracle_metric_id(metric);
+    idx_t ii, jj, k = 0, nn = X_indices == NULL ? n : n_X_indices;
+    if (id < 0) return -1;
+    for (ii = 0; ii < nn; ii++)
+        for (jj = ii + 1; jj < nn; jj++) {
+            idx_t i = X_indices == NULL ? ii : X_indices[ii], j = X_indices == NULL ? jj : X_indices[jj];
+            out[k++] = metric_f32(id, X + m * i, X + m * j, m);
+        }
+    return 0;
+}
+
+/* sumdist.hpp: sequential double sum over the listed pairs; -1 for an unknown metric */
+double oracle_sumdist_f64(const double *X, const char *metric, idx_t n, idx_t m, const idx_t *pairs, idx_t p)
+{
+    int id = oracle_metric_id(metric);
+    idx_t i;
+    double s = 0;
+    (void)n;
+    if (id < 0) return -1;
+    for (i = 0; i < p; i++) s += metric_f64(id, X + m * pairs[2 * i], X + m * pairs[2 * i + 1], m);
+    return s;
+}
+
+double oracle_sumdist_f32(const float *X, const char *metric, idx_t n, idx_t m, const idx_t *pairs, idx_t p)
+{
+    int id = oracle_metric_id(metric);
+    idx_t i;
+    double s = 0;
+    (void)n;
+    if (id < 0) return -1;
+    for (i = 0; i < p; i++) s += metric_f32(id, X + m * pairs[2 * i], X + m * pairs[2 * i + 1], m);
+    return s;
 }
 
 /* assign.hpp:6-47 / 50-91.  `min_dist` (nullable) additionally returns the

@@ -66,6 +66,8 @@ class Oracle:
         self.lib = C.CDLL(ORACLE_SO)
         self.lib.oracle_assign_nearest_f64.restype = C.c_double
         self.lib.oracle_assign_nearest_f32.restype = C.c_double
+        self.lib.oracle_sumdist_f64.restype = C.c_double
+        self.lib.oracle_sumdist_f32.restype = C.c_double
 
     def assign_nearest(self, X, Y, metric, X_indices=None, return_distances=False):
         kind = _check(X, Y, metric)
@@ -110,6 +112,27 @@ class Oracle:
             _ptr(out, _f64p))
         return out
 
+    def pdist(self, X, metric, X_indices=None):
+        kind = _check(X, X, metric)
+        X = np.ascontiguousarray(X)
+        idx = None if X_indices is None else np.ascontiguousarray(X_indices, dtype=np.int64)
+        n = X.shape[0] if idx is None else idx.shape[0]
+        out = np.zeros(n * (n - 1) // 2, dtype=np.float64)
+        getattr(self.lib, "oracle_pdist_" + kind)(
+            C.c_void_p(X.ctypes.data), metric.encode(), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]),
+            _ptr(idx, _i64p), C.c_int64(n), _ptr(out, _f64p))
+        return out
+
+    def sumdist(self, X, metric, pair_indices):
+        kind = _check(X, X, metric)
+        X = np.ascontiguousarray(X)
+        pairs = np.ascontiguousarray(pair_indices, dtype=np.int64)
+        if pairs.ndim != 2 or pairs.shape[1] != 2:
+            raise ValueError('pair_indices must be of shape = (n_pairs, 2)')
+        return getattr(self.lib, "oracle_sumdist_" + kind)(
+            C.c_void_p(X.ctypes.data), metric.encode(), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]),
+            _ptr(pairs, _i64p), C.c_int64(pairs.shape[0]))
+
     def kcenters_fit(self, X, n_clusters, metric, seed_index):
         """C restatement of _KCenters.fit (cluster/kcenters.py:79-102)."""
         X = np.ascontiguousarray(X)
@@ -139,6 +162,8 @@ class Ref:
         self.lib = C.CDLL(REF_SO)
         self.lib.ref_assign_nearest_double.restype = C.c_double
         self.lib.ref_assign_nearest_float.restype = C.c_double
+        self.lib.ref_sumdist_double.restype = C.c_double
+        self.lib.ref_sumdist_float.restype = C.c_double
 
     @staticmethod
     def available() -> bool:
@@ -170,6 +195,32 @@ class Ref:
         fn(C.c_void_p(XA.ctypes.data), C.c_void_p(XB.ctypes.data), metric.encode(),
            C.c_int64(XA.shape[0]), C.c_int64(XB.shape[0]), C.c_int64(XA.shape[1]), _ptr(out, _f64p))
         return out
+
+    def pdist(self, X, metric, X_indices=None):
+        kind = _check(X, X, metric)
+        X = np.ascontiguousarray(X)
+        sfx = "double" if kind == "f64" else "float"
+        if X_indices is None:
+            n = X.shape[0]
+            out = np.zeros(n * (n - 1) // 2, dtype=np.float64)
+            getattr(self.lib, "ref_pdist_" + sfx)(C.c_void_p(X.ctypes.data), metric.encode(), C.c_int64(n),
+                                                  C.c_int64(X.shape[1]), _ptr(out, _f64p))
+        else:
+            idx = np.ascontiguousarray(X_indices, dtype=np.int64)
+            n = idx.shape[0]
+            out = np.zeros(n * (n - 1) // 2, dtype=np.float64)
+            getattr(self.lib, "ref_pdist_%s_X_indices" % sfx)(
+                C.c_void_p(X.ctypes.data), metric.encode(), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]),
+                _ptr(idx, _i64p), C.c_int64(n), _ptr(out, _f64p))
+        return out
+
+    def sumdist(self, X, metric, pair_indices):
+        kind = _check(X, X, metric)
+        X = np.ascontiguousarray(X)
+        pairs = np.ascontiguousarray(pair_indices, dtype=np.int64)
+        fn = self.lib.ref_sumdist_double if kind == "f64" else self.lib.ref_sumdist_float
+        return fn(C.c_void_p(X.ctypes.data), metric.encode(), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]),
+                  _ptr(pairs, _i64p), C.c_int64(pairs.shape[0]))
 
     def dist(self, X, y, metric, X_indices=None):
         kind = _check(X, y, metric)

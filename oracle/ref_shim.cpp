@@ -22,6 +22,8 @@ typedef intptr_t npy_intp;
 #include "assign.hpp"
 #include "cdist.hpp"
 #include "dist.hpp"
+#include "pdist.hpp"
+#include "sumdist.hpp"
 
 extern "C" {
 
@@ -77,6 +79,40 @@ void ref_cdist_float(const float* XA, const float* XB, const char* metric, npy_i
                      npy_intp nb, npy_intp m, double* out)
 {
     cdist_float(XA, XB, metric, na, nb, m, out);
+}
+
+void ref_pdist_double(const double* X, const char* metric, npy_intp n, npy_intp m, double* out)
+{
+    pdist_double(X, metric, n, m, out);
+}
+
+void ref_pdist_float(const float* X, const char* metric, npy_intp n, npy_intp m, double* out)
+{
+    pdist_float(X, metric, n, m, out);
+}
+
+void ref_pdist_double_X_indices(const double* X, const char* metric, npy_intp n, npy_intp m,
+                                const npy_intp* X_indices, npy_intp n_X_indices, double* out)
+{
+    pdist_double_X_indices(X, metric, n, m, X_indices, n_X_indices, out);
+}
+
+void ref_pdist_float_X_indices(const float* X, const char* metric, npy_intp n, npy_intp m,
+                               const npy_intp* X_indices, npy_intp n_X_indices, double* out)
+{
+    pdist_float_X_indices(X, metric, n, m, X_indices, n_X_indices, out);
+}
+
+double ref_sumdist_double(const double* X, const char* metric, npy_intp n, npy_intp m,
+                          const npy_intp* pairs, npy_intp p)
+{
+    return sumdist_double(X, metric, n, m, pairs, p);
+}
+
+double ref_sumdist_float(const float* X, const char* metric, npy_intp n, npy_intp m,
+                         const npy_intp* pairs, npy_intp p)
+{
+    return sumdist_float(X, metric, n, m, pairs, p);
 }
 
 }  // extern "C"

@@ -69,6 +69,35 @@ def test_bit_exact_vs_oracle(gpu, oracle, metric, dtype, n, k, f):
         assert _same(ld.dist(X, Y[0], metric, idx), oracle.dist(X, Y[0], metric, idx))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("metric", METRICS)
+def test_pdist_sumdist_bit_exact(gpu, oracle, metric, dtype):
+    """'next' rows of SURVEY 8(f3): pdist / sumdist (pdist.hpp, sumdist.hpp; reference tests
+    tests/test_libdistance.py:128-148, 212-219)."""
+    import scipy.spatial.distance
+    from msmbuilder_amd import libdistance as ld
+    rs = np.random.RandomState(11)
+    for n, f in ((2, 1), (37, 5), (300, 33), (64, 1100)):
+        X = rs.randn(n, f).astype(dtype)
+        if metric in ("hamming", "jaccard"):
+            X = np.round(X).astype(dtype)
+        idx = rs.randint(0, n, size=min(n, 11)).astype(np.int64)
+        pairs = rs.randint(0, n, size=(29, 2)).astype(np.int64)
+        with np.errstate(all="ignore"):
+            got = ld.pdist(X, metric)
+            assert got.shape == (n * (n - 1) // 2,) and got.dtype == np.float64
+            assert _same(got, oracle.pdist(X, metric))
+            assert _same(ld.pdist(X, metric, idx), oracle.pdist(X, metric, idx))
+            a, b = ld.sumdist(X, metric, pairs), oracle.sumdist(X, metric, pairs)
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-13 * abs(b)
+            if metric != "jaccard" and f > 1:
+                np.testing.assert_almost_equal(got, scipy.spatial.distance.pdist(X, metric),
+                                               decimal=4 if dtype == np.float32 else 9)
+    with pytest.raises(ValueError):
+        ld.sumdist(X, metric, np.zeros((3, 3), dtype=np.int64))
+    assert ld.pdist(np.zeros((1, 3), dtype), metric).shape == (0,)
+
+
 def test_reference_test_contract(gpu):
     """Restated from the reference's tests/test_libdistance.py:28-73,115-196."""
     import scipy.spatial.distance

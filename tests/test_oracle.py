@@ -67,6 +67,11 @@ def test_libdistance_oracle_vs_compiled_reference(oracle):
                     assert np.array_equal(l1, l2) and _same(np.float64(i1), np.float64(i2))
                     assert _same(oracle.dist(X, Y[0], m), ref.dist(X, Y[0], m))
                     assert _same(oracle.dist(X, Y[0], m, idx), ref.dist(X, Y[0], m, idx))
+                    if n <= 60:
+                        assert _same(oracle.pdist(X, m), ref.pdist(X, m))
+                        assert _same(oracle.pdist(X, m, idx), ref.pdist(X, m, idx))
+                    pairs = rs.randint(0, n, size=(9, 2)).astype(np.int64)
+                    assert _same(np.float64(oracle.sumdist(X, m, pairs)), np.float64(ref.sumdist(X, m, pairs)))
 
 
 def test_libdistance_oracle_error_contract(oracle):
