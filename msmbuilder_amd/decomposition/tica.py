@@ -42,6 +42,33 @@ __all__ = ['tICA']
 
 _BATCH_BYTES = 1 << 30  # host trajectories are shipped in groups of about this size
 
+# Released device handles are parked here and re-used (after msm_tica_reset) by the next model of the
+# same shape: creating one costs eight hipMalloc and destroying one eight hipFree, each of which
+# synchronises the device -- tens of ms when models are fitted in a loop.
+_HANDLE_POOL = {}
+_HANDLE_POOL_MAX = 2
+
+
+def _acquire_handle(n_features, lag_time, mode):
+    key = (int(n_features), int(lag_time), int(mode))
+    free = _HANDLE_POOL.get(key)
+    if free:
+        h = free.pop()
+        check(_lib.lib().msm_tica_reset(h))
+        return h
+    h = C.c_void_p()
+    check(_lib.lib().msm_tica_create(C.byref(h), key[0], key[1], key[2]))
+    return h
+
+
+def _park_handle(h, n_features, lag_time, mode):
+    key = (int(n_features), int(lag_time), int(mode))
+    free = _HANDLE_POOL.setdefault(key, [])
+    if len(free) < _HANDLE_POOL_MAX:
+        free.append(h)
+    else:
+        _lib.lib().msm_tica_destroy(h)
+
 
 def _mode_from_env():
     m = os.environ.get("MSMBUILDER_AMD_TICA_MODE", "f32").lower()
@@ -130,9 +157,8 @@ class tICA(BaseEstimator, TransformerMixin):
         self.n_sequences_ = 0
         self._release()
         _lib.ensure_device()
-        h = C.c_void_p()
-        check(_lib.lib().msm_tica_create(C.byref(h), int(n_features), int(self.lag_time), _mode_from_env()))
-        self._handle = h
+        self._handle_key = (int(n_features), int(self.lag_time), _mode_from_env())
+        self._handle = _acquire_handle(*self._handle_key)
         self._outer_0_to_T_lagged = np.zeros((n_features, n_features))
         self._sum_0_to_TminusTau = np.zeros(n_features)
         self._sum_tau_to_T = np.zeros(n_features)
@@ -144,7 +170,7 @@ class tICA(BaseEstimator, TransformerMixin):
         h = getattr(self, "_handle", None)
         if h is not None:
             try:
-                _lib.lib().msm_tica_destroy(h)
+                _park_handle(h, *self._handle_key)
             except Exception:
                 pass
         self._handle = None
@@ -156,10 +182,8 @@ class tICA(BaseEstimator, TransformerMixin):
         """(Re)create the device handle from the host mirrors (after unpickling)."""
         if self._handle is None and self._initialized:
             _lib.ensure_device()
-            h = C.c_void_p()
-            check(_lib.lib().msm_tica_create(C.byref(h), int(self.n_features), int(self.lag_time),
-                                             _mode_from_env()))
-            self._handle = h
+            self._handle_key = (int(self.n_features), int(self.lag_time), _mode_from_env())
+            h = self._handle = _acquire_handle(*self._handle_key)
             c = np.ascontiguousarray(self._outer_0_to_T_lagged, dtype=np.float64)
             g = np.ascontiguousarray(self._outer_gram_sum, dtype=np.float64)
             s0 = np.ascontiguousarray(self._sum_0_to_TminusTau, dtype=np.float64)
@@ -189,6 +213,7 @@ class tICA(BaseEstimator, TransformerMixin):
             self._pull()
         d = dict(self.__dict__)
         d["_handle"] = None
+        d.pop("_handle_key", None)
         return d
 
     def __setstate__(self, d):
@@ -360,9 +385,16 @@ class tICA(BaseEstimator, TransformerMixin):
             classes.setdefault(key, []).append(X)
         L = _lib.lib()
         for (on_dev, nbytes), arrs in classes.items():
-            views = [Arr(a) for a in arrs]
-            n = len(views)
-            ptrs = (C.c_void_p * n)(*[v.ptr for v in views])
+            n = len(arrs)
+            if on_dev:
+                # one Arr() for the device/stream binding, raw pointers for the rest (1000 trajectories
+                # per call: per-item wrappers cost more than the launch)
+                views = arrs
+                Arr(arrs[0])
+                ptrs = (C.c_void_p * n)(*[a.data_ptr() for a in arrs])
+            else:
+                views = [Arr(a) for a in arrs]
+                ptrs = (C.c_void_p * n)(*[v.ptr for v in views])
             rows = (C.c_int64 * n)(*[v.shape[0] for v in views])
             skipped = C.c_int64(0)
             check(L.msm_tica_accumulate_batch(self._handle, ptrs, rows, n, nbytes,
