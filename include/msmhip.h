@@ -208,6 +208,30 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
                      double* batch_inertia, double* batch_sums, double* batch_counts,
                      int apply_update, int on_device);
 
+/* Device-resident MiniBatchKMeans state (centres [K, m], cumulative counts [K] and ||c||^2 stay in
+ * HBM for the whole fit).  A step ships the batch indices in and [inertia | counts] out.
+ *   msm_mbk_step(apply_update = 1): label the batch rows X[batch_idx[b]], streaming-mean update,
+ *       *batch_inertia (before the update) and counts_out (host, K; nullable) after it.
+ *   apply_update = 0 (multi-GPU): label + fp64 batch sums only; msm_mbk_export_packed() hands out
+ *       [K*m sums | K counts | inertia] doubles for the RCCL all-reduce, msm_mbk_apply_packed()
+ *       applies the reduced buffer identically on every rank.
+ *   msm_mbk_reassign: centres[which[i]] = X[rows[i]], counts[which[i]] = new_count
+ *       (scikit-learn's starved-centre reassignment, decided on the host with its RNG). */
+typedef struct msm_mbk msm_mbk_t;
+int msm_mbk_create(msm_mbk_t** h, msm_idx_t n_clusters, msm_idx_t n_features);
+int msm_mbk_destroy(msm_mbk_t* h);
+int msm_mbk_set(msm_mbk_t* h, const float* centers, const float* counts);
+int msm_mbk_set_counts(msm_mbk_t* h, const float* counts);
+int msm_mbk_get(msm_mbk_t* h, float* centers, float* counts);
+int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
+                 double* batch_inertia, float* counts_out, int apply_update, int on_device);
+msm_idx_t msm_mbk_packed_size(msm_mbk_t* h);
+int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device);
+int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int on_device);
+int msm_mbk_reassign(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
+                     msm_idx_t n_reassign, float new_count, int on_device);
+int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device);
+
 #ifdef __cplusplus
 }
 #endif

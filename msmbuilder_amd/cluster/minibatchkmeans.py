@@ -216,40 +216,33 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
             return True
         return False
 
-    def _step(self, ax, shard, batch_idx, centers, random_state, random_reassign):
-        """One ``_mini_batch_step`` (_kmeans.py:1557-1676): label + streaming-mean update on
-        the GPU, starved-centre reassignment on the host.  ``batch_idx`` are GLOBAL row numbers
-        (identical on every rank); each rank processes the rows it owns and, when sharded,
-        one all-reduce of [sums | counts | inertia] makes the update identical everywhere.
-        Updates ``centers`` / ``self._counts`` in place; returns the batch inertia (computed
-        before the update, as scikit-learn does)."""
+    def _step(self, ax, shard, batch_idx, random_state, random_reassign):
+        """One ``_mini_batch_step`` (_kmeans.py:1557-1676) on the device-resident state
+        (``self._mbk``): label + streaming-mean update on the GPU, starved-centre reassignment
+        decided on the host with scikit-learn's RNG calls.  ``batch_idx`` are GLOBAL row numbers
+        (identical on every rank); each rank processes the rows it owns and, when sharded, one
+        all-reduce of [sums | counts | inertia] makes the update identical everywhere.  Returns the
+        batch inertia (computed before the update, as scikit-learn does)."""
         from .. import parallel
-        K, F = centers.shape
+        K, F = self.n_clusters, ax.shape[1]
         B = len(batch_idx)
         inertia = C.c_double(0.0)
         L = _lib.lib()
         if parallel.active():
             _, sub = shard.local(batch_idx)
             sub = np.ascontiguousarray(sub, dtype=np.int64)
-            sums = np.zeros((K, F), dtype=np.float64)
-            cnts = np.zeros(K, dtype=np.float64)
+            n_packed = int(L.msm_mbk_packed_size(self._mbk))
+            packed = np.zeros(n_packed, dtype=np.float64)
             if len(sub):
-                check(L.msm_mbk_step_f32(ax.vp, ax.shape[0], F, sub.ctypes.data, len(sub), centers.ctypes.data,
-                                         self._counts.ctypes.data, K, C.byref(inertia), sums.ctypes.data,
-                                         cnts.ctypes.data, 0, ax.on_device))
-            packed = parallel.allreduce_array(np.concatenate([sums.ravel(), cnts, [inertia.value]]))
-            sums = packed[:K * F].reshape(K, F)
-            cnts = packed[K * F:K * F + K]
+                check(L.msm_mbk_step(self._mbk, ax.vp, ax.shape[0], sub.ctypes.data, len(sub), C.byref(inertia),
+                                     None, 0, ax.on_device))
+                check(L.msm_mbk_export_packed(self._mbk, packed.ctypes.data, 0))
+            packed = np.ascontiguousarray(parallel.allreduce_array(packed))
             inertia_v = float(packed[-1])
-            upd = cnts > 0
-            w_new = (self._counts + cnts).astype(np.float32)
-            centers[upd] = ((centers[upd].astype(np.float64) * self._counts[upd, None] + sums[upd])
-                            / w_new[upd, None]).astype(np.float32)
-            self._counts[:] = w_new
+            check(L.msm_mbk_apply_packed(self._mbk, packed.ctypes.data, self._counts.ctypes.data, 0))
         else:
-            check(L.msm_mbk_step_f32(ax.vp, ax.shape[0], F, batch_idx.ctypes.data, B, centers.ctypes.data,
-                                     self._counts.ctypes.data, K, C.byref(inertia), None, None, 1,
-                                     ax.on_device))
+            check(L.msm_mbk_step(self._mbk, ax.vp, ax.shape[0], batch_idx.ctypes.data, B, C.byref(inertia),
+                                 self._counts.ctypes.data, 1, ax.on_device))
             inertia_v = float(inertia.value)
 
         if random_reassign and self.reassignment_ratio > 0:
@@ -259,15 +252,44 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
             if to_reassign.sum() > 0.5 * B:
                 keep = np.argsort(weight_sums)[int(0.5 * B):]
                 to_reassign[keep] = False
-            n_reassigns = to_reassign.sum()
+            n_reassigns = int(to_reassign.sum())
             if n_reassigns:
                 new_centers = random_state.choice(B, replace=False, size=n_reassigns)
                 if self.verbose:
                     print("[MiniBatchKMeans] Reassigning %d cluster centers." % n_reassigns)
-                centers[to_reassign] = self._rows(ax, shard, batch_idx[new_centers])
-            # reset counts of reassigned centers, but don't reset them too small
-            weight_sums[to_reassign] = np.min(weight_sums[~to_reassign])
+                # reset counts of reassigned centers, but don't reset them too small
+                new_count = float(np.min(weight_sums[~to_reassign]))
+                rows = np.ascontiguousarray(self._rows(ax, shard, batch_idx[new_centers]), dtype=np.float32)
+                which = np.ascontiguousarray(np.nonzero(to_reassign)[0], dtype=np.int64)
+                ridx = np.arange(n_reassigns, dtype=np.int64)
+                check(L.msm_mbk_reassign(self._mbk, rows.ctypes.data, n_reassigns, ridx.ctypes.data,
+                                         which.ctypes.data, n_reassigns, new_count, 0))
+                weight_sums[to_reassign] = new_count
+            else:
+                mn = np.min(weight_sums[~to_reassign]) if (~to_reassign).any() else 0.0
+                if to_reassign.any():
+                    weight_sums[to_reassign] = mn
+                    check(L.msm_mbk_set_counts(self._mbk, weight_sums.ctypes.data))
         return inertia_v
+
+    def _mbk_open(self, centers, counts):
+        h = C.c_void_p()
+        check(_lib.lib().msm_mbk_create(C.byref(h), centers.shape[0], centers.shape[1]))
+        self._mbk = h
+        check(_lib.lib().msm_mbk_set(h, centers.ctypes.data, counts.ctypes.data))
+
+    def _mbk_close(self):
+        """Fetch the centres back and free the device state."""
+        h = self.__dict__.pop("_mbk", None)
+        if h is None:
+            return None
+        K, F = self.n_clusters, self.n_features_in_
+        centers = np.empty((K, F), dtype=np.float32)
+        try:
+            check(_lib.lib().msm_mbk_get(h, centers.ctypes.data, self._counts.ctypes.data))
+        finally:
+            _lib.lib().msm_mbk_destroy(h)
+        return centers
 
     @staticmethod
     def _rows(ax, shard, global_idx):
@@ -316,15 +338,24 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
 
         n_steps = (self.max_iter * n_samples) // self._batch_size
         i = -1
-        for i in range(n_steps):
-            minibatch_indices = random_state.randint(0, n_samples, self._batch_size)
-            minibatch_indices = np.ascontiguousarray(minibatch_indices, dtype=np.int64)
-            prev = centers.copy() if self._tol > 0.0 else None
-            batch_inertia = self._step(ax, shard, minibatch_indices, centers, random_state,
-                                       self._random_reassign())
-            centers_squared_diff = np.sum((centers - prev) ** 2) if self._tol > 0.0 else 0
-            if self._mini_batch_convergence(i, n_steps, n_samples, centers_squared_diff, batch_inertia):
-                break
+        self._mbk_open(centers, self._counts)
+        try:
+            for i in range(n_steps):
+                minibatch_indices = random_state.randint(0, n_samples, self._batch_size)
+                minibatch_indices = np.ascontiguousarray(minibatch_indices, dtype=np.int64)
+                if self._tol > 0.0:  # the tol criterion needs the centres on the host every step
+                    prev = np.empty_like(centers)
+                    check(_lib.lib().msm_mbk_get(self._mbk, prev.ctypes.data, None))
+                batch_inertia = self._step(ax, shard, minibatch_indices, random_state, self._random_reassign())
+                centers_squared_diff = 0
+                if self._tol > 0.0:
+                    cur = np.empty_like(centers)
+                    check(_lib.lib().msm_mbk_get(self._mbk, cur.ctypes.data, None))
+                    centers_squared_diff = np.sum((cur - prev) ** 2)
+                if self._mini_batch_convergence(i, n_steps, n_samples, centers_squared_diff, batch_inertia):
+                    break
+        finally:
+            centers = self._mbk_close()
 
         self.cluster_centers_ = centers
         self.n_steps_ = i + 1
@@ -358,8 +389,13 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
             self.n_steps_ = 0
         self._batch_size = n_samples
         from ..parallel import RowShard
-        self._step(ax, RowShard(n_samples), np.arange(n_samples, dtype=np.int64), self.cluster_centers_,
-                   self._random_state, self._random_reassign())
+        self.n_features_in_ = ax.shape[1]
+        self._mbk_open(np.ascontiguousarray(self.cluster_centers_, dtype=np.float32), self._counts)
+        try:
+            self._step(ax, RowShard(n_samples), np.arange(n_samples, dtype=np.int64), self._random_state,
+                       self._random_reassign())
+        finally:
+            self.cluster_centers_ = self._mbk_close()
         if self.compute_labels:
             self.labels_, self.inertia_ = label_inertia(ax, self.cluster_centers_)
         self.n_steps_ += 1

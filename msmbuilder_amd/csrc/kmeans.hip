@@ -35,6 +35,11 @@ struct KmArgs {
     const float* C;         // device [K, m]
     const float* cnorm;     // device [K]
     int32_t* labels;        // [n]
+    // centre-split launch (small batches): blockIdx.y owns centre tiles [y*jspan, (y+1)*jspan) and
+    // writes its (min value, index) candidates to pv/pi [gridDim.y][n]; a reduce kernel finishes
+    long long jspan;        // 0 = all centres in one workgroup
+    float* pv;
+    int* pi;
 };
 
 __device__ __forceinline__ void km_load(float4 (&xa)[4], float4 (&ca)[4], const KmArgs& P,
@@ -109,7 +114,9 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_kernel(KmArgs P)
             bidx[bi][r] = 0x7fffffff;
         }
 
-    for (long long j0 = 0; j0 < P.K; j0 += KCT) {
+    const long long jbeg = P.jspan ? (long long)blockIdx.y * P.jspan : 0;
+    const long long jend = P.jspan ? (jbeg + P.jspan < P.K ? jbeg + P.jspan : P.K) : P.K;
+    for (long long j0 = jbeg; j0 < jend; j0 += KCT) {
         f32x16 acc[2][2];
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi)
@@ -188,9 +195,15 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_kernel(KmArgs P)
         if (i < P.n) {
             float v0 = redv[tid], v1 = redv[KR + tid];
             int i0 = redi[tid], i1 = redi[KR + tid];
-            int lab = (v1 < v0 || (v1 == v0 && i1 < i0)) ? i1 : i0;
-            if (lab == 0x7fffffff) lab = 0;  // all-NaN row: sklearn's argmin returns 0
-            P.labels[i] = lab;
+            const bool second = (v1 < v0 || (v1 == v0 && i1 < i0));
+            int lab = second ? i1 : i0;
+            if (P.jspan) {
+                P.pv[(long long)blockIdx.y * P.n + i] = second ? v1 : v0;
+                P.pi[(long long)blockIdx.y * P.n + i] = lab;
+            } else {
+                if (lab == 0x7fffffff) lab = 0;  // all-NaN row: sklearn's argmin returns 0
+                P.labels[i] = lab;
+            }
         }
     }
 }
@@ -278,6 +291,81 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
     }
 }
 
+// finish a centre-split labelling: lowest (value, index) over the splits
+__global__ void kmeans_label_reduce_kernel(const float* __restrict__ pv, const int* __restrict__ pi, long long n,
+                                           int nsplit, int32_t* __restrict__ labels)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float bv = pv[i];
+    int bi = pi[i];
+    for (int s = 1; s < nsplit; ++s) {
+        const float v = pv[(long long)s * n + i];
+        const int ix = pi[(long long)s * n + i];
+        if (v < bv || (v == bv && ix < bi)) {
+            bv = v;
+            bi = ix;
+        }
+    }
+    labels[i] = (bi == 0x7fffffff) ? 0 : bi;
+}
+
+// ||c_j||^2 in fp32, one wave per centre
+__global__ __launch_bounds__(KNT) void kmeans_cnorm_kernel(const float* __restrict__ C, long long K, long long m,
+                                                           float* __restrict__ cnorm)
+{
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= K) return;
+    float s = 0.f;
+    for (long long f = lane; f < m; f += 64) s += C[j * m + f] * C[j * m + f];
+#pragma unroll
+    for (int msk = 32; msk > 0; msk >>= 1) s += __shfl_xor(s, msk, 64);
+    if (lane == 0) cnorm[j] = s;
+}
+
+// [inertia (double) | counts (K floats)] gathered into one small buffer for a single D2H per step
+__global__ __launch_bounds__(KNT) void mbk_finish_kernel(const double* __restrict__ partial, int nb,
+                                                         const float* __restrict__ counts, long long K,
+                                                         double* __restrict__ out_inertia, float* __restrict__ out_counts)
+{
+    __shared__ double red[KNT];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += KNT) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = KNT / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_inertia = red[0];
+    for (long long j = threadIdx.x; j < K; j += KNT) out_counts[j] = counts[j];
+}
+
+// centres (+counts) <- (centres * w + batch sums) / (w + n) from all-reduced fp64 sums (multi-GPU)
+__global__ void mbk_apply_kernel(float* __restrict__ centers, float* __restrict__ counts,
+                                 const double* __restrict__ packed, long long K, long long m)
+{
+    const long long j = blockIdx.x;
+    const double n = packed[K * m + j];
+    if (n <= 0.0) return;
+    const float w_old = counts[j];
+    const float w_new = (float)((double)w_old + n);
+    for (long long f = threadIdx.x; f < m; f += blockDim.x)
+        centers[j * m + f] = (float)(((double)centers[j * m + f] * (double)w_old + packed[j * m + f]) / (double)w_new);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[j] = w_new;
+}
+
+__global__ void mbk_reassign_kernel(float* __restrict__ centers, float* __restrict__ counts,
+                                    const float* __restrict__ X, long long m, const msm_idx_t* __restrict__ rows,
+                                    const msm_idx_t* __restrict__ which, float new_count)
+{
+    const msm_idx_t r = rows[blockIdx.x], j = which[blockIdx.x];
+    for (long long f = threadIdx.x; f < m; f += blockDim.x) centers[j * m + f] = X[r * m + f];
+    if (threadIdx.x == 0) counts[j] = new_count;
+}
+
 static int km_prepare(const float* centers, msm_idx_t K, msm_idx_t m, DevBuf& dC, float** dCent, float** dNorm)
 {
     int rc = dC.reserve(((size_t)K * m + (size_t)K) * sizeof(float));
@@ -322,7 +410,295 @@ static int km_label_and_inertia(KmArgs& P, double* inertia)
 
 using namespace msm;
 
+// Device-resident MiniBatchKMeans state: centres, cumulative counts and ||c||^2 live in HBM for the
+// whole fit; a step moves only the batch indices in and [inertia | counts] out.
+struct msm_mbk {
+    long long K = 0, m = 0;
+    float* centers = nullptr;
+    float* counts = nullptr;
+    float* cnorm = nullptr;
+    double* packed = nullptr;  // [K*m | K | 1] batch sums, counts, inertia (fp64)
+    char* outbuf = nullptr;    // [8 + 4K]
+    DevBuf labels, idx, xb, pv, pi, part, rows, which;
+};
+
+namespace {
+
+int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n, int32_t* labels_d, double* inertia_dev_partial,
+              int* nb_out)
+{
+    KmArgs P;
+    memset(&P, 0, sizeof(P));
+    P.X = Xd;
+    P.rows = rows_d;
+    P.n = n;
+    P.m = h->m;
+    P.K = h->K;
+    P.C = h->centers;
+    P.cnorm = h->cnorm;
+    P.labels = labels_d;
+    const long long rowblocks = ceil_div(n, KR);
+    const long long ctiles = ceil_div(h->K, KCT);
+    int nsplit = 1;
+    if (rowblocks < 256 && ctiles > 1) {  // small batch: split the centres over workgroups to fill the chip
+        nsplit = (int)std::min<long long>(ctiles, std::max<long long>(1, 512 / rowblocks));
+    }
+    int rc;
+    if (nsplit > 1) {
+        const long long tiles_per = ceil_div(ctiles, nsplit);
+        nsplit = (int)ceil_div(ctiles, tiles_per);
+        if ((rc = h->pv.reserve((size_t)nsplit * n * sizeof(float)))) return rc;
+        if ((rc = h->pi.reserve((size_t)nsplit * n * sizeof(int)))) return rc;
+        P.jspan = tiles_per * KCT;
+        P.pv = h->pv.as<float>();
+        P.pi = h->pi.as<int>();
+        hipLaunchKernelGGL(kmeans_label_kernel, dim3((unsigned)rowblocks, (unsigned)nsplit), dim3(KNT), 0, stream(), P);
+        MSM_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
+                           P.pv, P.pi, n, nsplit, labels_d);
+    } else {
+        hipLaunchKernelGGL(kmeans_label_kernel, dim3((unsigned)rowblocks), dim3(KNT), 0, stream(), P);
+    }
+    MSM_HIP_CHECK(hipGetLastError());
+    if (inertia_dev_partial) {
+        const int nb = (int)std::min<long long>(ceil_div(n, 4), 1024);
+        P.jspan = 0;
+        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial);
+        MSM_HIP_CHECK(hipGetLastError());
+        *nb_out = nb;
+    }
+    return MSM_OK;
+}
+
+// stage the batch: device X -> row indices on device; host X -> gathered rows on device
+int mbk_stage_batch(msm_mbk* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B, int on_device,
+                    const float** Xd, const msm_idx_t** rows_d)
+{
+    int rc;
+    for (msm_idx_t b = 0; b < B; ++b)
+        if (batch_idx[b] < 0 || batch_idx[b] >= n) return fail(MSM_ERR_INVALID, "mbk: batch index out of range");
+    if (on_device) {
+        if ((rc = h->idx.reserve((size_t)B * sizeof(msm_idx_t)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->idx.p, batch_idx, (size_t)B * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // batch_idx is caller-owned pageable memory
+        *Xd = X;
+        *rows_d = h->idx.as<msm_idx_t>();
+    } else {
+        std::vector<float> xb((size_t)B * h->m);
+        for (msm_idx_t b = 0; b < B; ++b)
+            memcpy(xb.data() + (size_t)b * h->m, X + batch_idx[b] * h->m, (size_t)h->m * sizeof(float));
+        if ((rc = h->xb.reserve(xb.size() * sizeof(float)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->xb.p, xb.data(), xb.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        *Xd = h->xb.as<float>();
+        *rows_d = nullptr;
+    }
+    return MSM_OK;
+}
+
+}  // namespace
+
 extern "C" {
+
+int msm_mbk_create(msm_mbk_t** out, msm_idx_t K, msm_idx_t m)
+{
+    if (!out || K < 1 || m < 1) return fail(MSM_ERR_INVALID, "msm_mbk_create: bad argument");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    msm_mbk* h = new msm_mbk();
+    h->K = K;
+    h->m = m;
+    hipError_t e = hipMalloc((void**)&h->centers, (size_t)K * m * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->counts, (size_t)K * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->cnorm, (size_t)K * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->packed, ((size_t)K * m + K + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->outbuf, 8 + (size_t)K * sizeof(float));
+    if (e != hipSuccess) {
+        msm_mbk_destroy(h);
+        return fail(MSM_ERR_HIP, "msm_mbk_create: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return MSM_OK;
+}
+
+int msm_mbk_destroy(msm_mbk_t* h)
+{
+    if (!h) return MSM_OK;
+    (void)hipStreamSynchronize(stream());
+    if (h->centers) (void)hipFree(h->centers);
+    if (h->counts) (void)hipFree(h->counts);
+    if (h->cnorm) (void)hipFree(h->cnorm);
+    if (h->packed) (void)hipFree(h->packed);
+    if (h->outbuf) (void)hipFree(h->outbuf);
+    delete h;
+    return MSM_OK;
+}
+
+int msm_mbk_set(msm_mbk_t* h, const float* centers, const float* counts)
+{
+    if (!h || !centers || !counts) return fail(MSM_ERR_STATE, "msm_mbk_set: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(h->centers, centers, (size_t)h->K * h->m * sizeof(float), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(h->counts, counts, (size_t)h->K * sizeof(float), hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
+    MSM_HIP_CHECK(hipGetLastError());
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_get(msm_mbk_t* h, float* centers, float* counts)
+{
+    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_get: null handle");
+    if (centers) MSM_HIP_CHECK(hipMemcpyAsync(centers, h->centers, (size_t)h->K * h->m * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    if (counts) MSM_HIP_CHECK(hipMemcpyAsync(counts, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
+                 double* batch_inertia, float* counts_out, int apply_update, int on_device)
+{
+    if (!h || !X || !batch_idx) return fail(MSM_ERR_STATE, "msm_mbk_step: null argument");
+    if (n < 1 || B < 1) return fail(MSM_ERR_INVALID, "msm_mbk_step: bad shape");
+    int rc;
+    const float* Xd;
+    const msm_idx_t* rows_d;
+    if ((rc = mbk_stage_batch(h, X, n, batch_idx, B, on_device, &Xd, &rows_d))) return rc;
+    if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
+    if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
+    int nb = 0;
+    if ((rc = mbk_label(h, Xd, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb))) return rc;
+    KmArgs P;
+    memset(&P, 0, sizeof(P));
+    P.X = Xd;
+    P.rows = rows_d;
+    P.n = B;
+    P.m = h->m;
+    P.K = h->K;
+    P.labels = h->labels.as<int32_t>();
+    hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
+                       h->counts, apply_update ? (double*)nullptr : h->packed,
+                       apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (apply_update) {
+        hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K,
+                           h->m, h->cnorm);
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    double* d_inertia = apply_update ? reinterpret_cast<double*>(h->outbuf) : h->packed + (size_t)h->K * h->m + h->K;
+    hipLaunchKernelGGL(mbk_finish_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->counts, h->K,
+                       d_inertia, reinterpret_cast<float*>(h->outbuf + 8));
+    MSM_HIP_CHECK(hipGetLastError());
+    std::vector<char> hb(8 + (size_t)h->K * sizeof(float));
+    if (apply_update) {
+        MSM_HIP_CHECK(hipMemcpyAsync(hb.data(), h->outbuf, hb.size(), hipMemcpyDeviceToHost, stream()));
+    } else {
+        MSM_HIP_CHECK(hipMemcpyAsync(hb.data(), d_inertia, 8, hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(hb.data() + 8, h->outbuf + 8, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    }
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    if (batch_inertia) memcpy(batch_inertia, hb.data(), 8);
+    if (counts_out) memcpy(counts_out, hb.data() + 8, (size_t)h->K * sizeof(float));
+    return MSM_OK;
+}
+
+msm_idx_t msm_mbk_packed_size(msm_mbk_t* h) { return h ? (msm_idx_t)(h->K * h->m + h->K + 1) : 0; }
+
+int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device)
+{
+    if (!h || !buf) return fail(MSM_ERR_STATE, "msm_mbk_export_packed: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(buf, h->packed, (size_t)msm_mbk_packed_size(h) * sizeof(double),
+                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int on_device)
+{
+    if (!h || !buf) return fail(MSM_ERR_STATE, "msm_mbk_apply_packed: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(h->packed, buf, (size_t)msm_mbk_packed_size(h) * sizeof(double),
+                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(mbk_apply_kernel, dim3((unsigned)h->K), dim3(256), 0, stream(), h->centers, h->counts, h->packed, h->K, h->m);
+    MSM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (counts_out) MSM_HIP_CHECK(hipMemcpyAsync(counts_out, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_reassign(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
+                     msm_idx_t n_reassign, float new_count, int on_device)
+{
+    if (!h || !X || !rows || !which) return fail(MSM_ERR_STATE, "msm_mbk_reassign: null argument");
+    if (n_reassign <= 0) return MSM_OK;
+    int rc;
+    for (msm_idx_t i = 0; i < n_reassign; ++i)
+        if (rows[i] < 0 || rows[i] >= n || which[i] < 0 || which[i] >= h->K) return fail(MSM_ERR_INVALID, "msm_mbk_reassign: index out of range");
+    const float* Xd = X;
+    std::vector<msm_idx_t> r2(rows, rows + n_reassign);
+    if (!on_device) {  // ship only the chosen rows
+        std::vector<float> xb((size_t)n_reassign * h->m);
+        for (msm_idx_t i = 0; i < n_reassign; ++i) {
+            memcpy(xb.data() + (size_t)i * h->m, X + rows[i] * h->m, (size_t)h->m * sizeof(float));
+            r2[(size_t)i] = i;
+        }
+        if ((rc = h->xb.reserve(xb.size() * sizeof(float)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->xb.p, xb.data(), xb.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        Xd = h->xb.as<float>();
+    }
+    if ((rc = h->rows.reserve((size_t)n_reassign * sizeof(msm_idx_t)))) return rc;
+    if ((rc = h->which.reserve((size_t)n_reassign * sizeof(msm_idx_t)))) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(h->rows.p, r2.data(), (size_t)n_reassign * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(h->which.p, which, (size_t)n_reassign * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(mbk_reassign_kernel, dim3((unsigned)n_reassign), dim3(256), 0, stream(), h->centers, h->counts, Xd,
+                       h->m, h->rows.as<msm_idx_t>(), h->which.as<msm_idx_t>(), new_count);
+    MSM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
+    MSM_HIP_CHECK(hipGetLastError());
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_set_counts(msm_mbk_t* h, const float* counts)
+{
+    if (!h || !counts) return fail(MSM_ERR_STATE, "msm_mbk_set_counts: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(h->counts, counts, (size_t)h->K * sizeof(float), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device)
+{
+    if (!h || !X || !labels) return fail(MSM_ERR_STATE, "msm_mbk_label: null argument");
+    if (inertia) *inertia = 0.0;
+    if (n <= 0) return MSM_OK;
+    int rc;
+    const float* Xd = X;
+    int32_t* lab_d = labels;
+    DevBuf &dX = pool(PS_X), &dL = pool(PS_LAB);
+    if (!on_device) {
+        if ((rc = dX.reserve((size_t)n * h->m * sizeof(float)))) return rc;
+        if ((rc = dL.reserve((size_t)n * sizeof(int32_t)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * h->m * sizeof(float), hipMemcpyHostToDevice, stream()));
+        Xd = dX.as<float>();
+        lab_d = dL.as<int32_t>();
+    }
+    if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
+    int nb = 0;
+    if ((rc = mbk_label(h, Xd, nullptr, n, lab_d, inertia ? h->part.as<double>() : nullptr, &nb))) return rc;
+    if (!on_device) MSM_HIP_CHECK(hipMemcpyAsync(labels, lab_d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
+    if (inertia) {
+        std::vector<double> hp((size_t)nb);
+        MSM_HIP_CHECK(hipMemcpyAsync(hp.data(), h->part.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        double sacc = 0.0;
+        for (int i = 0; i < nb; ++i) sacc += hp[(size_t)i];
+        *inertia = sacc;
+    } else {
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+    return MSM_OK;
+}
 
 int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* centers,
                          msm_idx_t K, int32_t* labels, double* inertia, int on_device)
