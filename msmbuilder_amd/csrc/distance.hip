@@ -82,9 +82,16 @@ __device__ __forceinline__ void stage_rows(T* Xs, const T* __restrict__ X,
                                            const msm_idx_t* __restrict__ X_indices, long long row0,
                                            long long n, long long m, int f0, int fw, int tid)
 {
-    constexpr int FC = FeatChunk<T>::FC;
-    for (int e = tid; e < DT * fw; e += DT) {
-        const int rr = e / fw, ff = e - rr * fw;
+    constexpr int FC = FeatChunk<T>::FC;  // power of two: lane -> (row, feature) needs no division
+    constexpr int RPP = DT / FC;          // rows covered per pass of the workgroup
+    const int ff = tid & (FC - 1);
+    const int rr0 = tid / FC;
+    if (ff >= fw) {
+        // nothing to load for this lane in a partial last chunk; the tile columns >= fw are never read
+        return;
+    }
+#pragma unroll 4
+    for (int rr = rr0; rr < DT; rr += RPP) {
         const long long i = row0 + rr;
         T v = (T)0;
         if (i < n) {
