@@ -219,7 +219,7 @@ def main():
             "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k != "mfma_ms"},
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             sample = [s.cpu().numpy() for s in seqs[:64]]
             out["cpu_baseline"] = cpu_baseline(sample, args.lag, args.components, args.clusters)
         print(json.dumps(out))

@@ -117,6 +117,8 @@ struct Stage32 {
 // `global_load_dwordx4 v, v_off32, s[base]`: no 64-bit VALU address math in the K loop.
 struct ChunkCtx {
     global_ptr<char> base;  // &X[row0][0]
+    global_ptr<char> baseB; // &X[row0 + tau][0] (lagged panel; == base for Gram tiles or when no pair is valid)
+    int nmaxB;              // kr <= nmaxB keeps the lagged row inside the trajectory
     int n;                  // rows in the chunk
     int lo;                 // kr >= lo  <=>  row >= lag           (second Gram term)
     int hi;                 // kr <  hi  <=>  row <  len - lag, and kr < n
@@ -139,7 +141,20 @@ __device__ __forceinline__ ChunkCtx make_ctx(const TicaArgs& P, const TicaChunk&
     c.hi = hi < ch.n ? hi : ch.n;
     c.nmax = sat_i32(ch.len - 1 - ch.row0);
     c.ldb = (unsigned)(P.ld * sizeof(float));
+    c.baseB = c.base;
+    c.nmaxB = c.nmax;
     return c;
+}
+
+// The lag goes into a 64-bit base pointer, never into the 32-bit per-lane offsets (lag * pitch can
+// exceed 4 GiB); if the lagged row of the chunk's first frame is already past the trajectory end
+// no pair of this chunk is valid (all weights are 0) and the B panel may read the A rows instead.
+__device__ __forceinline__ void set_lag(ChunkCtx& c, long long tauB, size_t elem_bytes, long long ld)
+{
+    if (tauB > 0 && c.nmax >= tauB) {
+        c.baseB = c.base + (size_t)tauB * (size_t)ld * elem_bytes;
+        c.nmaxB = sat_i32((long long)c.nmax - tauB);
+    }
 }
 
 template <bool VEC4>
@@ -170,9 +185,9 @@ __device__ __forceinline__ void stage_load32(Stage32<VEC4>& st, const ChunkCtx& 
         float sc = (kr < cx.hi) ? 1.f : 0.f;
         if (isG) sc += (kr >= cx.lo && kr < cx.n) ? 1.f : 0.f;
         const int ra = kr < cx.nmax ? kr : cx.nmax;
-        const int rb = (kr + tauB) < cx.nmax ? (kr + tauB) : cx.nmax;
+        const int rb = kr < cx.nmaxB ? kr : cx.nmaxB;
         st.a[j] = load_row4<VEC4>(cx.base, (unsigned)ra * cx.ldb, I0 + c4, F);
-        st.b[j] = load_row4<VEC4>(cx.base, (unsigned)rb * cx.ldb, J0 + c4, F);
+        st.b[j] = load_row4<VEC4>(cx.baseB, (unsigned)rb * cx.ldb, J0 + c4, F);
         st.sc[j] = sc;
     }
 }
@@ -245,7 +260,8 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
     for (long long c = cohort; c < P.nchunks; c += P.S) {
         const TicaChunk ch = get_chunk(P, c);
         const int nsteps = (ch.n + BK32 - 1) / BK32;
-        const ChunkCtx cx = make_ctx(P, ch);
+        ChunkCtx cx = make_ctx(P, ch);
+        set_lag(cx, tauB, sizeof(float), P.ld);
         // Register-staged software pipeline, TWO K-steps deep: while step s runs on the MFMA pipe
         // the panel of step s+1 sits in one register set (written to LDS at the end of step s) and
         // the loads of step s+2 are in flight into the other.  One step of lookahead is not enough:
@@ -385,13 +401,13 @@ __device__ __forceinline__ void stage_load64(Stage64<TIn>& st, const ChunkCtx& c
         double sc = (kr < cx.hi) ? 1.0 : 0.0;
         if (isG) sc += (kr >= cx.lo && kr < cx.n) ? 1.0 : 0.0;
         const int ra = kr < cx.nmax ? kr : cx.nmax;
-        const int rb = (kr + tauB) < cx.nmax ? (kr + tauB) : cx.nmax;
+        const int rb = kr < cx.nmaxB ? kr : cx.nmaxB;
         const unsigned oa = (unsigned)ra * cx.ldb, ob = (unsigned)rb * cx.ldb;
         if (vec) {
             const int ca = (I0 + ce < F) ? I0 + ce : F - E;
             const int cb = (J0 + ce < F) ? J0 + ce : F - E;
             st.a[j] = load16_global<char>(cx.base + (oa + (unsigned)ca * (unsigned)sizeof(TIn)));
-            st.b[j] = load16_global<char>(cx.base + (ob + (unsigned)cb * (unsigned)sizeof(TIn)));
+            st.b[j] = load16_global<char>(cx.baseB + (ob + (unsigned)cb * (unsigned)sizeof(TIn)));
         } else {
             TIn* pa = reinterpret_cast<TIn*>(&st.a[j]);
             TIn* pb = reinterpret_cast<TIn*>(&st.b[j]);
@@ -400,7 +416,7 @@ __device__ __forceinline__ void stage_load64(Stage64<TIn>& st, const ChunkCtx& c
                 const int ca = (I0 + ce + e < F) ? I0 + ce + e : F - 1;
                 const int cb = (J0 + ce + e < F) ? J0 + ce + e : F - 1;
                 pa[e] = *(global_ptr<TIn>)(cx.base + (oa + (unsigned)ca * (unsigned)sizeof(TIn)));
-                pb[e] = *(global_ptr<TIn>)(cx.base + (ob + (unsigned)cb * (unsigned)sizeof(TIn)));
+                pb[e] = *(global_ptr<TIn>)(cx.baseB + (ob + (unsigned)cb * (unsigned)sizeof(TIn)));
             }
         }
         st.sc[j] = sc;
@@ -465,6 +481,8 @@ __global__ __launch_bounds__(NT, 1) void tica_mfma_f64_kernel(TicaArgs P)
         ChunkCtx cx = make_ctx(P, ch);
         cx.base = as_global<char>(ch.base) + (size_t)ch.row0 * (size_t)P.ld * sizeof(TIn);
         cx.ldb = (unsigned)(P.ld * sizeof(TIn));
+        cx.baseB = cx.base;
+        set_lag(cx, tauB, sizeof(TIn), P.ld);
         const bool vec = (P.F % E == 0) && (P.ld % E == 0) && ((((uintptr_t)ch.base) & 15) == 0);
 
         Stage64<TIn> st0, st1;

@@ -48,6 +48,28 @@ def test_config2_tica_1M_x_128_vs_fp64_contraction(gpu, monkeypatch, mode, rtol)
         assert np.all(np.diff(m.eigenvalues_) <= 0) and m.eigenvalues_[0] < 1.0 + 1e-9
 
 
+@pytest.mark.parametrize("mode", ["f32", "f64"])
+def test_huge_lag_offsets_beyond_4GiB(gpu, monkeypatch, mode):
+    """lag * row pitch > 4 GiB: the lag must live in a 64-bit base pointer, not in 32-bit lane offsets."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, F, lag = 2_300_000, 512, 2_200_000           # 2.2M * 2 KiB = 4.5 GB
+    X = torch.randn(N, F, generator=g, device="cuda") + 0.25
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = tICA(n_components=2, lag_time=lag).fit([X])
+    Cm, Gm, s0, st = _accumulators(m)
+    A, B = X[:-lag].double(), X[lag:].double()
+    Cr = (A.T @ B).cpu().numpy()
+    Gr = (A.T @ A + B.T @ B).cpu().numpy()
+    tol = (2e-6 if mode == "f32" else 1e-12) * np.abs(Gr).max()   # fp32 partials of <= 8192 all-positive terms on the diagonal
+    np.testing.assert_allclose(Cm, Cr, rtol=0, atol=tol)
+    np.testing.assert_allclose(Gm, Gr, rtol=0, atol=tol)
+    np.testing.assert_allclose(s0, A.sum(0).cpu().numpy(), rtol=1e-11)
+    np.testing.assert_allclose(st, B.sum(0).cpu().numpy(), rtol=1e-11)
+
+
 def test_tica_additivity_and_import_export(gpu, monkeypatch):
     """sum of per-shard exports == one fit over everything (the multi-GPU exchange, single process);
     import(export(x)) is the identity; shift invariance of the covariance."""
