@@ -191,7 +191,7 @@ def main():
         mfma_ms = float(np.mean(times["mfma_ms"]))
         flops = 4.0 * F * F * frames                     # algorithmic: 2 dense F x F rank-1 updates per frame
         achieved = flops / (mfma_ms * 1e-3) / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if args.mode == "f32" else PEAK_F64_MFMA_TFLOPS
+        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f64": PEAK_F64_MFMA_TFLOPS}.get(args.mode, 2500.0)  # bf16 dense MFMA
         traffic = None   # PMC counters need their own rocprofv3 pass: read the committed measurement
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["tica_mfma_%s_kernel" % args.mode]
@@ -203,7 +203,7 @@ def main():
             "metric": "frames/sec tICA fit + KCenters assign, 10M x 512 feats",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.mode == "f32" else "f64", "data": "synthetic",
+            "dtype": args.mode, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] shape per GPU: %d x %d fp32 as %d trajectories x %d, "
                                    "tICA(n_components=%d, lag_time=%d) fit+solve+transform -> KCenters(k=%d) fit+predict"
                                    % (frames, F, n_seq, T, args.components, args.lag, args.clusters),

@@ -56,7 +56,9 @@ enum msm_status {
 /* accumulate precision of the tICA covariance kernel */
 enum msm_tica_mode {
     MSM_TICA_F32 = 0,  /* v_mfma_f32_32x32x2_f32, fp32 partials per <=4096-row chunk, fp64 merge */
-    MSM_TICA_F64 = 1   /* v_mfma_f64_16x16x4_f64 on fp64-widened inputs: the reference's arithmetic */
+    MSM_TICA_F64 = 1,  /* v_mfma_f64_16x16x4_f64 on fp64-widened inputs: the reference's arithmetic */
+    MSM_TICA_BF16 = 2, /* v_mfma_f32_32x32x16_bf16 on inputs rounded to bf16, fp32 partials, fp64 merge */
+    MSM_TICA_BF16X2 = 3 /* split x = hi + mid (two bf16 terms), four products on the bf16 MFMA: fp32-class sums */
 };
 
 /* ---- runtime ---------------------------------------------------------- */

@@ -24,6 +24,8 @@ MSM_ERR_STATE = -6
 
 TICA_F32 = 0
 TICA_F64 = 1
+TICA_BF16 = 2
+TICA_BF16X2 = 3
 
 _i64 = C.c_int64
 _p = C.c_void_p

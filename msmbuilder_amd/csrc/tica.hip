@@ -533,6 +533,188 @@ __global__ __launch_bounds__(NT, 1) void tica_mfma_f64_kernel(TicaArgs P)
 }
 
 // ---------------------------------------------------------------------------
+// bf16 kernels (BASELINE config 5: "bf16-MFMA covariance vs fp32"): v_mfma_f32_32x32x16_bf16,
+// fp32 accumulate, 16x the fp32 MFMA rate.
+//   X3 = false ("bf16")  : inputs rounded to bf16 (RNE), one product   (eigenvalue rtol 1e-3)
+//   X3 = true  ("bf16x2"): split x = hi + mid (two bf16 terms, 16 significant bits), all four
+//               products hi*hi + hi*mid + mid*hi + mid*mid: what is dropped is the 2^-17-relative,
+//               random-signed remainder x - hi - mid, so sums over frames keep fp32-class accuracy
+//               at 4/16 of the fp32 MFMA time.  (Without mid*mid the Gram diagonal is biased low by
+//               sum(mid^2): measured 2.9e-6 relative.)
+// The bf16 MFMA wants 8 CONSECUTIVE FRAMES of one feature per lane, i.e. a column walk of the
+// frame-major data.  The transpose is done in registers while staging: a thread loads the same
+// float4 (4 features) from 8 consecutive frames, converts, and writes one 16-byte
+// [8 frames] packet per feature into an LDS image [frame-group][feature][8]; fragments are then
+// plain conflict-free ds_read_b128.  With the MFMA phase this short the kernel is bound by the
+// L2 -> LDS staging path, not by the matrix pipe.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BKB = 32;  // frames per K-step: 4 groups of 8
+
+template <bool X3>
+struct StageB {
+    float4 v[8];  // 8 consecutive frames x 4 features of this thread's panel (A for threads 0-127, B for 128-255)
+    float sc[8];  // A-side weights
+};
+
+template <bool VEC4>
+__device__ __forceinline__ void stageB_load(float4 (&v)[8], float (&sc)[8], const ChunkCtx& cx, int F, int k0,
+                                            int isG, int col0, bool isB, int tid)
+{
+    const int c4 = (tid & 31) * 4;
+    const int kg = (tid >> 5) & 3;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int kr = k0 + kg * 8 + r;
+        float w = (kr < cx.hi) ? 1.f : 0.f;
+        if (isG) w += (kr >= cx.lo && kr < cx.n) ? 1.f : 0.f;
+        const int lim = isB ? cx.nmaxB : cx.nmax;
+        const int rr = kr < lim ? kr : lim;
+        v[r] = load_row4<VEC4>(isB ? cx.baseB : cx.base, (unsigned)rr * cx.ldb, col0 + c4, F);
+        sc[r] = isB ? 1.f : w;
+    }
+}
+
+template <bool X3>
+__device__ __forceinline__ void stageB_store(const float4 (&v)[8], const float (&sc)[8], bf16x8* hi, bf16x8* mid,
+                                             float4 colmask, int tid)
+{
+    const int c4 = (tid & 31) * 4;
+    const int kg = (tid >> 5) & 3;
+    const float m4[4] = {colmask.x, colmask.y, colmask.z, colmask.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bf16x8 h, m;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float x = (q == 0 ? v[r].x : q == 1 ? v[r].y : q == 2 ? v[r].z : v[r].w) * (sc[r] * m4[q]);
+            const __bf16 xh = (__bf16)x;
+            h[r] = xh;
+            if (X3) m[r] = (__bf16)(x - (float)xh);
+        }
+        hi[kg * TM + c4 + q] = h;
+        if (X3) mid[kg * TM + c4 + q] = m;
+    }
+}
+
+template <bool VEC4, bool X3>
+__global__ __launch_bounds__(NT, 2) void tica_mfma_bf16_kernel(TicaArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // per buffer: Ah [4][128] packets, Bh [4][128], (X3: Am, Bm)
+    constexpr int PK = 4 * TM;                     // packets per panel image
+    constexpr int IMG = (X3 ? 4 : 2) * PK;         // packets per buffer
+    bf16x8* L = reinterpret_cast<bf16x8*>(smem);   // [2][IMG]
+
+    const int tid = threadIdx.x;
+    const int p = xcd_linear_id();
+    const int cohort = p / P.ntiles, tile = p % P.ntiles;
+    int I, J, isG;
+    decode_tile(tile, P.T, I, J, isG);
+    const int I0 = I * TM, J0 = J * TM;
+    const int tauB = isG ? 0 : P.lag;
+    const bool isB = tid >= 128;                   // this thread stages the B panel
+    const int col0 = isB ? J0 : I0;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kl = lane >> 5, cl = lane & 31;
+    double* slab = P.slabs + (size_t)p * (TM * TM);
+    const int c4 = (tid & 31) * 4;
+    const float4 cm = make_float4(col0 + c4 + 0 < P.F ? 1.f : 0.f, col0 + c4 + 1 < P.F ? 1.f : 0.f,
+                                  col0 + c4 + 2 < P.F ? 1.f : 0.f, col0 + c4 + 3 < P.F ? 1.f : 0.f);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+    int rows_acc = 0;
+
+    for (long long c = cohort; c < P.nchunks; c += P.S) {
+        const TicaChunk ch = get_chunk(P, c);
+        const int nsteps = (ch.n + BKB - 1) / BKB;
+        ChunkCtx cx = make_ctx(P, ch);
+        set_lag(cx, tauB, sizeof(float), P.ld);
+
+        StageB<X3> s0, s1;
+        stageB_load<VEC4>(s0.v, s0.sc, cx, P.F, 0, isG, col0, isB, tid);
+        stageB_store<X3>(s0.v, s0.sc, L + (isB ? PK : 0), L + (isB ? PK : 0) + 2 * PK, cm, tid);
+        stageB_load<VEC4>(s0.v, s0.sc, cx, P.F, BKB, isG, col0, isB, tid);
+        __syncthreads();
+#define MSM_TICA_STEPB(SNEXT, SLOAD, BUF)                                                         \
+        {                                                                                         \
+            stageB_load<VEC4>(SLOAD.v, SLOAD.sc, cx, P.F, (s + 2) * BKB, isG, col0, isB, tid);    \
+            const bf16x8* Ah = L + (BUF) * IMG;                                                   \
+            const bf16x8* Bh = Ah + PK;                                                           \
+            _Pragma("unroll") for (int q = 0; q < BKB / 16; ++q) {                                \
+                const int kg = 2 * q + kl;                                                        \
+                const bf16x8 a0 = Ah[kg * TM + wr * 64 + cl], a1 = Ah[kg * TM + wr * 64 + 32 + cl]; \
+                const bf16x8 b0 = Bh[kg * TM + wc * 64 + cl], b1 = Bh[kg * TM + wc * 64 + 32 + cl]; \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);  \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);  \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);  \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);  \
+                if (X3) {                                                                         \
+                    const bf16x8* Am = Ah + 2 * PK;                                               \
+                    const bf16x8* Bm = Am + PK;                                                   \
+                    const bf16x8 am0 = Am[kg * TM + wr * 64 + cl], am1 = Am[kg * TM + wr * 64 + 32 + cl]; \
+                    const bf16x8 bm0 = Bm[kg * TM + wc * 64 + cl], bm1 = Bm[kg * TM + wc * 64 + 32 + cl]; \
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bm0, acc[0][0], 0, 0, 0); \
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bm1, acc[0][1], 0, 0, 0); \
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bm0, acc[1][0], 0, 0, 0); \
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bm1, acc[1][1], 0, 0, 0); \
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, b0, acc[0][0], 0, 0, 0); \
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, b1, acc[0][1], 0, 0, 0); \
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, b0, acc[1][0], 0, 0, 0); \
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, b1, acc[1][1], 0, 0, 0); \
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, bm0, acc[0][0], 0, 0, 0); \
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, bm1, acc[0][1], 0, 0, 0); \
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bm0, acc[1][0], 0, 0, 0); \
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bm1, acc[1][1], 0, 0, 0); \
+                }                                                                                 \
+            }                                                                                     \
+            if (s + 1 < nsteps) {                                                                 \
+                bf16x8* dst = L + ((BUF) ^ 1) * IMG + (isB ? PK : 0);                             \
+                stageB_store<X3>(SNEXT.v, SNEXT.sc, dst, dst + 2 * PK, cm, tid);                  \
+            }                                                                                     \
+            __syncthreads();                                                                      \
+        }
+        for (int s = 0; s < nsteps; s += 2) {
+            MSM_TICA_STEPB(s0, s1, 0)
+            ++s;
+            if (s < nsteps) MSM_TICA_STEPB(s1, s0, 1)
+            --s;
+        }
+#undef MSM_TICA_STEPB
+        rows_acc += ch.n;
+        if (rows_acc + P.kc > KFLUSH || c + P.S >= P.nchunks) {
+            rows_acc = 0;
+            unsigned toff = (unsigned)((wr * 64 + 4 * kl) * TM + wc * 64 + cl);
+            asm volatile("" : "+v"(toff));
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                double old[2][16];
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        old[bj][r] = (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff];
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff] = old[bj][r] + (double)acc[bi][bj][r];
+                        acc[bi][bj][r] = 0.f;
+                    }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Column sums s0 / stau (tica.py:418-419) + the finite check of
 // utils/validation.py:68-74, one streaming pass, fp64 accumulation.
 // Block b owns partial slot b and walks chunks b, b+grid, ...
@@ -654,7 +836,8 @@ __global__ void tica_export_kernel(const double* __restrict__ slabs, const doubl
         if (type == 0) {
             tile = ti * T + tj;
         } else {
-            if (ti > tj) {  // lower triangle: mirror of the computed upper tile
+            if (i > j) {  // lower triangle (also inside a diagonal tile): mirror of the upper element, so the
+                          // result is exactly symmetric whatever the kernel's product order was
                 int t = i; i = j; j = t;
                 t = ti; ti = tj; tj = t;
             }
@@ -762,7 +945,7 @@ using namespace msm;
 
 struct msm_tica {
     int F = 0, lag = 0, mode = 0, T = 0, ntiles = 0;
-    int S32 = 0, S64 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
+    int S32 = 0, S64 = 0, SB = 0, SB3 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
     double* slabs = nullptr;    // [G][TM*TM]
     double* base = nullptr;     // packed [2FF+2F] imported state
     double* colpart = nullptr;  // [NCB][2][F]
@@ -791,6 +974,8 @@ int query_slots(K kernel, size_t lds, int* slots)
 }
 
 constexpr size_t LDS32 = 2 * 2 * BK32 * TM * sizeof(float);  // 64 KiB
+constexpr size_t LDSB = 2 * 2 * 4 * TM * 16;                  // 32 KiB: [2 bufs][A,B][4 groups][128] 16-byte packets
+constexpr size_t LDSB3 = 2 * 4 * 4 * TM * 16;                 // 64 KiB: + mid images
 constexpr size_t LDS64 = 2 * 2 * BK64 * P64 * sizeof(double);  // 72 KiB (double-buffered, pitch 144)
 
 int tica_zero(msm_tica* h)
@@ -827,8 +1012,9 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
 
     // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
     const bool use32 = (h->mode == MSM_TICA_F32 && dtype_bytes == 4);
-    const int bk = use32 ? BK32 : BK64;
-    const int S = use32 ? h->S32 : h->S64;  // one resident round of S cohorts x ntiles workgroups
+    const bool useb = (h->mode == MSM_TICA_BF16 || h->mode == MSM_TICA_BF16X2) && dtype_bytes == 4;
+    const int bk = (use32 || useb) ? BK32 : BK64;
+    const int S = use32 ? h->S32 : useb ? (h->mode == MSM_TICA_BF16 ? h->SB : h->SB3) : h->S64;  // one resident round
     const int G = S * h->ntiles;
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
@@ -922,6 +1108,17 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             hipLaunchKernelGGL((tica_mfma_f32_kernel<true, true>), dim3(G), dim3(NT), LDS32, stream(), P);
         else
             hipLaunchKernelGGL((tica_mfma_f32_kernel<false, true>), dim3(G), dim3(NT), LDS32, stream(), P);
+    } else if (useb) {
+        const bool x3 = h->mode == MSM_TICA_BF16X2;
+        const size_t lds = x3 ? LDSB3 : LDSB;
+        if (aligned && x3)
+            hipLaunchKernelGGL((tica_mfma_bf16_kernel<true, true>), dim3(G), dim3(NT), lds, stream(), P);
+        else if (aligned)
+            hipLaunchKernelGGL((tica_mfma_bf16_kernel<true, false>), dim3(G), dim3(NT), lds, stream(), P);
+        else if (x3)
+            hipLaunchKernelGGL((tica_mfma_bf16_kernel<false, true>), dim3(G), dim3(NT), lds, stream(), P);
+        else
+            hipLaunchKernelGGL((tica_mfma_bf16_kernel<false, false>), dim3(G), dim3(NT), lds, stream(), P);
     } else if (dtype_bytes == 4) {
         hipLaunchKernelGGL(tica_mfma_f64_kernel<float>, dim3(G), dim3(NT), LDS64, stream(), P);
     } else {
@@ -961,7 +1158,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (!out) return fail(MSM_ERR_INVALID, "msm_tica_create: null handle pointer");
     if (n_features < 1 || n_features > (1 << 15)) return fail(MSM_ERR_INVALID, "n_features=%lld out of range", (long long)n_features);
     if (lag_time < 1) return fail(MSM_ERR_INVALID, "lag_time must be >= 1");
-    if (mode != MSM_TICA_F32 && mode != MSM_TICA_F64) return fail(MSM_ERR_INVALID, "unknown tica mode %d", mode);
+    if (mode < MSM_TICA_F32 || mode > MSM_TICA_BF16X2) return fail(MSM_ERR_INVALID, "unknown tica mode %d", mode);
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     msm_tica* h = new msm_tica();
     h->F = (int)n_features;
@@ -995,12 +1192,30 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
         if ((rc = query_slots(tica_mfma_f64_kernel<double>, LDS64, &sb))) { delete h; return rc; }
         slots64 = sa < sb ? sa : sb;
     }
+    int slotsb = 0, slotsb3 = 0;
+    {
+        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_bf16_kernel<true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB3));
+        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_bf16_kernel<false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB3));
+        int sa = 0, sb = 0;
+        if ((rc = query_slots(tica_mfma_bf16_kernel<true, false>, LDSB, &sa))) { delete h; return rc; }
+        if ((rc = query_slots(tica_mfma_bf16_kernel<false, false>, LDSB, &sb))) { delete h; return rc; }
+        slotsb = sa < sb ? sa : sb;
+        if ((rc = query_slots(tica_mfma_bf16_kernel<true, true>, LDSB3, &sa))) { delete h; return rc; }
+        if ((rc = query_slots(tica_mfma_bf16_kernel<false, true>, LDSB3, &sb))) { delete h; return rc; }
+        slotsb3 = sa < sb ? sa : sb;
+    }
     // one resident round per launch: S cohorts of ntiles workgroups, per kernel flavour
     h->S32 = slots32 / h->ntiles;
     h->S64 = slots64 / h->ntiles;
+    h->SB = slotsb / h->ntiles;
+    h->SB3 = slotsb3 / h->ntiles;
     if (h->S32 < 1) h->S32 = 1;
     if (h->S64 < 1) h->S64 = 1;
-    h->S = h->S32 > h->S64 ? h->S32 : h->S64;  // slabs exist for the larger; unused ones stay zero
+    if (h->SB < 1) h->SB = 1;
+    if (h->SB3 < 1) h->SB3 = 1;
+    h->S = std::max(std::max(h->S32, h->S64), std::max(h->SB, h->SB3));  // slabs exist for the largest; unused ones stay zero
     h->G = h->S * h->ntiles;
     const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipError_t e = hipSuccess;

@@ -16,7 +16,10 @@ Precision: ``MSMBUILDER_AMD_TICA_MODE=f32`` (default) accumulates float32 inputs
 with exact-fp32 MFMA in <=4096-frame chunks merged in fp64 (eigenvalues agree
 with the float64 reference to rtol 1e-5, typically 1e-7); ``f64`` uses the fp64
 MFMA on widened inputs and reproduces the reference's float64 arithmetic up to
-summation order (rtol 1e-10).  float64 inputs always take the fp64 kernel.
+summation order (rtol 1e-10); ``bf16`` rounds the inputs to bfloat16 for the 16x faster bf16 MFMA
+(rtol 1e-3); ``bf16x2`` splits every value into two bfloat16 terms and forms all four products
+(fp32-class accuracy, rtol 1e-5, at twice the fp32-MFMA speed).  float64 inputs always take the fp64
+kernel.
 
 Multi-GPU: every rank fits its own shard of trajectories, then
 ``allreduce()`` sums the packed accumulators with one RCCL all-reduce
@@ -72,9 +75,10 @@ def _park_handle(h, n_features, lag_time, mode):
 
 def _mode_from_env():
     m = os.environ.get("MSMBUILDER_AMD_TICA_MODE", "f32").lower()
-    if m not in ("f32", "f64"):
-        raise ValueError("MSMBUILDER_AMD_TICA_MODE must be 'f32' or 'f64'")
-    return _lib.TICA_F64 if m == "f64" else _lib.TICA_F32
+    modes = {"f32": _lib.TICA_F32, "f64": _lib.TICA_F64, "bf16": _lib.TICA_BF16, "bf16x2": _lib.TICA_BF16X2}
+    if m not in modes:
+        raise ValueError("MSMBUILDER_AMD_TICA_MODE must be one of %s" % sorted(modes))
+    return modes[m]
 
 
 class tICA(BaseEstimator, TransformerMixin):

@@ -16,7 +16,30 @@ def _accumulators(m):
     return m._outer_0_to_T_lagged, m._outer_gram_sum, m._sum_0_to_TminusTau, m._sum_tau_to_T
 
 
-@pytest.mark.parametrize("mode,rtol", [("f32", 2e-6), ("f64", 1e-12)])
+def test_config5_bf16_mfma_vs_fp32(gpu, monkeypatch):
+    """configs[4] at single-GPU scale: F = 2048, bf16-MFMA covariance against the fp32 path
+    (stated tolerance: eigenvalues rtol 1e-3 for bf16, 1e-5 for the two-term split)."""
+    from msmbuilder_amd import tICA
+    g = torch.Generator(device="cuda").manual_seed(9)
+    N, F, T = 200_000, 2048, 10_000
+    z = torch.randn(N, 12, generator=g, device="cuda")
+    for s in range(N // T):
+        z[s * T:(s + 1) * T] = z[s * T:(s + 1) * T].cumsum(0) * 0.02
+    X = (z @ torch.randn(12, F, generator=g, device="cuda") + torch.randn(N, F, generator=g, device="cuda")
+         + torch.linspace(-1, 1, F, device="cuda")).float().contiguous()
+    seqs = list(X.view(N // T, T, F).unbind(0))
+    ev = {}
+    for mode in ("f32", "bf16x2", "bf16"):
+        monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev[mode] = tICA(n_components=8, lag_time=100).fit(seqs).eigenvalues_
+    np.testing.assert_allclose(ev["bf16"], ev["f32"], rtol=1e-3)
+    np.testing.assert_allclose(ev["bf16x2"], ev["f32"], rtol=1e-5)
+    assert 0 < ev["f32"][-1] and ev["f32"][0] < 1
+
+
+@pytest.mark.parametrize("mode,rtol", [("f32", 2e-6), ("f64", 1e-12), ("bf16x2", 2e-6)])
 def test_config2_tica_1M_x_128_vs_fp64_contraction(gpu, monkeypatch, mode, rtol):
     """configs[1]: 1M x 128 fp32, lag 100, one trajectory and the same data as 100 trajectories."""
     from msmbuilder_amd import tICA
