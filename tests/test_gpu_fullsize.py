@@ -39,7 +39,7 @@ def test_config5_bf16_mfma_vs_fp32(gpu, monkeypatch):
     assert 0 < ev["f32"][-1] and ev["f32"][0] < 1
 
 
-@pytest.mark.parametrize("mode,rtol", [("f32", 2e-6), ("f64", 1e-12), ("bf16x2", 2e-6)])
+@pytest.mark.parametrize("mode,rtol", [("f32", 2e-6), ("f64", 1e-12), ("bf16x2", 1e-5)])
 def test_config2_tica_1M_x_128_vs_fp64_contraction(gpu, monkeypatch, mode, rtol):
     """configs[1]: 1M x 128 fp32, lag 100, one trajectory and the same data as 100 trajectories."""
     from msmbuilder_amd import tICA

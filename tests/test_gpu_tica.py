@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 RTOL = {"f32": 1e-5, "f64": 1e-10, "bf16x2": 1e-5, "bf16": 1e-3}   # stated eigenvalue tolerances
-ATOL_SCALE = {"f32": 5e-7, "bf16x2": 1e-6, "bf16": 2e-4}             # accumulators, relative to max|G|
+ATOL_SCALE = {"f32": 5e-7, "bf16x2": 1e-6, "bf16": 5e-4}             # accumulators, relative to max|G|
 
 
 def _ar1(seed, n_seq, n_frames, n_features, offset=3.0):
