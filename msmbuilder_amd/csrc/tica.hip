@@ -57,7 +57,6 @@ struct TicaArgs {
     int* flag;        // sticky non-finite flag
     unsigned* cosync; // [S] per-cohort arrival counters (zeroed per launch): keeps a cohort's workgroups within one chunk of each other
     long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
-    int ablate;       // profiling only (MSM_TICA_ABLATE): 1 skip global->LDS restaging, 2 skip barriers, 4 skip LDS fragment reads
 };
 
 __device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         stage_load32<VEC4>(st0, cx, P.F, 0, isG, tauB, I0, J0, tid);
         stage_store32<VEC4, PARTIAL>(st0, As, Bs, tid, ma, mb);
         stage_load32<VEC4>(st0, cx, P.F, BK32, isG, tauB, I0, J0, tid);
-        if (P.cosync && !(P.ablate & 32) && chunks_done > 0) {
+        if (P.cosync && chunks_done > 0) {
             if (tid == 0) {
                 const unsigned target = (unsigned)P.ntiles * (unsigned)chunks_done;
                 const long long t0 = clock64();
@@ -286,18 +285,17 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         {                                                                                         \
             /* unconditional (rows past the chunk are clamped and weighted 0): a branch here makes */ \
             /* the compiler wait vmcnt(0) instead of vmcnt(8) before the LDS store below          */ \
-            if (!(P.ablate & 8)) stage_load32<VEC4>(SLOAD, cx, P.F, (s + 2) * BK32, isG, tauB, I0, J0, tid); \
+            stage_load32<VEC4>(SLOAD, cx, P.F, (s + 2) * BK32, isG, tauB, I0, J0, tid);          \
             const float* Ab = As + (BUF) * (BK32 * TM) + kl * TM + wr * 64 + cl;                  \
             const float* Bb = Bs + (BUF) * (BK32 * TM) + kl * TM + wc * 64 + cl;                  \
             /* fragment reads run one k-pair ahead of the MFMAs that consume them */              \
             float a0 = Ab[0], a1 = Ab[32], b0 = Bb[0], b1 = Bb[32];                               \
-            _Pragma("unroll 4") for (int kk = 0; kk < BK32 / 2; ++kk) {                           \
+            /* fully unrolled: an inner loop makes the compiler's vmcnt bookkeeping give up and     */ \
+            /* wait vmcnt(0) at the top of every step, which cuts the register pipeline to 1 step */ \
+            _Pragma("unroll") for (int kk = 0; kk < BK32 / 2; ++kk) {                             \
                 const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;                                 \
-                float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;                                     \
-                if (!(P.ablate & 4)) {                                                            \
-                    na0 = Ab[kn * 2 * TM]; na1 = Ab[kn * 2 * TM + 32];                            \
-                    nb0 = Bb[kn * 2 * TM]; nb1 = Bb[kn * 2 * TM + 32];                            \
-                }                                                                                 \
+                const float na0 = Ab[kn * 2 * TM], na1 = Ab[kn * 2 * TM + 32];                    \
+                const float nb0 = Bb[kn * 2 * TM], nb1 = Bb[kn * 2 * TM + 32];                    \
                 __builtin_amdgcn_sched_barrier(0); /* keep the reads ABOVE the MFMAs they do not feed */ \
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);     \
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);     \
@@ -306,9 +304,9 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
                 __builtin_amdgcn_sched_barrier(0);                                                \
                 a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                           \
             }                                                                                     \
-            if (s + 1 < nsteps && !(P.ablate & 16))                                               \
+            if (s + 1 < nsteps)                                                                   \
                 stage_store32<VEC4, PARTIAL>(SNEXT, As + ((BUF) ^ 1) * (BK32 * TM), Bs + ((BUF) ^ 1) * (BK32 * TM), tid, ma, mb); \
-            if (!(P.ablate & 2)) __syncthreads();                                                 \
+            __syncthreads();                                                                      \
         }
         for (int s = 0; s < nsteps; s += 2) {
             MSM_TICA_STEP(st0, st1, 0)
@@ -323,7 +321,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         // at chunk boundaries, keeps them within one chunk of each other.  No data is exchanged
         // (no fences needed) and the wait is BOUNDED: if a member is not resident the others
         // simply run on, so this can cost performance but never correctness or liveness.
-        if (P.cosync && !(P.ablate & 32)) {
+        if (P.cosync) {
             ++chunks_done;  // arrive now, wait later (after the slab merge and the next chunk's prologue)
             if (tid == 0)
                 __hip_atomic_fetch_add(P.cosync + cohort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1040,7 +1038,6 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         const char* e = getenv("MSM_TICA_COHORT_PACING");
         P.cosync = (e && atoi(e)) ? h->cosync : nullptr;
     }
-    { const char* ab = getenv("MSM_TICA_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
 
     if (nvalid == 1 && n_seq == 1) {
         P.chunks = nullptr;
