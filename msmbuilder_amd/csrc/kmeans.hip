@@ -208,6 +208,245 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_kernel(KmArgs P)
     }
 }
 
+// running argmin over one finished centre tile (ascending j per lane, strict <); clears acc
+__device__ __forceinline__ void km4_argmin(f32x16 (&acc)[2][2], float (&best)[2][16], int (&bidx)[2][16],
+                                           const KmArgs& P, long long j0, int wc, int cl)
+{
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const long long j = j0 + wc * 64 + bj * 32 + cl;
+        if (j < P.K) {
+            const float cn = P.cnorm[j];
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = cn - 2.f * acc[bi][bj][r];
+                    if (v < best[bi][r]) {
+                        best[bi][r] = v;
+                        bidx[bi][r] = (int)j;
+                    }
+                }
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+    }
+}
+
+// wavefront min-reduction over the 32 lanes that share a row (value, lowest index), then the two
+// centre halves; writes labels (or the split launch's candidates)
+__device__ __forceinline__ void km_finish_rows(const float (&best)[2][16], const int (&bidx)[2][16], const KmArgs& P,
+                                               float* redv, int* redi, long long row0, int tid, int wr, int wc,
+                                               int kl, int cl)
+{
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = best[bi][r];
+            int ix = bidx[bi][r];
+#pragma unroll
+            for (int msk = 1; msk < 32; msk <<= 1) {
+                const float ov = __shfl_xor(v, msk, 64);
+                const int oi = __shfl_xor(ix, msk, 64);
+                if (ov < v || (ov == v && oi < ix)) {
+                    v = ov;
+                    ix = oi;
+                }
+            }
+            if (cl == 0) {
+                const int row = wr * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                redv[wc * KR + row] = v;
+                redi[wc * KR + row] = ix;
+            }
+        }
+    __syncthreads();
+    if (tid < KR) {
+        const long long i = row0 + tid;
+        if (i < P.n) {
+            float v0 = redv[tid], v1 = redv[KR + tid];
+            int i0 = redi[tid], i1 = redi[KR + tid];
+            const bool second = (v1 < v0 || (v1 == v0 && i1 < i0));
+            int lab = second ? i1 : i0;
+            if (P.jspan) {
+                P.pv[(long long)blockIdx.y * P.n + i] = second ? v1 : v0;
+                P.pi[(long long)blockIdx.y * P.n + i] = lab;
+            } else {
+                if (lab == 0x7fffffff) lab = 0;  // all-NaN row: sklearn's argmin returns 0
+                P.labels[i] = lab;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fast path (m % 4 == 0, 16-byte aligned rows): same tiling, restructured for the MFMA pipe.
+//  * LDS tiles stay row-major [128][KP4=36] (16-byte aligned rows -> ds_write_b128 in,
+//    ds_read_b128 out).  A lane's b128 fragment holds 4 CONSECUTIVE features of its row; the
+//    32x32x2 MFMA wants features (k, k+1) from lanes (kl=0, kl=1), so within every group of 8
+//    features MFMA q contracts features {q, 4+q}: a permutation of the summation order applied
+//    to rows and centres alike (the reference arithmetic is an sgemm whose order is unspecified).
+//    Pitch 36 words: 16 lanes x b128 cover all 64 banks exactly once.
+//  * (centre tile, K-step) pairs form ONE flat iteration stream; the register pipeline is two
+//    iterations deep and never drains at a centre-tile boundary.  Loads are unconditional
+//    (rows/centres/columns clamped, out-of-range columns zeroed at LDS-store time) and the
+//    4 feature groups of a step are fully unrolled: branches or loops around in-flight loads
+//    make the compiler wait vmcnt(0) (see tica.hip).
+// ---------------------------------------------------------------------------
+constexpr int KP4 = KBK + 4;
+
+struct KmStage {
+    float4 x[4], c[4];
+    int inb;  // this thread's 4 columns are inside [0, m)
+};
+
+__device__ __forceinline__ void km4_load(KmStage& st, const global_ptr<char> (&xp)[4], global_ptr<char> cb,
+                                         const unsigned (&co)[4], int col, int m)
+{
+    st.inb = col < m;
+    const unsigned cc = 4u * (unsigned)(col < m ? col : m - 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        st.x[j] = load16_global<char>(xp[j] + cc);
+        st.c[j] = load16_global<char>(cb + (co[j] + cc));
+    }
+}
+
+__device__ __forceinline__ void km4_store(const KmStage& st, float* Xs, float* Cs, int tid)
+{
+    const int c4 = (tid & 7) * 4;
+    const int r0 = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (value selects: `cond ? lvalue : lvalue` on structs selects an ADDRESS and forces scratch)
+        const bool in = st.inb != 0;
+        *reinterpret_cast<float4*>(Xs + (r0 + 32 * j) * KP4 + c4) =
+            make_float4(in ? st.x[j].x : 0.f, in ? st.x[j].y : 0.f, in ? st.x[j].z : 0.f, in ? st.x[j].w : 0.f);
+        *reinterpret_cast<float4*>(Cs + (r0 + 32 * j) * KP4 + c4) =
+            make_float4(in ? st.c[j].x : 0.f, in ? st.c[j].y : 0.f, in ? st.c[j].z : 0.f, in ? st.c[j].w : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char km_smem[];
+    float* Xs = reinterpret_cast<float*>(km_smem);  // [2][KR * KP4]
+    float* Cs = Xs + 2 * KR * KP4;                  // [2][KCT * KP4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, kl = lane >> 5, cl = lane & 31;
+    const long long row0 = (long long)blockIdx.x * KR;
+    const int m = (int)P.m;
+    const int nk = (m + KBK - 1) / KBK;
+    const unsigned ldb = (unsigned)m * 4u;
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;
+
+    float best[2][16];
+    int bidx[2][16];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            best[bi][r] = INFINITY;
+            bidx[bi][r] = 0x7fffffff;
+        }
+
+    // this thread's 4 staging rows of X (fixed for the workgroup's life; clamped into [0, n))
+    global_ptr<char> xp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long i = row0 + r0 + 32 * j;
+        if (i > P.n - 1) i = P.n - 1;
+        const long long r = P.rows ? as_global<msm_idx_t>(P.rows)[i] : i;
+        xp[j] = as_global<char>(P.X) + (size_t)r * ldb;
+    }
+    const global_ptr<char> Cg = as_global<char>(P.C);
+
+    const long long jbeg = P.jspan ? (long long)blockIdx.y * P.jspan : 0;
+    const long long jend = P.jspan ? (jbeg + P.jspan < P.K ? jbeg + P.jspan : P.K) : P.K;
+    const long long total = ((jend - jbeg + KCT - 1) / KCT) * nk;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+
+    // load cursor (runs two iterations ahead of the compute cursor; parks on the last tile)
+    int ls = 0;
+    long long lj0 = jbeg;
+#define KM4_LOAD(ST)                                                                              \
+    {                                                                                             \
+        const long long lim = P.K - 1 - lj0;                                                      \
+        unsigned co[4];                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            const int rr = r0 + 32 * j;                                                           \
+            co[j] = (unsigned)(rr < lim ? rr : (int)lim) * ldb;                                   \
+        }                                                                                         \
+        km4_load(ST, xp, Cg + (size_t)lj0 * ldb, co, ls * KBK + c4, m);                           \
+        if (++ls == nk) {                                                                         \
+            ls = 0;                                                                               \
+            if (lj0 + KCT < jend) lj0 += KCT;                                                     \
+        }                                                                                         \
+    }
+    KmStage st0, st1;
+    KM4_LOAD(st0)
+    km4_store(st0, Xs, Cs, tid);
+    KM4_LOAD(st0)
+    __syncthreads();
+
+    int s = 0;
+    long long j0 = jbeg;
+#define KM4_STEP(SNEXT, SLOAD, BUF)                                                               \
+    {                                                                                             \
+        KM4_LOAD(SLOAD)                                                                           \
+        const float* Ab = Xs + (BUF) * (KR * KP4) + (wr * 64 + cl) * KP4 + kl * 4;                \
+        const float* Bb = Cs + (BUF) * (KCT * KP4) + (wc * 64 + cl) * KP4 + kl * 4;               \
+        float4 a0 = *reinterpret_cast<const float4*>(Ab), a1 = *reinterpret_cast<const float4*>(Ab + 32 * KP4); \
+        float4 b0 = *reinterpret_cast<const float4*>(Bb), b1 = *reinterpret_cast<const float4*>(Bb + 32 * KP4); \
+        _Pragma("unroll") for (int g = 0; g < KBK / 8; ++g) {                                     \
+            const int gn = (g + 1 < KBK / 8) ? g + 1 : g;                                         \
+            const float4 na0 = *reinterpret_cast<const float4*>(Ab + gn * 8);                     \
+            const float4 na1 = *reinterpret_cast<const float4*>(Ab + 32 * KP4 + gn * 8);          \
+            const float4 nb0 = *reinterpret_cast<const float4*>(Bb + gn * 8);                     \
+            const float4 nb1 = *reinterpret_cast<const float4*>(Bb + 32 * KP4 + gn * 8);          \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            KM4_MFMA4(a0.x, a1.x, b0.x, b1.x)                                                     \
+            KM4_MFMA4(a0.y, a1.y, b0.y, b1.y)                                                     \
+            KM4_MFMA4(a0.z, a1.z, b0.z, b1.z)                                                     \
+            KM4_MFMA4(a0.w, a1.w, b0.w, b1.w)                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                               \
+        }                                                                                         \
+        if (it + 1 < total)                                                                       \
+            km4_store(SNEXT, Xs + ((BUF) ^ 1) * (KR * KP4), Cs + ((BUF) ^ 1) * (KCT * KP4), tid); \
+        __syncthreads();                                                                          \
+        if (++s == nk) {                                                                          \
+            s = 0;                                                                                \
+            km4_argmin(acc, best, bidx, P, j0, wc, cl);                                           \
+            j0 += KCT;                                                                            \
+        }                                                                                         \
+    }
+#define KM4_MFMA4(A0, A1, B0, B1)                                                                 \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc[0][0], 0, 0, 0);                 \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc[0][1], 0, 0, 0);                 \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc[1][0], 0, 0, 0);                 \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc[1][1], 0, 0, 0);
+    for (long long it = 0; it < total; it += 2) {
+        KM4_STEP(st0, st1, 0)
+        ++it;
+        if (it < total) KM4_STEP(st1, st0, 1)
+        --it;
+    }
+#undef KM4_STEP
+#undef KM4_MFMA4
+#undef KM4_LOAD
+    km_finish_rows(best, bidx, P, Xs, reinterpret_cast<int*>(Cs), row0, tid, wr, wc, kl, cl);
+}
+
 // per-row ||x - c_label||^2 (fp32 difference, fp64 accumulate), one wave per row;
 // per-block fp64 partial sums for the inertia.
 __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* __restrict__ partial)
@@ -384,10 +623,31 @@ static int km_prepare(const float* centers, msm_idx_t K, msm_idx_t m, DevBuf& dC
     return MSM_OK;
 }
 
+constexpr size_t KM4_LDS = (size_t)2 * (KR + KCT) * KP4 * sizeof(float);
+
+// picks the 16-byte fast path when the row pitch and both base pointers allow it
+static int km_launch_label(const KmArgs& P, dim3 grid)
+{
+    const bool v4 = P.m >= 4 && (P.m & 3) == 0 && (((uintptr_t)P.X | (uintptr_t)P.C) & 15) == 0 && P.m < (1 << 22);
+    if (v4) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_label_v4_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)KM4_LDS));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kmeans_label_v4_kernel, grid, dim3(KNT), KM4_LDS, stream(), P);
+    } else {
+        hipLaunchKernelGGL(kmeans_label_kernel, grid, dim3(KNT), 0, stream(), P);
+    }
+    MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
 static int km_label_and_inertia(KmArgs& P, double* inertia)
 {
     const unsigned grid = (unsigned)ceil_div(P.n, KR);
-    hipLaunchKernelGGL(kmeans_label_kernel, dim3(grid), dim3(KNT), 0, stream(), P);
+    { int rc0 = km_launch_label(P, dim3(grid)); if (rc0) return rc0; }
     MSM_HIP_CHECK(hipGetLastError());
     if (inertia) {
         const int nb = (int)std::min<long long>(ceil_div(P.n, 4), 1024);
@@ -452,12 +712,11 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
         P.jspan = tiles_per * KCT;
         P.pv = h->pv.as<float>();
         P.pi = h->pi.as<int>();
-        hipLaunchKernelGGL(kmeans_label_kernel, dim3((unsigned)rowblocks, (unsigned)nsplit), dim3(KNT), 0, stream(), P);
-        MSM_HIP_CHECK(hipGetLastError());
+        if ((rc = km_launch_label(P, dim3((unsigned)rowblocks, (unsigned)nsplit)))) return rc;
         hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
                            P.pv, P.pi, n, nsplit, labels_d);
     } else {
-        hipLaunchKernelGGL(kmeans_label_kernel, dim3((unsigned)rowblocks), dim3(KNT), 0, stream(), P);
+        if ((rc = km_launch_label(P, dim3((unsigned)rowblocks)))) return rc;
     }
     MSM_HIP_CHECK(hipGetLastError());
     if (inertia_dev_partial) {
