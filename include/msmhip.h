@@ -105,6 +105,16 @@ int msm_tica_accumulate(msm_tica_t* h, const void* X, int dtype_bytes, msm_idx_t
 int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
                               msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int on_device,
                               int check_finite, msm_idx_t* n_skipped);
+/* Slices of trajectories, for splitting ONE long trajectory over ranks (the sum over
+ * lagged pairs of tica.py:417-422 restricted to the pairs whose LEFT frame a rank owns).
+ * seg4[4*s + {0,1,2,3}] = {trajectory length, trajectory row of X_ptrs[s][0], own_begin, own_end}:
+ * the call adds the terms of the left frames t in [own_begin, own_end) only and needs the slice to
+ * reach row min(own_end + lag_time, length) - 1 (right halo; MSM_ERR_INVALID otherwise).
+ * n_observations grows by own_end - own_begin, n_sequences by 1 where own_begin == 0, so the
+ * all-reduced counters equal the unsplit fit's.  {n, 0, 0, n} is msm_tica_accumulate_batch. */
+int msm_tica_accumulate_segments(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
+                                 const msm_idx_t* seg4, msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld,
+                                 int on_device, int check_finite, msm_idx_t* n_skipped);
 int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until reset */
 /* HIP-event duration (ms) of the most recent MFMA accumulation launch of this handle,
  * measured on the stream it ran on (bench.py's roofline leg); synchronises on it. */

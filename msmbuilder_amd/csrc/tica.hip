@@ -43,6 +43,8 @@ struct TicaChunk {
     long long len;     // trajectory length
     int n;             // rows in this chunk
     int pad;
+    long long last;    // last ADDRESSABLE row of the trajectory's storage (len - 1, or the end of the
+                       // slice a rank holds when one long trajectory is split over ranks)
 };
 
 struct TicaArgs {
@@ -138,7 +140,7 @@ __device__ __forceinline__ ChunkCtx make_ctx(const TicaArgs& P, const TicaChunk&
     c.lo = sat_i32((long long)P.lag - ch.row0);
     const int hi = sat_i32(ch.len - P.lag - ch.row0);
     c.hi = hi < ch.n ? hi : ch.n;
-    c.nmax = sat_i32(ch.len - 1 - ch.row0);
+    c.nmax = sat_i32((ch.last < ch.len - 1 ? ch.last : ch.len - 1) - ch.row0);
     c.ldb = (unsigned)(P.ld * sizeof(float));
     c.baseB = c.base;
     c.nmaxB = c.nmax;
@@ -989,19 +991,34 @@ int tica_zero(msm_tica* h)
     return MSM_OK;
 }
 
+// A slice of one trajectory: `ptr` is trajectory row `off`, the slice holds n_rows rows, and this
+// call owns the LEFT indices t in [ob, oe) of the lagged pairs (t, t + lag) -- i.e. it adds
+// w_t x_t x_t^T, [t < len - lag] x_t x_{t+lag}^T and the matching column sums for those t only.
+// The slice must reach row min(oe + lag, len) - 1 (the right halo).  Whole trajectory: {n, 0, 0, n}.
+struct SegInfo {
+    long long len, off, ob, oe;
+};
+
 // device-resident trajectories only
 int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t* n_rows,
                            msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int check_finite,
-                           msm_idx_t* n_skipped)
+                           msm_idx_t* n_skipped, const SegInfo* segs = nullptr)
 {
     long long total = 0, nvalid = 0, skipped = 0;
     bool aligned = (h->F % 4 == 0) && (ld % 4 == 0);
+    auto seg_of = [&](msm_idx_t s) {
+        SegInfo g;
+        if (segs) g = segs[s];
+        else { g.len = n_rows[s]; g.off = 0; g.ob = 0; g.oe = n_rows[s]; }
+        return g;
+    };
     for (msm_idx_t s = 0; s < n_seq; ++s) {
-        if (n_rows[s] > h->lag) {
-            total += n_rows[s];
+        const SegInfo g = seg_of(s);
+        if (g.len > h->lag && g.oe > g.ob) {
+            total += g.oe - g.ob;
             ++nvalid;
             if (((uintptr_t)ptrs[s]) & 15) aligned = false;
-        } else {
+        } else if (g.len <= h->lag) {
             ++skipped;
         }
     }
@@ -1039,28 +1056,33 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         P.cosync = (e && atoi(e)) ? h->cosync : nullptr;
     }
 
-    if (nvalid == 1 && n_seq == 1) {
+    if (nvalid == 1 && n_seq == 1 && !segs) {
         P.chunks = nullptr;
         P.single.base = ptrs[0];
         P.single.row0 = 0;
         P.single.len = n_rows[0];
+        P.single.last = n_rows[0] - 1;
         P.single.n = 0;
         P.nchunks = ceil_div(n_rows[0], kc);
     } else {
         std::vector<TicaChunk> tab;
         tab.reserve((size_t)(total / kc + nvalid + 1));
         for (msm_idx_t s = 0; s < n_seq; ++s) {
-            const long long len = n_rows[s];
-            if (len <= h->lag) continue;
-            const long long nch = ceil_div(len, kc);
-            long long piece = ceil_div(ceil_div(len, nch), bk) * bk;
-            for (long long r0 = 0; r0 < len; r0 += piece) {
+            const SegInfo g = seg_of(s);
+            if (g.len <= h->lag || g.oe <= g.ob) continue;
+            const long long own = g.oe - g.ob;
+            const long long nch = ceil_div(own, kc);
+            long long piece = ceil_div(ceil_div(own, nch), bk) * bk;
+            for (long long r0 = g.ob; r0 < g.oe; r0 += piece) {
                 TicaChunk ch;
-                ch.base = ptrs[s];
+                // virtual row 0 of the trajectory (never dereferenced outside the slice: rows are
+                // clamped to [row0, last])
+                ch.base = (const char*)ptrs[s] - (ptrdiff_t)g.off * (ptrdiff_t)ld * dtype_bytes;
                 ch.row0 = r0;
-                ch.len = len;
-                ch.n = (int)((len - r0) < piece ? (len - r0) : piece);
+                ch.len = g.len;
+                ch.n = (int)((g.oe - r0) < piece ? (g.oe - r0) : piece);
                 ch.pad = 0;
+                ch.last = g.off + n_rows[s] - 1;
                 tab.push_back(ch);
             }
         }
@@ -1126,11 +1148,13 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipEventRecord(h->ev1, stream()));
         h->timed = true;
     }
-    for (msm_idx_t s = 0; s < n_seq; ++s)
-        if (n_rows[s] > h->lag) {
-            h->n_obs += n_rows[s];
-            h->n_seq += 1;
+    for (msm_idx_t s = 0; s < n_seq; ++s) {
+        const SegInfo g = seg_of(s);
+        if (g.len > h->lag && g.oe > g.ob) {
+            h->n_obs += g.oe - g.ob;       // summed over the ranks sharing a trajectory this is its length
+            h->n_seq += (g.ob == 0) ? 1 : 0;  // ... and the rank owning row 0 counts the sequence
         }
+    }
     return MSM_OK;
 }
 
@@ -1263,9 +1287,9 @@ int msm_tica_reset(msm_tica_t* h)
     return tica_zero(h);
 }
 
-int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
-                              msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int on_device,
-                              int check_finite, msm_idx_t* n_skipped)
+static int tica_accumulate_any(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
+                               msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int on_device,
+                               int check_finite, msm_idx_t* n_skipped, const SegInfo* segs)
 {
     if (!h) return fail(MSM_ERR_STATE, "null tica handle");
     if (n_seq < 0 || (n_seq > 0 && (!X_ptrs || !n_rows))) return fail(MSM_ERR_INVALID, "bad sequence table");
@@ -1275,7 +1299,7 @@ int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const ms
         if (n_rows[s] < 0 || (n_rows[s] > 0 && !X_ptrs[s])) return fail(MSM_ERR_INVALID, "bad sequence %lld", (long long)s);
     if (n_skipped) *n_skipped = 0;
     if (n_seq == 0) return MSM_OK;
-    if (on_device) return tica_accumulate_device(h, X_ptrs, n_rows, n_seq, dtype_bytes, ld, check_finite, n_skipped);
+    if (on_device) return tica_accumulate_device(h, X_ptrs, n_rows, n_seq, dtype_bytes, ld, check_finite, n_skipped, segs);
 
     // host trajectories: stage groups of them (compacted to ld = F) through a device buffer
     const size_t row_bytes = (size_t)h->F * dtype_bytes;
@@ -1307,7 +1331,7 @@ int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const ms
             off += ((size_t)n_rows[i] * row_bytes + 255) & ~(size_t)255;
         }
         msm_idx_t sk = 0;
-        rc = tica_accumulate_device(h, dptrs.data(), n_rows + s, e - s, dtype_bytes, h->F, check_finite, &sk);
+        rc = tica_accumulate_device(h, dptrs.data(), n_rows + s, e - s, dtype_bytes, h->F, check_finite, &sk, segs ? segs + s : nullptr);
         if (rc) return rc;
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // staging buffer is reused by the next group
         skipped_total += sk;
@@ -1315,6 +1339,41 @@ int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const ms
     }
     if (n_skipped) *n_skipped = skipped_total;
     return MSM_OK;
+}
+
+int msm_tica_accumulate_batch(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
+                              msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int on_device,
+                              int check_finite, msm_idx_t* n_skipped)
+{
+    return tica_accumulate_any(h, X_ptrs, n_rows, n_seq, dtype_bytes, ld, on_device, check_finite, n_skipped, nullptr);
+}
+
+int msm_tica_accumulate_segments(msm_tica_t* h, const void* const* X_ptrs, const msm_idx_t* n_rows,
+                                 const msm_idx_t* seg4, msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld,
+                                 int on_device, int check_finite, msm_idx_t* n_skipped)
+{
+    if (!h) return fail(MSM_ERR_STATE, "null tica handle");
+    if (n_seq < 0 || (n_seq > 0 && (!X_ptrs || !n_rows || !seg4))) return fail(MSM_ERR_INVALID, "bad segment table");
+    std::vector<SegInfo> segs((size_t)n_seq);
+    for (msm_idx_t s = 0; s < n_seq; ++s) {
+        SegInfo g;
+        g.len = seg4[4 * s + 0];
+        g.off = seg4[4 * s + 1];
+        g.ob = seg4[4 * s + 2];
+        g.oe = seg4[4 * s + 3];
+        if (g.len < 0 || g.off < 0 || n_rows[s] < 0 || g.off + n_rows[s] > g.len)
+            return fail(MSM_ERR_INVALID, "segment %lld: slice [%lld, %lld) is not inside a trajectory of %lld rows",
+                        (long long)s, (long long)g.off, (long long)(g.off + n_rows[s]), (long long)g.len);
+        if (g.oe > g.ob) {
+            const long long need = (g.oe + h->lag < g.len ? g.oe + h->lag : g.len);  // right halo
+            if (g.ob < g.off || need > g.off + n_rows[s])
+                return fail(MSM_ERR_INVALID, "segment %lld: owned rows [%lld, %lld) + lag %d need rows [%lld, %lld) but the slice holds [%lld, %lld)",
+                            (long long)s, (long long)g.ob, (long long)g.oe, h->lag, (long long)g.ob, need,
+                            (long long)g.off, (long long)(g.off + n_rows[s]));
+        }
+        segs[(size_t)s] = g;
+    }
+    return tica_accumulate_any(h, X_ptrs, n_rows, n_seq, dtype_bytes, ld, on_device, check_finite, n_skipped, segs.data());
 }
 
 int msm_tica_accumulate(msm_tica_t* h, const void* X, int dtype_bytes, msm_idx_t n_rows,

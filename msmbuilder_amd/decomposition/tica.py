@@ -410,6 +410,74 @@ class tICA(BaseEstimator, TransformerMixin):
         self._is_dirty = True
 
     # ------------------------------------------------------------------ multi-GPU
+    def partial_fit_segments(self, pieces):
+        """Accumulate slices of trajectories: ``pieces`` is a list of ``(X_slice, length,
+        row_offset, own_begin, own_end)`` where ``X_slice[0]`` is row ``row_offset`` of a
+        trajectory of ``length`` rows and this model owns the LEFT frames ``[own_begin,
+        own_end)`` of its lagged pairs (the slice must reach row ``min(own_end + lag_time,
+        length) - 1``).  Summed over the models that share a trajectory (``allreduce``), the
+        state equals ``partial_fit`` of the whole trajectory (tica.py:401-424)."""
+        classes = {}
+        for X, length, off, ob, oe in pieces:
+            X = self._prepare(X)
+            self._initialize(X.shape[1])
+            if X.shape[1] != self.n_features:
+                raise ValueError("shapes (%d,%d) and (%d,%d) not aligned" % (
+                    self.n_features, self.n_features, X.shape[1], X.shape[0]))
+            if not length > self.lag_time:
+                continue
+            key = (is_device_array(X), 8 if str(X.dtype).endswith("64") else 4)
+            classes.setdefault(key, []).append((X, int(length), int(off), int(ob), int(oe)))
+        if not classes:
+            return self
+        self._ensure_handle()
+        L = _lib.lib()
+        for (on_dev, nbytes), items in classes.items():
+            n = len(items)
+            views = [Arr(it[0]) for it in items]
+            ptrs = (C.c_void_p * n)(*[v.ptr for v in views])
+            rows = (C.c_int64 * n)(*[v.shape[0] for v in views])
+            seg4 = (C.c_int64 * (4 * n))(*[x for it in items for x in it[1:]])
+            skipped = C.c_int64(0)
+            check(L.msm_tica_accumulate_segments(self._handle, ptrs, rows, seg4, n, nbytes,
+                                                 int(self.n_features), int(on_dev), 1, C.byref(skipped)))
+            for it in items:
+                self.n_observations_ += max(0, it[4] - it[3])
+                self.n_sequences_ += 1 if (it[3] == 0 and it[4] > it[3]) else 0
+        self._host_stale = True
+        self._is_dirty = True
+        return self
+
+    def fit_sharded(self, sequences, group=None):
+        """SPMD ``fit``: every rank of ``torch.distributed`` calls this with the SAME list of
+        trajectories (arrays, or lazily loaded objects supporting ``len`` and row slicing);
+        each rank reads only its balanced share of the frame axis -- long trajectories are cut
+        between ranks with a ``lag_time``-row right halo (``parallel.split_frames``) -- and ONE
+        all-reduce leaves the global model on every rank.  With a single process this is
+        ``fit``."""
+        from .. import parallel
+        self._initialized = False
+        check_iter_of_sequences(sequences, max_iter=3)
+        lengths = [len(s) for s in sequences]
+        for n in lengths:
+            if not n > self.lag_time:
+                warnings.warn("length of data (%d) is too short for the lag time (%d)" % (n, self.lag_time))
+        if not any(n > self.lag_time for n in lengths):
+            raise ValueError('All sequences were shorter than '
+                             'the lag time, %d' % self.lag_time)
+        pieces = []
+        for i, ob, oe in parallel.split_frames(lengths, self.lag_time):
+            end = min(oe + self.lag_time, lengths[i])
+            pieces.append((sequences[i][ob:end], lengths[i], ob, ob, oe))
+        if pieces:
+            self.partial_fit_segments(pieces)
+        else:  # more ranks than frames: contribute zeros
+            self._initialize(int(np.shape(sequences[0])[1]))
+            self._ensure_handle()
+        if parallel.active():
+            self.allreduce(group=group)
+        return self
+
     def allreduce(self, group=None):
         """Sum the accumulators over all ranks of ``torch.distributed`` (RCCL over xGMI
         with the ``nccl`` backend; ``gloo`` on CPU-only test runs): one all-reduce of the

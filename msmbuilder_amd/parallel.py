@@ -85,6 +85,31 @@ def shard_sequences(sequences, rank_=None, world=None):
     return [i for i in range(len(lengths)) if owner[i] == rank_]
 
 
+def split_frames(lengths, lag_time, rank_=None, world=None):
+    """Balanced split of the FRAME axis over ranks, cutting inside trajectories where needed.
+
+    The usable trajectories (length > lag_time) are laid end to end and the axis is cut into
+    ``world`` equal spans; a rank owns, as LEFT frames of the lagged pairs, the rows of every
+    trajectory that fall into its span.  Returns this rank's ``[(sequence index, own_begin,
+    own_end), ...]``.  To accumulate a piece a rank needs rows ``[own_begin, min(own_end +
+    lag_time, length))`` of that trajectory (the right halo of ``lag_time`` rows is read, not
+    owned).  Trajectories shorter than the lag are skipped by every rank, like tica.py:410-412.
+    """
+    rank_ = rank() if rank_ is None else rank_
+    world = world_size() if world is None else world
+    usable = [(i, int(n)) for i, n in enumerate(lengths) if int(n) > lag_time]
+    total = sum(n for _, n in usable)
+    lo = (total * rank_) // world
+    hi = (total * (rank_ + 1)) // world
+    out, pos = [], 0
+    for i, n in usable:
+        b, e = max(lo, pos), min(hi, pos + n)
+        if e > b:
+            out.append((i, b - pos, e - pos))
+        pos += n
+    return out
+
+
 def _backend_is_nccl(group=None):
     return _dist().get_backend(group) == "nccl"
 

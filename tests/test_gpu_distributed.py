@@ -35,6 +35,17 @@ assert m.n_observations_ == ref.n_observations_ and m.n_sequences_ == ref.n_sequ
 np.testing.assert_allclose(m.eigenvalues_, ref.eigenvalues_, rtol=1e-11)
 np.testing.assert_allclose(m.means_, ref.means_, rtol=1e-12)
 
+# ---- tICA: SPMD fit of ONE long trajectory cut between the ranks (lag-row right halo)
+long = [(rs.randn(5000, 12) * 0.7 + 0.3).astype(np.float32), seqs[0], seqs[1][:4]]
+ms = tICA(n_components=3, lag_time=7).fit_sharded(long)
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "0"
+rl = tICA(n_components=3, lag_time=7).fit(long)
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "1"
+assert ms.n_observations_ == rl.n_observations_ and ms.n_sequences_ == rl.n_sequences_ == 2
+np.testing.assert_allclose(ms.eigenvalues_, rl.eigenvalues_, rtol=1e-11)
+np.testing.assert_allclose(ms.offset_correlation_, rl.offset_correlation_, rtol=1e-10, atol=1e-13)
+np.testing.assert_allclose(ms.covariance_, rl.covariance_, rtol=1e-10, atol=1e-13)
+
 # ---- KCenters: consecutive row blocks per rank
 X = np.concatenate(seqs).astype(np.float64)
 X[40:44] = X[3]                                   # duplicates: argmax ties across the shard boundary

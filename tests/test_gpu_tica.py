@@ -232,3 +232,50 @@ def test_f64_mfma_layout_asymmetric(gpu, monkeypatch):
         C = Xd[:-3].T @ Xd[3:]
         assert np.abs(C - C.T).max() > 1.0
         np.testing.assert_allclose(m._outer_0_to_T_lagged, C, rtol=1e-5, atol=1e-3 if mode != "bf16" else 0.5)
+
+
+# ---------------------------------------------------------------- trajectory segments
+@pytest.mark.parametrize("mode,rtol", [("f64", 1e-11), ("f32", 2e-6)])
+def test_segments_of_one_trajectory_sum_to_the_whole(gpu, monkeypatch, mode, rtol):
+    """Cutting one trajectory into pieces owned by different models (= ranks) and summing the
+    exported accumulators reproduces the unsplit partial_fit (tica.py:417-422)."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    rs = np.random.RandomState(5)
+    n, F, lag = 9137, 24, 13
+    X = (rs.randn(n, F) * 0.8 + 0.2).astype(np.float32)
+    whole = tICA(n_components=4, lag_time=lag).fit([X])
+    cuts = [0, 1, 2999, 3000 + lag - 1, 9130, n]       # includes a 1-row piece and a piece inside the last lag rows
+    parts = []
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        end = min(e + lag, n)
+        m = tICA(n_components=4, lag_time=lag)
+        m.partial_fit_segments([(X[b:end], n, b, b, e)])
+        parts.append(m)
+    assert sum(m.n_observations_ for m in parts) == n and sum(m.n_sequences_ for m in parts) == 1
+    for m in parts:
+        m._pull()
+    whole._pull()
+    scale = np.abs(whole._outer_gram_sum).max()
+    for name in ("_outer_0_to_T_lagged", "_outer_gram_sum", "_sum_0_to_TminusTau", "_sum_tau_to_T"):
+        got = sum(getattr(m, name) for m in parts)
+        np.testing.assert_allclose(got, getattr(whole, name), rtol=rtol, atol=rtol * scale, err_msg=name)
+    # the same pieces into ONE model, device-resident slices
+    import torch
+    Xd = torch.from_numpy(X).cuda()
+    one = tICA(n_components=4, lag_time=lag)
+    one.partial_fit_segments([(Xd[b:min(e + lag, n)], n, b, b, e) for b, e in zip(cuts[:-1], cuts[1:])])
+    assert one.n_observations_ == n and one.n_sequences_ == 1
+    np.testing.assert_allclose(one.eigenvalues_, whole.eigenvalues_, rtol=max(rtol, 1e-10) * 10)
+
+
+def test_segment_without_its_halo_is_rejected(gpu):
+    from msmbuilder_amd import tICA
+    X = np.random.RandomState(0).randn(500, 8).astype(np.float32)
+    m = tICA(lag_time=10)
+    with pytest.raises(ValueError, match="need rows"):
+        m.partial_fit_segments([(X[100:200], 500, 100, 100, 200)])    # needs rows up to 209
+    with pytest.raises(ValueError, match="need rows"):
+        m.partial_fit_segments([(X[100:220], 500, 100, 90, 200)])     # owns rows it does not hold
+    m.partial_fit_segments([(X[100:210], 500, 100, 100, 200)])
+    assert m.n_observations_ == 100 and m.n_sequences_ == 0

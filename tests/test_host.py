@@ -183,3 +183,20 @@ def test_gloo_world2_reductions(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def test_split_frames_covers_every_usable_row_once():
+    from msmbuilder_amd.parallel import split_frames
+    lengths, lag = [5, 1000, 37, 12, 4000, 13], 12
+    for world in (1, 2, 3, 8):
+        seen = {i: np.zeros(n, dtype=int) for i, n in enumerate(lengths)}
+        loads = []
+        for r in range(world):
+            pieces = split_frames(lengths, lag, r, world)
+            loads.append(sum(e - b for _, b, e in pieces))
+            for i, b, e in pieces:
+                assert lengths[i] > lag and 0 <= b < e <= lengths[i]
+                seen[i][b:e] += 1
+        for i, n in enumerate(lengths):
+            assert (seen[i] == (1 if n > lag else 0)).all()
+        assert max(loads) - min(loads) <= 1
