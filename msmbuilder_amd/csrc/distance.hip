@@ -438,6 +438,294 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
     }
 }
 
+struct WideArgs;
+// end of a centre group for one row: finalise the NC distances (assign: running strict minimum in
+// centre order, assign.hpp:22-31; cdist: write out[i, j])
+template <typename T, int M, int MODE, int NC>
+__device__ __forceinline__ void wide_group_end(const WideArgs& A, double (&a)[NC], double (&b)[NC], long long i,
+                                               long long j0, long long n, long long m, long long K, double& min_d,
+                                               long long& lab);
+template <typename T, int M, int MODE>
+__device__ __forceinline__ void wide_tile_end(const WideArgs& A, long long i, long long n, double& min_d,
+                                              long long& lab, double& inertia, double& bv, long long& bi);
+
+// ---------------------------------------------------------------------------
+// Wide-row streaming path (m > FC, rows 16-byte aligned, no X_indices): the HBM-bound scans
+// (dist, one k-centers pass, assign/cdist against a few centres) and the VALU-bound ones
+// (many centres) share one kernel.  A workgroup owns 256 rows per tile, one lane per row, and
+// walks the features in 128-byte chunks in the reference's order (one fp64 accumulator per
+// (row, centre), sequential features).  Staging is what the scalar path lacked:
+//  * every thread issues 8 x 16-byte loads per chunk (rows clamped -> unconditional), the tile
+//    goes to LDS as [256][WP = 36 words] with ds_write_b128 and comes back as ds_read_b128 per
+//    lane (16 lanes x 4 banks tile all 64 banks: conflict-free);
+//  * (tile, centre group, chunk) units form one flat stream with a two-deep register pipeline
+//    and double-buffered LDS, one barrier per unit, 2 workgroups per CU: 128 KB of loads in
+//    flight per CU, enough to cover HBM latency at full bandwidth.
+// Zero padding of a partial last chunk is exact for every metric (a 0/0 pair adds nothing).
+// MODE 0 assign_nearest, 1 cdist/dist, 2 one k-centers pass (NC == 1).
+// ---------------------------------------------------------------------------
+constexpr int WP = 36;   // staged row pitch in 32-bit words (128 B of data + 16 B pad)
+constexpr int WNC = 8;   // centres per register tile in MODE 0/1
+
+struct WideArgs {
+    PairArgs pa;   // MODE 0/1
+    KcArgs kc;     // MODE 2
+};
+
+struct WideStage {
+    raw_f32x4 x[8];
+    raw_f32x4 y;
+    int inb;
+};
+
+template <typename T, int M, int MODE>
+__global__ __launch_bounds__(DT, 2) void wide_kernel(WideArgs A)
+{
+    constexpr int E = 16 / (int)sizeof(T);    // elements per 16-byte vector
+    constexpr int FC = 128 / (int)sizeof(T);  // features per chunk
+    constexpr int NC = (MODE == 2) ? 1 : WNC;
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    float* Xs = reinterpret_cast<float*>(wsm);                   // [2][DT * WP]
+    float* Ys = Xs + 2 * DT * WP;                                // [2][NC * 32]
+    double* rv = reinterpret_cast<double*>(Ys + 2 * WNC * 32);   // [DT]
+    long long* ri = reinterpret_cast<long long*>(rv + DT);       // [DT]
+    const int tid = threadIdx.x;
+    const long long n = (MODE == 2) ? A.kc.n : A.pa.n;
+    const long long m = (MODE == 2) ? A.kc.m : A.pa.m;
+    const long long K = (MODE == 2) ? 1 : A.pa.K;
+    const global_ptr<char> Xg = as_global<char>((MODE == 2) ? A.kc.X : A.pa.X);
+
+    // ---- k-centers prologue: centre of this pass = global argmax of the previous partials ----
+    long long cidx = 0;
+    if (MODE == 2) {
+        if (A.kc.ycenter) {
+        } else if (A.kc.it == 0) {
+            cidx = A.kc.seed;
+        } else {
+            double bv = -1.0;
+            long long bi = 0x7fffffffffffffffLL;
+            for (int k = tid; k < A.kc.nblk; k += DT) {
+                const KcPartial q = A.kc.prev[k];
+                if (q.i >= 0 && kc_better(q.v, q.i, bv, bi)) {
+                    bv = q.v;
+                    bi = q.i;
+                }
+            }
+            rv[tid] = bv;
+            ri[tid] = bi;
+            __syncthreads();
+            for (int s = DT / 2; s > 0; s >>= 1) {
+                if (tid < s && kc_better(rv[tid + s], ri[tid + s], rv[tid], ri[tid])) {
+                    rv[tid] = rv[tid + s];
+                    ri[tid] = ri[tid + s];
+                }
+                __syncthreads();
+            }
+            cidx = ri[0];
+            __syncthreads();
+        }
+        if (!A.kc.ycenter && blockIdx.x == 0 && tid == 0) A.kc.ids[A.kc.it] = cidx;
+    }
+    const global_ptr<char> Yg =
+        (MODE == 2) ? (A.kc.ycenter ? as_global<char>(A.kc.ycenter) : Xg + (size_t)cidx * (size_t)m * sizeof(T))
+                    : as_global<char>(A.pa.Y);
+
+    const unsigned rowb = (unsigned)(m * sizeof(T));  // row pitch in bytes (host guarantees 256 * rowb < 2^32)
+    const int c8 = tid & 7, r0 = tid >> 3;
+    const long long ntile = (n + DT - 1) / DT;
+    const int nch = (int)((m + FC - 1) / FC);
+    const long long ngrp = (K + NC - 1) / NC;
+    const long long mytiles = blockIdx.x < ntile ? (ntile - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const long long total = mytiles * ngrp * nch;
+
+    // load cursor: two units ahead of the compute cursor, parks on the last unit
+    long long lt = blockIdx.x, lg = 0;
+    int lc = 0;
+#define WIDE_LOAD(ST)                                                                             \
+    {                                                                                             \
+        const long long row0 = lt * DT;                                                           \
+        const long long rlim = n - 1 - row0;                                                      \
+        const int col = lc * FC + c8 * E;                                                         \
+        (ST).inb = col < m;                                                                       \
+        const unsigned cb = (unsigned)((col < m ? col : (int)m - E) * (int)sizeof(T));            \
+        const global_ptr<char> xb = Xg + (size_t)row0 * rowb;                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                           \
+            const int rr = r0 + 32 * j;                                                           \
+            (ST).x[j] = *(global_ptr<raw_f32x4>)(xb + ((unsigned)(rr < rlim ? rr : (int)rlim) * rowb + cb)); \
+        }                                                                                         \
+        {                                                                                         \
+            const long long jc = lg * NC + (r0 < NC ? r0 : NC - 1);                               \
+            (ST).y = *(global_ptr<raw_f32x4>)(Yg + ((size_t)(jc < K ? jc : K - 1) * rowb + cb));  \
+        }                                                                                         \
+        if (++lc == nch) {                                                                        \
+            lc = 0;                                                                               \
+            if (++lg == ngrp) {                                                                   \
+                lg = 0;                                                                           \
+                if (lt + gridDim.x < ntile) lt += gridDim.x;                                      \
+            }                                                                                     \
+        }                                                                                         \
+    }
+#define WIDE_STORE(ST, BUF)                                                                       \
+    {                                                                                             \
+        const bool in = (ST).inb != 0;                                                            \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                           \
+            raw_f32x4 v = (ST).x[j];                                                              \
+            v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f; \
+            *reinterpret_cast<raw_f32x4*>(Xs + (BUF) * (DT * WP) + (r0 + 32 * j) * WP + c8 * 4) = v; \
+        }                                                                                         \
+        if (r0 < NC) {                                                                            \
+            raw_f32x4 v = (ST).y;                                                                 \
+            v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f; \
+            *reinterpret_cast<raw_f32x4*>(Ys + (BUF) * (WNC * 32) + r0 * 32 + c8 * 4) = v;        \
+        }                                                                                         \
+    }
+
+    // compute cursor and per-row state
+    long long t = blockIdx.x, g = 0;
+    int c = 0;
+    double a[NC], b[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) a[q] = b[q] = 0.0;
+    double min_d = 1.7976931348623157e308;  // assign.hpp:20
+    long long lab = 0;
+    double inertia = 0.0;
+    double bv = -1.0;    // k-centers: this block's (max distance, lowest row)
+    long long bi = -1;
+
+    WideStage st0, st1;
+    if (total > 0) {
+        WIDE_LOAD(st0)
+        WIDE_STORE(st0, 0)
+        WIDE_LOAD(st0)
+    }
+    __syncthreads();
+#define WIDE_STEP(SNEXT, SLOAD, BUF)                                                              \
+    {                                                                                             \
+        WIDE_LOAD(SLOAD)                                                                          \
+        const T* xr = reinterpret_cast<const T*>(Xs + (BUF) * (DT * WP) + tid * WP);              \
+        const T* yr = reinterpret_cast<const T*>(Ys + (BUF) * (WNC * 32));                        \
+        _Pragma("unroll") for (int v = 0; v < 8; ++v) {                                           \
+            const raw_f32x4 xq = *reinterpret_cast<const raw_f32x4*>(xr + v * E);                 \
+            const T* xe = reinterpret_cast<const T*>(&xq);                                        \
+            _Pragma("unroll") for (int q = 0; q < NC; ++q) {                                      \
+                const raw_f32x4 yq = *reinterpret_cast<const raw_f32x4*>(yr + q * FC + v * E);    \
+                const T* ye = reinterpret_cast<const T*>(&yq);                                    \
+                _Pragma("unroll") for (int e = 0; e < E; ++e) m_update<T, M>(a[q], b[q], xe[e], ye[e]); \
+            }                                                                                     \
+            /* pin the accumulators here: otherwise all 64 centre-fragment reads of a chunk are  */ \
+            /* hoisted above the arithmetic (256 live values -> the staged loads go to scratch)  */ \
+            if (NC > 1) {                                                                         \
+                _Pragma("unroll") for (int q = 0; q < NC; ++q) asm volatile("" : "+v"(a[q]) : : "memory"); \
+                if (M == M_BRAYCURTIS || M == M_JACCARD) {                                        \
+                    _Pragma("unroll") for (int q = 0; q < NC; ++q) asm volatile("" : "+v"(b[q]) : : "memory"); \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+        if (u + 1 < total) WIDE_STORE(SNEXT, (BUF) ^ 1)                                           \
+        __syncthreads();                                                                          \
+        if (++c == nch) {                                                                         \
+            c = 0;                                                                                \
+            wide_group_end<T, M, MODE, NC>(A, a, b, t * DT + tid, g * NC, n, m, K, min_d, lab);   \
+            if (++g == ngrp) {                                                                    \
+                g = 0;                                                                            \
+                wide_tile_end<T, M, MODE>(A, t * DT + tid, n, min_d, lab, inertia, bv, bi);       \
+                t += gridDim.x;                                                                   \
+            }                                                                                     \
+        }                                                                                         \
+    }
+    for (long long u = 0; u < total; u += 2) {
+        WIDE_STEP(st0, st1, 0)
+        ++u;
+        if (u < total) WIDE_STEP(st1, st0, 1)
+        --u;
+    }
+#undef WIDE_STEP
+#undef WIDE_STORE
+#undef WIDE_LOAD
+    if (MODE == 0) {
+        rv[tid] = inertia;
+        __syncthreads();
+        for (int s = DT / 2; s > 0; s >>= 1) {
+            if (tid < s) rv[tid] += rv[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) A.pa.partial[blockIdx.x] = rv[0];
+    } else if (MODE == 2) {
+        rv[tid] = bv;
+        ri[tid] = bi;
+        __syncthreads();
+        for (int s = DT / 2; s > 0; s >>= 1) {
+            if (tid < s) {
+                const long long oi = ri[tid + s];
+                if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + s], oi, rv[tid], ri[tid]))) {
+                    rv[tid] = rv[tid + s];
+                    ri[tid] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            KcPartial q;
+            q.v = rv[0];
+            q.i = ri[0];
+            A.kc.next[blockIdx.x] = q;
+        }
+    }
+}
+
+template <typename T, int M, int MODE, int NC>
+__device__ __forceinline__ void wide_group_end(const WideArgs& A, double (&a)[NC], double (&b)[NC], long long i,
+                                               long long j0, long long n, long long m, long long K, double& min_d,
+                                               long long& lab)
+{
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const double d = m_final<M>(a[q], b[q], m);
+        if (MODE == 0) {
+            if (j0 + q < K && d < min_d) {
+                min_d = d;
+                lab = j0 + q;
+            }
+        } else if (MODE == 1) {
+            if (j0 + q < K && i < n) A.pa.out[i * K + j0 + q] = d;
+        } else {
+            min_d = d;  // k-centers: the single distance of this pass
+        }
+        a[q] = 0.0;
+        b[q] = 0.0;
+    }
+}
+
+template <typename T, int M, int MODE>
+__device__ __forceinline__ void wide_tile_end(const WideArgs& A, long long i, long long n, double& min_d,
+                                              long long& lab, double& inertia, double& bv, long long& bi)
+{
+    if (MODE == 0) {
+        if (i < n) {
+            A.pa.labels[i] = lab;
+            if (A.pa.min_dist) A.pa.min_dist[i] = min_d;
+            inertia += min_d;
+        }
+        min_d = 1.7976931348623157e308;
+        lab = 0;
+    } else if (MODE == 2) {
+        if (i < n) {
+            const double d = min_d;
+            double cur = (A.kc.it == 0) ? INFINITY : A.kc.dist[i];  // distances_.fill(inf), kcenters.py:87-88
+            const bool upd = d < cur;                                // strict, kcenters.py:93
+            if (upd) cur = d;
+            if (A.kc.it == 0 || upd) {
+                A.kc.dist[i] = cur;
+                A.kc.labels[i] = upd ? A.kc.it : 0;
+            }
+            if (bi < 0 || kc_better(cur, i, bv, bi)) {
+                bv = cur;
+                bi = i;
+            }
+        }
+    }
+}
+
 // sharded driver: reduce the per-block partials of one pass to (max, lowest row) and fetch that row
 template <typename T>
 __global__ __launch_bounds__(DT) void kc_finalize_kernel(const KcPartial* __restrict__ part, int nblk,
@@ -573,13 +861,49 @@ static int row_vecw(const void* X, long long m, bool has_indices)
     return (a % sizeof(T) == 0) ? (int)sizeof(T) : 0;
 }
 
+constexpr size_t WIDE_LDS = (size_t)2 * DT * WP * 4 + (size_t)2 * WNC * 32 * 4 + (size_t)DT * 16;
+
+// wide-row streaming path applies: long rows, 16-byte aligned vectors, no row gather
+template <typename T>
+static bool wide_ok(const void* X, const void* Y, long long m, bool has_indices)
+{
+    constexpr int E = 16 / (int)sizeof(T);
+    static const bool disabled = getenv("MSM_DIST_NO_WIDE") != nullptr;  // A/B switch for scripts/distperf.py
+    if (disabled) return false;
+    return !has_indices && m > FeatChunk<T>::FC && (m % E) == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0 &&
+           (size_t)m * sizeof(T) < ((size_t)1 << 24);
+}
+
+static int wide_grid(long long n)
+{
+    return (int)std::min<long long>(ceil_div(n, DT), 2LL * num_cus());  // one resident round (2 workgroups / CU)
+}
+
+template <typename T, int MM, int MODE>
+static void launch_wide(int grid, const WideArgs& A)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel<T, MM, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wide_kernel<T, MM, MODE>), dim3(grid), dim3(DT), WIDE_LDS, stream(), A);
+}
+
 template <typename T, int MODE>
 void launch_pair(int metric, int grid, const PairArgs& P)
 {
+    const bool wide = wide_ok<T>(P.X, P.Y, P.m, P.X_indices != nullptr);
+    WideArgs A;
+    memset(&A, 0, sizeof(A));
+    A.pa = P;
 #define MSM_CASE(MM)                                                                              \
     case MM:                                                                                      \
         if (P.vecw > 0)                                                                           \
             hipLaunchKernelGGL((pair_small_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P); \
+        else if (wide)                                                                            \
+            launch_wide<T, MM, MODE>(grid, A);                                                    \
         else                                                                                      \
             hipLaunchKernelGGL((pair_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P); \
         break;
@@ -599,9 +923,16 @@ void launch_pair(int metric, int grid, const PairArgs& P)
 template <typename T>
 void launch_kc(int metric, int grid, const KcArgs& P)
 {
+    const bool wide = P.vecw == 0 && wide_ok<T>(P.X, P.ycenter ? P.ycenter : P.X, P.m, false);
+    WideArgs A;
+    memset(&A, 0, sizeof(A));
+    A.kc = P;
 #define MSM_CASE(MM)                                                                              \
     case MM:                                                                                      \
-        hipLaunchKernelGGL((kcenters_pass_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P);  \
+        if (wide)                                                                                 \
+            launch_wide<T, MM, 2>(grid, A);                                                       \
+        else                                                                                      \
+            hipLaunchKernelGGL((kcenters_pass_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P); \
         break;
     switch (metric) {
         MSM_CASE(M_EUCLIDEAN)
@@ -666,7 +997,7 @@ int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_id
     int rc;
     DevBuf &dX = pool(PS_X), &dY = pool(PS_Y), &dIdx = pool(PS_IDX), &dLab = pool(PS_LAB), &dMin = pool(PS_MIN),
            &dPart = pool(PS_PART);
-    const int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
+    int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
     if ((rc = dY.reserve((size_t)(n_Y ? n_Y : 1) * m * sizeof(T)))) return rc;
     if (n_Y) MSM_HIP_CHECK(hipMemcpyAsync(dY.p, Y, (size_t)n_Y * m * sizeof(T), hipMemcpyHostToDevice, stream()));
     if ((rc = dPart.reserve((size_t)grid * sizeof(double)))) return rc;
@@ -699,6 +1030,7 @@ int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_id
         }
     }
     P.vecw = row_vecw<T>(P.X, m, P.X_indices != nullptr);
+    if (P.vecw == 0 && wide_ok<T>(P.X, P.Y, m, P.X_indices != nullptr)) grid = wide_grid(n);
     launch_pair<T, 0>(mid, grid, P);
     MSM_HIP_CHECK(hipGetLastError());
     if (!on_device) {
@@ -725,7 +1057,7 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     int rc;
     DevBuf &dX = pool(PS_X), &dY = pool(PS_Y), &dIdx = pool(PS_IDX), &dOut = pool(PS_OUT);
-    const int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
+    int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
     if ((rc = dY.reserve((size_t)nb * m * sizeof(T)))) return rc;
     MSM_HIP_CHECK(hipMemcpyAsync(dY.p, XB, (size_t)nb * m * sizeof(T), hipMemcpyHostToDevice, stream()));
     PairArgs P;
@@ -751,6 +1083,7 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
         P.out = dOut.as<double>();
     }
     P.vecw = row_vecw<T>(P.X, m, P.X_indices != nullptr);
+    if (P.vecw == 0 && wide_ok<T>(P.X, P.Y, m, P.X_indices != nullptr)) grid = wide_grid(n);
     launch_pair<T, 1>(mid, grid, P);
     MSM_HIP_CHECK(hipGetLastError());
     if (!on_device)
@@ -773,7 +1106,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     int rc;
     DevBuf &dX = pool(PS_X), &dLab = pool(PS_LAB), &dDist = pool(PS_MIN), &dPart = pool(PS_PART), &dIds = pool(PS_IDS),
            &dSum = pool(PS_SUM);
-    const int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
+    int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
     if ((rc = dPart.reserve((size_t)2 * nblk * sizeof(KcPartial)))) return rc;
     if ((rc = dIds.reserve((size_t)K * sizeof(msm_idx_t)))) return rc;
     if ((rc = dSum.reserve((size_t)nblk * sizeof(double)))) return rc;
@@ -798,6 +1131,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         P.dist = dDist.as<double>();
     }
     P.vecw = row_vecw<T>(P.X, m, false);
+    if (P.vecw == 0 && wide_ok<T>(P.X, P.X, m, false)) P.nblk = nblk = std::min(nblk, wide_grid(n));
     KcPartial* part = dPart.as<KcPartial>();
     for (msm_idx_t it = 0; it < K; ++it) {
         P.it = (int)it;
@@ -912,7 +1246,7 @@ int kcenters_pass_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y, msm_idx
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     int rc;
     DevBuf &dPart = pool(PS_PART), &dY = pool(PS_Y), &dIds = pool(PS_IDS);
-    const int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
+    int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
     if ((rc = dPart.reserve((size_t)nblk * sizeof(KcPartial)))) return rc;
     if ((rc = dY.reserve((size_t)m * sizeof(T)))) return rc;
     if ((rc = dIds.reserve(sizeof(msm_idx_t)))) return rc;
@@ -931,6 +1265,7 @@ int kcenters_pass_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y, msm_idx
     P.ids = dIds.as<msm_idx_t>();
     P.ycenter = dY.p;
     P.vecw = row_vecw<T>(P.X, m, false);
+    if (P.vecw == 0 && wide_ok<T>(P.X, P.ycenter, m, false)) P.nblk = nblk = std::min(nblk, wide_grid(n));
     launch_kc<T>(mid, nblk, P);
     MSM_HIP_CHECK(hipGetLastError());
     // device-side final reduce + fetch of the winning row: ONE small D2H per pass

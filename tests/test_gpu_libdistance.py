@@ -45,7 +45,9 @@ def test_golden_vectors(gpu, golden_dir, metric, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("metric", METRICS)
-@pytest.mark.parametrize("n,k,f", [(1, 1, 1), (300, 9, 3), (1000, 37, 10), (777, 200, 45), (513, 17, 130)])
+@pytest.mark.parametrize("n,k,f", [(1, 1, 1), (300, 9, 3), (1000, 37, 10), (777, 200, 45), (513, 17, 130),
+                                   # wide-row streaming path (16-byte aligned rows longer than one chunk)
+                                   (777, 200, 44), (513, 17, 132), (2100, 8, 64), (300, 1, 36), (70000, 3, 40)])
 def test_bit_exact_vs_oracle(gpu, oracle, metric, dtype, n, k, f):
     from msmbuilder_amd import libdistance as ld
     rs = np.random.RandomState(n + k + f)
@@ -194,11 +196,13 @@ def test_kcenters_golden(gpu, golden_dir):
             assert m.summarize() == str(g[p + "summarize"])
 
 
-@pytest.mark.parametrize("n,f,k", [(5000, 10, 50), (70000, 10, 200), (3000, 171, 20), (1025, 40, 1025)])
-def test_kcenters_vs_oracle(gpu, oracle, n, f, k):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,f,k", [(5000, 10, 50), (70000, 10, 200), (3000, 171, 20), (1025, 40, 1025), (3000, 172, 20),
+                                   (140000, 36, 30)])
+def test_kcenters_vs_oracle(gpu, oracle, n, f, k, dtype):
     from msmbuilder_amd import KCenters
     rs = np.random.RandomState(n)
-    X = rs.randn(n, f).astype(np.float32)
+    X = rs.randn(n, f).astype(dtype)
     X[100:110] = X[5]       # duplicates -> zero distances and argmax ties
     m = KCenters(n_clusters=k, random_state=7).fit([X[: n // 2], X[n // 2:]])
     ids, labels, dist = oracle.kcenters_fit(X, k, "euclidean", m.cluster_ids_[0])
