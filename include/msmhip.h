@@ -244,6 +244,24 @@ int msm_mbk_reassign(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t*
                      msm_idx_t n_reassign, float new_count, int on_device);
 int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device);
 
+/* ------------------------------------------------------------------------------------------
+ * Pre-tICA column scan and scaling.  Replaces the fit / transform arithmetic of
+ * msmbuilder.preprocessing.{StandardScaler, MinMaxScaler, MaxAbsScaler}
+ * (/root/reference/msmbuilder/preprocessing/__init__.py:56-83 -- mixins over scikit-learn's
+ * scalers, base.py:14-199).
+ * msm_colstats: one pass over n_seq trajectories X_ptrs[s] -> n_rows[s] x n_features (common row
+ * stride ld, dtype_bytes 4 or 8; device-resident or host).  out5F[5][n_features] (host, float64) =
+ * per-column {count of non-NaN values, mean, sum of squared deviations M2, min, max}; NaN is a
+ * missing value (scikit-learn's convention), *has_inf != 0 if an infinity was seen.
+ * msm_scale_apply: mode 0 out = (x - shift) / scale, mode 1 out = x * scale + shift, every step
+ * computed in float64 and rounded to the array dtype like numpy's in-place operators; shift /
+ * scale are host float64 [n_features] or NULL (step skipped); out may alias X. */
+int msm_colstats(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int dtype_bytes,
+                 msm_idx_t n_features, msm_idx_t ld, int on_device, double* out5F, int* has_inf);
+int msm_scale_apply(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features, msm_idx_t ld,
+                    const double* shift, const double* scale, int mode, void* out, msm_idx_t ld_out,
+                    int on_device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,5 +7,6 @@ there is no CPU fallback."""
 __version__ = "0.1.0"
 
 from . import libdistance  # noqa: F401
+from . import preprocessing  # noqa: F401
 from .cluster import KCenters, MiniBatchKMeans  # noqa: F401
 from .decomposition import tICA  # noqa: F401

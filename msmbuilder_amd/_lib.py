@@ -86,6 +86,9 @@ def _declare(lib):
     f("msm_tica_import_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_project", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, _i64, _p, C.c_int, C.c_int)
 
+    f("msm_colstats", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, C.c_int, _p, C.POINTER(C.c_int))
+    f("msm_scale_apply", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, C.c_int, _p, _i64, C.c_int)
+
     for sfx in ("f32", "f64"):
         f("msm_dist_" + sfx, C.c_int, _p, _p, C.c_char_p, _i64, _i64, _p, _i64, _p, C.c_int)
         f("msm_pdist_" + sfx, C.c_int, _p, C.c_char_p, _i64, _i64, _p, _i64, _p, C.c_int)

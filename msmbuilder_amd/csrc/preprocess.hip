@@ -1,0 +1,425 @@
+// preprocess.hip -- the column scan in front of tICA: per-column count / mean / M2 /
+// min / max in ONE streaming pass (what msmbuilder.preprocessing.StandardScaler, MinMaxScaler and
+// MaxAbsScaler -- thin mixins over scikit-learn's scalers,
+// /root/reference/msmbuilder/preprocessing/__init__.py:56-83, base.py:14-199 -- compute in fit /
+// partial_fit), and the element-wise (x - shift) / scale of their transform.
+//
+// Arithmetic restated (scikit-learn, third party, unpinned by the reference -- DESIGN.md):
+//   mean/var : sklearn.utils.extmath._incremental_mean_and_var -- float64 sums, NaN = missing value,
+//              batches merged with Chan/Golub/LeVeque's update
+//                  delta = mean_b - mean;  mean += delta * n_b / (n + n_b)
+//                  M2   += M2_b + delta^2 * n * n_b / (n + n_b)
+//              here: every thread forms (n_b, mean_b, M2_b) of 8 rows in registers (two-pass, exact
+//              enough for any offset), merges into its running triple, and triples are merged
+//              lane -> block -> grid in a FIXED order (deterministic, no atomics).
+//   transform: numpy in-place `X -= mean_; X /= scale_` on the input dtype: each step is computed in
+//              float64 and rounded back to the array's dtype (StandardScaler.transform).
+// HBM-bound: F * sizeof(T) bytes per frame read once (scan), read + written once (transform).
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace msm {
+
+constexpr int PNT = 256;
+constexpr int PNB = 1024;  // scan blocks (= partial slots)
+
+struct ScanChunk {
+    const void* base;
+    long long n;  // rows (<= 4096)
+};
+
+struct ScanArgs {
+    const ScanChunk* chunks;
+    long long nchunks;
+    long long ld;
+    int F;
+    double* part;  // [gridDim][5][F]: n, mean, M2, min, max
+    int* flag;     // |= 1 if an infinity was seen
+};
+
+struct Stat {
+    double n, mean, m2, lo, hi;
+};
+
+__device__ __forceinline__ void stat_init(Stat& s)
+{
+    s.n = 0.0;
+    s.mean = 0.0;
+    s.m2 = 0.0;
+    s.lo = INFINITY;
+    s.hi = -INFINITY;
+}
+
+__device__ __forceinline__ void stat_merge(Stat& a, const Stat& b)
+{
+    if (b.n == 0.0) return;
+    const double tot = a.n + b.n;
+    const double delta = b.mean - a.mean;
+    const double w = b.n / tot;
+    a.mean = a.mean + delta * w;
+    a.m2 = a.m2 + b.m2 + delta * delta * a.n * w;
+    a.n = tot;
+    a.lo = b.lo < a.lo ? b.lo : a.lo;
+    a.hi = b.hi > a.hi ? b.hi : a.hi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(PNT) void colstats_kernel(ScanArgs P)
+{
+    constexpr int CW = 16 / sizeof(T);
+    constexpr int RU = 8;
+    __shared__ Stat red[PNT][CW];
+    const int tid = threadIdx.x;
+    const int ngroups = (P.F + CW - 1) / CW;
+    int cpb = 1;
+    while (cpb < ngroups && cpb < PNT) cpb <<= 1;
+    const int rl = PNT / cpb;
+    const int tc = tid % cpb, tr = tid / cpb;
+    const bool vec = (P.F % CW == 0) && (P.ld % CW == 0);
+    double* part = P.part + (size_t)blockIdx.x * 5 * P.F;
+    int inf_seen = 0;
+    for (int g0 = 0; g0 < ngroups; g0 += cpb) {
+        const int col = (g0 + tc) * CW;
+        Stat run[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) stat_init(run[e]);
+        if (col < P.F) {
+            for (long long c = blockIdx.x; c < P.nchunks; c += gridDim.x) {
+                const ScanChunk ch = P.chunks[c];
+                const global_ptr<T> X = as_global<T>(ch.base);
+                const bool al = vec && ((((uintptr_t)ch.base) & 15) == 0);
+                for (long long k0 = tr; k0 < ch.n; k0 += (long long)rl * RU) {
+                    T v[RU][CW];
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const long long kr = k0 + (long long)u * rl;
+                        const long long rr = kr < ch.n ? kr : ch.n - 1;  // clamped: unconditional loads
+                        const global_ptr<T> p = X + rr * P.ld + col;
+                        if (al) {
+                            *reinterpret_cast<float4*>(&v[u][0]) = load16_global<T>(p);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < CW; ++e) v[u][e] = (col + e < P.F) ? p[e] : (T)0;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) {
+                        // batch of <= RU rows of one column: count the non-NaN ones, two-pass mean / M2.
+                        // NaN / inf tests, min and max stay in the input type (cheap), sums are float64.
+                        Stat b;
+                        stat_init(b);
+                        double sum = 0.0;
+                        int cnt = 0;
+                        T lo = (T)INFINITY, hi = (T)-INFINITY;
+                        unsigned okmask = 0;
+#pragma unroll
+                        for (int u = 0; u < RU; ++u) {
+                            const T xt = v[u][e];
+                            const bool ok = (k0 + (long long)u * rl < ch.n) && (xt == xt);  // NaN = missing
+                            okmask |= ok ? (1u << u) : 0u;
+                            if (ok) {
+                                ++cnt;
+                                sum += (double)xt;
+                                lo = xt < lo ? xt : lo;
+                                hi = xt > hi ? xt : hi;
+                            }
+                        }
+                        if (cnt > 0) {
+                            inf_seen |= (lo == (T)-INFINITY || hi == (T)INFINITY) ? 1 : 0;
+                            b.n = (double)cnt;
+                            b.lo = (double)lo;
+                            b.hi = (double)hi;
+                            b.mean = sum / b.n;
+#pragma unroll
+                            for (int u = 0; u < RU; ++u) {
+                                const double d = (double)v[u][e] - b.mean;
+                                if (okmask & (1u << u)) b.m2 += d * d;
+                            }
+                            stat_merge(run[e], b);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < CW; ++e) red[tid][e] = run[e];
+        __syncthreads();
+        if (tr == 0 && col < P.F) {
+            for (int k = 1; k < rl; ++k)
+#pragma unroll
+                for (int e = 0; e < CW; ++e) stat_merge(run[e], red[k * cpb + tc][e]);
+#pragma unroll
+            for (int e = 0; e < CW; ++e)
+                if (col + e < P.F) {
+                    part[0 * P.F + col + e] = run[e].n;
+                    part[1 * P.F + col + e] = run[e].mean;
+                    part[2 * P.F + col + e] = run[e].m2;
+                    part[3 * P.F + col + e] = run[e].lo;
+                    part[4 * P.F + col + e] = run[e].hi;
+                }
+        }
+        __syncthreads();
+    }
+    if (inf_seen) atomicOr(P.flag, 1);
+}
+
+// one thread per column: merge the block partials in block order
+__global__ void colstats_merge_kernel(const double* __restrict__ part, int nb, int F, double* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    Stat a;
+    stat_init(a);
+    for (int b = 0; b < nb; ++b) {
+        const double* p = part + (size_t)b * 5 * F;
+        Stat s;
+        s.n = p[c];
+        s.mean = p[F + c];
+        s.m2 = p[2 * F + c];
+        s.lo = p[3 * F + c];
+        s.hi = p[4 * F + c];
+        stat_merge(a, s);
+    }
+    out[c] = a.n;
+    out[F + c] = a.mean;
+    out[2 * F + c] = a.m2;
+    out[3 * F + c] = a.lo;
+    out[4 * F + c] = a.hi;
+}
+
+// mode 0: out = ((T)((double)x - shift)) / scale      (StandardScaler / MaxAbsScaler.transform)
+// mode 1: out = ((T)((double)x * scale)) + shift      (MinMaxScaler.transform: X *= scale_; X += min_)
+// each step rounded to T (numpy in-place semantics); a null array skips its step
+template <typename T>
+__global__ __launch_bounds__(PNT) void scale_apply_kernel(const T* __restrict__ X, long long n, int F, long long ld,
+                                                          const double* __restrict__ shift,
+                                                          const double* __restrict__ scale, T* __restrict__ out,
+                                                          long long ldo, int vec, int mode)
+{
+    // thread -> one group of CW consecutive columns (its shift / scale live in registers) and a row
+    // lane; RU rows in flight per thread.  No per-element index arithmetic.
+    constexpr int CW = 16 / sizeof(T);
+    constexpr int RU = 4;
+    const int tid = threadIdx.x;
+    const int ngroups = (F + CW - 1) / CW;
+    int cpb = 1;
+    while (cpb < ngroups && cpb < PNT) cpb <<= 1;
+    const int rl = PNT / cpb;
+    const int tc = tid % cpb, tr = tid / cpb;
+    for (int g0 = 0; g0 < ngroups; g0 += cpb) {
+        const int col = (g0 + tc) * CW;
+        if (col >= F) continue;
+        double sh[CW], sc[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+            const int c = col + e < F ? col + e : F - 1;
+            sh[e] = shift ? shift[c] : 0.0;
+            sc[e] = scale ? scale[c] : 1.0;
+        }
+        for (long long r0 = (long long)blockIdx.x * rl * RU + tr; r0 < n; r0 += (long long)gridDim.x * rl * RU) {
+            T v[RU][CW];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const long long r = r0 + (long long)u * rl;
+                const long long rr = r < n ? r : n - 1;
+                if (vec) {
+                    *reinterpret_cast<float4*>(&v[u][0]) = *reinterpret_cast<const float4*>(X + rr * ld + col);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) v[u][e] = (col + e < F) ? X[rr * ld + col + e] : (T)0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const long long r = r0 + (long long)u * rl;
+                if (r >= n) continue;
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    T x = v[u][e];
+                    if (mode == 0) {
+                        if (shift) x = (T)((double)x - sh[e]);
+                        if (scale) x = (T)((double)x / sc[e]);
+                    } else {
+                        if (scale) x = (T)((double)x * sc[e]);
+                        if (shift) x = (T)((double)x + sh[e]);
+                    }
+                    v[u][e] = x;
+                }
+                if (vec) {
+                    *reinterpret_cast<float4*>(out + r * ldo + col) = *reinterpret_cast<float4*>(&v[u][0]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CW; ++e)
+                        if (col + e < F) out[r * ldo + col + e] = v[u][e];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" {
+
+int msm_colstats(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int dtype_bytes,
+                 msm_idx_t n_features, msm_idx_t ld, int on_device, double* out5F, int* has_inf)
+{
+    if (n_seq < 0 || (n_seq > 0 && (!X_ptrs || !n_rows)) || !out5F)
+        return fail(MSM_ERR_INVALID, "msm_colstats: bad argument");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (n_features < 1 || ld < n_features) return fail(MSM_ERR_INVALID, "msm_colstats: bad shape");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    const int F = (int)n_features;
+    int rc;
+    DevBuf &dPart = pool(PS_PART), &dTab = pool(PS_IDS), &dOut = pool(PS_SUM), &dX = pool(PS_X);
+    // host trajectories are staged in groups of <= 1 GiB; statistics of the groups are merged on the host
+    std::vector<double> acc((size_t)5 * F, 0.0);
+    for (int c = 0; c < F; ++c) {
+        acc[(size_t)3 * F + c] = INFINITY;
+        acc[(size_t)4 * F + c] = -INFINITY;
+    }
+    int any_inf = 0;
+    const size_t row_bytes = (size_t)F * dtype_bytes;
+    msm_idx_t s = 0;
+    while (s < n_seq) {
+        msm_idx_t e = s;
+        std::vector<ScanChunk> tab;
+        size_t bytes = 0;
+        if (on_device) {
+            e = n_seq;
+        } else {
+            while (e < n_seq && (e == s || bytes + (size_t)n_rows[e] * row_bytes <= ((size_t)1 << 30))) {
+                bytes += ((size_t)n_rows[e] * row_bytes + 255) & ~(size_t)255;
+                ++e;
+            }
+            if ((rc = dX.reserve(bytes ? bytes : 256))) return rc;
+        }
+        size_t off = 0;
+        long long group_ld = on_device ? ld : F;
+        for (msm_idx_t i = s; i < e; ++i) {
+            if (n_rows[i] < 0 || (n_rows[i] > 0 && !X_ptrs[i])) return fail(MSM_ERR_INVALID, "msm_colstats: bad sequence %lld", (long long)i);
+            const char* base = (const char*)X_ptrs[i];
+            if (!on_device) {
+                char* d = dX.as<char>() + off;
+                if (n_rows[i] > 0) {
+                    if (ld == F)
+                        MSM_HIP_CHECK(hipMemcpyAsync(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes, hipMemcpyHostToDevice, stream()));
+                    else
+                        MSM_HIP_CHECK(hipMemcpy2DAsync(d, row_bytes, X_ptrs[i], (size_t)ld * dtype_bytes, row_bytes,
+                                                       (size_t)n_rows[i], hipMemcpyHostToDevice, stream()));
+                }
+                base = d;
+                off += ((size_t)n_rows[i] * row_bytes + 255) & ~(size_t)255;
+            }
+            for (long long r0 = 0; r0 < n_rows[i]; r0 += 4096) {
+                ScanChunk ch;
+                ch.base = base + (size_t)r0 * (size_t)group_ld * dtype_bytes;
+                ch.n = std::min<long long>(4096, n_rows[i] - r0);
+                tab.push_back(ch);
+            }
+        }
+        if (!tab.empty()) {
+            const int nb = (int)std::min<size_t>(tab.size(), (size_t)PNB);
+            if ((rc = dTab.reserve(tab.size() * sizeof(ScanChunk) + 16))) return rc;
+            if ((rc = dPart.reserve((size_t)nb * 5 * F * sizeof(double)))) return rc;
+            if ((rc = dOut.reserve((size_t)5 * F * sizeof(double) + 16))) return rc;
+            int* dflag = reinterpret_cast<int*>(dOut.as<double>() + (size_t)5 * F);
+            MSM_HIP_CHECK(hipMemcpyAsync(dTab.p, tab.data(), tab.size() * sizeof(ScanChunk), hipMemcpyHostToDevice, stream()));
+            MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
+            ScanArgs P;
+            P.chunks = dTab.as<ScanChunk>();
+            P.nchunks = (long long)tab.size();
+            P.ld = group_ld;
+            P.F = F;
+            P.part = dPart.as<double>();
+            P.flag = dflag;
+            if (dtype_bytes == 4)
+                hipLaunchKernelGGL(colstats_kernel<float>, dim3(nb), dim3(PNT), 0, stream(), P);
+            else
+                hipLaunchKernelGGL(colstats_kernel<double>, dim3(nb), dim3(PNT), 0, stream(), P);
+            MSM_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(colstats_merge_kernel, dim3((unsigned)ceil_div(F, 128)), dim3(128), 0, stream(),
+                               P.part, nb, F, dOut.as<double>());
+            MSM_HIP_CHECK(hipGetLastError());
+            std::vector<double> h((size_t)5 * F + 2);
+            MSM_HIP_CHECK(hipMemcpyAsync(h.data(), dOut.p, (size_t)5 * F * sizeof(double) + sizeof(int), hipMemcpyDeviceToHost, stream()));
+            MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // also: `tab` and the staging buffer are free again
+            int f;
+            memcpy(&f, h.data() + (size_t)5 * F, sizeof(int));
+            any_inf |= f;
+            for (int c = 0; c < F; ++c) {  // Chan merge of this group into the running statistics
+                const double nb_ = h[c];
+                if (nb_ == 0.0) continue;
+                const double na = acc[c], tot = na + nb_;
+                const double delta = h[(size_t)F + c] - acc[(size_t)F + c];
+                const double w = nb_ / tot;
+                acc[(size_t)F + c] += delta * w;
+                acc[(size_t)2 * F + c] += h[(size_t)2 * F + c] + delta * delta * na * w;
+                acc[c] = tot;
+                acc[(size_t)3 * F + c] = std::min(acc[(size_t)3 * F + c], h[(size_t)3 * F + c]);
+                acc[(size_t)4 * F + c] = std::max(acc[(size_t)4 * F + c], h[(size_t)4 * F + c]);
+            }
+        }
+        s = e;
+    }
+    memcpy(out5F, acc.data(), (size_t)5 * F * sizeof(double));
+    if (has_inf) *has_inf = any_inf;
+    return MSM_OK;
+}
+
+int msm_scale_apply(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features, msm_idx_t ld,
+                    const double* shift, const double* scale, int mode, void* out, msm_idx_t ld_out, int on_device)
+{
+    if (mode != 0 && mode != 1) return fail(MSM_ERR_INVALID, "msm_scale_apply: mode must be 0 or 1");
+    if (!X || !out) return fail(MSM_ERR_INVALID, "msm_scale_apply: null pointer");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (n_rows < 0 || n_features < 1 || ld < n_features || ld_out < n_features) return fail(MSM_ERR_INVALID, "msm_scale_apply: bad shape");
+    if (n_rows == 0) return MSM_OK;
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    const int F = (int)n_features;
+    int rc;
+    DevBuf &dPar = pool(PS_PAR), &dX = pool(PS_X), &dO = pool(PS_OUT);
+    if ((rc = dPar.reserve((size_t)2 * F * sizeof(double)))) return rc;
+    double* dshift = shift ? dPar.as<double>() : nullptr;
+    double* dscale = scale ? dPar.as<double>() + F : nullptr;
+    if (shift) MSM_HIP_CHECK(hipMemcpyAsync(dshift, shift, (size_t)F * sizeof(double), hipMemcpyHostToDevice, stream()));
+    if (scale) MSM_HIP_CHECK(hipMemcpyAsync(dscale, scale, (size_t)F * sizeof(double), hipMemcpyHostToDevice, stream()));
+    const void* xin = X;
+    void* xout = out;
+    long long ldi = ld, ldo = ld_out;
+    const size_t row_bytes = (size_t)F * dtype_bytes;
+    if (!on_device) {
+        if ((rc = dX.reserve((size_t)n_rows * row_bytes))) return rc;
+        if ((rc = dO.reserve((size_t)n_rows * row_bytes))) return rc;
+        MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, row_bytes, X, (size_t)ld * dtype_bytes, row_bytes, (size_t)n_rows,
+                                       hipMemcpyHostToDevice, stream()));
+        xin = dX.p;
+        xout = dO.p;
+        ldi = ldo = F;
+    }
+    const int CW = 16 / dtype_bytes;
+    const int vec = (F % CW == 0) && (ldi % CW == 0) && (ldo % CW == 0) && ((((uintptr_t)xin | (uintptr_t)xout) & 15) == 0);
+    int cpb = 1;
+    while (cpb < ceil_div(F, CW) && cpb < PNT) cpb <<= 1;
+    const long long rows_per_block = (long long)(PNT / cpb) * 4;
+    const unsigned grid = (unsigned)std::min<long long>(ceil_div(n_rows, rows_per_block), 8LL * 2048);
+    if (dtype_bytes == 4)
+        hipLaunchKernelGGL(scale_apply_kernel<float>, dim3(grid), dim3(PNT), 0, stream(), (const float*)xin, (long long)n_rows, F,
+                           ldi, dshift, dscale, (float*)xout, ldo, vec, mode);
+    else
+        hipLaunchKernelGGL(scale_apply_kernel<double>, dim3(grid), dim3(PNT), 0, stream(), (const double*)xin, (long long)n_rows,
+                           F, ldi, dshift, dscale, (double*)xout, ldo, vec, mode);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (!on_device)
+        MSM_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ld_out * dtype_bytes, xout, row_bytes, row_bytes, (size_t)n_rows,
+                                       hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // shift/scale staging and scratch are reused
+    return MSM_OK;
+}
+
+}  // extern "C"

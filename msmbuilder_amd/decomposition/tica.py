@@ -141,6 +141,10 @@ class tICA(BaseEstimator, TransformerMixin):
         # apart but only ever reads their sum, tica.py:245)
         self._outer_gram_sum = None
         self._host_stale = False
+        # optional per-column affine map of the INPUT, x' = (x - shift) / scale, applied
+        # algebraically to the F x F moments (set_input_scaling / preprocessing.fold_into_tica)
+        self._input_shift = None
+        self._input_scale = None
 
         # Cached results of the eigendecompsition
         self._components_ = None
@@ -279,21 +283,49 @@ class tICA(BaseEstimator, TransformerMixin):
     def _n_pairs(self):
         return _moments.pair_count(self.n_observations_, self.n_sequences_, self.lag_time)
 
-    @property
-    def means_(self):
+    def set_input_scaling(self, shift=None, scale=None):
+        """Treat every input row as ``(x - shift) / scale`` (per-column float64 arrays; ``None``
+        removes the map).  The accumulators keep the RAW sums; since the centred moments
+        transform as ``mu' = (mu - shift) / scale``, ``OC' = D OC D`` and ``S' = D S D`` with
+        ``D = diag(1 / scale)``, the model is exactly the one a fit on the scaled data would
+        give (up to rounding), ``transform`` keeps taking raw rows, and no scaled copy of the
+        data set is ever written (the StandardScaler -> tICA pipeline of the reference's
+        workflows)."""
+        if shift is None and scale is None:
+            self._input_shift = self._input_scale = None
+        else:
+            F = self.n_features if self.n_features is not None else len(np.atleast_1d(shift if shift is not None else scale))
+            self._input_shift = np.zeros(F) if shift is None else np.array(np.broadcast_to(shift, (F,)), dtype=np.float64)
+            self._input_scale = np.ones(F) if scale is None else np.array(np.broadcast_to(scale, (F,)), dtype=np.float64)
+        self._is_dirty = True
+        return self
+
+    def _raw_means(self):
         self._pull()
         return _moments.mean_vector(self._sum_0_to_TminusTau, self._sum_tau_to_T, self._n_pairs)
 
     @property
+    def means_(self):
+        mu = self._raw_means()
+        if getattr(self, "_input_scale", None) is not None:
+            mu = (mu - self._input_shift) / self._input_scale
+        return mu
+
+    @property
     def offset_correlation_(self):
         self._pull()
-        return _moments.offset_correlation(self._outer_0_to_T_lagged, self.means_, self._n_pairs)
+        oc = _moments.offset_correlation(self._outer_0_to_T_lagged, self._raw_means(), self._n_pairs)
+        if getattr(self, "_input_scale", None) is not None:
+            oc = oc / np.outer(self._input_scale, self._input_scale)
+        return oc
 
     @property
     def covariance_(self):
         """Shrunk covariance; reading it also sets ``shrinkage_`` (as in the reference)."""
         self._pull()
-        S = _moments.sample_covariance(self._outer_gram_sum, self.means_, self._n_pairs)
+        S = _moments.sample_covariance(self._outer_gram_sum, self._raw_means(), self._n_pairs)
+        if getattr(self, "_input_scale", None) is not None:
+            S = S / np.outer(self._input_scale, self._input_scale)
         if self.shrinkage is None:
             self.shrinkage_ = _moments.rblw_shrinkage(S, n=self.n_observations_)
         else:
@@ -503,7 +535,10 @@ class tICA(BaseEstimator, TransformerMixin):
             # (negative eigenvalue / timescale below the lag) zeroes the column
             scale = np.where(np.isnan(scale), 0.0, scale)
             comps = comps * scale[:, None]
-        return np.ascontiguousarray(self.means_, dtype=np.float64), np.ascontiguousarray(comps)
+        if getattr(self, "_input_scale", None) is not None:
+            # ((x - m)/s - (mu - m)/s) . V  ==  (x - mu) . (V / s): raw rows, raw mean, D folded into V
+            comps = comps / self._input_scale[None, :]
+        return np.ascontiguousarray(self._raw_means(), dtype=np.float64), np.ascontiguousarray(comps)
 
     def transform(self, sequences):
         """Apply the dimensionality reduction on X.
@@ -558,6 +593,8 @@ class tICA(BaseEstimator, TransformerMixin):
                             lag_time=self.lag_time)
         for X in sequences:
             m2.partial_fit(X)
+        if getattr(self, "_input_scale", None) is not None:
+            m2.set_input_scaling(self._input_shift, self._input_scale)
 
         numerator = V.T.dot(m2.offset_correlation_).dot(V)
         denominator = V.T.dot(m2.covariance_).dot(V)
