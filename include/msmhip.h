@@ -262,6 +262,26 @@ int msm_scale_apply(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t 
                     const double* shift, const double* scale, int mode, void* out, msm_idx_t ld_out,
                     int on_device);
 
+/* ------------------------------------------------------------------------------------------
+ * Post-clustering transition counts.  Replaces the counting loop of
+ * msmbuilder.msm._transition_counts (/root/reference/msmbuilder/msm/core.py:487-596) for integer
+ * labels: y_ptrs[s] -> n_rows[s] int64 labels (device-resident, e.g. KCenters.labels_, or host).
+ * msm_label_range: min / max label over all sequences (*hi < *lo if there are no labels).
+ * msm_label_histogram: hist[b] (host, int64[n_bins]) = #labels equal to lo + b -- the class discovery
+ *   behind np.unique (core.py:544); labels outside [lo, lo + n_bins) are ignored.
+ * msm_transition_counts: counts (host, int64 [n_states][n_states], row-major) [i][j] = number of
+ *   (t, t + lag_time) pairs inside one sequence with state(y[t]) = i and state(y[t+lag]) = j, where
+ *   state(v) = remap[v - lo] (host int32[n_bins], -1 = no mapping: the pair is dropped, as for
+ *   NaN / None upstream) or v - lo when remap is NULL (then n_bins must equal n_states).  The caller
+ *   divides by lag_time for the sliding-window normalisation (core.py:594). */
+int msm_label_range(const msm_idx_t* const* y_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int on_device,
+                    msm_idx_t* lo, msm_idx_t* hi, msm_idx_t* n_total);
+int msm_label_histogram(const msm_idx_t* const* y_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int on_device,
+                        msm_idx_t lo, msm_idx_t n_bins, int64_t* hist);
+int msm_transition_counts(const msm_idx_t* const* y_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int on_device,
+                          msm_idx_t lag_time, msm_idx_t lo, const int32_t* remap, msm_idx_t n_bins,
+                          msm_idx_t n_states, int64_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ def _declare(lib):
     f("msm_tica_import_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_project", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, _i64, _p, C.c_int, C.c_int)
 
+    f("msm_label_range", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64p, _i64p, _i64p)
+    f("msm_label_histogram", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, _p)
+    f("msm_transition_counts", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, _p, _i64, _i64, _p)
     f("msm_colstats", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, C.c_int, _p, C.POINTER(C.c_int))
     f("msm_scale_apply", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, C.c_int, _p, _i64, C.c_int)
 

@@ -10,6 +10,7 @@ small ``.npz`` fixtures next to this script:
 * kcenters_golden.npz    msmbuilder/cluster/kcenters.py + cluster/base.py over
                          the reference's libdistance headers (oracle/_ref)
 * libdistance_golden.npz msmbuilder/libdistance/src/*.hpp compiled (oracle/_ref)
+* transition_golden.npz  msmbuilder/msm/core.py (_transition_counts)
 * mbkm_golden.npz        scikit-learn MiniBatchKMeans (the third-party
                          arithmetic behind msmbuilder.cluster.MiniBatchKMeans,
                          cluster/__init__.py:67-69; unpinned upstream)
@@ -251,5 +252,78 @@ def main():
     print("mbkm_golden.npz: sklearn", sklearn.__version__, "inertia", g["inertia"], "steps", g["n_steps"])
 
 
+def transition_golden():
+    """msmbuilder.msm._transition_counts itself (msm/core.py:487-596), loaded by file path with a stub
+    for the compiled _ratematrix extension and the numpy aliases (np.int / np.float) it still uses."""
+    if not hasattr(np, "int"):
+        np.int = int
+    if not hasattr(np, "float"):
+        np.float = float
+    if "msmbuilder" not in sys.modules:
+        pkg = types.ModuleType("msmbuilder")
+        pkg.__path__ = [REF]
+        sys.modules["msmbuilder"] = pkg
+    if "msmbuilder.utils" not in sys.modules or not hasattr(sys.modules["msmbuilder.utils"], "list_of_1d"):
+        utils = sys.modules.get("msmbuilder.utils") or types.ModuleType("msmbuilder.utils")
+        utils.__path__ = [os.path.join(REF, "utils")]
+        sys.modules["msmbuilder.utils"] = utils
+        if "mdtraj" not in sys.modules:
+            md = types.ModuleType("mdtraj")
+            md.Trajectory = type("Trajectory", (object,), {})
+            sys.modules["mdtraj"] = md
+        val = sys.modules.get("msmbuilder.utils.validation") or _load(
+            "msmbuilder.utils.validation", os.path.join(REF, "utils", "validation.py"), "msmbuilder.utils")
+        utils.list_of_1d = val.list_of_1d
+    msm = types.ModuleType("msmbuilder.msm")
+    msm.__path__ = [os.path.join(REF, "msm")]
+    sys.modules["msmbuilder.msm"] = msm
+    sys.modules["msmbuilder.msm._ratematrix"] = types.ModuleType("msmbuilder.msm._ratematrix")
+    core = _load("msmbuilder.msm.core", os.path.join(REF, "msm", "core.py"), "msmbuilder.msm")
+    tc = core._transition_counts
+
+    g = {}
+    rs = np.random.RandomState(21)
+
+    def metastable(n, k, stay=0.97):
+        y = np.empty(n, dtype=np.int64)
+        y[0] = rs.randint(k)
+        for t in range(1, n):
+            y[t] = y[t - 1] if rs.rand() < stay else rs.randint(k)
+        return y
+
+    cases = {
+        "ident": ([metastable(5000, 12), metastable(37, 12), metastable(1, 12), metastable(9000, 12)], 1, True),
+        "lag7": ([metastable(5000, 12), metastable(7, 12), metastable(8, 12), metastable(4100, 12)], 7, True),
+        "gaps": ([metastable(3000, 9) * 5 + 100, metastable(2000, 9) * 5 + 100], 3, True),          # non-identity mapping
+        "nosw": ([metastable(5000, 6), metastable(1234, 6)], 4, False),
+        "neg": ([metastable(2500, 7) - 3], 2, True),
+    }
+    for name, (seqs, lag, sw) in cases.items():
+        c, m = tc(seqs, lag_time=lag, sliding_window=sw)
+        for i, y in enumerate(seqs):
+            g["%s_seq%d" % (name, i)] = y
+        g[name + "_nseq"] = np.int64(len(seqs))
+        g[name + "_lag"] = np.int64(lag)
+        g[name + "_sw"] = np.bool_(sw)
+        g[name + "_counts"] = c
+        g[name + "_keys"] = np.array(list(m.keys()), dtype=np.int64)
+        g[name + "_vals"] = np.array(list(m.values()), dtype=np.int64)
+    # float labels with NaN, and strings
+    yf = metastable(4000, 5).astype(float)
+    yf[rs.randint(0, 4000, 60)] = np.nan
+    c, m = tc([yf, yf[:100]], lag_time=2)
+    g["nan_seq0"], g["nan_counts"] = yf, c
+    g["nan_keys"] = np.array(list(m.keys()), dtype=float)
+    ys = np.array(["s%02d" % v for v in metastable(500, 4)])
+    c, m = tc([ys], lag_time=1)
+    g["str_seq0"], g["str_counts"], g["str_keys"] = ys, c, np.array(list(m.keys()))
+    np.savez_compressed(os.path.join(HERE, "transition_golden.npz"), **g)
+    print("transition_golden.npz:", len(g), "arrays; ident counts sum", g["ident_counts"].sum())
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "transition":
+        transition_golden()
+    else:
+        main()
+        transition_golden()

@@ -152,3 +152,40 @@ def test_tica_oracle_ragged_and_mappings(golden_dir):
     assert lagged_moments(seqs[4], 7) is None      # len == lag: skipped
     with pytest.raises(ValueError):
         TicaOracle(lag_time=500).fit(seqs)
+
+
+# ------------------------------------------------------------------ transition counts
+def _transition_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "transition_golden.npz"), allow_pickle=False)
+    for name in ("ident", "lag7", "gaps", "nosw", "neg"):
+        seqs = [g["%s_seq%d" % (name, i)] for i in range(int(g[name + "_nseq"]))]
+        yield name, seqs, int(g[name + "_lag"]), bool(g[name + "_sw"]), g[name + "_counts"], g[name + "_keys"]
+    yield "nan", [g["nan_seq0"], g["nan_seq0"][:100]], 2, True, g["nan_counts"], g["nan_keys"]
+    yield "str", [g["str_seq0"]], 1, True, g["str_counts"], g["str_keys"]
+
+
+def test_transition_oracle_matches_reference_golden(golden_dir):
+    from oracle.transition_oracle import transition_counts
+    for name, seqs, lag, sw, counts, keys in _transition_cases(golden_dir):
+        c, m = transition_counts(seqs, lag_time=lag, sliding_window=sw)
+        assert np.array_equal(c, counts), name
+        assert list(m.keys()) == list(keys) and list(m.values()) == list(range(len(keys))), name
+
+
+def test_transition_oracle_reference_known_answers():
+    """tests/test_transition_counts.py of the reference, restated."""
+    from oracle.transition_oracle import transition_counts as tc
+    with pytest.raises(ValueError):
+        tc([1, 2, 3])
+    c, m = tc([np.arange(10)])
+    assert np.array_equal(c, np.eye(10, k=1)) and list(m.keys()) == list(range(10))
+    assert np.array_equal(tc([range(10)], lag_time=2)[0], 0.5 * np.eye(10, k=2))
+    c, m = tc([['alpha', 'b', 'b', 'b', 'c']])
+    assert np.array_equal(c, [[0, 1, 0], [0, 2, 1], [0, 0, 0]]) and m == {'alpha': 0, 'b': 1, 'c': 2}
+    c, m = tc([[100000000, 100000000, 100000001, 100000001]])
+    assert np.array_equal(c, [[1, 1], [0, 1]]) and m == {100000000: 0, 100000001: 1}
+    c, m = tc([[0, np.nan]])
+    assert m == {0: 0} and np.array_equal(c, np.zeros((1, 1)))
+    c, m = tc([[np.nan]])
+    assert m == {} and c.shape == (0, 0)
+    np.testing.assert_array_almost_equal(tc([np.arange(6)], lag_time=3)[0], np.eye(6, k=3) / 3)
