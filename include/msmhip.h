@@ -282,6 +282,25 @@ int msm_transition_counts(const msm_idx_t* const* y_ptrs, const msm_idx_t* n_row
                           msm_idx_t lag_time, msm_idx_t lo, const int32_t* remap, msm_idx_t n_bins,
                           msm_idx_t n_states, int64_t* counts);
 
+/* ------------------------------------------------------------------------------------------
+ * dir-npy trajectories straight into HBM.  MSMBuilder's NumpyDirDataset is a directory
+ * of %08d.npy files read with np.load (/root/reference/msmbuilder/dataset.py:290-331).
+ * msm_npy_info: parse a .npy header (format 1.0-3.0, little-endian bool/int/uint/float): item size,
+ *   kind ('f','i','u','b'), fortran_order, ndim, shape (up to 4), byte offset of the payload.
+ * Loader: n_buffers reader threads, each with one pinned host buffer of buffer_bytes and its own
+ *   stream, pread() buffer-sized pieces of the submitted files and copy them to the caller's device
+ *   pointer; submit() validates the header, queues the pieces and returns a job id at once, wait(job)
+ *   returns when that job and every earlier one are completely in HBM, so disk, PCIe and the kernels
+ *   on previously loaded trajectories overlap.  nbytes must equal the file's payload size (from
+ *   msm_npy_info); read / copy errors surface at wait(). */
+typedef struct msm_npy_loader msm_npy_loader_t;
+int msm_npy_info(const char* path, int* dtype_bytes, int* kind, int* fortran_order, int* ndim, msm_idx_t* shape4,
+                 msm_idx_t* data_offset);
+int msm_npy_loader_create(msm_npy_loader_t** out, int n_buffers, size_t buffer_bytes);
+int msm_npy_loader_submit(msm_npy_loader_t* h, const char* path, void* dptr, msm_idx_t nbytes, msm_idx_t* job_id);
+int msm_npy_loader_wait(msm_npy_loader_t* h, msm_idx_t job_id);
+int msm_npy_loader_destroy(msm_npy_loader_t* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,12 @@ def _declare(lib):
     f("msm_label_range", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64p, _i64p, _i64p)
     f("msm_label_histogram", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, _p)
     f("msm_transition_counts", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, _p, _i64, _i64, _p)
+    f("msm_npy_info", C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+      _i64p, _i64p)
+    f("msm_npy_loader_create", C.c_int, C.POINTER(_p), C.c_int, C.c_size_t)
+    f("msm_npy_loader_submit", C.c_int, _p, C.c_char_p, _p, _i64, _i64p)
+    f("msm_npy_loader_wait", C.c_int, _p, _i64)
+    f("msm_npy_loader_destroy", C.c_int, _p)
     f("msm_colstats", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, C.c_int, _p, C.POINTER(C.c_int))
     f("msm_scale_apply", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, C.c_int, _p, _i64, C.c_int)
 
