@@ -301,6 +301,17 @@ int msm_npy_loader_submit(msm_npy_loader_t* h, const char* path, void* dptr, msm
 int msm_npy_loader_wait(msm_npy_loader_t* h, msm_idx_t job_id);
 int msm_npy_loader_destroy(msm_npy_loader_t* h);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side generalized eigensolve.  Replaces scipy.linalg.eigh(A, b=B,
+ * eigvals=(n-k, n-1)) of /root/reference/msmbuilder/decomposition/tica.py:188-194: the k LARGEST
+ * solutions of A v = lambda B v (A symmetric, B symmetric positive definite, float64 n x n, host or
+ * device), evals[k] descending, evecs[k][n] row j = eigenvector j, normalised v^T B v = 1, sign
+ * arbitrary (LAPACK's conventions).  Runs dpotrf + dtrsm + dsyevd of rocSOLVER / rocBLAS; the library is dlopen'ed at first use
+ * (MSM_ERR_STATE if it is not installed).  MSM_ERR_INVALID with LAPACK's message if B is not positive
+ * definite. */
+int msm_sygv_top(const double* A, const double* B, msm_idx_t n, msm_idx_t k, double* evals, double* evecs,
+                 int on_device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -279,3 +279,40 @@ def test_segment_without_its_halo_is_rejected(gpu):
         m.partial_fit_segments([(X[100:220], 500, 100, 90, 200)])     # owns rows it does not hold
     m.partial_fit_segments([(X[100:210], 500, 100, 100, 200)])
     assert m.n_observations_ == 100 and m.n_sequences_ == 0
+
+
+# ---------------------------------------------------------------- device eigensolve
+@pytest.mark.parametrize("F,k", [(7, 7), (64, 5), (300, 10), (1100, 12)])
+def test_device_eigensolve_matches_lapack(gpu, F, k):
+    import scipy.linalg
+    from msmbuilder_amd.decomposition import _moments
+    rs = np.random.RandomState(F)
+    A = rs.randn(F, 3 * F)
+    S = A.dot(A.T) / (3 * F) + 0.05 * np.eye(F)
+    B = rs.randn(F, F)
+    OC = 0.4 * S + 0.03 * (B + B.T)
+    vals, vecs = _moments.device_generalized_eigenpairs(OC, S, k)
+    w, v = scipy.linalg.eigh(OC, b=S, subset_by_index=[F - k, F - 1])
+    np.testing.assert_allclose(vals, w[::-1], rtol=1e-10, atol=1e-12)
+    v = v[:, ::-1]
+    np.testing.assert_allclose(np.abs(np.sum(vecs * S.dot(v), axis=0)), 1.0, rtol=1e-8)   # same vectors up to sign, B-orthonormal
+    np.testing.assert_allclose(vecs.T.dot(S).dot(vecs), np.eye(k), atol=1e-9)
+    with pytest.raises(np.linalg.LinAlgError):
+        _moments.device_generalized_eigenpairs(OC, S - 10 * np.eye(F), k)
+
+
+def test_tica_with_device_solve(gpu, monkeypatch):
+    from msmbuilder_amd import tICA
+    seqs = _ar1(3, 3, 1500, 16)
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkeypatch.setenv("MSMBUILDER_AMD_DEVICE_SOLVE", "0")
+        host = tICA(n_components=4, lag_time=3).fit(seqs)
+        ev_h, y_h = host.eigenvalues_, host.transform(seqs[:1])[0]
+        monkeypatch.setenv("MSMBUILDER_AMD_DEVICE_SOLVE", "1")
+        dev = tICA(n_components=4, lag_time=3).fit(seqs)
+        ev_d, y_d = dev.eigenvalues_, dev.transform(seqs[:1])[0]
+    np.testing.assert_allclose(ev_d, ev_h, rtol=1e-11)
+    s = np.sign(np.sum(y_d * y_h, axis=0))
+    np.testing.assert_allclose(y_d * s, y_h, rtol=1e-7, atol=1e-9)
