@@ -203,6 +203,25 @@ int msm_kcenters_pass_f64(const double* X, msm_idx_t n, msm_idx_t m, const doubl
                           const char* metric, msm_idx_t* labels, double* distances, double* max_dist,
                           msm_idx_t* argmax, double* argmax_row, int on_device);
 
+/* The same pass with NOTHING on the host (multi-GPU driver, one collective per centre and no
+ * synchronisation): y_dev is the centre on the device; after the pass the shard's candidate record
+ * cand_dev[2 + m] (device, float64) = {max distance, row_offset + lowest local row attaining it,
+ * that row's coordinates}, or {-1, -1, 0...} for an empty shard.  Ranks all-gather their records
+ * (RCCL) into cands_dev[world][2 + m]; msm_kcenters_select picks the winner (largest distance, ties
+ * to the lowest global row = numpy's argmax on the concatenated array) and writes its coordinates
+ * to y_dev and to row `slot` of centers_dev, its global row to ids_dev[slot].  All asynchronous on
+ * the library stream. */
+int msm_kcenters_pass_dev_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* y_dev, msm_idx_t it,
+                              const char* metric, msm_idx_t* labels, double* distances, msm_idx_t row_offset,
+                              double* cand_dev);
+int msm_kcenters_pass_dev_f64(const double* X, msm_idx_t n, msm_idx_t m, const double* y_dev, msm_idx_t it,
+                              const char* metric, msm_idx_t* labels, double* distances, msm_idx_t row_offset,
+                              double* cand_dev);
+int msm_kcenters_select_f32(const double* cands_dev, msm_idx_t world, msm_idx_t m, float* y_dev, float* centers_dev,
+                            msm_idx_t* ids_dev, msm_idx_t slot);
+int msm_kcenters_select_f64(const double* cands_dev, msm_idx_t world, msm_idx_t m, double* y_dev, double* centers_dev,
+                            msm_idx_t* ids_dev, msm_idx_t slot);
+
 /* ---- k-means labelling / mini-batch step (fp32, GEMM form on MFMA) ---- */
 /* labels[i] = argmin_j ||X[i]-C[j]||^2 computed as ||c||^2 - 2 x.c (+||x||^2 for the
  * inertia), fp32 like scikit-learn's _labels_inertia; centers host [K, m].

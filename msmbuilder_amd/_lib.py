@@ -110,6 +110,8 @@ def _declare(lib):
           C.c_int)
     for sfx in ("f32", "f64"):
         f("msm_kcenters_pass_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, C.c_char_p, _p, _p, _f64p, _i64p, _p, C.c_int)
+        f("msm_kcenters_pass_dev_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, C.c_char_p, _p, _p, _i64, _p)
+        f("msm_kcenters_select_" + sfx, C.c_int, _p, _i64, _i64, _p, _p, _p, _i64)
     f("msm_kmeans_label_f32", C.c_int, _p, _i64, _i64, _p, _i64, _p, _f64p, C.c_int)
     f("msm_mbk_create", C.c_int, C.POINTER(_p), _i64, _i64)
     f("msm_mbk_destroy", C.c_int, _p)

@@ -101,10 +101,13 @@ class _KCenters(ClusterMixin, TransformerMixin):
 
     def _fit_sharded(self, X, metric):
         """Row-sharded k-centers (one process per GPU): X is THIS rank's block of rows, ranks own
-        consecutive blocks of the global array.  Every pass runs locally on each rank; two tiny
-        all-reduces per centre exchange the (max distance, global row) candidates and the winner's
-        coordinates.  Results equal the single-process fit of the concatenated data bit for bit
-        (ties go to the lowest GLOBAL row, numpy's argmax).  labels_/distances_ stay sharded."""
+        consecutive blocks of the global array.  Every pass runs locally on each rank; ONE
+        all-gather per centre exchanges the candidate records ``[max distance | global row | that
+        row's coordinates]`` and every rank picks the same winner on the device
+        (``msm_kcenters_pass_dev`` / ``msm_kcenters_select``): the centre loop never touches the
+        host, so the K launches and collectives queue up asynchronously on the stream.  Results
+        equal the single-process fit of the concatenated data bit for bit (ties go to the lowest
+        GLOBAL row, numpy's argmax).  labels_/distances_ stay sharded."""
         from .. import parallel
         import torch
         if isinstance(X, np.ndarray):
@@ -113,43 +116,46 @@ class _KCenters(ClusterMixin, TransformerMixin):
         n_local, m = ax.shape
         shard = parallel.RowShard(n_local)
         kind = "f64" if ax.dtype == np.float64 else "f32"
+        tdt = torch.float64 if kind == "f64" else torch.float32
         K = int(self.n_clusters)
         world, rank = parallel.world_size(), parallel.rank()
+        dev = ax.keep.device
         # rank 0's draw decides (random_state=None would differ per process)
         seed = check_random_state(self.random_state).randint(0, shard.n_total)
         seed = int(parallel.allreduce_array(np.array([float(seed) if rank == 0 else 0.0]))[0])
         labels = empty_like_placement(ax, (n_local,), np.int64)
         distances = empty_like_placement(ax, (n_local,), np.float64)
         al, ad = Arr(labels, np.int64), Arr(distances, np.float64)
-        fn = getattr(_lib.lib(), "msm_kcenters_pass_" + kind)
-        fetch = lambda loc: ax.keep[torch.as_tensor(loc, device=ax.keep.device)].cpu().numpy()
-        ids, centers = [], []
-        c = seed
-        y = np.ascontiguousarray(shard.gather_rows(fetch, np.array([c]), m, dtype=ax.dtype)[0])
+        L = _lib.lib()
+        fpass = getattr(L, "msm_kcenters_pass_dev_" + kind)
+        fsel = getattr(L, "msm_kcenters_select_" + kind)
+        cand = torch.zeros(2 + m, dtype=torch.float64, device=dev)
+        cands = torch.zeros(world, 2 + m, dtype=torch.float64, device=dev)
+        y = torch.zeros(m, dtype=tdt, device=dev)
+        centers = torch.zeros(K, m, dtype=tdt, device=dev)
+        ids = torch.zeros(K, dtype=torch.int64, device=dev)
+
+        def exchange(slot):
+            parallel.all_gather_rows(cands, cand)
+            _lib.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            check(fsel(C.c_void_p(cands.data_ptr()), world, m, C.c_void_p(y.data_ptr()),
+                       C.c_void_p(centers.data_ptr()), C.c_void_p(ids.data_ptr()), slot))
+
+        # centre 0: the rank that owns the seed row publishes it through the same exchange
+        cand[0], cand[1] = -1.0, -1.0
+        if shard.offset <= seed < shard.offset + n_local:
+            cand[0], cand[1] = 1.0, float(seed)
+            cand[2:] = ax.keep[seed - shard.offset].to(torch.float64)
+        exchange(0)
         for it in range(K):
-            lmax, larg = C.c_double(-1.0), C.c_int64(-1)
-            lrow = np.zeros(m, dtype=ax.dtype)
-            if n_local > 0:
-                check(fn(ax.vp, n_local, m, y.ctypes.data, it, metric.encode(), al.vp, ad.vp,
-                         C.byref(lmax), C.byref(larg), lrow.ctypes.data, 1))
-            ids.append(int(c))
-            centers.append(y)
-            # ONE all-reduce per centre: every rank contributes (max, global row, that row's coordinates)
-            cand = np.zeros((world, 2 + m))
-            cand[rank, 0] = lmax.value if larg.value >= 0 else -1.0
-            cand[rank, 1] = float(shard.offset + larg.value) if larg.value >= 0 else -1.0
-            cand[rank, 2:] = lrow
-            cand = parallel.allreduce_array(cand.ravel()).reshape(world, 2 + m)
-            ok = cand[:, 1] >= 0
-            best = cand[ok, 0].max()
-            win = np.nonzero(ok & (cand[:, 0] == best))[0]
-            w = win[np.argmin(cand[win, 1])]                     # first occurrence of the maximum
-            c = int(cand[w, 1])
-            y = np.ascontiguousarray(cand[w, 2:].astype(ax.dtype))   # float32 coordinates are exact in float64
+            check(fpass(ax.vp, n_local, m, C.c_void_p(y.data_ptr()), it, metric.encode(), al.vp, ad.vp,
+                        shard.offset, C.c_void_p(cand.data_ptr())))
+            if it + 1 < K:
+                exchange(it + 1)
         self.labels_ = labels
         self.distances_ = distances
-        self.cluster_ids_ = ids
-        self.cluster_centers_ = np.stack(centers).astype(ax.dtype)
+        self.cluster_ids_ = [int(i) for i in ids.cpu().numpy()]
+        self.cluster_centers_ = centers.cpu().numpy()
         local_sum = float(distances.sum().item()) if n_local else 0.0
         self.inertia_ = float(parallel.allreduce_array(np.array([local_sum]))[0])
         return self

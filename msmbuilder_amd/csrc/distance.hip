@@ -765,6 +765,77 @@ __global__ __launch_bounds__(DT) void kc_finalize_kernel(const KcPartial* __rest
         for (long long f = tid; f < m; f += DT) row[f] = X[ri[0] * m + f];
 }
 
+// Device-resident exchange for the multi-GPU driver (no host round trip per centre):
+// candidate record of a rank = [max distance | GLOBAL row of the first maximum | its coordinates], all
+// float64 (rows < 2^53 and float32 coordinates are exact); -1 / -1 when the shard is empty.
+template <typename T>
+__global__ __launch_bounds__(DT) void kc_candidate_kernel(const KcPartial* __restrict__ part, int nblk,
+                                                          const T* __restrict__ X, long long m, long long row_offset,
+                                                          double* __restrict__ cand)
+{
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    const int tid = threadIdx.x;
+    double bv = -1.0;
+    long long bi = -1;
+    for (int k = tid; k < nblk; k += DT) {
+        const KcPartial q = part[k];
+        if (q.i >= 0 && (bi < 0 || kc_better(q.v, q.i, bv, bi))) {
+            bv = q.v;
+            bi = q.i;
+        }
+    }
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int s = DT / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const long long oi = ri[tid + s];
+            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + s], oi, rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + s];
+                ri[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const long long w = ri[0];
+    if (tid == 0) {
+        cand[0] = w >= 0 ? rv[0] : -1.0;
+        cand[1] = w >= 0 ? (double)(row_offset + w) : -1.0;
+    }
+    for (long long f = tid; f < m; f += DT) cand[2 + f] = w >= 0 ? (double)X[w * m + f] : 0.0;
+}
+
+// all ranks run this on the all-gathered records [world][2 + m]: the winner is the largest distance,
+// ties to the lowest global row (numpy's argmax over the concatenated array); its coordinates become
+// the next centre (y, and row `slot` of `centers`), its row id goes to ids[slot].
+template <typename T>
+__global__ __launch_bounds__(DT) void kc_select_kernel(const double* __restrict__ cands, int world, long long m,
+                                                       T* __restrict__ y, T* __restrict__ centers,
+                                                       msm_idx_t* __restrict__ ids, long long slot)
+{
+    __shared__ int win;
+    if (threadIdx.x == 0) {
+        int w = -1;
+        for (int r = 0; r < world; ++r) {
+            const double v = cands[(size_t)r * (2 + m)], g = cands[(size_t)r * (2 + m) + 1];
+            if (g < 0.0) continue;
+            if (w < 0 || v > cands[(size_t)w * (2 + m)] ||
+                (v == cands[(size_t)w * (2 + m)] && g < cands[(size_t)w * (2 + m) + 1]))
+                w = r;
+        }
+        win = w;
+        ids[slot] = w >= 0 ? (msm_idx_t)cands[(size_t)w * (2 + m) + 1] : -1;
+    }
+    __syncthreads();
+    const int w = win;
+    for (long long f = threadIdx.x; f < m; f += DT) {
+        const T v = w >= 0 ? (T)cands[(size_t)w * (2 + m) + 2 + f] : (T)0;
+        y[f] = v;
+        centers[slot * m + f] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // pdist (pdist.hpp:4-88): condensed upper triangle, row i -> out[i*n - i(i+1)/2 + (j-i-1)], and
 // sumdist (sumdist.hpp:4-44): sum of metric over a pair list.  Same exact per-pair arithmetic:
@@ -1285,6 +1356,59 @@ int kcenters_pass_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y, msm_idx
     return MSM_OK;
 }
 
+// one pass + candidate record, everything on the stream, no synchronisation
+template <typename T>
+int kcenters_pass_dev_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y_dev, msm_idx_t it, const char* metric,
+                           msm_idx_t* labels, double* distances, msm_idx_t row_offset, double* cand_dev)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!y_dev || !cand_dev || (n > 0 && (!X || !labels || !distances))) return fail(MSM_ERR_INVALID, "kcenters_pass_dev: null pointer");
+    if (n < 0 || m < 1 || it < 0) return fail(MSM_ERR_INVALID, "kcenters_pass_dev: bad shape");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    int rc;
+    DevBuf &dPart = pool(PS_PART), &dIds = pool(PS_IDS);
+    int nblk = (int)std::min<long long>(ceil_div(std::max<long long>(n, 1), DT), KC_MAXBLK);
+    if ((rc = dPart.reserve((size_t)nblk * sizeof(KcPartial)))) return rc;
+    if ((rc = dIds.reserve(sizeof(msm_idx_t)))) return rc;
+    KcArgs P;
+    memset(&P, 0, sizeof(P));
+    P.X = X;
+    P.n = n;
+    P.m = m;
+    P.it = (int)it;
+    P.next = dPart.as<KcPartial>();
+    P.dist = distances;
+    P.labels = labels;
+    P.ids = dIds.as<msm_idx_t>();
+    P.ycenter = y_dev;
+    if (n > 0) {
+        P.vecw = row_vecw<T>(P.X, m, false);
+        if (P.vecw == 0 && wide_ok<T>(P.X, P.ycenter, m, false)) nblk = std::min(nblk, wide_grid(n));
+        P.nblk = nblk;
+        launch_kc<T>(mid, nblk, P);
+        MSM_HIP_CHECK(hipGetLastError());
+    } else {
+        nblk = 0;  // empty shard: the candidate kernel reports "none"
+    }
+    hipLaunchKernelGGL((kc_candidate_kernel<T>), dim3(1), dim3(DT), 0, stream(), P.next, nblk, X, (long long)m,
+                       (long long)row_offset, cand_dev);
+    MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
+template <typename T>
+int kcenters_select_impl(const double* cands_dev, msm_idx_t world, msm_idx_t m, T* y_dev, T* centers_dev,
+                         msm_idx_t* ids_dev, msm_idx_t slot)
+{
+    if (!cands_dev || !y_dev || !centers_dev || !ids_dev || world < 1 || m < 1 || slot < 0)
+        return fail(MSM_ERR_INVALID, "kcenters_select: bad argument");
+    hipLaunchKernelGGL((kc_select_kernel<T>), dim3(1), dim3(DT), 0, stream(), cands_dev, (int)world, (long long)m, y_dev,
+                       centers_dev, ids_dev, (long long)slot);
+    MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -1303,6 +1427,32 @@ int msm_kcenters_pass_f64(const double* X, msm_idx_t n, msm_idx_t m, const doubl
                           msm_idx_t* argmax, double* argmax_row, int on_device)
 {
     return kcenters_pass_impl<double>(X, n, m, y, it, metric, labels, distances, max_dist, argmax, argmax_row, on_device);
+}
+
+int msm_kcenters_pass_dev_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* y_dev, msm_idx_t it,
+                              const char* metric, msm_idx_t* labels, double* distances, msm_idx_t row_offset,
+                              double* cand_dev)
+{
+    return kcenters_pass_dev_impl<float>(X, n, m, y_dev, it, metric, labels, distances, row_offset, cand_dev);
+}
+
+int msm_kcenters_pass_dev_f64(const double* X, msm_idx_t n, msm_idx_t m, const double* y_dev, msm_idx_t it,
+                              const char* metric, msm_idx_t* labels, double* distances, msm_idx_t row_offset,
+                              double* cand_dev)
+{
+    return kcenters_pass_dev_impl<double>(X, n, m, y_dev, it, metric, labels, distances, row_offset, cand_dev);
+}
+
+int msm_kcenters_select_f32(const double* cands_dev, msm_idx_t world, msm_idx_t m, float* y_dev, float* centers_dev,
+                            msm_idx_t* ids_dev, msm_idx_t slot)
+{
+    return kcenters_select_impl<float>(cands_dev, world, m, y_dev, centers_dev, ids_dev, slot);
+}
+
+int msm_kcenters_select_f64(const double* cands_dev, msm_idx_t world, msm_idx_t m, double* y_dev, double* centers_dev,
+                            msm_idx_t* ids_dev, msm_idx_t slot)
+{
+    return kcenters_select_impl<double>(cands_dev, world, m, y_dev, centers_dev, ids_dev, slot);
 }
 
 int msm_pdist_f32(const float* X, const char* metric, msm_idx_t n, msm_idx_t m, const msm_idx_t* X_indices,

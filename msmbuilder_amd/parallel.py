@@ -127,6 +127,16 @@ def allreduce_array(a, group=None, op="sum"):
     return t.cpu().numpy()
 
 
+def all_gather_rows(out2d, row, group=None):
+    """out2d[r] = rank r's `row` (device tensors; RCCL all-gather with the nccl backend)."""
+    dist = _dist()
+    try:
+        dist.all_gather_into_tensor(out2d.view(-1), row, group=group)
+    except (RuntimeError, NotImplementedError):   # backends without the flat variant (gloo)
+        dist.all_gather([out2d[r] for r in range(out2d.shape[0])], row, group=group)
+    return out2d
+
+
 def allreduce_tica(model, group=None):
     """All-reduce(sum) a fitted local tICA's accumulators in place."""
     if not active():

@@ -63,6 +63,19 @@ assert abs(kc.inertia_ - kref.inertia_) <= 1e-12 * kref.inertia_
 assert np.array_equal(kc.cluster_centers_, kref.cluster_centers_)
 assert np.array_equal(kc.predict([block])[0], kref.predict([X])[0][lo:hi])
 
+# an EMPTY shard on one rank, float32 rows longer than one chunk (wide-row kernel)
+Xw = rs.randn(3000, 40).astype(np.float32)
+blockw = Xw if rank == 0 else Xw[:0]
+kcw = KCenters(n_clusters=9, random_state=1).fit([blockw])
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "0"
+kwref = KCenters(n_clusters=9, random_state=1).fit([Xw])
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "1"
+assert kcw.cluster_ids_ == kwref.cluster_ids_ and np.array_equal(kcw.cluster_centers_, kwref.cluster_centers_)
+if rank == 0:
+    assert np.array_equal(kcw.labels_[0].cpu().numpy(), kwref.labels_[0])
+    assert np.array_equal(kcw.distances_[0].cpu().numpy(), kwref.distances_[0])
+assert abs(kcw.inertia_ - kwref.inertia_) <= 1e-12 * kwref.inertia_
+
 # ---- MiniBatchKMeans: global batches, per-rank partial sums, one all-reduce per step
 Xf = X.astype(np.float32)
 init = Xf[rs.choice(len(Xf), 6, replace=False)].copy()
