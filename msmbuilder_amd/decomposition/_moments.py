@@ -66,16 +66,17 @@ def rao_blackwell_ledoit_wolf(S, n):
 
 
 def _blas_threads(F):
-    """BLAS/LAPACK worker threads for an F x F solve.  A 512 x 512 dsygvx is FASTER on one thread
-    (13.7 ms vs 17.3 ms on a 256-core host), and -- more importantly -- OpenBLAS workers keep
-    spinning for tens of ms after the call, which starves the thread that is about to enqueue
-    hundreds of small kernel launches (measured: the 200 k-centers launches went from 31 ms to
-    48-90 ms right after a many-threaded solve)."""
+    """BLAS/LAPACK worker threads for an F x F solve: a handful.  Measured for a 512 x 512 dsygvx
+    on the GPU boxes' hosts: 1 thread 10-26 ms (depends on the CPU), 2-8 threads 9.4-9.7 ms, all
+    256 threads 17 ms -- and, more importantly, a large OpenBLAS pool keeps spinning for tens of
+    ms after the call, which starves the thread that is about to enqueue hundreds of small
+    kernel launches (the 200 k-centers launches went from 31 ms to 48-90 ms right after a
+    256-thread solve)."""
     import os
     env = os.environ.get("MSMBUILDER_AMD_SOLVE_THREADS")
     if env:
         return max(1, int(env))
-    return 1 if F <= 768 else 8
+    return 4 if F <= 768 else 8
 
 
 DEVICE_SOLVE_MIN_FEATURES = 1024   # measured crossover (host dsygvx 42 ms vs device dsygvd 31 ms at F = 1024)
@@ -113,13 +114,39 @@ def top_generalized_eigenpairs(lhs, rhs, k):
     F = lhs.shape[0]
     if _use_device_solve(F):
         return device_generalized_eigenpairs(lhs, rhs, k)
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=_blas_threads(F), user_api="blas")
-    except Exception:  # threadpoolctl missing: solve with whatever BLAS does
-        import contextlib
-        ctx = contextlib.nullcontext()
-    with ctx:
+    with _blas_limit(_blas_threads(F)):
         vals, vecs = scipy.linalg.eigh(lhs, b=rhs, subset_by_index=[F - k, F - 1])
     order = np.argsort(vals)[::-1]
     return vals[order], vecs[:, order]
+
+
+_controller = None
+
+
+def _blas_limit(n_threads):
+    """threadpoolctl context limiting BLAS threads.  The controller is built ONCE: constructing it
+    walks every loaded shared object (1.3 ms per solve when done per call)."""
+    global _controller
+    try:
+        if _controller is None:
+            from threadpoolctl import ThreadpoolController
+            _controller = ThreadpoolController()
+        return _controller.limit(limits=n_threads, user_api="blas")
+    except Exception:  # threadpoolctl missing: solve with whatever BLAS does
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def is_symmetric(a, rtol=1e-05, atol=1e-08):
+    """``np.allclose(a, a.T)`` (tica.py:183-186), cheaper: the moments built here are symmetric
+    bit for bit, so an exact comparison settles it; otherwise the same element-wise criterion
+    |a - a.T| <= atol + rtol |a.T| (NaN fails it, as it does there) on contiguous copies."""
+    if np.array_equal(a, a.T):
+        return True
+    at = np.ascontiguousarray(a.T)
+    d = a - at
+    np.abs(d, out=d)
+    np.abs(at, out=at)
+    at *= rtol
+    at += atol
+    return bool((d <= at).all())

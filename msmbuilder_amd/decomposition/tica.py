@@ -242,9 +242,9 @@ class tICA(BaseEstimator, TransformerMixin):
         lhs = self.offset_correlation_
         rhs = self.covariance_
 
-        if not np.allclose(lhs, lhs.T):
+        if not _moments.is_symmetric(lhs):
             raise RuntimeError('offset correlation matrix is not symmetric')
-        if not np.allclose(rhs, rhs.T):
+        if not _moments.is_symmetric(rhs):
             raise RuntimeError('correlation matrix is not symmetric')
 
         vals, vecs = _moments.top_generalized_eigenpairs(lhs, rhs, self.n_components)
