@@ -121,6 +121,10 @@ int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until 
 int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
 /* profiling: {shader-clock start, end, 100 MHz wall-clock start, end} of workgroup 0 of that launch */
 int msm_tica_debug_clocks(msm_tica_t* h, long long* out4);
+/* profiling builds (csrc built with -DMSM_TICA_PROFILE) only: out64[8 + 8*slot + i] = shader cycles wave 0 of
+ * five sample workgroups spent in section i of the fp32 kernel {chunk prologue, step head, MFMA loop,
+ * step tail, final merge, inter-chunk merge}; zeros in a product build */
+int msm_tica_debug_profile(msm_tica_t* h, long long* out64);
 
 /* Accumulators as the reference defines them (float64, row-major F x F / F):
  *   C    = sum_traj X[:-tau].T @ X[tau:]                    (tica.py:417)

@@ -79,6 +79,7 @@ def _declare(lib):
     f("msm_tica_nonfinite", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_last_kernel_ms", C.c_int, _p, C.POINTER(C.c_float))
     f("msm_tica_debug_clocks", C.c_int, _p, _i64p)
+    f("msm_tica_debug_profile", C.c_int, _p, _i64p)
     f("msm_tica_export", C.c_int, _p, _p, _p, _p, _p, _i64p, _i64p)
     f("msm_tica_import", C.c_int, _p, _p, _p, _p, _p, _i64, _i64)
     f("msm_tica_packed_size", _i64, _p)

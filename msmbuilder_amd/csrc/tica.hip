@@ -217,6 +217,197 @@ __device__ __forceinline__ void stage_store32(const Stage32<VEC4>& st, float* As
     }
 }
 
+// Compile-time section timers (make EXTRA_tica=-DMSM_TICA_PROFILE): every wave reads s_memtime at the
+// section boundaries of the fp32 kernel and wave 0 of a few workgroups reports the sums through
+// P.dbg[8 + 8*slot ..].  Perturbs the kernel (each read drains lgkmcnt); never built into the product.
+#ifdef MSM_TICA_PROFILE
+#define PROF_DECL long long pf_t = clock64(), pf_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PROF_MARK(i) { const long long pf_n = clock64(); pf_acc[i] += pf_n - pf_t; pf_t = pf_n; }
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#endif
+
+// ---- staging with an INTERIOR fast path ------------------------------------------------------
+// Section timers showed that a wave's non-MFMA instructions run ~10x slower than their count
+// suggests while the co-resident wave streams MFMAs (the matrix instruction monopolises the SIMD's
+// issue port / register ports: ~100 VALU instructions of clamps, weights and address products cost
+// 2,000+ cycles per K-step).  So the K-step is put on a diet.  A step is INTERIOR when none of its 32
+// frames needs a clamp and all of them carry the same weight (97 % of the steps of a 10,000-frame
+// trajectory): its 8 loads then use per-lane offsets that are CONSTANT for the whole chunk on top
+// of a scalar base that advances by 32 rows (SALU), and its LDS store writes the loaded registers
+// unchanged.  To make the Gram weight of an interior frame 1 instead of 2, Gram tiles accumulate
+// HALF weights {0, 1/2, 1} (exact scalings) and the slab merge multiplies by 2 (exact): bit-identical
+// results.  Loads stay unconditional; only VALU work sits inside the branch.
+struct LaneOffs {
+    unsigned a[4], b[4];  // (rr0 + 8 j) * ldb + column bytes, relative to the step's first row
+};
+
+template <bool VEC4>
+__device__ __forceinline__ LaneOffs make_lane_offs(const ChunkCtx& cx, int F, int I0, int J0, int tid)
+{
+    LaneOffs o;
+    const int c4 = (tid & 31) * 4;
+    const int rr0 = tid >> 5;
+    const int ca = I0 + c4 < F ? I0 + c4 : F - 4, cb = J0 + c4 < F ? J0 + c4 : F - 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o.a[j] = (unsigned)(rr0 + 8 * j) * cx.ldb + 4u * (unsigned)ca;
+        o.b[j] = (unsigned)(rr0 + 8 * j) * cx.ldb + 4u * (unsigned)cb;
+    }
+    return o;
+}
+
+// uniform: may step k0 (32 frames) take the fast path?  wsel: 0 = lagged tile (weight [t < len - lag]),
+// 1 = Gram tile (half weights: 1 needs lag <= t < len - lag)
+__device__ __forceinline__ bool step_interior(const ChunkCtx& cx, int k0, int isG)
+{
+    const int last = k0 + BK32 - 1;
+    bool ok = last <= cx.nmax && last <= cx.nmaxB && last < cx.hi;
+    if (isG) ok = ok && k0 >= cx.lo && last < cx.n;
+    return ok;
+}
+
+template <bool VEC4>
+__device__ __forceinline__ void stage_load32x(Stage32<VEC4>& st, int& uniform, const ChunkCtx& cx, const LaneOffs& lo,
+                                              int F, int k0, int isG, int tauB, int I0, int J0, int tid)
+{
+    if (!VEC4) {  // element-wise loads: no fast path
+        stage_load32<VEC4>(st, cx, F, k0, isG, tauB, I0, J0, tid);
+        if (isG) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st.sc[j] *= 0.5f;
+        }
+        uniform = 0;
+        return;
+    }
+    // the branch holds VALU/SALU work only; the 8 loads are issued after the join so that the
+    // compiler keeps counting vmcnt across it
+    global_ptr<char> pa = cx.base, pb = cx.baseB;
+    unsigned oa[4], ob[4];
+    if (step_interior(cx, k0, isG)) {
+        pa += (size_t)k0 * cx.ldb;  // scalar
+        pb += (size_t)k0 * cx.ldb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            oa[j] = lo.a[j];
+            ob[j] = lo.b[j];
+        }
+        uniform = 1;
+    } else {
+        const int c4 = (tid & 31) * 4;
+        const int rr0 = tid >> 5;
+        const float wfull = isG ? 0.5f : 1.f;
+        const unsigned ca = 4u * (unsigned)(I0 + c4 < F ? I0 + c4 : F - 4), cb = 4u * (unsigned)(J0 + c4 < F ? J0 + c4 : F - 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kr = k0 + rr0 + 8 * j;
+            float sc = (kr < cx.hi) ? wfull : 0.f;
+            if (isG) sc += (kr >= cx.lo && kr < cx.n) ? 0.5f : 0.f;
+            const int ra = kr < cx.nmax ? kr : cx.nmax;
+            const int rb = kr < cx.nmaxB ? kr : cx.nmaxB;
+            oa[j] = (unsigned)ra * cx.ldb + ca;
+            ob[j] = (unsigned)rb * cx.ldb + cb;
+            st.sc[j] = sc;
+        }
+        uniform = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        st.a[j] = load16_global<char>(pa + oa[j]);
+        st.b[j] = load16_global<char>(pb + ob[j]);
+    }
+}
+
+// addresses (and, on edge steps, weights) of the 8 loads of step k0 -- no load is issued here.
+// VEC4: a scalar base pair + one 32-bit byte offset per load; !VEC4: the offset addresses the ROW,
+// the four elements are fetched one by one with clamped columns (stage_ld).
+struct StageAddr {
+    global_ptr<char> pa, pb;
+    unsigned oa[4], ob[4];
+};
+
+template <bool VEC4>
+__device__ __forceinline__ void stage_addr32(StageAddr& sa, Stage32<VEC4>& st, int& uniform, const ChunkCtx& cx,
+                                             const LaneOffs& lo, int F, int k0, int isG, int I0, int J0, int tid)
+{
+    sa.pa = cx.base;
+    sa.pb = cx.baseB;
+    if (VEC4 && step_interior(cx, k0, isG)) {
+        sa.pa += (size_t)k0 * cx.ldb;  // scalar
+        sa.pb += (size_t)k0 * cx.ldb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sa.oa[j] = lo.a[j];
+            sa.ob[j] = lo.b[j];
+        }
+        uniform = 1;
+    } else {
+        const int c4 = (tid & 31) * 4;
+        const int rr0 = tid >> 5;
+        const float wfull = isG ? 0.5f : 1.f;
+        const unsigned ca = VEC4 ? 4u * (unsigned)(I0 + c4 < F ? I0 + c4 : F - 4) : 0u;
+        const unsigned cb = VEC4 ? 4u * (unsigned)(J0 + c4 < F ? J0 + c4 : F - 4) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kr = k0 + rr0 + 8 * j;
+            float sc = (kr < cx.hi) ? wfull : 0.f;
+            if (isG) sc += (kr >= cx.lo && kr < cx.n) ? 0.5f : 0.f;
+            const int ra = kr < cx.nmax ? kr : cx.nmax;
+            const int rb = kr < cx.nmaxB ? kr : cx.nmaxB;
+            sa.oa[j] = (unsigned)ra * cx.ldb + ca;
+            sa.ob[j] = (unsigned)rb * cx.ldb + cb;
+            st.sc[j] = sc;
+        }
+        uniform = 0;
+    }
+}
+
+template <bool VEC4>
+__device__ __forceinline__ float4 stage_ld(global_ptr<char> base, unsigned off, int F, int col)
+{
+    if (VEC4) return load16_global<char>(base + off);
+    return load_row4<false>(base, off, col, F);
+}
+
+// apply the per-row weight (edge steps) and the column masks (partial tiles) to a loaded stage in place
+template <bool VEC4, bool PARTIAL>
+__device__ __forceinline__ void stage_scale32(Stage32<VEC4>& st, int uniform, float4 ma, float4 mb)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sc = uniform ? 1.f : st.sc[j];
+        if (PARTIAL) {
+            st.a[j] = make_float4(st.a[j].x * (sc * ma.x), st.a[j].y * (sc * ma.y), st.a[j].z * (sc * ma.z), st.a[j].w * (sc * ma.w));
+            st.b[j] = make_float4(st.b[j].x * mb.x, st.b[j].y * mb.y, st.b[j].z * mb.z, st.b[j].w * mb.w);
+        } else {
+            st.a[j] = make_float4(st.a[j].x * sc, st.a[j].y * sc, st.a[j].z * sc, st.a[j].w * sc);
+        }
+    }
+}
+
+template <bool VEC4, bool PARTIAL>
+__device__ __forceinline__ void stage_store32x(const Stage32<VEC4>& st, int uniform, float* As, float* Bs, int tid,
+                                               float4 ma, float4 mb)
+{
+    if (!PARTIAL && uniform) {
+        const int c4 = (tid & 31) * 4;
+        const int rr0 = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<float4*>(As + (rr0 + 8 * j) * TM + c4) = st.a[j];
+            *reinterpret_cast<float4*>(Bs + (rr0 + 8 * j) * TM + c4) = st.b[j];
+        }
+        return;
+    }
+    Stage32<VEC4> t = st;
+    if (uniform) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t.sc[j] = 1.f;
+    }
+    stage_store32<VEC4, PARTIAL>(t, As, Bs, tid, ma, mb);
+}
+
 template <bool VEC4, bool PARTIAL>
 __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 {
@@ -251,6 +442,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+    const double gscale = isG ? 2.0 : 1.0;  // Gram tiles accumulate half weights (see stage_load32x)
     int rows_acc = 0;
     int chunks_done = 0;
     if (P.dbg && blockIdx.x == 0 && tid == 0) {
@@ -258,20 +450,30 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         P.dbg[2] = wall_clock64();
     }
 
+    PROF_DECL;
     for (long long c = cohort; c < P.nchunks; c += P.S) {
+        PROF_MARK(5)
         const TicaChunk ch = get_chunk(P, c);
         const int nsteps = (ch.n + BK32 - 1) / BK32;
         ChunkCtx cx = make_ctx(P, ch);
         set_lag(cx, tauB, sizeof(float), P.ld);
         // Register-staged software pipeline, TWO K-steps deep: while step s runs on the MFMA pipe
-        // the panel of step s+1 sits in one register set (written to LDS at the end of step s) and
-        // the loads of step s+2 are in flight into the other.  One step of lookahead is not enough:
-        // every step has first-touch L2 misses (the lagged panel), and an HBM round trip under load
-        // is about as long as one step, which stalled 16 % of the kernel on vmcnt.
+        // the panel of step s+1 sits in one register set (written to the other LDS buffer during
+        // step s) and the loads of step s+2 go into the other.  (One step of lookahead is not
+        // enough: the lagged panel misses L2 on first touch and an HBM round trip under load is as
+        // long as a step.)
+        // The 8 global loads and the 8 LDS writes of a step are interleaved INTO the unrolled MFMA
+        // stream (k-pairs 0-3 and 8-15), where they issue in the shadow of this wave's own MFMAs;
+        // issued in a block before / after the loop they wait on the CO-RESIDENT wave's MFMAs instead
+        // (section timers: 17 % of the kernel).  Everything data-dependent -- edge clamps, weights,
+        // column masks -- is resolved in two uniform branches at the top of the step that hold VALU
+        // work only and are skipped on interior steps, so the stream itself is branch-free.
         Stage32<VEC4> st0, st1;
-        stage_load32<VEC4>(st0, cx, P.F, 0, isG, tauB, I0, J0, tid);
-        stage_store32<VEC4, PARTIAL>(st0, As, Bs, tid, ma, mb);
-        stage_load32<VEC4>(st0, cx, P.F, BK32, isG, tauB, I0, J0, tid);
+        int un0 = 0, un1 = 0;
+        const LaneOffs lofs = make_lane_offs<VEC4>(cx, P.F, I0, J0, tid);
+        stage_load32x<VEC4>(st0, un0, cx, lofs, P.F, 0, isG, tauB, I0, J0, tid);
+        stage_store32x<VEC4, PARTIAL>(st0, un0, As, Bs, tid, ma, mb);
+        stage_load32x<VEC4>(st0, un0, cx, lofs, P.F, BK32, isG, tauB, I0, J0, tid);
         if (P.cosync && chunks_done > 0) {
             if (tid == 0) {
                 const unsigned target = (unsigned)P.ntiles * (unsigned)chunks_done;
@@ -283,21 +485,36 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
             }
         }
         __syncthreads();
-#define MSM_TICA_STEP(SNEXT, SLOAD, BUF)                                                          \
+        PROF_MARK(0)  /* chunk prologue: descriptor, first two stage loads, first LDS store */
+        const int srow = tid >> 5, scol = (tid & 31) * 4;  // this thread's staging row / column
+#define MSM_TICA_STEP(SNEXT, UNEXT, SLOAD, ULOAD, BUF)                                            \
         {                                                                                         \
-            /* unconditional (rows past the chunk are clamped and weighted 0): a branch here makes */ \
-            /* the compiler wait vmcnt(0) instead of vmcnt(8) before the LDS store below          */ \
-            stage_load32<VEC4>(SLOAD, cx, P.F, (s + 2) * BK32, isG, tauB, I0, J0, tid);          \
             const float* Ab = As + (BUF) * (BK32 * TM) + kl * TM + wr * 64 + cl;                  \
             const float* Bb = Bs + (BUF) * (BK32 * TM) + kl * TM + wc * 64 + cl;                  \
+            float* Aw = As + ((BUF) ^ 1) * (BK32 * TM) + srow * TM + scol;                        \
+            float* Bw = Bs + ((BUF) ^ 1) * (BK32 * TM) + srow * TM + scol;                        \
+            /* addresses of step s+2 and (edge steps only) weights; no loads issued here */       \
+            StageAddr sa;                                                                         \
+            stage_addr32<VEC4>(sa, SLOAD, ULOAD, cx, lofs, P.F, (s + 2) * BK32, isG, I0, J0, tid); \
+            /* step s+1's panel becomes what LDS must hold: weights / masks applied in registers */ \
+            if (PARTIAL || !UNEXT) stage_scale32<VEC4, PARTIAL>(SNEXT, UNEXT, ma, mb);            \
             /* fragment reads run one k-pair ahead of the MFMAs that consume them */              \
             float a0 = Ab[0], a1 = Ab[32], b0 = Bb[0], b1 = Bb[32];                               \
+            PROF_MARK(1) /* step head */                                                          \
             /* fully unrolled: an inner loop makes the compiler's vmcnt bookkeeping give up and     */ \
             /* wait vmcnt(0) at the top of every step, which cuts the register pipeline to 1 step */ \
             _Pragma("unroll") for (int kk = 0; kk < BK32 / 2; ++kk) {                             \
                 const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;                                 \
                 const float na0 = Ab[kn * 2 * TM], na1 = Ab[kn * 2 * TM + 32];                    \
                 const float nb0 = Bb[kn * 2 * TM], nb1 = Bb[kn * 2 * TM + 32];                    \
+                if (kk < 4) { /* step s+2 -> registers */                                         \
+                    SLOAD.a[kk] = stage_ld<VEC4>(sa.pa, sa.oa[kk], P.F, I0 + scol);               \
+                    SLOAD.b[kk] = stage_ld<VEC4>(sa.pb, sa.ob[kk], P.F, J0 + scol);               \
+                }                                                                                 \
+                if (kk >= 8 && (kk & 1) == 0) { /* step s+1 -> the other LDS buffer */            \
+                    *reinterpret_cast<float4*>(Aw + ((kk - 8) / 2) * 8 * TM) = SNEXT.a[(kk - 8) / 2]; \
+                    *reinterpret_cast<float4*>(Bw + ((kk - 8) / 2) * 8 * TM) = SNEXT.b[(kk - 8) / 2]; \
+                }                                                                                 \
                 __builtin_amdgcn_sched_barrier(0); /* keep the reads ABOVE the MFMAs they do not feed */ \
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);     \
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);     \
@@ -306,14 +523,14 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
                 __builtin_amdgcn_sched_barrier(0);                                                \
                 a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                           \
             }                                                                                     \
-            if (s + 1 < nsteps)                                                                   \
-                stage_store32<VEC4, PARTIAL>(SNEXT, As + ((BUF) ^ 1) * (BK32 * TM), Bs + ((BUF) ^ 1) * (BK32 * TM), tid, ma, mb); \
+            PROF_MARK(2) /* MFMA loop */                                                          \
             __syncthreads();                                                                      \
+            PROF_MARK(3) /* step tail: barrier */                                                 \
         }
         for (int s = 0; s < nsteps; s += 2) {
-            MSM_TICA_STEP(st0, st1, 0)
+            MSM_TICA_STEP(st0, un0, st1, un1, 0)
             ++s;
-            if (s < nsteps) MSM_TICA_STEP(st1, st0, 1)
+            if (s < nsteps) MSM_TICA_STEP(st1, un1, st0, un0, 1)
             --s;
         }
 #undef MSM_TICA_STEP
@@ -354,12 +571,19 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
-                        q[toff] = old[bj][r] + (double)acc[bi][bj][r];
+                        q[toff] = old[bj][r] + gscale * (double)acc[bi][bj][r];
                         acc[bi][bj][r] = 0.f;
                     }
             }
         }
     }
+    PROF_MARK(4) /* since the last step: slab merges (and the idle tail of the last chunk) */
+#ifdef MSM_TICA_PROFILE
+    if (P.dbg && tid == 0 && (blockIdx.x < 3 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) {
+        const int slot = blockIdx.x < 3 ? blockIdx.x : (blockIdx.x == gridDim.x / 2 ? 3 : 4);
+        for (int i = 0; i < 6; ++i) P.dbg[8 + 8 * slot + i] = pf_acc[i];
+    }
+#endif
     if (P.dbg && blockIdx.x == 0 && tid == 0) {
         P.dbg[1] = clock64();
         P.dbg[3] = wall_clock64();
@@ -1246,7 +1470,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->coltmp, (size_t)NCB * 2 * h->F * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->packed, (FF2 + 2) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->flag, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->dbg, 4 * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->dbg, 64 * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void**)&h->cosync, (size_t)(h->S + 1) * sizeof(unsigned));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
@@ -1409,6 +1633,14 @@ int msm_tica_debug_clocks(msm_tica_t* h, long long* out4)
 {
     if (!h || !out4) return fail(MSM_ERR_STATE, "null argument");
     MSM_HIP_CHECK(hipMemcpyAsync(out4, h->dbg, 4 * sizeof(long long), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_tica_debug_profile(msm_tica_t* h, long long* out64)
+{
+    if (!h || !out64) return fail(MSM_ERR_STATE, "null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(out64, h->dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
 }
