@@ -498,15 +498,19 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
             stage_addr32<VEC4>(sa, SLOAD, ULOAD, cx, lofs, P.F, (s + 2) * BK32, isG, I0, J0, tid); \
             /* step s+1's panel becomes what LDS must hold: weights / masks applied in registers */ \
             if (PARTIAL || !UNEXT) stage_scale32<VEC4, PARTIAL>(SNEXT, UNEXT, ma, mb);            \
-            /* fragment reads run one k-pair ahead of the MFMAs that consume them */              \
-            float a0 = Ab[0], a1 = Ab[32], b0 = Bb[0], b1 = Bb[32];                               \
             PROF_MARK(1) /* step head */                                                          \
             /* fully unrolled: an inner loop makes the compiler's vmcnt bookkeeping give up and     */ \
             /* wait vmcnt(0) at the top of every step, which cuts the register pipeline to 1 step */ \
             _Pragma("unroll") for (int kk = 0; kk < BK32 / 2; ++kk) {                             \
-                const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;                                 \
-                const float na0 = Ab[kn * 2 * TM], na1 = Ab[kn * 2 * TM + 32];                    \
-                const float nb0 = Bb[kn * 2 * TM], nb1 = Bb[kn * 2 * TM + 32];                    \
+                /* fragment reads run one k-pair ahead of the MFMAs that consume them -- across  */ \
+                /* the step boundary too: before its last four MFMAs a step passes the barrier     */ \
+                /* (every wave has written step s+1's panel by then) and fetches the first          */ \
+                /* fragments of step s+1, so the next step starts without an LDS round trip        */ \
+                if (kk == BK32 / 2 - 1) __syncthreads();                                          \
+                const float* An = (kk == BK32 / 2 - 1) ? Ab + (((BUF) ^ 1) - (BUF)) * (BK32 * TM) : Ab + (kk + 1) * 2 * TM; \
+                const float* Bn = (kk == BK32 / 2 - 1) ? Bb + (((BUF) ^ 1) - (BUF)) * (BK32 * TM) : Bb + (kk + 1) * 2 * TM; \
+                const float na0 = An[0], na1 = An[32];                                            \
+                const float nb0 = Bn[0], nb1 = Bn[32];                                            \
                 if (kk < 4) { /* step s+2 -> registers */                                         \
                     SLOAD.a[kk] = stage_ld<VEC4>(sa.pa, sa.oa[kk], P.F, I0 + scol);               \
                     SLOAD.b[kk] = stage_ld<VEC4>(sa.pb, sa.ob[kk], P.F, J0 + scol);               \
@@ -523,10 +527,11 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
                 __builtin_amdgcn_sched_barrier(0);                                                \
                 a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                           \
             }                                                                                     \
-            PROF_MARK(2) /* MFMA loop */                                                          \
-            __syncthreads();                                                                      \
-            PROF_MARK(3) /* step tail: barrier */                                                 \
+            PROF_MARK(2) /* MFMA loop (with the barrier before its last k-pair) */                \
         }
+        /* first fragments of step 0 (lane: frame kl, columns wr*64+cl / +32 of the tile) */
+        float a0 = As[kl * TM + wr * 64 + cl], a1 = As[kl * TM + wr * 64 + cl + 32];
+        float b0 = Bs[kl * TM + wc * 64 + cl], b1 = Bs[kl * TM + wc * 64 + cl + 32];
         for (int s = 0; s < nsteps; s += 2) {
             MSM_TICA_STEP(st0, un0, st1, un1, 0)
             ++s;
