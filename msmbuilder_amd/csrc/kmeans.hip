@@ -299,36 +299,15 @@ constexpr int KP4 = KBK + 4;
 
 struct KmStage {
     float4 x[4], c[4];
-    int inb;  // this thread's 4 columns are inside [0, m)
 };
 
-__device__ __forceinline__ void km4_load(KmStage& st, const global_ptr<char> (&xp)[4], global_ptr<char> cb,
-                                         const unsigned (&co)[4], int col, int m)
-{
-    st.inb = col < m;
-    const unsigned cc = 4u * (unsigned)(col < m ? col : m - 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        st.x[j] = load16_global<char>(xp[j] + cc);
-        st.c[j] = load16_global<char>(cb + (co[j] + cc));
-    }
-}
-
-__device__ __forceinline__ void km4_store(const KmStage& st, float* Xs, float* Cs, int tid)
-{
-    const int c4 = (tid & 7) * 4;
-    const int r0 = tid >> 3;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // (value selects: `cond ? lvalue : lvalue` on structs selects an ADDRESS and forces scratch)
-        const bool in = st.inb != 0;
-        *reinterpret_cast<float4*>(Xs + (r0 + 32 * j) * KP4 + c4) =
-            make_float4(in ? st.x[j].x : 0.f, in ? st.x[j].y : 0.f, in ? st.x[j].z : 0.f, in ? st.x[j].w : 0.f);
-        *reinterpret_cast<float4*>(Cs + (r0 + 32 * j) * KP4 + c4) =
-            make_float4(in ? st.c[j].x : 0.f, in ? st.c[j].y : 0.f, in ? st.c[j].z : 0.f, in ? st.c[j].w : 0.f);
-    }
-}
-
+// Like the tICA kernel (tica.hip, "staging with an INTERIOR fast path"): a wave's non-MFMA instructions
+// crawl while the co-resident wave streams MFMAs, so a K-step carries as few of them as possible and
+// issues its 8 global loads and 8 LDS writes from INSIDE its own MFMA stream.  Interior steps (all 32
+// columns inside [0, m), every step but a partial last one) load through per-lane offsets that are
+// constant per centre tile on top of scalar bases, and write the loaded registers to LDS unchanged;
+// clamps and zero-masks live in uniform branches that hold VALU work only.
+template <bool GATHER>
 __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char km_smem[];
@@ -352,14 +331,22 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
             bidx[bi][r] = 0x7fffffff;
         }
 
-    // this thread's 4 staging rows of X (fixed for the workgroup's life; clamped into [0, n))
+    // this thread's 4 staging rows of X (fixed for the workgroup's life; clamped into [0, n)):
+    // contiguous rows -> one scalar base + 32-bit lane offsets; gathered rows -> 64-bit lane pointers
+    const global_ptr<char> Xg = as_global<char>(P.X) + (GATHER ? (size_t)0 : (size_t)row0 * ldb);
     global_ptr<char> xp[4];
+    unsigned xo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         long long i = row0 + r0 + 32 * j;
         if (i > P.n - 1) i = P.n - 1;
-        const long long r = P.rows ? as_global<msm_idx_t>(P.rows)[i] : i;
-        xp[j] = as_global<char>(P.X) + (size_t)r * ldb;
+        if (GATHER) {
+            xp[j] = Xg + (size_t)as_global<msm_idx_t>(P.rows)[i] * ldb + 4u * (unsigned)c4;
+            xo[j] = 0;
+        } else {
+            xp[j] = Xg;
+            xo[j] = (unsigned)(i - row0) * ldb + 4u * (unsigned)c4;
+        }
     }
     const global_ptr<char> Cg = as_global<char>(P.C);
 
@@ -375,36 +362,107 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
 
-    // load cursor (runs two iterations ahead of the compute cursor; parks on the last tile)
+    // load cursor (runs two iterations ahead of the compute cursor; parks on the last tile) and the
+    // centre-row lane offsets of its tile (rows clamped to K - 1: recomputed when the tile changes)
     int ls = 0;
     long long lj0 = jbeg;
-#define KM4_LOAD(ST)                                                                              \
+    unsigned co[4];
+#define KM4_TILE_OFFS                                                                             \
     {                                                                                             \
         const long long lim = P.K - 1 - lj0;                                                      \
-        unsigned co[4];                                                                           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
             const int rr = r0 + 32 * j;                                                           \
-            co[j] = (unsigned)(rr < lim ? rr : (int)lim) * ldb;                                   \
-        }                                                                                         \
-        km4_load(ST, xp, Cg + (size_t)lj0 * ldb, co, ls * KBK + c4, m);                           \
-        if (++ls == nk) {                                                                         \
-            ls = 0;                                                                               \
-            if (lj0 + KCT < jend) lj0 += KCT;                                                     \
+            co[j] = (unsigned)(rr < lim ? rr : (int)lim) * ldb + 4u * (unsigned)c4;               \
         }                                                                                         \
     }
+    KM4_TILE_OFFS
+    // addresses of the load cursor's step: scalar byte offset of its first column + (partial last step
+    // only) a per-lane column correction; `un` = the step needs no zero-masking when it reaches LDS
+#define KM4_ADDR(KOFF, CADJ, UN)                                                                  \
+    {                                                                                             \
+        KOFF = (unsigned)ls * (KBK * 4u);                                                         \
+        CADJ = 0;                                                                                 \
+        UN = 1;                                                                                   \
+        if (ls * KBK + KBK > m) { /* partial last K-step: clamp this lane's columns into the row */ \
+            const int col = ls * KBK + c4;                                                        \
+            CADJ = col < m ? 0u : 4u * (unsigned)(col - (m - 4));                                 \
+            UN = 0;                                                                               \
+        }                                                                                         \
+    }
+#define KM4_ADVANCE                                                                               \
+    if (++ls == nk) {                                                                             \
+        ls = 0;                                                                                   \
+        if (lj0 + KCT < jend) {                                                                   \
+            lj0 += KCT;                                                                           \
+            KM4_TILE_OFFS                                                                         \
+        }                                                                                         \
+    }
+#define KM4_LD_X(J, KOFF, CADJ)                                                                   \
+    (GATHER ? load16_global<char>(xp[J] + ((long long)(KOFF) - (long long)(CADJ)))                \
+            : load16_global<char>(xp[J] + (size_t)(KOFF) + (xo[J] - (CADJ))))
+#define KM4_LD_C(J, KOFF, CADJ) load16_global<char>(Cg + (size_t)lj0c * ldb + (size_t)(KOFF) + (co_c[J] - (CADJ)))
+    // zero this lane's out-of-range columns of a loaded stage (partial last K-step only)
+#define KM4_MASK(ST, INB)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        ST.x[j] = make_float4(INB ? ST.x[j].x : 0.f, INB ? ST.x[j].y : 0.f, INB ? ST.x[j].z : 0.f, INB ? ST.x[j].w : 0.f); \
+        ST.c[j] = make_float4(INB ? ST.c[j].x : 0.f, INB ? ST.c[j].y : 0.f, INB ? ST.c[j].z : 0.f, INB ? ST.c[j].w : 0.f); \
+    }
     KmStage st0, st1;
-    KM4_LOAD(st0)
-    km4_store(st0, Xs, Cs, tid);
-    KM4_LOAD(st0)
+    int un0 = 1, un1 = 1, inb0 = 1, inb1 = 1;
+    {   // prologue: step 0 -> LDS, step 1 -> registers
+        unsigned koff, cadj;
+        int un;
+        long long lj0c = lj0;
+        unsigned co_c[4] = {co[0], co[1], co[2], co[3]};
+        KM4_ADDR(koff, cadj, un)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st0.x[j] = KM4_LD_X(j, koff, cadj);
+            st0.c[j] = KM4_LD_C(j, koff, cadj);
+        }
+        const bool inb = cadj == 0;
+        if (!un) { KM4_MASK(st0, inb) }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<float4*>(Xs + (r0 + 32 * j) * KP4 + c4) = st0.x[j];
+            *reinterpret_cast<float4*>(Cs + (r0 + 32 * j) * KP4 + c4) = st0.c[j];
+        }
+        KM4_ADVANCE
+        lj0c = lj0;
+        co_c[0] = co[0]; co_c[1] = co[1]; co_c[2] = co[2]; co_c[3] = co[3];
+        KM4_ADDR(koff, cadj, un0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st0.x[j] = KM4_LD_X(j, koff, cadj);
+            st0.c[j] = KM4_LD_C(j, koff, cadj);
+        }
+        inb0 = cadj == 0;
+        KM4_ADVANCE
+    }
     __syncthreads();
 
     int s = 0;
     long long j0 = jbeg;
-#define KM4_STEP(SNEXT, SLOAD, BUF)                                                               \
+#define KM4_MFMA4(A0, A1, B0, B1)                                                                 \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc[0][0], 0, 0, 0);                 \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc[0][1], 0, 0, 0);                 \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc[1][0], 0, 0, 0);                 \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc[1][1], 0, 0, 0);
+#define KM4_STEP(SNEXT, UNEXT, INEXT, SLOAD, ULOAD, ILOAD, BUF)                                   \
     {                                                                                             \
-        KM4_LOAD(SLOAD)                                                                           \
+        /* addresses of iteration it+2 (no loads yet); the cursor moves on */                     \
+        unsigned koff, cadj;                                                                      \
+        const long long lj0c = lj0;                                                               \
+        const unsigned co_c[4] = {co[0], co[1], co[2], co[3]};                                    \
+        KM4_ADDR(koff, cadj, ULOAD)                                                               \
+        ILOAD = cadj == 0;                                                                        \
+        KM4_ADVANCE                                                                               \
+        /* iteration it+1's panel is about to go to LDS: zero-mask it if it is a partial step */  \
+        if (!UNEXT) { const bool inb = INEXT != 0; KM4_MASK(SNEXT, inb) }                         \
         const float* Ab = Xs + (BUF) * (KR * KP4) + (wr * 64 + cl) * KP4 + kl * 4;                \
         const float* Bb = Cs + (BUF) * (KCT * KP4) + (wc * 64 + cl) * KP4 + kl * 4;               \
+        float* Xw = Xs + ((BUF) ^ 1) * (KR * KP4) + r0 * KP4 + c4;                                \
+        float* Cw = Cs + ((BUF) ^ 1) * (KCT * KP4) + r0 * KP4 + c4;                               \
         float4 a0 = *reinterpret_cast<const float4*>(Ab), a1 = *reinterpret_cast<const float4*>(Ab + 32 * KP4); \
         float4 b0 = *reinterpret_cast<const float4*>(Bb), b1 = *reinterpret_cast<const float4*>(Bb + 32 * KP4); \
         _Pragma("unroll") for (int g = 0; g < KBK / 8; ++g) {                                     \
@@ -413,16 +471,24 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
             const float4 na1 = *reinterpret_cast<const float4*>(Ab + 32 * KP4 + gn * 8);          \
             const float4 nb0 = *reinterpret_cast<const float4*>(Bb + gn * 8);                     \
             const float4 nb1 = *reinterpret_cast<const float4*>(Bb + 32 * KP4 + gn * 8);          \
+            /* memory ops of this step, spread over the four MFMA quads of each feature group:   */ \
+            /* groups 0-1: the 8 loads of iteration it+2; groups 2-3: the 8 LDS writes of it+1    */ \
+            if (g < 2) { SLOAD.x[2 * g] = KM4_LD_X(2 * g, koff, cadj); SLOAD.c[2 * g] = KM4_LD_C(2 * g, koff, cadj); } \
+            if (g >= 2) { *reinterpret_cast<float4*>(Xw + (2 * (g - 2)) * 32 * KP4) = SNEXT.x[2 * (g - 2)];           \
+                          *reinterpret_cast<float4*>(Cw + (2 * (g - 2)) * 32 * KP4) = SNEXT.c[2 * (g - 2)]; }         \
             __builtin_amdgcn_sched_barrier(0);                                                    \
             KM4_MFMA4(a0.x, a1.x, b0.x, b1.x)                                                     \
             KM4_MFMA4(a0.y, a1.y, b0.y, b1.y)                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            if (g < 2) { SLOAD.x[2 * g + 1] = KM4_LD_X(2 * g + 1, koff, cadj); SLOAD.c[2 * g + 1] = KM4_LD_C(2 * g + 1, koff, cadj); } \
+            if (g >= 2) { *reinterpret_cast<float4*>(Xw + (2 * (g - 2) + 1) * 32 * KP4) = SNEXT.x[2 * (g - 2) + 1];   \
+                          *reinterpret_cast<float4*>(Cw + (2 * (g - 2) + 1) * 32 * KP4) = SNEXT.c[2 * (g - 2) + 1]; } \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
             KM4_MFMA4(a0.z, a1.z, b0.z, b1.z)                                                     \
             KM4_MFMA4(a0.w, a1.w, b0.w, b1.w)                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                    \
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                               \
         }                                                                                         \
-        if (it + 1 < total)                                                                       \
-            km4_store(SNEXT, Xs + ((BUF) ^ 1) * (KR * KP4), Cs + ((BUF) ^ 1) * (KCT * KP4), tid); \
         __syncthreads();                                                                          \
         if (++s == nk) {                                                                          \
             s = 0;                                                                                \
@@ -430,20 +496,20 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
             j0 += KCT;                                                                            \
         }                                                                                         \
     }
-#define KM4_MFMA4(A0, A1, B0, B1)                                                                 \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc[0][0], 0, 0, 0);                 \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc[0][1], 0, 0, 0);                 \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc[1][0], 0, 0, 0);                 \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc[1][1], 0, 0, 0);
     for (long long it = 0; it < total; it += 2) {
-        KM4_STEP(st0, st1, 0)
+        KM4_STEP(st0, un0, inb0, st1, un1, inb1, 0)
         ++it;
-        if (it < total) KM4_STEP(st1, st0, 1)
+        if (it < total) KM4_STEP(st1, un1, inb1, st0, un0, inb0, 1)
         --it;
     }
 #undef KM4_STEP
 #undef KM4_MFMA4
-#undef KM4_LOAD
+#undef KM4_MASK
+#undef KM4_LD_C
+#undef KM4_LD_X
+#undef KM4_ADVANCE
+#undef KM4_ADDR
+#undef KM4_TILE_OFFS
     km_finish_rows(best, bidx, P, Xs, reinterpret_cast<int*>(Cs), row0, tid, wr, wc, kl, cl);
 }
 
@@ -632,11 +698,16 @@ static int km_launch_label(const KmArgs& P, dim3 grid)
     if (v4) {
         static bool attr_set = false;
         if (!attr_set) {
-            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_label_v4_kernel),
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_label_v4_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)KM4_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_label_v4_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)KM4_LDS));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kmeans_label_v4_kernel, grid, dim3(KNT), KM4_LDS, stream(), P);
+        if (P.rows)
+            hipLaunchKernelGGL(kmeans_label_v4_kernel<true>, grid, dim3(KNT), KM4_LDS, stream(), P);
+        else
+            hipLaunchKernelGGL(kmeans_label_v4_kernel<false>, grid, dim3(KNT), KM4_LDS, stream(), P);
     } else {
         hipLaunchKernelGGL(kmeans_label_kernel, grid, dim3(KNT), 0, stream(), P);
     }
