@@ -1168,6 +1168,124 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
     if (bad) atomicOr(flag, 1);
 }
 
+// ---------------------------------------------------------------------------
+// Projection on the fp64 matrix pipe (16-byte aligned rows): out[N, k] = X . Vp - muV with
+// v_mfma_f64_16x16x4_f64 -- 16 rows x 4 features x 16 components per instruction, inputs widened to
+// fp64 exactly as the vector kernel does, fp64 accumulation (same products, the sum of a row is
+// merely associated in groups of four features).  A wave owns 64 rows (4 row blocks); per
+// 128-byte chunk of a row every lane loads its own 32 bytes STRAIGHT from global memory -- lane
+// (r = lane & 15, g = lane >> 4) takes the 8 floats / 4 doubles at column 8g (4g) of row r -- and
+// MFMA t of the chunk contracts the features {c0 + E2*g + t : g = 0..3}: a fixed permutation that the
+// component panel Vp follows (staged in LDS per chunk as [feature][16 comps], pitch 20 doubles, k
+// padded with zeros), so X needs no LDS at all.  Per chunk and wave: 8 loads, 8 fragment reads, 32
+// MFMAs (2,048 pipe cycles) for 8 KiB of input -- the matrix time per byte is about the HBM time
+// per byte, so the kernel streams at HBM rate instead of being bound by LDS broadcast reads like the
+// one-lane-per-row kernel above (2.9 TB/s).  Non-finite INPUT makes non-finite OUTPUT (x finite
+// always gives a finite sum), so the finite check of validation.py:68-74 is applied to the k outputs.
+// ---------------------------------------------------------------------------
+constexpr int PVP = 20;  // LDS pitch of a Vp feature row in doubles (16 comps + 4: lanes of different g hit different banks)
+
+template <typename TIn>
+__global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __restrict__ X, long long n, int F,
+                                                                  long long ld, const double* __restrict__ muV,
+                                                                  const double* __restrict__ Vp /* [F][16] */, int k,
+                                                                  int kbase, int ktot, double* __restrict__ out,
+                                                                  int* flag)
+{
+    constexpr int FCH = 128 / (int)sizeof(TIn);  // features per chunk (32 f32 / 16 f64)
+    constexpr int NT4 = FCH / 4;                 // MFMAs per chunk and row block (8 / 4)
+    constexpr int RB = 4;                        // row blocks of 16 per wave
+    __shared__ double Vs[2][FCH * PVP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const long long row0 = (long long)blockIdx.x * (4 * RB * 16) + wave * (RB * 16);
+    const int nch = (F + FCH - 1) / FCH;
+    const unsigned ldb = (unsigned)(ld * sizeof(TIn));
+
+    // per-lane byte offsets of this lane's rows (clamped into [0, n)) relative to the tile's first row
+    const long long tile0 = (long long)blockIdx.x * (4 * RB * 16);
+    const global_ptr<char> Xg = as_global<char>(X) + (size_t)tile0 * ldb;
+    unsigned xo[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        long long i = row0 + b * 16 + r;
+        if (i > n - 1) i = n - 1;
+        xo[b] = (unsigned)(i - tile0) * ldb;
+    }
+    // Vp staging: thread -> (feature tid >> 3, component pair (tid & 7) * 2) of the chunk
+    const int vf = tid >> 3, vc = (tid & 7) * 2;
+    const global_ptr<char> Vg = as_global<char>(Vp);
+
+    f64x4 acc[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[b][q] = 0.0;
+
+    raw_f32x4 xs0[RB][2], xs1[RB][2], vreg;
+    // byte offsets of this lane's two 16-byte halves of chunk c inside a row; a half that lies past the
+    // row (partial last chunk) re-reads the row's last 16 bytes instead: finite data against zero Vp rows
+#define MSM_PJ_LOAD(XS, C)                                                                        \
+    {                                                                                             \
+        const int last16 = F * (int)sizeof(TIn) - 16;                                             \
+        const int h0 = (C) * 128 + g * 32, h1 = h0 + 16;                                          \
+        const unsigned a0 = (unsigned)(h0 < last16 ? h0 : last16), a1 = (unsigned)(h1 < last16 ? h1 : last16); \
+        _Pragma("unroll") for (int b = 0; b < RB; ++b) {                                          \
+            XS[b][0] = *(global_ptr<raw_f32x4>)(Xg + (xo[b] + a0));                               \
+            XS[b][1] = *(global_ptr<raw_f32x4>)(Xg + (xo[b] + a1));                               \
+        }                                                                                         \
+        const int feat = (C) * FCH + vf;                                                          \
+        vreg = *(global_ptr<raw_f32x4>)(Vg + (size_t)(feat < F ? feat : F - 1) * 128 + vc * 8);    \
+        if (feat >= F || vf >= FCH) vreg = raw_f32x4{0.f, 0.f, 0.f, 0.f};                         \
+    }
+#define MSM_PJ_VSTORE(BUF)                                                                        \
+    if (vf < FCH) *reinterpret_cast<raw_f32x4*>(&Vs[BUF][vf * PVP + vc]) = vreg;
+    MSM_PJ_LOAD(xs0, 0)
+    MSM_PJ_VSTORE(0)
+    __syncthreads();
+#define MSM_PJ_STEP(XCUR, XNXT, BUF)                                                              \
+    {                                                                                             \
+        if (c + 1 < nch) MSM_PJ_LOAD(XNXT, c + 1)                                                 \
+        const double* vb = &Vs[BUF][(g * (FCH / 4)) * PVP + r];                                   \
+        _Pragma("unroll") for (int t = 0; t < NT4; ++t) {                                         \
+            const double bv = vb[t * PVP];                                                        \
+            _Pragma("unroll") for (int b = 0; b < RB; ++b) {                                      \
+                const TIn* xe = reinterpret_cast<const TIn*>(&XCUR[b][0]);                        \
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xe[t], bv, acc[b], 0, 0, 0); \
+            }                                                                                     \
+        }                                                                                         \
+        if (c + 1 < nch) MSM_PJ_VSTORE((BUF) ^ 1)                                                 \
+        __syncthreads();                                                                          \
+    }
+    for (int c = 0; c < nch; c += 2) {
+        MSM_PJ_STEP(xs0, xs1, 0)
+        ++c;
+        if (c < nch) MSM_PJ_STEP(xs1, xs0, 1)
+        --c;
+    }
+#undef MSM_PJ_STEP
+#undef MSM_PJ_VSTORE
+#undef MSM_PJ_LOAD
+    // C/D layout: component = lane & 15, row = (lane >> 4) + 4 * reg
+    int bad = 0;
+    const int comp = r;
+    if (comp < k) {
+        const double mv = muV[kbase + comp];
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long i = row0 + b * 16 + g + 4 * q;
+                const double v = acc[b][q] - mv;
+                if (i < n) {
+                    out[i * ktot + kbase + comp] = v;
+                    bad |= !isfinite(v);
+                }
+            }
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -1756,6 +1874,39 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     const unsigned grid = (unsigned)ceil_div(n_rows, 128);
     const int cw = 16 / dtype_bytes;
     const int vec = (((uintptr_t)Xd) % 16 == 0) && (ldd % cw == 0) && (n_features % cw == 0);
+    static const bool no_mfma = getenv("MSM_PROJECT_NO_MFMA") != nullptr;  // A/B switch for scripts
+    if (vec && !no_mfma && (size_t)256 * ldd * dtype_bytes < ((size_t)1 << 32)) {
+        // fp64-MFMA path: components in blocks of 16, panel Vp[F][16] (feature-major, zero padded)
+        DevBuf& dVp = pool(PS_W);
+        const msm_idx_t nkb = ceil_div(k, 16);
+        if ((rc = dVp.reserve((size_t)nkb * n_features * 16 * sizeof(double)))) return rc;
+        std::vector<double> vp((size_t)nkb * n_features * 16, 0.0);
+        for (msm_idx_t c = 0; c < k; ++c)
+            for (msm_idx_t f = 0; f < n_features; ++f)
+                vp[((size_t)(c / 16) * n_features + f) * 16 + (c % 16)] = comps[c * n_features + f];
+        MSM_HIP_CHECK(hipMemcpyAsync(dVp.p, vp.data(), vp.size() * sizeof(double), hipMemcpyHostToDevice, stream()));
+        const unsigned g2 = (unsigned)ceil_div(n_rows, 256);
+        for (msm_idx_t kb = 0; kb < nkb; ++kb) {
+            const int kk = (int)std::min<msm_idx_t>(16, k - kb * 16);
+            const double* vpk = dVp.as<double>() + (size_t)kb * n_features * 16;
+            if (dtype_bytes == 4)
+                hipLaunchKernelGGL((tica_project_mfma_kernel<float>), dim3(g2), dim3(NT), 0, stream(), (const float*)Xd,
+                                   (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
+                                   outd, dflag);
+            else
+                hipLaunchKernelGGL((tica_project_mfma_kernel<double>), dim3(g2), dim3(NT), 0, stream(), (const double*)Xd,
+                                   (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
+                                   outd, dflag);
+        }
+        MSM_HIP_CHECK(hipGetLastError());
+        if (!on_device)
+            MSM_HIP_CHECK(hipMemcpyAsync(out, outd, (size_t)n_rows * k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        int f2 = 0;
+        if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f2, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // `vp` and the scratch buffers die with this frame
+        if (check_finite && f2) return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
+        return MSM_OK;
+    }
     const int npw = (int)std::min<msm_idx_t>(8, ceil_div(k, 4));  // components per wave
 #define MSM_PROJ(TT, NN)                                                                              \
     hipLaunchKernelGGL((tica_project_kernel<TT, NN>), dim3(grid), dim3(NT), 0, stream(), (const TT*)Xd, \

@@ -316,3 +316,36 @@ def test_tica_with_device_solve(gpu, monkeypatch):
     np.testing.assert_allclose(ev_d, ev_h, rtol=1e-11)
     s = np.sign(np.sum(y_d * y_h, axis=0))
     np.testing.assert_allclose(y_d * s, y_h, rtol=1e-7, atol=1e-9)
+
+
+# ---------------------------------------------------------------- projection kernels (tica.py:329-352)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,F,k", [(1, 4, 1), (255, 20, 3), (257, 36, 10), (1000, 100, 16), (513, 512, 17), (300, 130, 40), (64, 6, 6)])
+def test_project_matches_numpy(gpu, dtype, n, F, k):
+    """msm_tica_project (fp64-MFMA kernel for 16-byte aligned rows, lane-per-row kernel otherwise)
+    against (X - mu) . V^T in float64."""
+    import ctypes as C
+    import torch
+    from msmbuilder_amd import _lib
+    from msmbuilder_amd._lib import Arr, check
+    rs = np.random.RandomState(n + F + k)
+    X = (rs.randn(n, F) * 3 + 1).astype(dtype)
+    mu = rs.randn(F)
+    V = rs.randn(k, F)
+    want = (X.astype(np.float64) - mu).dot(V.T)
+    for dev in (False, True):
+        src = torch.from_numpy(X).cuda() if dev else X
+        ax = Arr(src)
+        out = _lib.empty_like_placement(ax, (n, k), np.float64)
+        ao = Arr(out, np.float64)
+        check(_lib.lib().msm_tica_project(ax.vp, ax.dtype.itemsize, n, F, F, mu.ctypes.data, np.ascontiguousarray(V).ctypes.data,
+                                          k, ao.vp, ax.on_device, 1))
+        got = out.cpu().numpy() if dev else out
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-11 * np.abs(want).max())
+    Xb = X.copy()
+    Xb[n // 2, F - 1] = np.inf
+    ax = Arr(Xb)
+    out = np.zeros((n, k))
+    rc = _lib.lib().msm_tica_project(ax.vp, ax.dtype.itemsize, n, F, F, mu.ctypes.data, np.ascontiguousarray(V).ctypes.data, k,
+                                     Arr(out, np.float64).vp, 0, 1)
+    assert rc == _lib.MSM_ERR_NONFINITE
