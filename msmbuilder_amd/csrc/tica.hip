@@ -676,7 +676,7 @@ __device__ __forceinline__ void stage_store64(const Stage64<TIn>& st, double* As
 }
 
 template <typename TIn>
-__global__ __launch_bounds__(NT, 1) void tica_mfma_f64_kernel(TicaArgs P)
+__global__ __launch_bounds__(NT, 2) void tica_mfma_f64_kernel(TicaArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* As = reinterpret_cast<double*>(smem);  // [2][BK64][P64]
