@@ -164,9 +164,14 @@ def main():
                 record.setdefault("transform", []).append(time.perf_counter() - t1)
             t2 = time.perf_counter()
             kc = KCenters(n_clusters=args.clusters, random_state=0).fit([Y])
+            if record is not None:
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                record.setdefault("kcenters_fit", []).append(t3 - t2)
             labels = kc.predict([Y])[0]
             if record is not None:
                 torch.cuda.synchronize()
+                record.setdefault("kcenters_predict", []).append(time.perf_counter() - t3)
                 record.setdefault("cluster", []).append(time.perf_counter() - t2)
         return ev, labels, kc
 
@@ -219,6 +224,11 @@ def main():
             "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k != "mfma_ms"},
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
+        # the clustering half of the metric on its own: HBM-bound exact-arithmetic scans of the [frames, k] float64 projection
+        fit_s, pred_s = float(np.mean(times["kcenters_fit"])), float(np.mean(times["kcenters_predict"]))
+        pass_bytes = frames * (args.components * 8 + 16)          # read X row + distances_, update distances_/labels_
+        out["clustering"] = {"kcenters_fit_frames_per_s": world * frames / fit_s, "assign_frames_per_s": world * frames / pred_s,
+                             "kcenters_pass_TBps": args.clusters * pass_bytes / fit_s / 1e12, "hbm_peak_TBps": 8.0}
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             sample = [s.cpu().numpy() for s in seqs[:64]]
             out["cpu_baseline"] = cpu_baseline(sample, args.lag, args.components, args.clusters)
