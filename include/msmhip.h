@@ -284,6 +284,15 @@ int msm_colstats(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n
 int msm_scale_apply(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features, msm_idx_t ld,
                     const double* shift, const double* scale, int mode, void* out, msm_idx_t ld_out,
                     int on_device);
+/* One pass of the radix SELECT behind RobustScaler's per-column median / percentiles (exact order
+ * statistics without a sort): DEVICE-resident trajectories only.  Values map to order-preserving keys
+ * (sign-flipped IEEE bits, NaN skipped).  prefix == NULL: hist[0][f][d] = number of values of column f
+ * whose key digit (key >> shift) & ((1 << bits) - 1) equals d.  prefix != NULL (host uint64
+ * [n_targets][n_features]): hist[t][f][d] counts only the values whose higher bits
+ * key >> (shift + bits) equal prefix[t][f].  hist is host int64 [n_targets or 1][n_features][1 << bits]. */
+int msm_col_digit_hist(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int dtype_bytes,
+                       msm_idx_t n_features, msm_idx_t ld, const uint64_t* prefix, int n_targets, int shift, int bits,
+                       int64_t* hist);
 
 /* ------------------------------------------------------------------------------------------
  * Post-clustering transition counts.  Replaces the counting loop of

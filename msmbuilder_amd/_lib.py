@@ -98,6 +98,7 @@ def _declare(lib):
     f("msm_npy_loader_destroy", C.c_int, _p)
     f("msm_sygv_top", C.c_int, _p, _p, _i64, _i64, _p, _p, C.c_int)
     f("msm_colstats", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, C.c_int, _p, C.POINTER(C.c_int))
+    f("msm_col_digit_hist", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, _p, C.c_int, C.c_int, C.c_int, _p)
     f("msm_scale_apply", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, C.c_int, _p, _i64, C.c_int)
 
     for sfx in ("f32", "f64"):

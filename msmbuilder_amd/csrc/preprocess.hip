@@ -260,6 +260,166 @@ __global__ __launch_bounds__(PNT) void scale_apply_kernel(const T* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Exact per-column order statistics (RobustScaler: np.nanmedian / np.nanpercentile per feature,
+// sklearn/preprocessing/_data.py RobustScaler.fit) by most-significant-digit radix SELECT: values map
+// to order-preserving unsigned keys; one pass histograms the next `bits` bits of the keys that match
+// the already-known high bits of a target, the host picks the digit holding the wanted rank and the
+// next pass refines -- 3 passes for float32, 6 for float64, each one HBM stream over the data, no
+// sort and no transposed copy.  Same thread mapping as colstats_kernel (column group x row lane, 8
+// rows in flight): the lanes of a wave own different columns, so their atomics never collide, and a
+// thread run-length merges its 8 consecutive frames of a column (MD features move slowly: same digit).
+// ---------------------------------------------------------------------------
+struct DigitArgs {
+    const ScanChunk* chunks;
+    long long nchunks;
+    long long ld;
+    int F;
+    int R;                            // targets per column (1 in the first pass: the histogram is shared)
+    const unsigned long long* prefix; // [R][F] high bits already known (right-aligned), nullptr in the first pass
+    int shift;                        // LSB position of the digit
+    int bits;                         // digit width
+    unsigned long long* hist;         // [R][F][1 << bits]
+};
+
+__device__ __forceinline__ unsigned long long order_key(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? (unsigned)~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long order_key(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+template <typename T>
+__global__ __launch_bounds__(PNT) void col_digit_kernel(DigitArgs P)
+{
+    constexpr int CW = 16 / sizeof(T);
+    constexpr int RU = 8;
+    const int tid = threadIdx.x;
+    const int ngroups = (P.F + CW - 1) / CW;
+    int cpb = 1;
+    while (cpb < ngroups && cpb < PNT) cpb <<= 1;
+    const int rl = PNT / cpb;
+    const int tc = tid % cpb, tr = tid / cpb;
+    const bool vec = (P.F % CW == 0) && (P.ld % CW == 0);
+    const unsigned long long mask = (1ull << P.bits) - 1ull;
+    const size_t nbin = (size_t)1 << P.bits;
+    for (int g0 = 0; g0 < ngroups; g0 += cpb) {
+        const int col = (g0 + tc) * CW;
+        if (col >= P.F) continue;
+        for (long long c = blockIdx.x; c < P.nchunks; c += gridDim.x) {
+            const ScanChunk ch = P.chunks[c];
+            const global_ptr<T> X = as_global<T>(ch.base);
+            const bool al = vec && ((((uintptr_t)ch.base) & 15) == 0);
+            for (long long k0 = tr; k0 < ch.n; k0 += (long long)rl * RU) {
+                T v[RU][CW];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const long long kr = k0 + (long long)u * rl;
+                    const long long rr = kr < ch.n ? kr : ch.n - 1;
+                    const global_ptr<T> p = X + rr * P.ld + col;
+                    if (al) {
+                        *reinterpret_cast<float4*>(&v[u][0]) = load16_global<T>(p);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[u][e] = (col + e < P.F) ? p[e] : (T)0;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    if (col + e >= P.F) continue;
+                    for (int r = 0; r < P.R; ++r) {
+                        unsigned long long* h = P.hist + ((size_t)r * P.F + col + e) * nbin;
+                        const unsigned long long want = P.prefix ? P.prefix[(size_t)r * P.F + col + e] : 0ull;
+                        long long cur = -1;
+                        unsigned long long run = 0;
+#pragma unroll
+                        for (int u = 0; u < RU; ++u) {
+                            const T x = v[u][e];
+                            const unsigned long long key = order_key(x);
+                            const bool ok = (k0 + (long long)u * rl < ch.n) && (x == x) &&
+                                            (!P.prefix || (key >> (P.shift + P.bits)) == want);
+                            const long long d = ok ? (long long)((key >> P.shift) & mask) : -1;
+                            if (d != cur) {
+                                if (cur >= 0) atomicAdd(h + cur, run);
+                                cur = d;
+                                run = 0;
+                            }
+                            ++run;
+                        }
+                        if (cur >= 0) atomicAdd(h + cur, run);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// First pass of the select (no prefix yet: EVERY value is counted): global atomics would be ~5e9 at
+// 10M x 512, so this pass keeps workgroup-private histograms in LDS instead -- a workgroup owns a tile
+// of DCOLS = 16 columns (one 64-byte segment per row for float32) and all 1 << bits <= 2048 bins of each
+// (128 KiB), streams its share of the rows, and adds its counts to the global histogram once at the end.
+constexpr int DCOLS = 16;
+
+template <typename T>
+__global__ __launch_bounds__(PNT, 1) void col_digit_lds_kernel(DigitArgs P)
+{
+    extern __shared__ unsigned dh[];  // [DCOLS][1 << bits]
+    constexpr int CW = 16 / sizeof(T);
+    constexpr int GPT = DCOLS / CW;   // column groups per tile (4 f32 / 8 f64)
+    constexpr int RL = PNT / GPT;     // row lanes
+    constexpr int RU = 8;
+    const int tid = threadIdx.x;
+    const int nbin = 1 << P.bits;
+    const int ntile = (P.F + DCOLS - 1) / DCOLS;
+    const int tile = blockIdx.x % ntile, part = blockIdx.x / ntile, nparts = gridDim.x / ntile;
+    const int tc = tid % GPT, tr = tid / GPT;
+    const int col = tile * DCOLS + tc * CW;
+    const bool vec = (P.F % CW == 0) && (P.ld % CW == 0);
+    for (int i = tid; i < DCOLS * nbin; i += PNT) dh[i] = 0u;
+    __syncthreads();
+    if (col < P.F && part < nparts) {
+        for (long long c = part; c < P.nchunks; c += nparts) {
+            const ScanChunk ch = P.chunks[c];
+            const global_ptr<T> X = as_global<T>(ch.base);
+            const bool al = vec && ((((uintptr_t)ch.base) & 15) == 0);
+            for (long long k0 = tr; k0 < ch.n; k0 += (long long)RL * RU) {
+                T v[RU][CW];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const long long kr = k0 + (long long)u * RL;
+                    const long long rr = kr < ch.n ? kr : ch.n - 1;
+                    const global_ptr<T> p = X + rr * P.ld + col;
+                    if (al) {
+                        *reinterpret_cast<float4*>(&v[u][0]) = load16_global<T>(p);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[u][e] = (col + e < P.F) ? p[e] : (T)0;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    if (col + e >= P.F) continue;
+                    unsigned* h = dh + (tc * CW + e) * nbin;
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const T x = v[u][e];
+                        if ((k0 + (long long)u * RL < ch.n) && (x == x)) atomicAdd(h + (int)(order_key(x) >> P.shift), 1u);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < DCOLS * nbin; i += PNT) {
+        const int cc = tile * DCOLS + i / nbin;
+        if (cc < P.F && dh[i]) atomicAdd(P.hist + (size_t)cc * nbin + (i % nbin), (unsigned long long)dh[i]);
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -419,6 +579,80 @@ int msm_scale_apply(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t 
         MSM_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ld_out * dtype_bytes, xout, row_bytes, row_bytes, (size_t)n_rows,
                                        hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // shift/scale staging and scratch are reused
+    return MSM_OK;
+}
+
+int msm_col_digit_hist(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int dtype_bytes,
+                       msm_idx_t n_features, msm_idx_t ld, const uint64_t* prefix, int n_targets, int shift, int bits,
+                       int64_t* hist)
+{
+    if (n_seq < 0 || (n_seq > 0 && (!X_ptrs || !n_rows)) || !hist) return fail(MSM_ERR_INVALID, "msm_col_digit_hist: bad argument");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (n_features < 1 || ld < n_features || n_targets < 1 || bits < 1 || bits > 16 || shift < 0 || shift + bits > dtype_bytes * 8)
+        return fail(MSM_ERR_INVALID, "msm_col_digit_hist: bad shape");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    const int F = (int)n_features;
+    const int R = prefix ? n_targets : 1;
+    const size_t nh = (size_t)R * F * ((size_t)1 << bits);
+    int rc;
+    DevBuf &dTab = pool(PS_IDS), &dHist = pool(PS_OUT), &dPre = pool(PS_PAR);
+    std::vector<ScanChunk> tab;
+    for (msm_idx_t i = 0; i < n_seq; ++i) {
+        if (n_rows[i] < 0 || (n_rows[i] > 0 && !X_ptrs[i])) return fail(MSM_ERR_INVALID, "msm_col_digit_hist: bad sequence %lld", (long long)i);
+        for (long long r0 = 0; r0 < n_rows[i]; r0 += 4096) {
+            ScanChunk ch;
+            ch.base = (const char*)X_ptrs[i] + (size_t)r0 * (size_t)ld * dtype_bytes;
+            ch.n = std::min<long long>(4096, n_rows[i] - r0);
+            tab.push_back(ch);
+        }
+    }
+    if ((rc = dHist.reserve(nh * sizeof(int64_t)))) return rc;
+    MSM_HIP_CHECK(hipMemsetAsync(dHist.p, 0, nh * sizeof(int64_t), stream()));
+    if (!tab.empty()) {
+        if ((rc = dTab.reserve(tab.size() * sizeof(ScanChunk) + 16))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dTab.p, tab.data(), tab.size() * sizeof(ScanChunk), hipMemcpyHostToDevice, stream()));
+        DigitArgs P;
+        P.chunks = dTab.as<ScanChunk>();
+        P.nchunks = (long long)tab.size();
+        P.ld = ld;
+        P.F = F;
+        P.R = R;
+        P.prefix = nullptr;
+        if (prefix) {
+            if ((rc = dPre.reserve((size_t)R * F * sizeof(uint64_t)))) return rc;
+            MSM_HIP_CHECK(hipMemcpyAsync(dPre.p, prefix, (size_t)R * F * sizeof(uint64_t), hipMemcpyHostToDevice, stream()));
+            P.prefix = dPre.as<unsigned long long>();
+        }
+        P.shift = shift;
+        P.bits = bits;
+        P.hist = dHist.as<unsigned long long>();
+        const int nb = (int)std::min<size_t>(tab.size(), (size_t)PNB);
+        if (!prefix && bits <= 11 && shift + bits == dtype_bytes * 8) {
+            // first pass: workgroup-private LDS histograms (a workgroup's count of one bin stays below 2^32)
+            const size_t lds = (size_t)DCOLS * ((size_t)1 << bits) * sizeof(unsigned);
+            const int ntile = (int)ceil_div(F, DCOLS);
+            const int nparts = (int)std::max<long long>(1, std::min<long long>((long long)tab.size(), (2LL * num_cus()) / ntile));
+            static bool attr_set = false;
+            if (!attr_set) {
+                MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(col_digit_lds_kernel<float>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(col_digit_lds_kernel<double>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                attr_set = true;
+            }
+            if (dtype_bytes == 4)
+                hipLaunchKernelGGL(col_digit_lds_kernel<float>, dim3(ntile * nparts), dim3(PNT), lds, stream(), P);
+            else
+                hipLaunchKernelGGL(col_digit_lds_kernel<double>, dim3(ntile * nparts), dim3(PNT), lds, stream(), P);
+        } else if (dtype_bytes == 4) {
+            hipLaunchKernelGGL(col_digit_kernel<float>, dim3(nb), dim3(PNT), 0, stream(), P);
+        } else {
+            hipLaunchKernelGGL(col_digit_kernel<double>, dim3(nb), dim3(PNT), 0, stream(), P);
+        }
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    MSM_HIP_CHECK(hipMemcpyAsync(hist, dHist.p, nh * sizeof(int64_t), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
 }
 

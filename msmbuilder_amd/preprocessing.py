@@ -31,7 +31,8 @@ from ._lib import Arr, check, empty_like_placement, is_device_array
 from .base import BaseEstimator
 from .utils.validation import array2d, check_iter_of_sequences
 
-__all__ = ['StandardScaler', 'MinMaxScaler', 'MaxAbsScaler', 'column_statistics', 'fold_into_tica']
+__all__ = ['StandardScaler', 'MinMaxScaler', 'MaxAbsScaler', 'RobustScaler', 'column_statistics',
+           'column_order_statistics', 'fold_into_tica']
 
 
 def _prepare(X):
@@ -252,6 +253,156 @@ class MaxAbsScaler(_MultiSequenceScaler):
     def partial_transform(self, sequence):
         self._check_fitted(sequence)
         return _apply(sequence, None, self.scale_, 0)
+
+
+def column_order_statistics(sequences, ranks):
+    """Exact order statistics per column without sorting: ``ranks`` is an int64 array [R, F];
+    the result [R, F] (dtype of the data) holds, for every column f, the element that would sit at
+    index ``ranks[r, f]`` of the sorted non-NaN values of that column (NaN where the rank is negative).
+
+    Most-significant-digit radix select on the device (``msm_col_digit_hist``): the data are
+    streamed once per 11-bit digit of their order-preserving keys -- 3 passes for float32, 6 for
+    float64 -- and between passes the host only walks the [R, F, 2048] histograms."""
+    import torch
+    arrs = [_prepare(X) for X in sequences]
+    wide = any(str(a.dtype).endswith("64") for a in arrs)
+    tdt, ndt, nbits = (torch.float64, np.float64, 64) if wide else (torch.float32, np.float32, 32)
+    dev = [a.to(tdt) if is_device_array(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=ndt)).cuda() for a in arrs]
+    dev = [a.contiguous() for a in dev]
+    F = dev[0].shape[1]
+    ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+    R = ranks.shape[0]
+    Arr(dev[0])
+    n = len(dev)
+    ptrs = (C.c_void_p * n)(*[a.data_ptr() for a in dev])
+    rows = (C.c_int64 * n)(*[a.shape[0] for a in dev])
+    L = _lib.lib()
+    rem = np.where(ranks >= 0, ranks, 0).astype(np.int64)
+    prefix = np.zeros((R, F), dtype=np.uint64)
+    digits = []                      # (shift, bits): 11-bit digits from the top (the first pass counts in LDS)
+    top = nbits
+    while top > 0:
+        b = min(11, top)
+        digits.append((top - b, b))
+        top -= b
+    for i, (shift, bits) in enumerate(digits):
+        first = i == 0
+        if first:
+            hist = np.zeros((1, F, 1 << bits), dtype=np.int64)
+            check(L.msm_col_digit_hist(ptrs, rows, n, nbits // 8, F, F, None, R, shift, bits, hist.ctypes.data))
+            hist = np.broadcast_to(hist, (R, F, 1 << bits))
+        else:
+            # targets of a column usually share their prefix (ranks k and k+1; nearby quantiles): count each
+            # DISTINCT prefix once.  Unused slots get a prefix no key can have.
+            order = np.argsort(prefix, axis=0, kind="stable")
+            srt = np.take_along_axis(prefix, order, axis=0)
+            newgrp = np.ones((R, F), dtype=bool)
+            newgrp[1:] = srt[1:] != srt[:-1]
+            gid_sorted = np.cumsum(newgrp, axis=0) - 1                     # group id of each sorted target
+            U = int(gid_sorted.max()) + 1
+            uniq = np.full((U, F), np.uint64(1) << np.uint64(nbits - shift - bits), dtype=np.uint64)
+            np.put_along_axis(uniq, gid_sorted, srt, axis=0)
+            gid = np.empty((R, F), dtype=np.int64)
+            np.put_along_axis(gid, order, gid_sorted, axis=0)
+            uh = np.zeros((U, F, 1 << bits), dtype=np.int64)
+            check(L.msm_col_digit_hist(ptrs, rows, n, nbits // 8, F, F, uniq.ctypes.data, U, shift, bits, uh.ctypes.data))
+            hist = np.take_along_axis(uh, gid[..., None], axis=0)
+        cum = np.cumsum(hist, axis=-1)
+        d = np.argmax(cum > rem[..., None], axis=-1)                        # digit holding the wanted rank
+        below = np.where(d > 0, np.take_along_axis(cum, np.maximum(d - 1, 0)[..., None], axis=-1)[..., 0], 0)
+        rem = rem - below
+        prefix = (prefix << np.uint64(bits)) | d.astype(np.uint64)
+    sign = np.uint64(1) << np.uint64(nbits - 1)
+    full = np.uint64((1 << nbits) - 1)
+    bitsu = np.where(prefix & sign, prefix & ~sign, ~prefix & full)          # undo the order-preserving map
+    vals = (bitsu.astype(np.uint32).view(np.float32) if nbits == 32 else bitsu.view(np.float64)).astype(ndt)
+    return np.where(ranks >= 0, vals, np.nan).astype(ndt)
+
+
+def _lerp(a, b, t):
+    """numpy.lib._function_base_impl._lerp (the arithmetic np.percentile's 'linear' method ends in)."""
+    diff = np.subtract(b, a)
+    out = np.asanyarray(np.add(a, diff * t))
+    np.subtract(b, diff * (1 - t), out=out, where=t >= 0.5, casting='unsafe', dtype=type(out.dtype))
+    return out
+
+
+class RobustScaler(_MultiSequenceScaler):
+    """Scale features using statistics that are robust to outliers: median and inter-quantile range
+    (sklearn.preprocessing.RobustScaler -- the scaler of the reference's own workflow,
+    tests/workflows/basic.sh; ``center_``, ``scale_``).  ``fit`` computes the exact per-column order
+    statistics with ``column_order_statistics`` (one counting pass + 3 / 6 radix-select passes over the
+    data) and then applies numpy's own median / percentile interpolation formulas to them."""
+
+    def __init__(self, with_centering=True, with_scaling=True, quantile_range=(25.0, 75.0), copy=True,
+                 unit_variance=False):
+        self.with_centering = with_centering
+        self.with_scaling = with_scaling
+        self.quantile_range = quantile_range
+        self.copy = copy
+        self.unit_variance = unit_variance
+
+    def partial_fit(self, sequence, y=None):
+        # not an online estimator upstream either: preprocessing/base.py:140-157 maps partial_fit to fit
+        return self.fit([sequence])
+
+    def fit(self, sequences, y=None):
+        check_iter_of_sequences(sequences)
+        q_min, q_max = self.quantile_range
+        if not 0 <= q_min <= q_max <= 100:
+            raise ValueError("Invalid quantile range: %s" % str(self.quantile_range))
+        sequences = list(sequences)
+        st = column_statistics(sequences)                  # non-NaN counts, infinity check
+        n = st["n"].astype(np.int64)
+        F = len(n)
+        self.n_features_in_ = F
+        self._stats = np.stack([st["n"], st["mean"], st["m2"], st["min"], st["max"]])
+        ranks = []
+        if self.with_centering:
+            ranks += [np.where(n > 0, (n - 1) // 2, -1), np.where(n > 0, n // 2, -1)]
+        gammas = []
+        if self.with_scaling:
+            for q in (q_min, q_max):
+                quant = np.true_divide(q, 100)
+                virt = (n - 1) * quant                                   # numpy's 'linear' method: get_virtual_index
+                prev = np.floor(virt).astype(np.int64)
+                nxt = prev + 1
+                above = virt >= n - 1
+                prev, nxt = np.where(above, n - 1, prev), np.where(above, n - 1, nxt)
+                below = virt < 0
+                prev, nxt = np.where(below, 0, prev), np.where(below, 0, nxt)
+                gammas.append(np.asanyarray(virt - np.floor(virt), dtype=np.float64))
+                ranks += [np.where(n > 0, prev, -1), np.where(n > 0, nxt, -1)]
+        vals = column_order_statistics(sequences, np.stack(ranks)) if ranks else np.zeros((0, F))
+        k = 0
+        if self.with_centering:
+            # np.median: mean of the two middle elements in the array's own precision
+            self.center_ = np.mean(np.stack([vals[0], vals[1]]), axis=0)
+            k = 2
+        else:
+            self.center_ = None
+        if self.with_scaling:
+            qs = [_lerp(vals[k], vals[k + 1], gammas[0]), _lerp(vals[k + 2], vals[k + 3], gammas[1])]
+            self.scale_ = _handle_zeros_in_scale(np.asarray(qs[1]) - np.asarray(qs[0]))
+            if self.unit_variance:
+                from scipy import stats
+                self.scale_ = self.scale_ / (stats.norm.ppf(q_max / 100.0) - stats.norm.ppf(q_min / 100.0))
+        else:
+            self.scale_ = None
+        return self
+
+    def partial_transform(self, sequence):
+        self._check_fitted(sequence)
+        return _apply(sequence, self.center_ if self.with_centering else None,
+                      self.scale_ if self.with_scaling else None, 0)
+
+    def partial_inverse_transform(self, sequence):
+        self._check_fitted(sequence)
+        return _apply(sequence, self.center_ if self.with_centering else None,
+                      self.scale_ if self.with_scaling else None, 1)
+
+    def inverse_transform(self, sequences):
+        return [self.partial_inverse_transform(X) for X in sequences]
 
 
 def fold_into_tica(scaler, tica, sequences=None):

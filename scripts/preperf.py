@@ -21,3 +21,15 @@ for dtype, N, F in ((torch.float32, 10_000_000, 512), (torch.float64, 4_000_000,
     t = timeit(lambda: sc.partial_transform(X))
     print("%s %dx%d StandardScaler.transform: %7.2f ms  %.2f TB/s (read+write)" % (str(dtype)[6:], N, F, t, 2 * gb / t))
     del X, seqs
+
+from msmbuilder_amd.preprocessing import RobustScaler
+X = torch.randn(10_000_000, 512, device="cuda") * 3 + 1
+seqs = list(X.view(1000, 10000, 512).unbind(0))
+rb = RobustScaler()
+t = timeit(lambda: rb.fit(seqs), 2)
+print("float32 10000000x512 RobustScaler.fit (count pass + 3 radix-select passes): %7.2f ms" % t)
+Z = torch.randn(10_000_000, 16, device="cuda").cumsum(0) * 0.01
+X = Z @ torch.randn(16, 512, device="cuda") + 0.3 * torch.randn(10_000_000, 512, device="cuda")
+seqs = list(X.view(1000, 10000, 512).unbind(0))
+t = timeit(lambda: rb.fit(seqs), 2)
+print("float32 10000000x512 RobustScaler.fit on slowly varying features:          %7.2f ms" % t)

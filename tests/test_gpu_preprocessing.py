@@ -121,3 +121,45 @@ def test_fold_into_tica_equals_the_two_step_pipeline(gpu, monkeypatch):
         s = np.sign(np.sum(y1 * y2, axis=0))
         np.testing.assert_allclose(y1 * s, y2, rtol=1e-7, atol=1e-8)
     assert one.score(seqs) == pytest.approx(two.score(sc.transform(seqs)), rel=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_column_order_statistics_exact(gpu, dtype):
+    from msmbuilder_amd.preprocessing import column_order_statistics
+    rs = np.random.RandomState(4)
+    X = (rs.randn(7001, 13) * rs.uniform(1e-3, 1e3, 13) - 2).astype(dtype)
+    X[:, 3] = np.round(X[:, 3])                      # heavy ties
+    X[:, 7] = -0.0
+    X[5, 7] = 0.0
+    X[rs.randint(0, 7001, 30), 2] = np.nan           # missing values are not ranked
+    srt = np.sort(X, axis=0)                         # NaN sorts last
+    n = (~np.isnan(X)).sum(0)
+    ranks = np.stack([np.zeros(13, np.int64), n // 2, n - 1, rs.randint(0, n.min(), 13), np.full(13, -1)])
+    got = column_order_statistics([X[:1000], X[1000:1001], X[1001:]], ranks)
+    assert got.dtype == dtype
+    for r in range(4):
+        assert np.array_equal(got[r], srt[ranks[r], np.arange(13)]), r
+    assert np.isnan(got[4]).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_robust_scaler_matches_sklearn(gpu, dtype):
+    import torch
+    from sklearn.preprocessing import RobustScaler as Ref
+    from msmbuilder_amd.preprocessing import RobustScaler
+    for seed, kw in ((0, {}), (1, dict(quantile_range=(10.0, 90.0), unit_variance=True)), (2, dict(with_centering=False))):
+        seqs = _seqs(seed, dtype, F=21)
+        seqs[1][7, 2] = np.nan
+        cat = np.concatenate(seqs)
+        ref, m = Ref(**kw).fit(cat), RobustScaler(**kw).fit(seqs)
+        if ref.center_ is None:
+            assert m.center_ is None
+        else:
+            assert m.center_.dtype == ref.center_.dtype and np.array_equal(m.center_, ref.center_)
+        assert m.scale_.dtype == ref.scale_.dtype and np.array_equal(m.scale_, ref.scale_)
+        for X, Y in zip(seqs, m.transform(seqs)):
+            assert Y.dtype == dtype and np.array_equal(Y, ref.transform(X), equal_nan=True)
+        md = RobustScaler(**kw).fit([torch.from_numpy(s).cuda() for s in seqs])
+        assert np.array_equal(md.scale_, ref.scale_)
+    even = [np.arange(10, dtype=dtype).reshape(10, 1)[::-1].copy()]      # even count: mean of the middle pair
+    assert np.array_equal(RobustScaler().fit(even).center_, Ref().fit(even[0]).center_)
