@@ -1,0 +1,86 @@
+"""The reference's canonical pipeline (tests/workflows/basic.sh: RobustScaler -> tICA(n_components=4,
+shrinkage=0, kinetic_mapping, lag_time=2) -> KCenters(metric=cityblock) -> transition counts) end to end
+on the device, fed from a dir-npy dataset, every stage checked against its CPU oracle."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle.libdistance_oracle import Oracle
+    return Oracle()
+
+
+def _features(seed, n_traj=6, F=15):
+    rs = np.random.RandomState(seed)
+    k = 3
+    M = rs.randn(k, F)
+    a = np.exp(-1.0 / np.array([60.0, 20.0, 7.0]))
+    scale = rs.uniform(0.05, 30.0, F)
+    out = []
+    for n in rs.randint(1500, 4000, size=n_traj):
+        z = np.zeros((n, k))
+        e = rs.randn(n, k)
+        for t in range(1, n):
+            z[t] = a * z[t - 1] + np.sqrt(1 - a * a) * e[t]
+        out.append(((z.dot(M) + 0.4 * rs.randn(n, F)) * scale + 3.0).astype(np.float32))
+    return out
+
+
+def test_basic_workflow(gpu, oracle, tmp_path, monkeypatch):
+    from sklearn.preprocessing import RobustScaler as RefScaler
+    from msmbuilder_amd import tICA, KCenters
+    from msmbuilder_amd.dataset import dataset
+    from msmbuilder_amd.msm import _transition_counts
+    from msmbuilder_amd.preprocessing import RobustScaler
+    from oracle.tica_oracle import TicaOracle
+    from oracle.transition_oracle import transition_counts
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    feats = _features(0)
+    ds = dataset(str(tmp_path / "atom_pairs"), mode="w", fmt="dir-npy")
+    for i, x in enumerate(feats):
+        ds[i] = x
+    ds = dataset(str(tmp_path / "atom_pairs"))
+    warnings.simplefilter("ignore")
+
+    # msmb RobustScaler -i atom_pairs/ -t scaled_atom_pairs
+    scaler = ds.fit_with(RobustScaler())
+    ref_scaler = RefScaler().fit(np.concatenate(feats))
+    assert np.array_equal(scaler.center_, ref_scaler.center_) and np.array_equal(scaler.scale_, ref_scaler.scale_)
+    scaled = ds.transform_with(scaler, str(tmp_path / "scaled_atom_pairs"))
+    for x, y in zip(feats, scaled):
+        assert np.array_equal(y, ref_scaler.transform(x))
+
+    # msmb tICA --n_components 4 --shrinkage 0 --kinetic_mapping --lag_time 2
+    kw = dict(n_components=4, shrinkage=0, kinetic_mapping=True, lag_time=2)
+    tica = tICA(**kw).fit(scaled.device_sequences())          # streamed from the dir-npy files into HBM
+    otica = TicaOracle(**kw).fit(list(scaled))
+    np.testing.assert_allclose(tica.eigenvalues_, otica.eigenvalues_, rtol=1e-10)
+    np.testing.assert_allclose(tica.timescales_, otica.timescales_, rtol=1e-8)
+    tics = scaled.transform_with(tica, str(tmp_path / "atom_pairs_tica"))
+    otics = otica.transform(list(scaled))
+    for y, yo in zip(tics, otics):
+        s = np.sign(np.sum(y * yo, axis=0))
+        np.testing.assert_allclose(y * s, yo, rtol=1e-6, atol=1e-9)
+
+    # msmb KCenters --metric cityblock   (default n_clusters = 8), on the projection the device produced
+    seqs = list(tics)
+    kc = KCenters(metric="cityblock", random_state=0).fit(seqs)
+    X = np.concatenate(seqs)
+    ids, labels, dist = oracle.kcenters_fit(X, 8, "cityblock", kc.cluster_ids_[0])
+    assert kc.cluster_ids_ == list(ids)
+    assert np.array_equal(np.concatenate(kc.labels_), labels)
+    assert np.array_equal(np.concatenate(kc.distances_), dist)
+
+    # msmb MarkovStateModel: the counting step, on device-resident labels
+    import torch
+    dev_labels = [torch.from_numpy(np.ascontiguousarray(l)).cuda() for l in kc.labels_]
+    counts, mapping = _transition_counts(dev_labels, lag_time=1)
+    ocounts, omapping = transition_counts([np.asarray(l) for l in kc.labels_], lag_time=1)
+    assert np.array_equal(counts, ocounts) and list(mapping.items()) == list(omapping.items())
+    assert counts.sum() == sum(len(l) - 1 for l in kc.labels_)
