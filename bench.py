@@ -152,6 +152,7 @@ def main():
                 ms = C.c_float(0.0)
                 _lib.check(_lib.lib().msm_tica_last_kernel_ms(tica._handle, C.byref(ms)))
                 record.setdefault("mfma_ms", []).append(ms.value)
+                record["sym"] = tica._lagged_symmetrised
                 torch.cuda.synchronize()
                 record.setdefault("fit", []).append(time.perf_counter() - t)
             if world > 1:
@@ -194,12 +195,19 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * frames / (elapsed / args.steps)
         mfma_ms = float(np.mean(times["mfma_ms"]))
-        flops = 4.0 * F * F * frames                     # algorithmic: 2 dense F x F rank-1 updates per frame
+        sym = bool(times.pop("sym", False))
+        flops = 4.0 * F * F * frames                     # algorithmic (SURVEY 8d): 2 dense F x F rank-1 updates per frame
+        # MFMA flops the kernel really issues per frame, in 128 x 128 tiles: G upper tiles + all C tiles, or -- fp32
+        # sum/difference kernel -- the H and the D block of the upper tiles only
+        nt = (F + 127) // 128
+        tiles = nt * (nt + 1) if sym else nt * nt + nt * (nt + 1) // 2
+        executed = 2.0 * 128 * 128 * tiles * frames
+        kernel = "tica_sym_f32_kernel" if sym else "tica_mfma_%s_kernel" % args.mode
         achieved = flops / (mfma_ms * 1e-3) / 1e12
         peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f64": PEAK_F64_MFMA_TFLOPS}.get(args.mode, 2500.0)  # bf16 dense MFMA
         traffic = None   # PMC counters need their own rocprofv3 pass: read the committed measurement
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["tica_mfma_%s_kernel" % args.mode]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
             if tj["workload"].startswith("%dx%d " % (frames, F)):
                 traffic = tj["bytes_per_launch"]
         except Exception:
@@ -215,13 +223,17 @@ def main():
                        "frames_per_gpu": frames, "n_features": F, "lag_time": args.lag,
                        "n_components": args.components, "n_clusters": args.clusters,
                        "parallelism": "frames sharded x%d, 1 all-reduce" % world},
-            "roofline": {"bound": "mfma", "kernel": "tica_mfma_%s_kernel" % args.mode, "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "executed": executed / (mfma_ms * 1e-3) / 1e12, "executed_frac": executed / (mfma_ms * 1e-3) / 1e12 / peak,
+                         "frac_note": "achieved = SURVEY 8d's algorithmic 4 F^2 flop/frame / kernel time; executed = the MFMA flops "
+                                      "actually issued (%d tile products of 128x128 per frame). The symmetric kernel needs fewer "
+                                      "flops than 4 F^2, so achieved/peak can exceed 1; executed_frac is the pipe utilisation" % tiles,
                          "traffic_note": "bytes/launch at the L2 fabric side (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC pass, "
                                          "profiles/traffic.json); includes Infinity-Cache hits; algorithmic bytes/launch = %d" % (frames * F * 4),
                          "kernel_ms": mfma_ms, "algorithmic_flop_per_frame": 4 * F * F,
                          "tica_accumulate_frames_per_s": frames / (mfma_ms * 1e-3)},
-            "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k != "mfma_ms"},
+            "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k not in ("mfma_ms", "sym")},
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
         # the clustering half of the metric on its own: HBM-bound exact-arithmetic scans of the [frames, k] float64 projection

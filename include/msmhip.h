@@ -116,6 +116,11 @@ int msm_tica_accumulate_segments(msm_tica_t* h, const void* const* X_ptrs, const
                                  const msm_idx_t* seg4, msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld,
                                  int on_device, int check_finite, msm_idx_t* n_skipped);
 int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until reset */
+/* 1 when this handle accumulates fp32 input with the symmetric sum/difference kernel (MSM_TICA_F32,
+ * 256 <= n_features <= 1024 or so, n_features % 4 == 0; MSM_TICA_SYM=0 disables): the "C" it exports is then
+ * already (C + C^T) / 2 -- the only form the estimator reads (tica.py:234-241) -- and the raw
+ * X[:-tau].T @ X[tau:] is not kept. */
+int msm_tica_lagged_symmetrised(msm_tica_t* h, int* flag);
 /* HIP-event duration (ms) of the most recent MFMA accumulation launch of this handle,
  * measured on the stream it ran on (bench.py's roofline leg); synchronises on it. */
 int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
@@ -127,7 +132,8 @@ int msm_tica_debug_clocks(msm_tica_t* h, long long* out4);
 int msm_tica_debug_profile(msm_tica_t* h, long long* out64);
 
 /* Accumulators as the reference defines them (float64, row-major F x F / F):
- *   C    = sum_traj X[:-tau].T @ X[tau:]                    (tica.py:417)
+ *   C    = sum_traj X[:-tau].T @ X[tau:]                    (tica.py:417; its symmetric part only when
+ *                                                            msm_tica_lagged_symmetrised says so)
  *   G    = sum_traj X[:-tau].T @ X[:-tau] + X[tau:].T @ X[tau:]   (tica.py:421-422, only their sum is ever read: :245)
  *   s0   = sum_traj X[:-tau].sum(0)   stau = sum_traj X[tau:].sum(0)   (tica.py:418-419)
  *   n_observations, n_sequences                               (tica.py:414-415)

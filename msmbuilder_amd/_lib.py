@@ -77,6 +77,7 @@ def _declare(lib):
     f("msm_tica_accumulate_segments", C.c_int, _p, C.POINTER(_p), _i64p, _i64p, _i64, C.c_int, _i64, C.c_int,
       C.c_int, _i64p)
     f("msm_tica_nonfinite", C.c_int, _p, C.POINTER(C.c_int))
+    f("msm_tica_lagged_symmetrised", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_last_kernel_ms", C.c_int, _p, C.POINTER(C.c_float))
     f("msm_tica_debug_clocks", C.c_int, _p, _i64p)
     f("msm_tica_debug_profile", C.c_int, _p, _i64p)

@@ -596,6 +596,290 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 }
 
 // ---------------------------------------------------------------------------
+// Symmetric fp32 kernel (the default up to F = 1024): 20 instead of 26 tile products at F = 512.
+// Only the SYMMETRISED lagged moment is ever used (offset_correlation = (C + C^T) / 2N' - mu mu^T,
+// tica.py:234-241), and with the sum and difference frames of a pair, u = x_t + x_{t+tau},
+// d = x_t - x_{t+tau},
+//     H = sum_t u u^T = G + (C + C^T),     D = sum_t d d^T = G - (C + C^T)        (over valid pairs)
+// so G = (H + D) / 2 and C + C^T = (H - D) / 2: TWO symmetric matrices, T(T+1) upper tile products
+// instead of T^2 + T(T+1)/2, and no per-row weights {0,1,2} (a frame counts once per pair it is in).
+// A workgroup owns one upper tile (I <= J) and computes BOTH its H and its D block from the same four
+// loaded panels (x_t and x_{t+tau}, columns I and J): 128 MFMAs per wave and K-step, so the step boundary
+// is amortised twice as well; 128 accumulator registers (AGPRs), two workgroups per CU with ONE 64 KiB LDS
+// image each (interleaved (u, d) pairs).  The sums and differences are formed when a staged step is written
+// to LDS.  fp32 rounding of u and d is 2^-24 relative and zero-mean: its contribution to the sums is
+// ~eps/sqrt(N), far below the fp32 accumulation error, which is bounded by flushing to the fp64 slabs every
+// KFLUSH_SYM frames (|H| is up to twice |G|).  The raw, non-symmetrised C is not available in this mode:
+// the exported "C" is already (C + C^T) / 2, which is what every consumer of the handle forms anyway.
+// Used for 2 <= T <= 8 (256 <= F <= 1024 or so): a single tile has nothing to save (1 H + 1 D against 1 G +
+// 1 C), and beyond T = 8 the grid of the C/G kernel fills the chip better.
+// ---------------------------------------------------------------------------
+constexpr int KFLUSH_SYM = 4096;
+
+struct StageS {
+    float4 xa[4], xb[4], ya[4], yb[4];  // rows t / t+tau, columns I (x) and J (y)
+    float sc[4];                        // pair validity per row (edge steps only)
+};
+
+struct StageAddrS {
+    global_ptr<char> pa, pb;
+    unsigned oxa[4], oxb[4], oya[4], oyb[4];
+};
+
+__device__ __forceinline__ void stage_addr_sym(StageAddrS& sa, StageS& st, int& uniform, const ChunkCtx& cx,
+                                               const LaneOffs& lo, int F, int k0, int I0, int J0, int tid)
+{
+    sa.pa = cx.base;
+    sa.pb = cx.baseB;
+    if (step_interior(cx, k0, 0)) {
+        sa.pa += (size_t)k0 * cx.ldb;  // scalar
+        sa.pb += (size_t)k0 * cx.ldb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sa.oxa[j] = sa.oxb[j] = lo.a[j];
+            sa.oya[j] = sa.oyb[j] = lo.b[j];
+        }
+        uniform = 1;
+    } else {
+        const int c4 = (tid & 31) * 4;
+        const int rr0 = tid >> 5;
+        const unsigned ca = 4u * (unsigned)(I0 + c4 < F ? I0 + c4 : F - 4), cb = 4u * (unsigned)(J0 + c4 < F ? J0 + c4 : F - 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kr = k0 + rr0 + 8 * j;
+            const int ra = kr < cx.nmax ? kr : cx.nmax;
+            const int rb = kr < cx.nmaxB ? kr : cx.nmaxB;
+            sa.oxa[j] = (unsigned)ra * cx.ldb + ca;
+            sa.oxb[j] = (unsigned)rb * cx.ldb + ca;
+            sa.oya[j] = (unsigned)ra * cx.ldb + cb;
+            sa.oyb[j] = (unsigned)rb * cx.ldb + cb;
+            st.sc[j] = (kr < cx.hi) ? 1.f : 0.f;
+        }
+        uniform = 0;
+    }
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 m) { return make_float4(a.x * m.x, a.y * m.y, a.z * m.z, a.w * m.w); }
+
+// edge steps / partial tiles: fold the pair validity into x (both rows of an invalid pair -> 0, so u = d = 0)
+// and the column masks into x and y, in registers
+template <bool PARTIAL>
+__device__ __forceinline__ void stage_scale_sym(StageS& st, int uniform, float4 ma, float4 mb)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sc = uniform ? 1.f : st.sc[j];
+        const float4 wa = PARTIAL ? make_float4(sc * ma.x, sc * ma.y, sc * ma.z, sc * ma.w) : make_float4(sc, sc, sc, sc);
+        st.xa[j] = f4mul(st.xa[j], wa);
+        st.xb[j] = f4mul(st.xb[j], wa);
+        if (PARTIAL) {
+            st.ya[j] = f4mul(st.ya[j], mb);
+            st.yb[j] = f4mul(st.yb[j], mb);
+        }
+    }
+}
+
+// one row's four columns of (u, d) = (a + b, a - b), interleaved: 32 contiguous bytes, two ds_write_b128
+__device__ __forceinline__ void sym_store(float __attribute__((ext_vector_type(2)))* dst, float4 a, float4 b)
+{
+    float4* p = reinterpret_cast<float4*>(dst);
+    p[0] = make_float4(a.x + b.x, a.x - b.x, a.y + b.y, a.y - b.y);
+    p[1] = make_float4(a.z + b.z, a.z - b.z, a.w + b.w, a.w - b.w);
+}
+
+template <bool PARTIAL>
+__global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PAN = BK32 * TM;                  // floats per panel
+    // LDS images are INTERLEAVED: [buffer][frame][column] pairs (u, d) for the I columns and for the J columns,
+    // so that the 8 fragment values of a k-pair arrive with two ds_read2_b64.  For a lone wave per SIMD every
+    // LDS instruction costs ~12 cycles of MFMA issue (microbenchmarks, scripts/micro/mfma_sym.hip: 8 MFMAs fed
+    // by six ds_read_b32/read2_b32 from four separate panels run at 72 cycles per MFMA, by two ds_read2_b64 at 65).
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v* UD = reinterpret_cast<f2v*>(smem);        // [PAN] (u, d) = x_t +- x_{t+tau}, columns I
+    f2v* VE = UD + PAN;                            // [PAN] the same for columns J
+
+    const int tid = threadIdx.x;
+    const int p = xcd_linear_id();
+    const int cohort = p / P.ntiles, tile = p % P.ntiles;  // ntiles = T (T + 1) / 2 upper tiles
+    int I = 0, u = tile;
+    while (u >= P.T - I) {
+        u -= P.T - I;
+        ++I;
+    }
+    const int J = I + u;
+    const int I0 = I * TM, J0 = J * TM;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kl = lane >> 5, cl = lane & 31;
+    double* slabH = P.slabs + (size_t)p * (2 * TM * TM);
+    double* slabD = slabH + TM * TM;
+
+    const int c4 = (tid & 31) * 4;
+    const float4 ma = make_float4(I0 + c4 + 0 < P.F ? 1.f : 0.f, I0 + c4 + 1 < P.F ? 1.f : 0.f,
+                                  I0 + c4 + 2 < P.F ? 1.f : 0.f, I0 + c4 + 3 < P.F ? 1.f : 0.f);
+    const float4 mb = make_float4(J0 + c4 + 0 < P.F ? 1.f : 0.f, J0 + c4 + 1 < P.F ? 1.f : 0.f,
+                                  J0 + c4 + 2 < P.F ? 1.f : 0.f, J0 + c4 + 3 < P.F ? 1.f : 0.f);
+
+    f32x16 aH[2][2], aD[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aH[bi][bj][r] = aD[bi][bj][r] = 0.f;
+    int rows_acc = 0;
+    if (P.dbg && blockIdx.x == 0 && tid == 0) {
+        P.dbg[0] = clock64();
+        P.dbg[2] = wall_clock64();
+    }
+
+    PROF_DECL;
+    for (long long c = cohort; c < P.nchunks; c += P.S) {
+        PROF_MARK(5)
+        const TicaChunk ch = get_chunk(P, c);
+        const int nsteps = (ch.n + BK32 - 1) / BK32;
+        ChunkCtx cx = make_ctx(P, ch);
+        set_lag(cx, P.lag, sizeof(float), P.ld);
+        const LaneOffs lofs = make_lane_offs<true>(cx, P.F, I0, J0, tid);
+        const int srow = tid >> 5, scol = (tid & 31) * 4;
+        // TWO workgroups per CU, ONE LDS image per workgroup (64 KiB): while this workgroup rewrites its image at
+        // the step boundary (barrier, 16 ds_write_b128 with the sums/differences, barrier) the co-resident one
+        // keeps the matrix pipes busy, as in the kernel above -- a lone workgroup per CU with a double-buffered
+        // image could not hide its own LDS / VMEM instructions (measured 56 ms against 67 ms for the C/G kernel;
+        // every non-MFMA instruction of a lone wave costs MFMA issue time).  The 16 global loads of step s+2 are
+        // interleaved into the MFMA stream of step s+1... i.e. the registers are refilled during k-pairs 0-7
+        // right after they were written to LDS, and have until the next boundary to land.
+        StageS st;
+        StageAddrS sa;
+        int un = 0;
+        stage_addr_sym(sa, st, un, cx, lofs, P.F, 0, I0, J0, tid);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st.xa[j] = load16_global<char>(sa.pa + sa.oxa[j]);
+            st.xb[j] = load16_global<char>(sa.pb + sa.oxb[j]);
+            st.ya[j] = load16_global<char>(sa.pa + sa.oya[j]);
+            st.yb[j] = load16_global<char>(sa.pb + sa.oyb[j]);
+        }
+        const int fa = kl * TM + wr * 64 + cl, fb = kl * TM + wc * 64 + cl;
+        for (int s = 0; s < nsteps; ++s) {
+            // ---- boundary: the image of step s (sums and differences of the staged rows) replaces that of step s-1 ----
+            __syncthreads();  // every wave has read its last fragments of the previous step
+            if (PARTIAL || !un) stage_scale_sym<PARTIAL>(st, un, ma, mb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sym_store(UD + (srow + 8 * j) * TM + scol, st.xa[j], st.xb[j]);
+                sym_store(VE + (srow + 8 * j) * TM + scol, st.ya[j], st.yb[j]);
+            }
+            stage_addr_sym(sa, st, un, cx, lofs, P.F, (s + 1) * BK32, I0, J0, tid);
+            __syncthreads();
+            f2v p0 = UD[fa], p1 = UD[fa + 32], q0 = VE[fb], q1 = VE[fb + 32];
+            PROF_MARK(1)
+#pragma unroll
+            for (int kk = 0; kk < BK32 / 2; ++kk) {
+                const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;
+                const f2v np0 = UD[kn * 2 * TM + fa], np1 = UD[kn * 2 * TM + fa + 32];
+                const f2v nq0 = VE[kn * 2 * TM + fb], nq1 = VE[kn * 2 * TM + fb + 32];
+                if (kk < 8) {  // step s+1 -> registers: two rows of x (even kk) or y (odd kk) per k-pair
+                    if ((kk & 1) == 0) {
+                        st.xa[kk / 2] = load16_global<char>(sa.pa + sa.oxa[kk / 2]);
+                        st.xb[kk / 2] = load16_global<char>(sa.pb + sa.oxb[kk / 2]);
+                    } else {
+                        st.ya[kk / 2] = load16_global<char>(sa.pa + sa.oya[kk / 2]);
+                        st.yb[kk / 2] = load16_global<char>(sa.pb + sa.oyb[kk / 2]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                aH[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.x, q0.x, aH[0][0], 0, 0, 0);
+                aH[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.x, q1.x, aH[0][1], 0, 0, 0);
+                aH[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.x, q0.x, aH[1][0], 0, 0, 0);
+                aH[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.x, q1.x, aH[1][1], 0, 0, 0);
+                aD[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.y, q0.y, aD[0][0], 0, 0, 0);
+                aD[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.y, q1.y, aD[0][1], 0, 0, 0);
+                aD[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.y, q0.y, aD[1][0], 0, 0, 0);
+                aD[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.y, q1.y, aD[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                p0 = np0; p1 = np1; q0 = nq0; q1 = nq1;
+            }
+            PROF_MARK(2)
+        }
+        rows_acc += ch.n;
+        if (rows_acc + P.kc > KFLUSH_SYM || c + P.S >= P.nchunks) {
+            rows_acc = 0;
+            unsigned toff = (unsigned)((wr * 64 + 4 * kl) * TM + wc * 64 + cl);
+            asm volatile("" : "+v"(toff));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double* slab = h ? slabD : slabH;
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi) {
+                    double old[2][16];
+#pragma unroll
+                    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) old[bj][r] = (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff];
+#pragma unroll
+                    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
+                            if (h) {
+                                q[toff] = old[bj][r] + (double)aD[bi][bj][r];
+                                aD[bi][bj][r] = 0.f;
+                            } else {
+                                q[toff] = old[bj][r] + (double)aH[bi][bj][r];
+                                aH[bi][bj][r] = 0.f;
+                            }
+                        }
+                }
+            }
+        }
+    }
+    PROF_MARK(4)
+#ifdef MSM_TICA_PROFILE
+    if (P.dbg && tid == 0 && blockIdx.x < 5) {
+        for (int i = 0; i < 6; ++i) P.dbg[8 + 8 * blockIdx.x + i] = pf_acc[i];
+    }
+#endif
+    if (P.dbg && blockIdx.x == 0 && tid == 0) {
+        P.dbg[1] = clock64();
+        P.dbg[3] = wall_clock64();
+    }
+}
+
+// packed C and G contributions of the symmetric kernel's slabs: G += (H + D) / 2 and "C" += (H - D) / 4
+// (a symmetric matrix whose symmetrisation (C + C^T) / 2 is the lagged moment's)
+__global__ void tica_export_sym_kernel(const double* __restrict__ slabs, double* __restrict__ out, int F, int T,
+                                       int ntiles, int S)
+{
+    const size_t FF = (size_t)F * F;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * FF) return;
+    const int type = idx >= FF;
+    const size_t e = idx - (type ? FF : 0);
+    int i = (int)(e / F), j = (int)(e % F);
+    if (i > j) {
+        const int t = i;
+        i = j;
+        j = t;
+    }
+    const int ti = i / TM, tj = j / TM;
+    const int tile = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+    const size_t off = (size_t)(i % TM) * TM + (j % TM);
+    double h = 0.0, d = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double* sl = slabs + ((size_t)s * ntiles + tile) * (2 * TM * TM);
+        h += sl[off];
+        d += sl[TM * TM + off];
+    }
+    out[idx] += type ? 0.5 * (h + d) : 0.25 * (h - d);
+}
+
+// ---------------------------------------------------------------------------
 // fp64 kernel: v_mfma_f64_16x16x4_f64 on inputs widened to fp64 while staging.
 // fp32 x fp32 products are exact in fp64, so this is the reference's float64
 // arithmetic up to summation order.  Structural twin of the fp32 kernel: K-step =
@@ -1293,6 +1577,8 @@ using namespace msm;
 struct msm_tica {
     int F = 0, lag = 0, mode = 0, T = 0, ntiles = 0;
     int S32 = 0, S64 = 0, SB = 0, SB3 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
+    int sym = 0, ntiles_sym = 0, S_sym = 0;                // symmetric fp32 kernel: upper tiles, cohorts (1 workgroup per CU)
+    double* slabs_sym = nullptr;                           // [S_sym * ntiles_sym][2][TM*TM]: H and D blocks
     double* slabs = nullptr;    // [G][TM*TM]
     double* base = nullptr;     // packed [2FF+2F] imported state
     double* colpart = nullptr;  // [NCB][2][F]
@@ -1321,6 +1607,7 @@ int query_slots(K kernel, size_t lds, int* slots)
 }
 
 constexpr size_t LDS32 = 2 * 2 * BK32 * TM * sizeof(float);  // 64 KiB
+constexpr size_t LDSSYM = 4 * BK32 * TM * sizeof(float);  // 64 KiB: the (u, d) images for columns I and J
 constexpr size_t LDSB = 2 * 2 * 4 * TM * 16;                  // 32 KiB: [2 bufs][A,B][4 groups][128] 16-byte packets
 constexpr size_t LDSB3 = 2 * 4 * 4 * TM * 16;                 // 64 KiB: + mid images
 constexpr size_t LDS64 = 2 * 2 * BK64 * P64 * sizeof(double);  // 72 KiB (double-buffered, pitch 144)
@@ -1329,6 +1616,8 @@ int tica_zero(msm_tica* h)
 {
     const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     MSM_HIP_CHECK(hipMemsetAsync(h->slabs, 0, (size_t)h->G * TM * TM * sizeof(double), stream()));
+    if (h->slabs_sym)
+        MSM_HIP_CHECK(hipMemsetAsync(h->slabs_sym, 0, (size_t)h->S_sym * h->ntiles_sym * 2 * TM * TM * sizeof(double), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->base, 0, FF2 * sizeof(double), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->colpart, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
@@ -1376,8 +1665,9 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     const bool use32 = (h->mode == MSM_TICA_F32 && dtype_bytes == 4);
     const bool useb = (h->mode == MSM_TICA_BF16 || h->mode == MSM_TICA_BF16X2) && dtype_bytes == 4;
     const int bk = (use32 || useb) ? BK32 : BK64;
-    const int S = use32 ? h->S32 : useb ? (h->mode == MSM_TICA_BF16 ? h->SB : h->SB3) : h->S64;  // one resident round
-    const int G = S * h->ntiles;
+    const bool usesym = use32 && h->sym && aligned;  // H/D kernel: 16-byte aligned rows only
+    const int S = usesym ? h->S_sym : use32 ? h->S32 : useb ? (h->mode == MSM_TICA_BF16 ? h->SB : h->SB3) : h->S64;  // one resident round
+    const int G = S * (usesym ? h->ntiles_sym : h->ntiles);
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
@@ -1390,9 +1680,9 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     P.F = h->F;
     P.lag = h->lag;
     P.T = h->T;
-    P.ntiles = h->ntiles;
+    P.ntiles = usesym ? h->ntiles_sym : h->ntiles;
     P.S = S;
-    P.slabs = h->slabs;
+    P.slabs = usesym ? h->slabs_sym : h->slabs;
     P.colpart = h->coltmp;
     P.flag = h->flag;
     P.dbg = h->dbg;
@@ -1467,7 +1757,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // 2) the MFMA pass
     MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(h->S + 1) * sizeof(unsigned), stream()));
     if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
-    if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
+    if (usesym) {
+        if (h->F % TM == 0)
+            hipLaunchKernelGGL((tica_sym_f32_kernel<false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+        else
+            hipLaunchKernelGGL((tica_sym_f32_kernel<true>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+    } else if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
         if (aligned && h->F % TM == 0)
             hipLaunchKernelGGL((tica_mfma_f32_kernel<true, false>), dim3(G), dim3(NT), LDS32, stream(), P);
         else if (aligned)
@@ -1511,6 +1806,12 @@ int tica_export_device(msm_tica* h)
     hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
                        h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
     MSM_HIP_CHECK(hipGetLastError());
+    if (h->sym) {
+        const size_t ff2 = 2 * (size_t)h->F * h->F;
+        hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->slabs_sym,
+                           h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
+        MSM_HIP_CHECK(hipGetLastError());
+    }
     const double cnt[2] = {(double)h->n_obs, (double)h->n_seq};
     MSM_HIP_CHECK(hipMemcpyAsync(h->packed + total, cnt, sizeof(cnt), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
@@ -1583,11 +1884,29 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (h->S64 < 1) h->S64 = 1;
     if (h->SB < 1) h->SB = 1;
     if (h->SB3 < 1) h->SB3 = 1;
+    {
+        // symmetric fp32 kernel (H/D blocks of the upper tiles): two 64-KiB workgroups per CU
+        const char* sym_env = getenv("MSM_TICA_SYM");
+        const bool sym_off = sym_env && atoi(sym_env) == 0;
+        h->ntiles_sym = h->T * (h->T + 1) / 2;
+        if (mode == MSM_TICA_F32 && !sym_off && h->T >= 2 && h->T <= 8 && n_features % 4 == 0) {
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
+            int sa = 0, sb = 0;
+            if ((rc = query_slots(tica_sym_f32_kernel<false>, LDSSYM, &sa))) { delete h; return rc; }
+            if ((rc = query_slots(tica_sym_f32_kernel<true>, LDSSYM, &sb))) { delete h; return rc; }
+            h->S_sym = std::max(1, std::min(sa, sb) / h->ntiles_sym);
+            h->sym = 1;
+        }
+    }
     h->S = std::max(std::max(h->S32, h->S64), std::max(h->SB, h->SB3));  // slabs exist for the largest; unused ones stay zero
     h->G = h->S * h->ntiles;
     const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void**)&h->slabs, (size_t)h->G * TM * TM * sizeof(double));
+    if (e == hipSuccess && h->sym) e = hipMalloc((void**)&h->slabs_sym, (size_t)h->S_sym * h->ntiles_sym * 2 * TM * TM * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->base, FF2 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->colpart, (size_t)NCB * 2 * h->F * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->coltmp, (size_t)NCB * 2 * h->F * sizeof(double));
@@ -1615,6 +1934,7 @@ int msm_tica_destroy(msm_tica_t* h)
     if (!h) return MSM_OK;
     (void)hipStreamSynchronize(stream());
     if (h->slabs) (void)hipFree(h->slabs);
+    if (h->slabs_sym) (void)hipFree(h->slabs_sym);
     if (h->base) (void)hipFree(h->base);
     if (h->colpart) (void)hipFree(h->colpart);
     if (h->coltmp) (void)hipFree(h->coltmp);
@@ -1740,6 +2060,13 @@ int msm_tica_nonfinite(msm_tica_t* h, int* flag)
     MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     *flag = f[0];
+    return MSM_OK;
+}
+
+int msm_tica_lagged_symmetrised(msm_tica_t* h, int* flag)
+{
+    if (!h || !flag) return fail(MSM_ERR_STATE, "null argument");
+    *flag = h->sym ? 1 : 0;
     return MSM_OK;
 }
 

@@ -52,8 +52,8 @@ _HANDLE_POOL = {}
 _HANDLE_POOL_MAX = 2
 
 
-def _acquire_handle(n_features, lag_time, mode):
-    key = (int(n_features), int(lag_time), int(mode))
+def _acquire_handle(n_features, lag_time, mode, sym=""):
+    key = (int(n_features), int(lag_time), int(mode), str(sym))
     free = _HANDLE_POOL.get(key)
     if free:
         h = free.pop()
@@ -64,8 +64,8 @@ def _acquire_handle(n_features, lag_time, mode):
     return h
 
 
-def _park_handle(h, n_features, lag_time, mode):
-    key = (int(n_features), int(lag_time), int(mode))
+def _park_handle(h, n_features, lag_time, mode, sym=""):
+    key = (int(n_features), int(lag_time), int(mode), str(sym))
     free = _HANDLE_POOL.setdefault(key, [])
     if len(free) < _HANDLE_POOL_MAX:
         free.append(h)
@@ -165,7 +165,7 @@ class tICA(BaseEstimator, TransformerMixin):
         self.n_sequences_ = 0
         self._release()
         _lib.ensure_device()
-        self._handle_key = (int(n_features), int(self.lag_time), _mode_from_env())
+        self._handle_key = (int(n_features), int(self.lag_time), _mode_from_env(), os.environ.get("MSM_TICA_SYM", ""))
         self._handle = _acquire_handle(*self._handle_key)
         self._outer_0_to_T_lagged = np.zeros((n_features, n_features))
         self._sum_0_to_TminusTau = np.zeros(n_features)
@@ -190,7 +190,7 @@ class tICA(BaseEstimator, TransformerMixin):
         """(Re)create the device handle from the host mirrors (after unpickling)."""
         if self._handle is None and self._initialized:
             _lib.ensure_device()
-            self._handle_key = (int(self.n_features), int(self.lag_time), _mode_from_env())
+            self._handle_key = (int(self.n_features), int(self.lag_time), _mode_from_env(), os.environ.get("MSM_TICA_SYM", ""))
             h = self._handle = _acquire_handle(*self._handle_key)
             c = np.ascontiguousarray(self._outer_0_to_T_lagged, dtype=np.float64)
             g = np.ascontiguousarray(self._outer_gram_sum, dtype=np.float64)
@@ -199,6 +199,16 @@ class tICA(BaseEstimator, TransformerMixin):
             check(_lib.lib().msm_tica_import(h, c.ctypes.data, g.ctypes.data, s0.ctypes.data,
                                              st.ctypes.data, int(self.n_observations_),
                                              int(self.n_sequences_)))
+
+    @property
+    def _lagged_symmetrised(self):
+        """True when ``_outer_0_to_T_lagged`` holds (C + C^T)/2 instead of the raw X[:-tau].T @ X[tau:]
+        (fp32 symmetric sum/difference kernel; only the symmetric part is ever read, tica.py:234-241)."""
+        if self._handle is None:
+            return False
+        flag = C.c_int(0)
+        check(_lib.lib().msm_tica_lagged_symmetrised(self._handle, C.byref(flag)))
+        return bool(flag.value)
 
     def _pull(self):
         """Refresh the host mirrors of the accumulators (one D2H of 2F^2+2F doubles)."""

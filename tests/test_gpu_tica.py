@@ -41,6 +41,12 @@ def _fit_pair(seqs, mode, monkeypatch, **kw):
     return m, o
 
 
+def _lagged(m, C):
+    """What ``_outer_0_to_T_lagged`` must equal: the raw lagged moment, or its symmetric part when the handle runs
+    the fp32 sum/difference kernel (msm_tica_lagged_symmetrised)."""
+    return 0.5 * (C + C.T) if m._lagged_symmetrised else C
+
+
 def _vec_match(V, Vref, Sigma, tol=1e-4):
     """eigenvectors up to sign: |v^T Sigma v_ref| >= 1 - tol (both Sigma-orthonormal)."""
     ov = np.abs(np.einsum("ik,ij,jk->k", V, Sigma, Vref))
@@ -60,7 +66,7 @@ def test_accumulators_and_eigs_vs_oracle(gpu, monkeypatch, mode, F, lag, nf):
     # fp32 chunk partials: |err| <= ~1e-7 * sum|a*b|, i.e. relative to the matrix SCALE, not per element
     G = o.S0 + o.Stau
     tol = dict(rtol=1e-12, atol=1e-9) if mode == "f64" else dict(rtol=0, atol=ATOL_SCALE[mode] * np.abs(G).max())
-    np.testing.assert_allclose(m._outer_0_to_T_lagged, o.C, **tol)
+    np.testing.assert_allclose(m._outer_0_to_T_lagged, _lagged(m, o.C), **tol)
     np.testing.assert_allclose(m._outer_gram_sum, G, **tol)
     np.testing.assert_allclose(m._sum_0_to_TminusTau, o.s0, rtol=1e-12, atol=1e-9)
     np.testing.assert_allclose(m._sum_tau_to_T, o.stau, rtol=1e-12, atol=1e-9)
@@ -119,7 +125,7 @@ def test_golden_ragged_mappings(gpu, monkeypatch, golden_dir):
         np.testing.assert_allclose(Y * sign, Yg, rtol=1e-6, atol=1e-8)
         if tag == "B":
             m._pull()
-            np.testing.assert_allclose(m._outer_0_to_T_lagged, g["B_C"], rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(m._outer_0_to_T_lagged, _lagged(m, g["B_C"]), rtol=1e-12, atol=1e-9)
             np.testing.assert_allclose(m._outer_gram_sum, g["B_S0"] + g["B_Stau"], rtol=1e-12, atol=1e-9)
             np.testing.assert_allclose(m._sum_0_to_TminusTau, g["B_s0"], rtol=1e-12, atol=1e-9)
             assert [m.n_observations_, m.n_sequences_] == list(g["B_n_obs_seq"])
@@ -231,7 +237,55 @@ def test_f64_mfma_layout_asymmetric(gpu, monkeypatch):
         Xd = X.astype(np.float64)
         C = Xd[:-3].T @ Xd[3:]
         assert np.abs(C - C.T).max() > 1.0
-        np.testing.assert_allclose(m._outer_0_to_T_lagged, C, rtol=1e-5, atol=1e-3 if mode != "bf16" else 0.5)
+        np.testing.assert_allclose(m._outer_0_to_T_lagged, _lagged(m, C), rtol=1e-5, atol=1e-3 if mode != "bf16" else 0.5)
+
+
+@pytest.mark.parametrize("F,lag", [(256, 1), (260, 37), (512, 100), (516, 5), (1024, 250)])
+def test_symmetric_sum_difference_kernel(gpu, monkeypatch, F, lag):
+    """fp32 default for 2 <= T <= 8 tiles: H = sum u u^T, D = sum d d^T of the upper tiles, G = (H + D)/2,
+    (C + C^T)/2 = (H - D)/4.  Against float64 numpy, and against the C/G kernel (MSM_TICA_SYM=0), with trajectories
+    that cross the 4096-frame chunks, end inside a 32-frame step, are not longer than the lag, or hold one pair."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
+    lens = [9001, 4096 + lag, lag, lag + 1, 33 + lag, 1, 2 * lag + 5]
+    seqs = [x[:n] for x, n in zip(_ar1(F + lag, len(lens), max(lens), F), lens)]
+    m = tICA(n_components=4, lag_time=lag).fit(seqs)
+    assert m._lagged_symmetrised
+    m._pull()
+    monkeypatch.setenv("MSM_TICA_SYM", "0")
+    m0 = tICA(n_components=4, lag_time=lag).fit(seqs)
+    assert not m0._lagged_symmetrised
+    m0._pull()
+    C = np.zeros((F, F)); G = np.zeros((F, F)); s0 = np.zeros(F); st = np.zeros(F); n = 0
+    for x in seqs:
+        if len(x) <= lag:
+            continue
+        x = x.astype(np.float64)
+        a, b = x[:-lag], x[lag:]
+        C += a.T @ b; G += a.T @ a + b.T @ b; s0 += a.sum(0); st += b.sum(0); n += len(x)      # n_observations_ counts frames (tica.py:414)
+    assert m.n_observations_ == n == m0.n_observations_
+    scale = np.abs(G).max()
+    np.testing.assert_allclose(m._outer_gram_sum, G, rtol=0, atol=ATOL_SCALE["f32"] * scale)
+    np.testing.assert_allclose(m._outer_0_to_T_lagged, 0.5 * (C + C.T), rtol=0, atol=ATOL_SCALE["f32"] * scale)
+    np.testing.assert_allclose(m0._outer_0_to_T_lagged, C, rtol=0, atol=ATOL_SCALE["f32"] * scale)
+    np.testing.assert_allclose(m._sum_0_to_TminusTau, s0, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(m._sum_tau_to_T, st, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(m._outer_gram_sum, m._outer_gram_sum.T)
+    assert np.array_equal(m._outer_0_to_T_lagged, m._outer_0_to_T_lagged.T)
+    # at lags far beyond the slowest mode the leading eigenvalues are a cluster of sampling noise (13k frames, up to
+    # 1024 features): ill-conditioned, so two fp32 roundings agree absolutely, not to 1e-5 relative
+    np.testing.assert_allclose(m.eigenvalues_, m0.eigenvalues_, rtol=RTOL["f32"] if lag < 50 else 0,
+                               atol=0 if lag < 50 else 5e-5)
+    np.testing.assert_allclose(m.offset_correlation_, m0.offset_correlation_, rtol=0,
+                               atol=2 * ATOL_SCALE["f32"] * scale / n)
+    # float64 input to the same handle takes the fp64 kernel (raw C): the export is then the sum of both parts and
+    # its symmetric part is still exact
+    m.partial_fit(seqs[0].astype(np.float64))
+    m._pull()
+    x = seqs[0].astype(np.float64)
+    C2 = C + x[:-lag].T @ x[lag:]
+    got = m._outer_0_to_T_lagged
+    np.testing.assert_allclose(0.5 * (got + got.T), 0.5 * (C2 + C2.T), rtol=0, atol=ATOL_SCALE["f32"] * scale)
 
 
 # ---------------------------------------------------------------- trajectory segments (SURVEY 8e)
