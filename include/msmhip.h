@@ -117,7 +117,7 @@ int msm_tica_accumulate_segments(msm_tica_t* h, const void* const* X_ptrs, const
                                  int on_device, int check_finite, msm_idx_t* n_skipped);
 int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until reset */
 /* 1 when this handle accumulates fp32 input with the symmetric sum/difference kernel (MSM_TICA_F32,
- * 256 <= n_features <= 1024 or so, n_features % 4 == 0; MSM_TICA_SYM=0 disables): the "C" it exports is then
+ * 128 < n_features <= 3968, n_features % 4 == 0; MSM_TICA_SYM=0 disables): the "C" it exports is then
  * already (C + C^T) / 2 -- the only form the estimator reads (tica.py:234-241) -- and the raw
  * X[:-tau].T @ X[tau:] is not kept. */
 int msm_tica_lagged_symmetrised(msm_tica_t* h, int* flag);

@@ -611,8 +611,8 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 // ~eps/sqrt(N), far below the fp32 accumulation error, which is bounded by flushing to the fp64 slabs every
 // KFLUSH_SYM frames (|H| is up to twice |G|).  The raw, non-symmetrised C is not available in this mode:
 // the exported "C" is already (C + C^T) / 2, which is what every consumer of the handle forms anyway.
-// Used for 2 <= T <= 8 (256 <= F <= 1024 or so): a single tile has nothing to save (1 H + 1 D against 1 G +
-// 1 C), and beyond T = 8 the grid of the C/G kernel fills the chip better.
+// Used from T = 2 tiles (F > 128) up to the width whose T(T+1)/2 upper tiles still fit one resident round
+// (F <= 3968 on 256 CUs); a single tile has nothing to save (1 H + 1 D against 1 G + 1 C).
 // ---------------------------------------------------------------------------
 constexpr int KFLUSH_SYM = 4096;
 
@@ -1889,7 +1889,9 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
         const char* sym_env = getenv("MSM_TICA_SYM");
         const bool sym_off = sym_env && atoi(sym_env) == 0;
         h->ntiles_sym = h->T * (h->T + 1) / 2;
-        if (mode == MSM_TICA_F32 && !sym_off && h->T >= 2 && h->T <= 8 && n_features % 4 == 0) {
+        const char* tmax_env = getenv("MSM_TICA_SYM_TMAX");
+        const int tmax = tmax_env ? atoi(tmax_env) : 64;  // and one resident cohort must fit (checked below)
+        if (mode == MSM_TICA_F32 && !sym_off && h->T >= 2 && h->T <= tmax && n_features % 4 == 0) {
             MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
             MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<true>),
@@ -1897,8 +1899,8 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
             int sa = 0, sb = 0;
             if ((rc = query_slots(tica_sym_f32_kernel<false>, LDSSYM, &sa))) { delete h; return rc; }
             if ((rc = query_slots(tica_sym_f32_kernel<true>, LDSSYM, &sb))) { delete h; return rc; }
-            h->S_sym = std::max(1, std::min(sa, sb) / h->ntiles_sym);
-            h->sym = 1;
+            h->S_sym = std::min(sa, sb) / h->ntiles_sym;
+            h->sym = h->S_sym >= 1;  // at least one whole cohort resident (F <= 3968 on 256 CUs), else the C/G kernel
         }
     }
     h->S = std::max(std::max(h->S32, h->S64), std::max(h->SB, h->SB3));  // slabs exist for the largest; unused ones stay zero

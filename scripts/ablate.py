@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from msmbuilder_amd import tICA, _lib
 T, lag = 10000, 100
-for F, n_seq in ((512, 1000), (128, 1000), (2048, 200), (500, 1000)):
+WIDTHS = [(int(a), 1000 if int(a) <= 768 else 200) for a in sys.argv[1:]] or [(512, 1000), (128, 1000), (2048, 200), (500, 1000)]
+for F, n_seq in WIDTHS:
     X = torch.randn(n_seq * T, F, device="cuda")
     seqs = list(X.view(n_seq, T, F).unbind(0))
     ts = []

@@ -10,7 +10,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 RTOL = {"f32": 1e-5, "f64": 1e-10, "bf16x2": 1e-5, "bf16": 5e-3}   # stated eigenvalue tolerances; bf16: 1e-3 at >= 1e5 frames (test_config5), 5e-3 on these short ill-conditioned inputs
-ATOL_SCALE = {"f32": 5e-7, "bf16x2": 1e-6, "bf16": 5e-4}             # accumulators, relative to max|G|
+ATOL_SCALE = {"f32": 1e-6, "bf16x2": 1e-6, "bf16": 5e-4}             # accumulators, relative to max|G| (f32: the sum/difference
+# kernel keeps H = G + (C + C^T), up to twice |G|, in fp32 partials of <= 4096 frames; the error is per partial, so relative to the
+# totals it shrinks with the number of partials -- these short inputs are the worst case)
 
 
 def _ar1(seed, n_seq, n_frames, n_features, offset=3.0):
@@ -240,9 +242,9 @@ def test_f64_mfma_layout_asymmetric(gpu, monkeypatch):
         np.testing.assert_allclose(m._outer_0_to_T_lagged, _lagged(m, C), rtol=1e-5, atol=1e-3 if mode != "bf16" else 0.5)
 
 
-@pytest.mark.parametrize("F,lag", [(256, 1), (260, 37), (512, 100), (516, 5), (1024, 250)])
+@pytest.mark.parametrize("F,lag", [(256, 1), (260, 37), (512, 100), (516, 5), (1024, 250), (1284, 3), (2048, 20)])
 def test_symmetric_sum_difference_kernel(gpu, monkeypatch, F, lag):
-    """fp32 default for 2 <= T <= 8 tiles: H = sum u u^T, D = sum d d^T of the upper tiles, G = (H + D)/2,
+    """fp32 default from 2 tiles (F > 128) on: H = sum u u^T, D = sum d d^T of the upper tiles, G = (H + D)/2,
     (C + C^T)/2 = (H - D)/4.  Against float64 numpy, and against the C/G kernel (MSM_TICA_SYM=0), with trajectories
     that cross the 4096-frame chunks, end inside a 32-frame step, are not longer than the lag, or hold one pair."""
     from msmbuilder_amd import tICA
@@ -272,10 +274,10 @@ def test_symmetric_sum_difference_kernel(gpu, monkeypatch, F, lag):
     np.testing.assert_allclose(m._sum_tau_to_T, st, rtol=1e-12, atol=1e-9)
     assert np.array_equal(m._outer_gram_sum, m._outer_gram_sum.T)
     assert np.array_equal(m._outer_0_to_T_lagged, m._outer_0_to_T_lagged.T)
-    # at lags far beyond the slowest mode the leading eigenvalues are a cluster of sampling noise (13k frames, up to
-    # 1024 features): ill-conditioned, so two fp32 roundings agree absolutely, not to 1e-5 relative
-    np.testing.assert_allclose(m.eigenvalues_, m0.eigenvalues_, rtol=RTOL["f32"] if lag < 50 else 0,
-                               atol=0 if lag < 50 else 5e-5)
+    # at lags far beyond the slowest mode, or with only ~6 frames per feature, the leading eigenvalues are a cluster of
+    # sampling noise on an ill-conditioned covariance: two fp32 roundings agree absolutely, not to 1e-5 relative
+    loose = lag >= 50 or F >= 2048
+    np.testing.assert_allclose(m.eigenvalues_, m0.eigenvalues_, rtol=0 if loose else RTOL["f32"], atol=5e-5 if loose else 0)
     np.testing.assert_allclose(m.offset_correlation_, m0.offset_correlation_, rtol=0,
                                atol=2 * ATOL_SCALE["f32"] * scale / n)
     # float64 input to the same handle takes the fp64 kernel (raw C): the export is then the sum of both parts and
