@@ -689,6 +689,18 @@ __device__ __forceinline__ void sym_store(float __attribute__((ext_vector_type(2
     p[1] = make_float4(a.z + b.z, a.z - b.z, a.w + b.w, a.w - b.w);
 }
 
+// a - b on four floats as two v_pk_add_f32 with the negate modifiers on the second source (the compiler splits a
+// vector fsub into scalar v_sub_f32: there is no v_pk_sub_f32)
+__device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(float __attribute__((ext_vector_type(4))) a,
+                                                                             float __attribute__((ext_vector_type(4))) b)
+{
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(a.xy), "v"(b.xy));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(a.zw), "v"(b.zw));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 template <bool PARTIAL>
 __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 {
@@ -699,8 +711,16 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
     // LDS instruction costs ~12 cycles of MFMA issue (microbenchmarks, scripts/micro/mfma_sym.hip: 8 MFMAs fed
     // by six ds_read_b32/read2_b32 from four separate panels run at 72 cycles per MFMA, by two ds_read2_b64 at 65).
     typedef float f2v __attribute__((ext_vector_type(2)));
-    f2v* UD = reinterpret_cast<f2v*>(smem);        // [PAN] (u, d) = x_t +- x_{t+tau}, columns I
-    f2v* VE = UD + PAN;                            // [PAN] the same for columns J
+#define MSM_F2(P, O) (*reinterpret_cast<const f2v*>((P) + (O)))
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    // four planes [32 frames][128 columns]: u = x_t + x_{t+tau} and d = x_t - x_{t+tau} for the I columns, then for the
+    // J columns.  A lane's two MFMA row blocks are the ADJACENT columns 2l and 2l+1 (the accumulators hold a permuted
+    // tile, undone at the slab merge), so one ds_read2st64_b64 (u plane + d plane, 16 KiB apart) feeds four MFMAs,
+    // and the writer forms its sums/differences with packed adds on the loaded float4s -- no lane or register shuffles.
+    float* UI = reinterpret_cast<float*>(smem);
+    float* DI = UI + PAN;
+    float* UJ = DI + PAN;
+    float* DJ = UJ + PAN;
 
     const int tid = threadIdx.x;
     const int p = xcd_linear_id();
@@ -765,25 +785,30 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
             st.ya[j] = load16_global<char>(sa.pa + sa.oya[j]);
             st.yb[j] = load16_global<char>(sa.pb + sa.oyb[j]);
         }
-        const int fa = kl * TM + wr * 64 + cl, fb = kl * TM + wc * 64 + cl;
+        const int fa = kl * TM + wr * 64 + 2 * cl, fb = kl * TM + wc * 64 + 2 * cl;  // floats
         for (int s = 0; s < nsteps; ++s) {
             // ---- boundary: the image of step s (sums and differences of the staged rows) replaces that of step s-1 ----
             __syncthreads();  // every wave has read its last fragments of the previous step
             if (PARTIAL || !un) stage_scale_sym<PARTIAL>(st, un, ma, mb);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                sym_store(UD + (srow + 8 * j) * TM + scol, st.xa[j], st.xb[j]);
-                sym_store(VE + (srow + 8 * j) * TM + scol, st.ya[j], st.yb[j]);
+                const int o = (srow + 8 * j) * TM + scol;
+                const f4v xa = *reinterpret_cast<const f4v*>(&st.xa[j]), xb = *reinterpret_cast<const f4v*>(&st.xb[j]);
+                const f4v ya = *reinterpret_cast<const f4v*>(&st.ya[j]), yb = *reinterpret_cast<const f4v*>(&st.yb[j]);
+                *reinterpret_cast<f4v*>(UI + o) = xa + xb;
+                *reinterpret_cast<f4v*>(DI + o) = pk_sub4(xa, xb);
+                *reinterpret_cast<f4v*>(UJ + o) = ya + yb;
+                *reinterpret_cast<f4v*>(DJ + o) = pk_sub4(ya, yb);
             }
             stage_addr_sym(sa, st, un, cx, lofs, P.F, (s + 1) * BK32, I0, J0, tid);
             __syncthreads();
-            f2v p0 = UD[fa], p1 = UD[fa + 32], q0 = VE[fb], q1 = VE[fb + 32];
+            f2v pu = MSM_F2(UI, fa), pd = MSM_F2(DI, fa), qu = MSM_F2(UJ, fb), qd = MSM_F2(DJ, fb);
             PROF_MARK(1)
 #pragma unroll
             for (int kk = 0; kk < BK32 / 2; ++kk) {
                 const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;
-                const f2v np0 = UD[kn * 2 * TM + fa], np1 = UD[kn * 2 * TM + fa + 32];
-                const f2v nq0 = VE[kn * 2 * TM + fb], nq1 = VE[kn * 2 * TM + fb + 32];
+                const f2v npu = MSM_F2(UI, kn * 2 * TM + fa), npd = MSM_F2(DI, kn * 2 * TM + fa);
+                const f2v nqu = MSM_F2(UJ, kn * 2 * TM + fb), nqd = MSM_F2(DJ, kn * 2 * TM + fb);
                 if (kk < 8) {  // step s+1 -> registers: two rows of x (even kk) or y (odd kk) per k-pair
                     if ((kk & 1) == 0) {
                         st.xa[kk / 2] = load16_global<char>(sa.pa + sa.oxa[kk / 2]);
@@ -794,47 +819,46 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                aH[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.x, q0.x, aH[0][0], 0, 0, 0);
-                aH[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.x, q1.x, aH[0][1], 0, 0, 0);
-                aH[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.x, q0.x, aH[1][0], 0, 0, 0);
-                aH[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.x, q1.x, aH[1][1], 0, 0, 0);
-                aD[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.y, q0.y, aD[0][0], 0, 0, 0);
-                aD[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0.y, q1.y, aD[0][1], 0, 0, 0);
-                aD[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.y, q0.y, aD[1][0], 0, 0, 0);
-                aD[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1.y, q1.y, aD[1][1], 0, 0, 0);
+                aH[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.x, qu.x, aH[0][0], 0, 0, 0);
+                aH[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.x, qu.y, aH[0][1], 0, 0, 0);
+                aH[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.y, qu.x, aH[1][0], 0, 0, 0);
+                aH[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.y, qu.y, aH[1][1], 0, 0, 0);
+                aD[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.x, qd.x, aD[0][0], 0, 0, 0);
+                aD[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.x, qd.y, aD[0][1], 0, 0, 0);
+                aD[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.y, qd.x, aD[1][0], 0, 0, 0);
+                aD[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.y, qd.y, aD[1][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                p0 = np0; p1 = np1; q0 = nq0; q1 = nq1;
+                pu = npu; pd = npd; qu = nqu; qd = nqd;
             }
             PROF_MARK(2)
         }
         rows_acc += ch.n;
         if (rows_acc + P.kc > KFLUSH_SYM || c + P.S >= P.nchunks) {
             rows_acc = 0;
-            unsigned toff = (unsigned)((wr * 64 + 4 * kl) * TM + wc * 64 + cl);
+            // accumulator register r of block (bi, bj), lane (kl, cl) = tile row wr*64 + 2*rho + bi with
+            // rho = (r & 3) + 8 (r >> 2) + 4 kl, tile column wc*64 + 2*cl + bj: the two bj of a lane are adjacent doubles
+            unsigned toff = (unsigned)((wr * 64 + 8 * kl) * TM + wc * 64 + 2 * cl);
             asm volatile("" : "+v"(toff));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 double* slab = h ? slabD : slabH;
 #pragma unroll
                 for (int bi = 0; bi < 2; ++bi) {
-                    double old[2][16];
+                    double2 old[16];
 #pragma unroll
-                    for (int bj = 0; bj < 2; ++bj)
+                    for (int r = 0; r < 16; ++r)
+                        old[r] = *reinterpret_cast<const double2*>(slab + (2 * ((r & 3) + 8 * (r >> 2)) + bi) * TM + toff);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) old[bj][r] = (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff];
-#pragma unroll
-                    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            double* q = slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32;
-                            if (h) {
-                                q[toff] = old[bj][r] + (double)aD[bi][bj][r];
-                                aD[bi][bj][r] = 0.f;
-                            } else {
-                                q[toff] = old[bj][r] + (double)aH[bi][bj][r];
-                                aH[bi][bj][r] = 0.f;
-                            }
+                    for (int r = 0; r < 16; ++r) {
+                        double2* q = reinterpret_cast<double2*>(slab + (2 * ((r & 3) + 8 * (r >> 2)) + bi) * TM + toff);
+                        if (h) {
+                            *q = make_double2(old[r].x + (double)aD[bi][0][r], old[r].y + (double)aD[bi][1][r]);
+                            aD[bi][0][r] = aD[bi][1][r] = 0.f;
+                        } else {
+                            *q = make_double2(old[r].x + (double)aH[bi][0][r], old[r].y + (double)aH[bi][1][r]);
+                            aH[bi][0][r] = aH[bi][1][r] = 0.f;
                         }
+                    }
                 }
             }
         }
@@ -850,6 +874,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
         P.dbg[3] = wall_clock64();
     }
 }
+#undef MSM_F2
 
 // packed C and G contributions of the symmetric kernel's slabs: G += (H + D) / 2 and "C" += (H - D) / 4
 // (a symmetric matrix whose symmetrisation (C + C^T) / 2 is the lagged moment's)
