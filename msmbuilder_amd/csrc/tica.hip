@@ -705,22 +705,24 @@ template <bool PARTIAL>
 __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PAN = BK32 * TM;                  // floats per panel
-    // LDS images are INTERLEAVED: [buffer][frame][column] pairs (u, d) for the I columns and for the J columns,
-    // so that the 8 fragment values of a k-pair arrive with two ds_read2_b64.  For a lone wave per SIMD every
-    // LDS instruction costs ~12 cycles of MFMA issue (microbenchmarks, scripts/micro/mfma_sym.hip: 8 MFMAs fed
-    // by six ds_read_b32/read2_b32 from four separate panels run at 72 cycles per MFMA, by two ds_read2_b64 at 65).
+    constexpr int HK = BK32 / 2;                   // frames per half-step
+    constexpr int PAN = HK * TM;                    // floats per plane
     typedef float f2v __attribute__((ext_vector_type(2)));
-#define MSM_F2(P, O) (*reinterpret_cast<const f2v*>((P) + (O)))
     typedef float f4v __attribute__((ext_vector_type(4)));
-    // four planes [32 frames][128 columns]: u = x_t + x_{t+tau} and d = x_t - x_{t+tau} for the I columns, then for the
-    // J columns.  A lane's two MFMA row blocks are the ADJACENT columns 2l and 2l+1 (the accumulators hold a permuted
-    // tile, undone at the slab merge), so one ds_read2st64_b64 (u plane + d plane, 16 KiB apart) feeds four MFMAs,
-    // and the writer forms its sums/differences with packed adds on the loaded float4s -- no lane or register shuffles.
-    float* UI = reinterpret_cast<float*>(smem);
-    float* DI = UI + PAN;
-    float* UJ = DI + PAN;
-    float* DJ = UJ + PAN;
+#define MSM_F2(O) (*reinterpret_cast<const f2v*>(lds + (O)))
+#define MSM_SYM_UD(A, B)                                                                               \
+    {                                                                                                  \
+        const f4v a_ = *reinterpret_cast<const f4v*>(&(A)), b_ = *reinterpret_cast<const f4v*>(&(B));  \
+        const f4v u_ = a_ + b_, d_ = pk_sub4(a_, b_);                                                  \
+        A = *reinterpret_cast<const float4*>(&u_);                                                     \
+        B = *reinterpret_cast<const float4*>(&d_);                                                     \
+    }
+    // LDS: two buffers (half-steps of 16 frames ping-pong between them) of four planes [16 frames][128 columns]:
+    // u = x_t + x_{t+tau} and d = x_t - x_{t+tau} for the I columns, then for the J columns.  A lane's two MFMA row
+    // blocks are the ADJACENT columns 2l and 2l+1 (the accumulators hold a permuted tile, undone at the slab merge),
+    // so one ds_read2st64_b64 (u plane + d plane, 8 KiB apart) feeds four MFMAs, and the writer forms its
+    // sums/differences with packed adds on the loaded float4s -- no lane or register shuffles.
+    float* lds = reinterpret_cast<float*>(smem);   // [2 buffers][UI, DI, UJ, DJ][HK][TM]
 
     const int tid = threadIdx.x;
     const int p = xcd_linear_id();
@@ -765,73 +767,146 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
         const int nsteps = (ch.n + BK32 - 1) / BK32;
         ChunkCtx cx = make_ctx(P, ch);
         set_lag(cx, P.lag, sizeof(float), P.ld);
-        const LaneOffs lofs = make_lane_offs<true>(cx, P.F, I0, J0, tid);
         const int srow = tid >> 5, scol = (tid & 31) * 4;
-        // TWO workgroups per CU, ONE LDS image per workgroup (64 KiB): while this workgroup rewrites its image at
-        // the step boundary (barrier, 16 ds_write_b128 with the sums/differences, barrier) the co-resident one
-        // keeps the matrix pipes busy, as in the kernel above -- a lone workgroup per CU with a double-buffered
-        // image could not hide its own LDS / VMEM instructions (measured 56 ms against 67 ms for the C/G kernel;
-        // every non-MFMA instruction of a lone wave costs MFMA issue time).  The 16 global loads of step s+2 are
-        // interleaved into the MFMA stream of step s+1... i.e. the registers are refilled during k-pairs 0-7
-        // right after they were written to LDS, and have until the next boundary to land.
-        StageS st;
-        StageAddrS sa;
-        int un = 0;
-        stage_addr_sym(sa, st, un, cx, lofs, P.F, 0, I0, J0, tid);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            st.xa[j] = load16_global<char>(sa.pa + sa.oxa[j]);
-            st.xb[j] = load16_global<char>(sa.pb + sa.oxb[j]);
-            st.ya[j] = load16_global<char>(sa.pa + sa.oya[j]);
-            st.yb[j] = load16_global<char>(sa.pb + sa.oyb[j]);
+        const unsigned ca = 4u * (unsigned)(I0 + scol < P.F ? I0 + scol : P.F - 4), cb = 4u * (unsigned)(J0 + scol < P.F ? J0 + scol : P.F - 4);
+        // TWO workgroups per CU (64 KiB of LDS each).  Section timers of the single-image version showed what a step
+        // boundary costs there: each of its instructions (adds, LDS writes) issues only about once per MFMA of the
+        // co-resident wave (~90 cycles), while an instruction inside this wave's own MFMA stream costs ~10.  So nothing
+        // is left at the boundary: half-steps of 16 frames ping-pong between two LDS buffers, and while the 64 MFMAs of
+        // half-step h run, the wave loads half-step h+1 (k-pairs 0-1: 8 global_load_dwordx4, scalar base + one lane
+        // offset per panel), turns (x_t, x_{t+tau}) into (u, d) in place (k-pairs 5-6: packed adds) and writes it to
+        // the other buffer (k-pairs 6-7: 8 ds_write_b128).  One barrier per half-step.
+        // Half-steps that touch a trajectory edge (clamped rows, invalid pairs; a few per chunk) and the first one of
+        // a chunk are staged by a plain, exposed sequence instead (MSM_STAGE_EDGE).
+        const unsigned offx = (unsigned)srow * cx.ldb + ca, offy = (unsigned)srow * cx.ldb + cb;
+        float4 xa[2], xb[2], ya[2], yb[2];  // rows srow, srow + 8 of the half-step: t / t+tau, columns I (x) and J (y)
+        const int wofs = srow * TM + scol;  // floats; + buffer, plane, 8 rows
+#define MSM_STORE_X(BUF)                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                \
+            *reinterpret_cast<float4*>(lds + (BUF) * 4 * PAN + 0 * PAN + j * 8 * TM + wofs) = xa[j];   \
+            *reinterpret_cast<float4*>(lds + (BUF) * 4 * PAN + 1 * PAN + j * 8 * TM + wofs) = xb[j];   \
         }
+#define MSM_STORE_Y(BUF)                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                \
+            *reinterpret_cast<float4*>(lds + (BUF) * 4 * PAN + 2 * PAN + j * 8 * TM + wofs) = ya[j];   \
+            *reinterpret_cast<float4*>(lds + (BUF) * 4 * PAN + 3 * PAN + j * 8 * TM + wofs) = yb[j];   \
+        }
+#define MSM_STAGE_EDGE(K0, BUF)                                                                        \
+        {                                                                                              \
+            float sc_[2];                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+                const int kr = (K0) + srow + 8 * j;                                                    \
+                const unsigned ra = (unsigned)(kr < cx.nmax ? kr : cx.nmax) * cx.ldb;                  \
+                const unsigned rb = (unsigned)(kr < cx.nmaxB ? kr : cx.nmaxB) * cx.ldb;                \
+                xa[j] = load16_global<char>(cx.base + (ra + ca));                                      \
+                xb[j] = load16_global<char>(cx.baseB + (rb + ca));                                     \
+                ya[j] = load16_global<char>(cx.base + (ra + cb));                                      \
+                yb[j] = load16_global<char>(cx.baseB + (rb + cb));                                     \
+                sc_[j] = (kr < cx.hi) ? 1.f : 0.f;                                                     \
+            }                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+                const float4 wa = PARTIAL ? make_float4(sc_[j] * ma.x, sc_[j] * ma.y, sc_[j] * ma.z, sc_[j] * ma.w) \
+                                          : make_float4(sc_[j], sc_[j], sc_[j], sc_[j]);               \
+                xa[j] = f4mul(xa[j], wa);                                                              \
+                xb[j] = f4mul(xb[j], wa);                                                              \
+                if (PARTIAL) {                                                                         \
+                    ya[j] = f4mul(ya[j], mb);                                                          \
+                    yb[j] = f4mul(yb[j], mb);                                                          \
+                }                                                                                      \
+                MSM_SYM_UD(xa[j], xb[j])                                                               \
+                MSM_SYM_UD(ya[j], yb[j])                                                               \
+            }                                                                                          \
+            MSM_STORE_X(BUF)                                                                           \
+            MSM_STORE_Y(BUF)                                                                           \
+        }
+#define MSM_SYM_FRAGS(BUF, KK)                                                                         \
+                    const f2v npu = MSM_F2((BUF) * 4 * PAN + 0 * PAN + (KK) * 2 * TM + fa),            \
+                              npd = MSM_F2((BUF) * 4 * PAN + 1 * PAN + (KK) * 2 * TM + fa),            \
+                              nqu = MSM_F2((BUF) * 4 * PAN + 2 * PAN + (KK) * 2 * TM + fb),            \
+                              nqd = MSM_F2((BUF) * 4 * PAN + 3 * PAN + (KK) * 2 * TM + fb);
+#define MSM_SYM_MFMAS                                                                                  \
+                    __builtin_amdgcn_sched_barrier(0);                                                 \
+                    aH[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.x, qu.x, aH[0][0], 0, 0, 0);    \
+                    aH[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.x, qu.y, aH[0][1], 0, 0, 0);    \
+                    aH[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.y, qu.x, aH[1][0], 0, 0, 0);    \
+                    aH[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.y, qu.y, aH[1][1], 0, 0, 0);    \
+                    aD[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.x, qd.x, aD[0][0], 0, 0, 0);    \
+                    aD[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.x, qd.y, aD[0][1], 0, 0, 0);    \
+                    aD[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.y, qd.x, aD[1][0], 0, 0, 0);    \
+                    aD[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.y, qd.y, aD[1][1], 0, 0, 0);    \
+                    __builtin_amdgcn_sched_barrier(0);                                                 \
+                    pu = npu; pd = npd; qu = nqu; qd = nqd;
+        __syncthreads();  // every wave is done with both buffers (previous chunk)
+        MSM_STAGE_EDGE(0, 0)
+        __syncthreads();
+        PROF_MARK(0)
         const int fa = kl * TM + wr * 64 + 2 * cl, fb = kl * TM + wc * 64 + 2 * cl;  // floats
         for (int s = 0; s < nsteps; ++s) {
-            // ---- boundary: the image of step s (sums and differences of the staged rows) replaces that of step s-1 ----
-            __syncthreads();  // every wave has read its last fragments of the previous step
-            if (PARTIAL || !un) stage_scale_sym<PARTIAL>(st, un, ma, mb);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = (srow + 8 * j) * TM + scol;
-                const f4v xa = *reinterpret_cast<const f4v*>(&st.xa[j]), xb = *reinterpret_cast<const f4v*>(&st.xb[j]);
-                const f4v ya = *reinterpret_cast<const f4v*>(&st.ya[j]), yb = *reinterpret_cast<const f4v*>(&st.yb[j]);
-                *reinterpret_cast<f4v*>(UI + o) = xa + xb;
-                *reinterpret_cast<f4v*>(DI + o) = pk_sub4(xa, xb);
-                *reinterpret_cast<f4v*>(UJ + o) = ya + yb;
-                *reinterpret_cast<f4v*>(DJ + o) = pk_sub4(ya, yb);
-            }
-            stage_addr_sym(sa, st, un, cx, lofs, P.F, (s + 1) * BK32, I0, J0, tid);
-            __syncthreads();
-            f2v pu = MSM_F2(UI, fa), pd = MSM_F2(DI, fa), qu = MSM_F2(UJ, fb), qd = MSM_F2(DJ, fb);
-            PROF_MARK(1)
+            for (int b = 0; b < 2; ++b) {  // half-step h = 2 s + b reads buffer b and fills buffer b ^ 1 with h + 1
+                const int k1 = s * BK32 + (b + 1) * HK;
+                const bool more = b == 0 || s + 1 < nsteps;
+                const int lastrow = k1 + HK - 1;
+                const bool fast = more && lastrow <= cx.nmax && lastrow <= cx.nmaxB && lastrow < cx.hi;  // uniform
+                // ONE code path through the MFMAs (two variants of the loop make the compiler keep two copies of the 128
+                // accumulators): a half-step that must not take the fast staging still runs it, on row 0 of the chunk
+                // (always readable), and the edge sequence after the loop overwrites what it wrote
+                const size_t kb = fast ? (size_t)k1 * cx.ldb : 0, r8 = fast ? (size_t)8 * cx.ldb : 0;  // scalar
+                const global_ptr<char> pa = cx.base + kb, pb = cx.baseB + kb;
+                const unsigned ox = fast ? offx : ca, oy = fast ? offy : cb;
+                f2v pu = MSM_F2(b * 4 * PAN + 0 * PAN + fa), pd = MSM_F2(b * 4 * PAN + 1 * PAN + fa);
+                f2v qu = MSM_F2(b * 4 * PAN + 2 * PAN + fb), qd = MSM_F2(b * 4 * PAN + 3 * PAN + fb);
+                PROF_MARK(1)
 #pragma unroll
-            for (int kk = 0; kk < BK32 / 2; ++kk) {
-                const int kn = (kk + 1 < BK32 / 2) ? kk + 1 : kk;
-                const f2v npu = MSM_F2(UI, kn * 2 * TM + fa), npd = MSM_F2(DI, kn * 2 * TM + fa);
-                const f2v nqu = MSM_F2(UJ, kn * 2 * TM + fb), nqd = MSM_F2(DJ, kn * 2 * TM + fb);
-                if (kk < 8) {  // step s+1 -> registers: two rows of x (even kk) or y (odd kk) per k-pair
-                    if ((kk & 1) == 0) {
-                        st.xa[kk / 2] = load16_global<char>(sa.pa + sa.oxa[kk / 2]);
-                        st.xb[kk / 2] = load16_global<char>(sa.pb + sa.oxb[kk / 2]);
-                    } else {
-                        st.ya[kk / 2] = load16_global<char>(sa.pa + sa.oya[kk / 2]);
-                        st.yb[kk / 2] = load16_global<char>(sa.pb + sa.oyb[kk / 2]);
+                for (int kk = 0; kk < HK / 2; ++kk) {
+                    MSM_SYM_FRAGS(b, (kk + 1 < HK / 2 ? kk + 1 : kk))
+                    if (kk == 0) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            xa[j] = load16_global<char>(pa + j * r8 + ox);
+                            xb[j] = load16_global<char>(pb + j * r8 + ox);
+                        }
+                    } else if (kk == 1) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            ya[j] = load16_global<char>(pa + j * r8 + oy);
+                            yb[j] = load16_global<char>(pb + j * r8 + oy);
+                        }
+                    } else if (kk == 5) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (PARTIAL) {
+                                xa[j] = f4mul(xa[j], ma);
+                                xb[j] = f4mul(xb[j], ma);
+                            }
+                            MSM_SYM_UD(xa[j], xb[j])
+                        }
+                    } else if (kk == 6) {
+                        MSM_STORE_X(b ^ 1)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (PARTIAL) {
+                                ya[j] = f4mul(ya[j], mb);
+                                yb[j] = f4mul(yb[j], mb);
+                            }
+                            MSM_SYM_UD(ya[j], yb[j])
+                        }
+                    } else if (kk == 7) {
+                        MSM_STORE_Y(b ^ 1)
                     }
+                    MSM_SYM_MFMAS
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                aH[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.x, qu.x, aH[0][0], 0, 0, 0);
-                aH[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.x, qu.y, aH[0][1], 0, 0, 0);
-                aH[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.y, qu.x, aH[1][0], 0, 0, 0);
-                aH[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu.y, qu.y, aH[1][1], 0, 0, 0);
-                aD[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.x, qd.x, aD[0][0], 0, 0, 0);
-                aD[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.x, qd.y, aD[0][1], 0, 0, 0);
-                aD[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.y, qd.x, aD[1][0], 0, 0, 0);
-                aD[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd.y, qd.y, aD[1][1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                pu = npu; pd = npd; qu = nqu; qd = nqd;
+                if (more && !fast) MSM_STAGE_EDGE(k1, b ^ 1)
+                PROF_MARK(2)
+                __syncthreads();  // buffer b ^ 1 is complete, buffer b is free
+                PROF_MARK(3)
             }
-            PROF_MARK(2)
         }
+#undef MSM_STAGE_EDGE
+#undef MSM_SYM_MFMAS
+#undef MSM_SYM_FRAGS
+#undef MSM_STORE_X
+#undef MSM_STORE_Y
         rows_acc += ch.n;
         if (rows_acc + P.kc > KFLUSH_SYM || c + P.S >= P.nchunks) {
             rows_acc = 0;
@@ -875,6 +950,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
     }
 }
 #undef MSM_F2
+#undef MSM_SYM_UD
 
 // packed C and G contributions of the symmetric kernel's slabs: G += (H + D) / 2 and "C" += (H - D) / 4
 // (a symmetric matrix whose symmetrisation (C + C^T) / 2 is the lagged moment's)

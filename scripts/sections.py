@@ -13,7 +13,7 @@ ms = C.c_float(); _lib.check(_lib.lib().msm_tica_last_kernel_ms(m._handle, C.byr
 out = (C.c_int64 * 64)()
 _lib.check(_lib.lib().msm_tica_debug_profile(m._handle, out))
 print("kernel %.2f ms; wave-0 clocks %d" % (ms.value, out[1] - out[0]))
-names = (["chunk prologue", "stores..barrier 2", "MFMA loop", "wait at barrier 1", "final", "slab merge + chunk switch"] if os.environ.get("MSM_TICA_SYM", "1") != "0"
+names = (["chunk prologue", "first fragments", "MFMA stream", "barrier", "final", "slab merge + chunk switch"] if os.environ.get("MSM_TICA_SYM", "1") != "0"
          else ["chunk prologue", "step head", "MFMA loop", "step tail", "final merge", "inter-chunk merge"])
 for slot in range(5):
     v = [out[8 + 8 * slot + i] for i in range(6)]
