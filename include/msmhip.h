@@ -266,6 +266,16 @@ int msm_mbk_set_counts(msm_mbk_t* h, const float* counts);
 int msm_mbk_get(msm_mbk_t* h, float* centers, float* counts);
 int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
                  double* batch_inertia, float* counts_out, int apply_update, int on_device);
+/* S consecutive plain steps (label + streaming-mean update, as msm_mbk_step with apply_update = 1) on device-resident X
+ * with ONE host synchronisation: batch_idx is [S][B] (host), and sklearn's _mini_batch_convergence (_kmeans.py:1963-2027,
+ * the tol == 0 / verbose == 0 branch) runs on the device after every step -- state6 = {ewa_inertia, ewa_inertia_min,
+ * no_improvement, have_ewa, have_min, (out) steps executed}, alpha = min(1, 2 B / (n_samples + 1)), max_no_improvement < 0
+ * = None.  Steps queued behind the one at which the criterion fires are not executed: *steps_done <= S says how many were,
+ * inertias[0 .. steps_done) are their batch inertias, *converged the criterion.  first_step = index of the run's first
+ * step in the fit (step 0 is excluded from the moving average, as in sklearn). */
+int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
+                msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
 msm_idx_t msm_mbk_packed_size(msm_mbk_t* h);
 int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device);
 int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int on_device);

@@ -70,27 +70,40 @@ def kmeans_plusplus(X, n_clusters, random_state):
     center_id = random_state.choice(n_samples, p=sample_weight / sample_weight.sum())
     centers[0] = X[center_id]
     xsq = np.einsum("ij,ij->i", X, X)
+    Xm2 = np.ascontiguousarray(-2.0 * X)  # -2 x.c as c.(-2 x): an exact scaling, one pass less per round
+    d = np.empty((n_local_trials, n_samples), dtype=X.dtype)
 
-    def sqdist(c):  # [len(c), n_samples], same ||x||^2 - 2 x.c + ||c||^2 form as sklearn
-        d = -2.0 * (c @ X.T)
-        d += xsq[None, :]
-        d += np.einsum("ij,ij->i", c, c)[:, None]
-        np.maximum(d, 0, out=d)
-        return d
+    def sqdist(c, out):  # [len(c), n_samples], same ||x||^2 - 2 x.c + ||c||^2 form as sklearn
+        np.dot(c, Xm2.T, out=out)
+        out += xsq[None, :]
+        out += np.einsum("ij,ij->i", c, c)[:, None]
+        np.maximum(out, 0, out=out)
+        return out
 
-    closest = sqdist(centers[0:1])[0]
+    import os
+    from ..decomposition._moments import _blas_limit
+    closest = sqdist(centers[0:1], np.empty((1, n_samples), dtype=X.dtype))[0].copy()
     current_pot = closest @ sample_weight
+    cum = np.empty(n_samples)
+    # a thousand tiny sgemms: a large BLAS pool costs more in wake-ups than it computes (and keeps spinning afterwards)
+    with _blas_limit(int(os.environ.get("MSMBUILDER_AMD_KPP_THREADS", "8"))):
+        _kpp_rounds(X, centers, n_clusters, n_local_trials, sample_weight, random_state, sqdist, d, closest, current_pot, cum)
+    return centers
+
+
+def _kpp_rounds(X, centers, n_clusters, n_local_trials, sample_weight, random_state, sqdist, d, closest, current_pot, cum):
+    n_samples = X.shape[0]
     for c in range(1, n_clusters):
         rand_vals = random_state.uniform(size=n_local_trials) * current_pot
-        cum = np.cumsum(sample_weight * closest, dtype=np.float64)
+        np.cumsum(closest, dtype=np.float64, out=cum)   # sample_weight == 1
         candidate_ids = np.searchsorted(cum, rand_vals)
-        np.clip(candidate_ids, None, closest.size - 1, out=candidate_ids)
-        d_cand = sqdist(X[candidate_ids])
+        np.clip(candidate_ids, None, n_samples - 1, out=candidate_ids)
+        d_cand = sqdist(X[candidate_ids], d)
         np.minimum(closest, d_cand, out=d_cand)
-        pots = (d_cand @ sample_weight.reshape(-1, 1)).ravel()
+        pots = d_cand @ sample_weight
         best = np.argmin(pots)
         current_pot = pots[best]
-        closest = d_cand[best]
+        closest = d_cand[best].copy()
         centers[c] = X[candidate_ids[best]]
     return centers
 
@@ -245,7 +258,16 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                                  self._counts.ctypes.data, 1, ax.on_device))
             inertia_v = float(inertia.value)
 
-        if random_reassign and self.reassignment_ratio > 0:
+        if random_reassign:
+            self._reassign(ax, shard, batch_idx, random_state)
+        return inertia_v
+
+    def _reassign(self, ax, shard, batch_idx, random_state):
+        """The starved-centre part of ``_mini_batch_step`` (_kmeans.py:1620-1662), decided on the host from the
+        counts the step returned, with scikit-learn's RNG calls."""
+        L = _lib.lib()
+        B = len(batch_idx)
+        if self.reassignment_ratio > 0:
             weight_sums = self._counts
             to_reassign = weight_sums < self.reassignment_ratio * weight_sums.max()
             # pick at most .5 * batch_size samples as new centers
@@ -270,7 +292,48 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                 if to_reassign.any():
                     weight_sums[to_reassign] = mn
                     check(L.msm_mbk_set_counts(self._mbk, weight_sums.ctypes.data))
-        return inertia_v
+
+    def _run(self, ax, shard, first_step, n_steps, n_samples, random_state):
+        """Steps ``first_step ...`` up to and including the next one that looks at the counts for a random
+        reassignment, queued on the device in one go (``msm_mbk_run``): the batches are drawn up front, the
+        convergence bookkeeping of ``_mini_batch_convergence`` runs on the device after every step, and the host
+        synchronises once per run instead of twice per step.  Returns (steps executed, converged).  Only the last step
+        of a run may reassign, so the ``RandomState`` call sequence is scikit-learn's; if the criterion fires early the
+        generator is rewound to where scikit-learn would have left it."""
+        L = _lib.lib()
+        B = self._batch_size
+        plan, since = [], self._n_since_last_reassign
+        while first_step + len(plan) < n_steps and len(plan) < 256:
+            since += B
+            hit = since >= 10 * self.n_clusters
+            plan.append(hit)
+            if hit:
+                break
+        S = len(plan)
+        idx = np.empty((S, B), dtype=np.int64)
+        states = []
+        for k in range(S):
+            idx[k] = random_state.randint(0, n_samples, B)
+            states.append(random_state.get_state() if k + 1 < S else None)
+        alpha = min(B * 2.0 / (n_samples + 1), 1)
+        st = np.array([self._ewa_inertia or 0.0, self._ewa_inertia_min or 0.0, float(self._no_improvement),
+                       0.0 if self._ewa_inertia is None else 1.0, 0.0 if self._ewa_inertia_min is None else 1.0, 0.0])
+        done, conv = C.c_int64(0), C.c_int(0)
+        inertias = np.empty(S)
+        mni = -1 if self.max_no_improvement is None else int(self.max_no_improvement)
+        check(L.msm_mbk_run(self._mbk, ax.vp, ax.shape[0], idx.ctypes.data, S, B, first_step, alpha, mni,
+                            st.ctypes.data, C.byref(done), C.byref(conv), inertias.ctypes.data, self._counts.ctypes.data))
+        done = int(done.value)
+        self._ewa_inertia = float(st[0]) if st[3] else None
+        self._ewa_inertia_min = float(st[1]) if st[4] else None
+        self._no_improvement = int(st[2])
+        self._n_since_last_reassign += done * B
+        if done == S and plan[-1]:
+            self._n_since_last_reassign = 0
+            self._reassign(ax, shard, idx[-1], random_state)
+        elif done < S:
+            random_state.set_state(states[done - 1])
+        return done, bool(conv.value)
 
     def _mbk_open(self, centers, counts):
         h = C.c_void_p()
@@ -339,20 +402,30 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         n_steps = (self.max_iter * n_samples) // self._batch_size
         i = -1
         self._mbk_open(centers, self._counts)
+        import os
+        from .. import parallel
+        runs = (ax.on_device and not parallel.active() and not self.verbose and self._tol == 0.0
+                and os.environ.get("MSMBUILDER_AMD_MBK_RUNS", "1") != "0")
         try:
-            for i in range(n_steps):
-                minibatch_indices = random_state.randint(0, n_samples, self._batch_size)
-                minibatch_indices = np.ascontiguousarray(minibatch_indices, dtype=np.int64)
-                if self._tol > 0.0:  # the tol criterion needs the centres on the host every step
-                    prev = np.empty_like(centers)
-                    check(_lib.lib().msm_mbk_get(self._mbk, prev.ctypes.data, None))
-                batch_inertia = self._step(ax, shard, minibatch_indices, random_state, self._random_reassign())
-                centers_squared_diff = 0
-                if self._tol > 0.0:
-                    cur = np.empty_like(centers)
-                    check(_lib.lib().msm_mbk_get(self._mbk, cur.ctypes.data, None))
-                    centers_squared_diff = np.sum((cur - prev) ** 2)
-                if self._mini_batch_convergence(i, n_steps, n_samples, centers_squared_diff, batch_inertia):
+            while i + 1 < n_steps:
+                if runs and not (self._counts == 0).any():
+                    done, converged = self._run(ax, shard, i + 1, n_steps, n_samples, random_state)
+                    i += done
+                else:  # one step at a time: starved centres (the first steps), tol > 0, verbose, host data, multi-GPU
+                    i += 1
+                    minibatch_indices = random_state.randint(0, n_samples, self._batch_size)
+                    minibatch_indices = np.ascontiguousarray(minibatch_indices, dtype=np.int64)
+                    if self._tol > 0.0:  # the tol criterion needs the centres on the host every step
+                        prev = np.empty_like(centers)
+                        check(_lib.lib().msm_mbk_get(self._mbk, prev.ctypes.data, None))
+                    batch_inertia = self._step(ax, shard, minibatch_indices, random_state, self._random_reassign())
+                    centers_squared_diff = 0
+                    if self._tol > 0.0:
+                        cur = np.empty_like(centers)
+                        check(_lib.lib().msm_mbk_get(self._mbk, cur.ctypes.data, None))
+                        centers_squared_diff = np.sum((cur - prev) ** 2)
+                    converged = self._mini_batch_convergence(i, n_steps, n_samples, centers_squared_diff, batch_inertia)
+                if converged:
                     break
         finally:
             centers = self._mbk_close()

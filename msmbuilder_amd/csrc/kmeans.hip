@@ -40,6 +40,8 @@ struct KmArgs {
     long long jspan;        // 0 = all centres in one workgroup
     float* pv;
     int* pi;
+    const int* stop;        // optional device flag: non-zero -> the launch does nothing (msm_mbk_run: steps queued
+                            // behind the one at which the convergence criterion fired)
 };
 
 __device__ __forceinline__ void km_load(float4 (&xa)[4], float4 (&ca)[4], const KmArgs& P,
@@ -97,6 +99,7 @@ __device__ __forceinline__ void km_store(const float4 (&xa)[4], const float4 (&c
 
 __global__ __launch_bounds__(KNT, 2) void kmeans_label_kernel(KmArgs P)
 {
+    if (P.stop && *P.stop) return;  // uniform
     __shared__ float Xs[2][KR * KP];
     __shared__ float Cs[2][KCT * KP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -310,6 +313,7 @@ struct KmStage {
 template <bool GATHER>
 __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 {
+    if (P.stop && *P.stop) return;  // uniform
     extern __shared__ __attribute__((aligned(16))) char km_smem[];
     float* Xs = reinterpret_cast<float*>(km_smem);  // [2][KR * KP4]
     float* Cs = Xs + 2 * KR * KP4;                  // [2][KCT * KP4]
@@ -517,6 +521,7 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 // per-block fp64 partial sums for the inertia.
 __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* __restrict__ partial)
 {
+    if (P.stop && *P.stop) return;  // uniform
     __shared__ double red[KNT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double tot = 0.0;
@@ -538,20 +543,23 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// One workgroup per centre: scan the batch labels, visit members in batch order.
-// apply != 0: sklearn's streaming-mean update in fp32, in place on centers/counts.
+// One workgroup per centre: find the centre's members in the batch (ordered compaction by the whole workgroup:
+// wave ballots + a 4-entry prefix; the first version let thread 0 walk the labels alone, 183 us per step at
+// K = 1000, B = 1024), visit them in batch order.
+// apply != 0: sklearn's streaming-mean update in fp32, in place on centers/counts, and the centre's new ||c||^2
+//             (same lane partition and butterfly as kmeans_cnorm_kernel: bit-identical to a separate launch).
 // sums/cnts (nullable): fp64 batch sums and counts for the multi-GPU all-reduce.
 __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __restrict__ centers,
-                                                         float* __restrict__ counts,
+                                                         float* __restrict__ counts, float* __restrict__ cnorm,
                                                          double* __restrict__ sums,
                                                          double* __restrict__ cnts, int apply)
 {
-    extern __shared__ int members[];  // compacted member positions, chunked
-    __shared__ int nmem;
-    const int j = blockIdx.x, tid = threadIdx.x;
+    if (P.stop && *P.stop) return;
+    extern __shared__ int members[];  // compacted member positions of one chunk
+    __shared__ int wcnt[KNT / 64];
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int CH = 4096;
     const float w_old = counts[j];
-    // per-thread feature accumulators live in a loop over feature blocks of KNT
     long long total = 0;
     for (long long f0 = 0; f0 < P.m; f0 += KNT) {
         const long long f = f0 + tid;
@@ -559,13 +567,19 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
         double acc64 = 0.0;
         long long cnt = 0;
         for (long long b0 = 0; b0 < P.n; b0 += CH) {
-            __syncthreads();
-            if (tid == 0) {
-                int k = 0;
-                const long long be = std::min<long long>(P.n, b0 + CH);
-                for (long long b = b0; b < be; ++b)
-                    if (P.labels[b] == j) members[k++] = (int)(b - b0);
-                nmem = k;
+            const long long be = std::min<long long>(P.n, b0 + CH);
+            int nmem = 0;
+            for (long long sb = b0; sb < be; sb += KNT) {
+                const long long pos = sb + tid;
+                const bool mine = pos < be && P.labels[pos] == j;
+                const unsigned long long bal = __ballot(mine);
+                __syncthreads();  // wcnt / members of the previous round are consumed
+                if (lane == 0) wcnt[wave] = __popcll(bal);
+                __syncthreads();
+                int base = nmem;
+                for (int w = 0; w < wave; ++w) base += wcnt[w];
+                if (mine) members[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)(pos - b0);
+                nmem += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             }
             __syncthreads();
             cnt += nmem;
@@ -589,17 +603,29 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
             }
         }
     }
-    __syncthreads();
+    __syncthreads();  // the centre row is complete (workgroup-scope visibility)
     if (tid == 0) {
         if (cnts) cnts[j] = (double)total;
         if (apply && total > 0) counts[j] = w_old + (float)total;
+    }
+    if (apply && cnorm && total > 0 && wave == 0) {
+        const volatile float* c = centers + (long long)j * P.m;
+        float sq = 0.f;
+        for (long long f = lane; f < P.m; f += 64) {
+            const float v = c[f];
+            sq += v * v;
+        }
+#pragma unroll
+        for (int msk = 32; msk > 0; msk >>= 1) sq += __shfl_xor(sq, msk, 64);
+        if (lane == 0) cnorm[j] = sq;
     }
 }
 
 // finish a centre-split labelling: lowest (value, index) over the splits
 __global__ void kmeans_label_reduce_kernel(const float* __restrict__ pv, const int* __restrict__ pi, long long n,
-                                           int nsplit, int32_t* __restrict__ labels)
+                                           int nsplit, int32_t* __restrict__ labels, const int* __restrict__ stop)
 {
+    if (stop && *stop) return;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float bv = pv[i];
@@ -645,6 +671,49 @@ __global__ __launch_bounds__(KNT) void mbk_finish_kernel(const double* __restric
     }
     if (threadIdx.x == 0) *out_inertia = red[0];
     for (long long j = threadIdx.x; j < K; j += KNT) out_counts[j] = counts[j];
+}
+
+// msm_mbk_run: end of one queued step.  Sums the inertia partials, then plays sklearn's _mini_batch_convergence
+// (_kmeans.py:1963-2027, tol = 0 and verbose = 0 branch) in float64 on the device so that the host does not have to
+// look at every step: st = {ewa, ewa_min, no_improvement, have_ewa, have_min, steps_done}.  Plain IEEE operations in
+// the host's order (no contraction: the file's arithmetic here is written with __dmul_rn / __dadd_rn).
+__global__ __launch_bounds__(KNT) void mbk_converge_kernel(const double* __restrict__ partial, int nb, double* __restrict__ st,
+                                                           int* __restrict__ stop, double* __restrict__ inertias,
+                                                           long long step_index, double batch_size, double alpha,
+                                                           long long max_no_improvement)
+{
+    if (*stop) return;
+    __shared__ double red[KNT];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += KNT) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = KNT / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double inertia = red[0];
+    inertias[(long long)st[5]] = inertia;
+    st[5] += 1.0;
+    if (step_index == 0) return;  // "ignore first iteration because it's inertia from initialization"
+    const double bi = inertia / batch_size;
+    double ewa;
+    if (st[3] == 0.0) {
+        ewa = bi;
+        st[3] = 1.0;
+    } else {
+        ewa = __dadd_rn(__dmul_rn(st[0], __dadd_rn(1.0, -alpha)), __dmul_rn(bi, alpha));
+    }
+    st[0] = ewa;
+    if (st[4] == 0.0 || ewa < st[1]) {
+        st[2] = 0.0;
+        st[1] = ewa;
+        st[4] = 1.0;
+    } else {
+        st[2] += 1.0;
+    }
+    if (max_no_improvement >= 0 && st[2] >= (double)max_no_improvement) *stop = 1;
 }
 
 // centres (+counts) <- (centres * w + batch sums) / (w + n) from all-reduced fp64 sums (multi-GPU)
@@ -751,12 +820,17 @@ struct msm_mbk {
     double* packed = nullptr;  // [K*m | K | 1] batch sums, counts, inertia (fp64)
     char* outbuf = nullptr;    // [8 + 4K]
     DevBuf labels, idx, xb, pv, pi, part, rows, which;
+    // msm_mbk_run: [6 doubles of convergence state | S inertias] and the stop flag on the device; pinned host mirror
+    DevBuf runbuf;
+    int* stop = nullptr;
+    char* pinned = nullptr;
+    size_t pinned_bytes = 0;
 };
 
 namespace {
 
 int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n, int32_t* labels_d, double* inertia_dev_partial,
-              int* nb_out)
+              int* nb_out, const int* stop = nullptr)
 {
     KmArgs P;
     memset(&P, 0, sizeof(P));
@@ -768,6 +842,7 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
     P.C = h->centers;
     P.cnorm = h->cnorm;
     P.labels = labels_d;
+    P.stop = stop;
     const long long rowblocks = ceil_div(n, KR);
     const long long ctiles = ceil_div(h->K, KCT);
     int nsplit = 1;
@@ -785,7 +860,7 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
         P.pi = h->pi.as<int>();
         if ((rc = km_launch_label(P, dim3((unsigned)rowblocks, (unsigned)nsplit)))) return rc;
         hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
-                           P.pv, P.pi, n, nsplit, labels_d);
+                           P.pv, P.pi, n, nsplit, labels_d, P.stop);
     } else {
         if ((rc = km_launch_label(P, dim3((unsigned)rowblocks)))) return rc;
     }
@@ -859,6 +934,8 @@ int msm_mbk_destroy(msm_mbk_t* h)
     if (h->cnorm) (void)hipFree(h->cnorm);
     if (h->packed) (void)hipFree(h->packed);
     if (h->outbuf) (void)hipFree(h->outbuf);
+    if (h->stop) (void)hipFree(h->stop);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     delete h;
     return MSM_OK;
 }
@@ -905,14 +982,9 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
     P.K = h->K;
     P.labels = h->labels.as<int32_t>();
     hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
-                       h->counts, apply_update ? (double*)nullptr : h->packed,
+                       h->counts, h->cnorm, apply_update ? (double*)nullptr : h->packed,
                        apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update);
     MSM_HIP_CHECK(hipGetLastError());
-    if (apply_update) {
-        hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K,
-                           h->m, h->cnorm);
-        MSM_HIP_CHECK(hipGetLastError());
-    }
     double* d_inertia = apply_update ? reinterpret_cast<double*>(h->outbuf) : h->packed + (size_t)h->K * h->m + h->K;
     hipLaunchKernelGGL(mbk_finish_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->counts, h->K,
                        d_inertia, reinterpret_cast<float*>(h->outbuf + 8));
@@ -927,6 +999,76 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     if (batch_inertia) memcpy(batch_inertia, hb.data(), 8);
     if (counts_out) memcpy(counts_out, hb.data() + 8, (size_t)h->K * sizeof(float));
+    return MSM_OK;
+}
+
+int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
+                msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
+{
+    if (!h || !X || !batch_idx || !state6 || !steps_done || !converged || !inertias)
+        return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
+    if (n < 1 || B < 1 || S < 1 || S > 4096) return fail(MSM_ERR_INVALID, "msm_mbk_run: bad shape");
+    for (msm_idx_t b = 0; b < S * B; ++b)
+        if (batch_idx[b] < 0 || batch_idx[b] >= n) return fail(MSM_ERR_INVALID, "mbk: batch index out of range");
+    int rc;
+    const size_t idx_bytes = (size_t)S * B * sizeof(msm_idx_t);
+    const size_t st_bytes = (6 + (size_t)S) * sizeof(double);
+    const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(float);
+    const size_t need = idx_bytes + 64 + out_bytes;  // [indices | initial state | results]
+    if (h->pinned_bytes < need) {
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        h->pinned = nullptr;
+        h->pinned_bytes = 0;
+        MSM_HIP_CHECK(hipHostMalloc((void**)&h->pinned, need, hipHostMallocDefault));
+        h->pinned_bytes = need;
+    }
+    if (!h->stop) MSM_HIP_CHECK(hipMalloc((void**)&h->stop, sizeof(int)));
+    if ((rc = h->idx.reserve(idx_bytes))) return rc;
+    if ((rc = h->runbuf.reserve(st_bytes))) return rc;
+    if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
+    if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
+    double* st = h->runbuf.as<double>();
+    // in: indices of all S batches, convergence state (steps_done restarts at 0)
+    memcpy(h->pinned, batch_idx, idx_bytes);
+    MSM_HIP_CHECK(hipMemcpyAsync(h->idx.p, h->pinned, idx_bytes, hipMemcpyHostToDevice, stream()));
+    double* st0 = reinterpret_cast<double*>(h->pinned + idx_bytes);
+    for (int i = 0; i < 5; ++i) st0[i] = state6[i];
+    st0[5] = 0.0;
+    MSM_HIP_CHECK(hipMemcpyAsync(st, st0, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, sizeof(int), stream()));
+    for (msm_idx_t s = 0; s < S; ++s) {
+        const msm_idx_t* rows_d = h->idx.as<msm_idx_t>() + (size_t)s * B;
+        int nb = 0;
+        if ((rc = mbk_label(h, X, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
+        KmArgs P;
+        memset(&P, 0, sizeof(P));
+        P.X = X;
+        P.rows = rows_d;
+        P.n = B;
+        P.m = h->m;
+        P.K = h->K;
+        P.labels = h->labels.as<int32_t>();
+        P.stop = h->stop;
+        hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
+                           h->counts, h->cnorm, (double*)nullptr, (double*)nullptr, 1);
+        hipLaunchKernelGGL(mbk_converge_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, st, h->stop,
+                           st + 6, (long long)(first_step + s), (double)B, alpha, (long long)max_no_improvement);
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    // out: [state | inertias | stop | counts] through the pinned mirror, one synchronisation for the whole run
+    char* o = h->pinned + idx_bytes + 64;
+    MSM_HIP_CHECK(hipMemcpyAsync(o, st, st_bytes, hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes, h->stop, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes + 8, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    const double* so = reinterpret_cast<const double*>(o);
+    for (int i = 0; i < 5; ++i) state6[i] = so[i];
+    state6[5] = so[5];
+    *steps_done = (msm_idx_t)so[5];
+    memcpy(inertias, so + 6, (size_t)(*steps_done) * sizeof(double));
+    *converged = *reinterpret_cast<const int*>(o + st_bytes);
+    if (counts_out) memcpy(counts_out, o + st_bytes + 8, (size_t)h->K * sizeof(float));
     return MSM_OK;
 }
 
@@ -1115,7 +1257,7 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
         dCnts = dSums + (size_t)K * m;
     }
     hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)K), dim3(KNT), 4096 * sizeof(int), stream(), P,
-                       dCent, dW.as<float>(), dSums, dCnts, apply_update);
+                       dCent, dW.as<float>(), (float*)nullptr, dSums, dCnts, apply_update);
     MSM_HIP_CHECK(hipGetLastError());
     if (apply_update) {
         MSM_HIP_CHECK(hipMemcpyAsync(centers, dCent, (size_t)K * m * sizeof(float), hipMemcpyDeviceToHost, stream()));

@@ -98,3 +98,33 @@ def test_minibatch_device_resident(gpu):
     np.testing.assert_array_equal(host.cluster_centers_, dev.cluster_centers_)
     assert dev.labels_[0].is_cuda
     np.testing.assert_array_equal(host.labels_[0], dev.labels_[0].cpu().numpy())
+
+
+@pytest.mark.parametrize("K,B,mni", [(200, 128, 10), (50, 256, 3), (300, 1024, None)])
+def test_minibatch_queued_runs_equal_step_by_step(gpu, monkeypatch, K, B, mni):
+    """msm_mbk_run (steps queued on the device, convergence bookkeeping on the device, one synchronisation per run)
+    against the step-by-step path: the same kernels in the same order, so bit-identical centres, step count and
+    inertia -- also against scikit-learn -- and the caller's RandomState is left where scikit-learn leaves it."""
+    torch = pytest.importorskip("torch")
+    sk = pytest.importorskip("sklearn.cluster")
+    from msmbuilder_amd import MiniBatchKMeans
+    rs = np.random.RandomState(K + B)
+    cent = rs.randn(K // 4, 24) * 4
+    X = (cent[rs.randint(0, len(cent), 60000)] + rs.randn(60000, 24)).astype(np.float32)
+    Xd = torch.from_numpy(X).cuda()
+    out = {}
+    for runs in ("1", "0"):
+        monkeypatch.setenv("MSMBUILDER_AMD_MBK_RUNS", runs)
+        gen = np.random.RandomState(11)
+        m = MiniBatchKMeans(n_clusters=K, batch_size=B, max_iter=4, n_init=1, max_no_improvement=mni, random_state=gen).fit([Xd])
+        out[runs] = (m.cluster_centers_.copy(), m.n_steps_, m.inertia_, gen.randint(0, 1 << 30, 4))
+    a, b = out["1"], out["0"]
+    assert a[1] == b[1]
+    np.testing.assert_array_equal(a[0], b[0])
+    assert a[2] == b[2]
+    np.testing.assert_array_equal(a[3], b[3])
+    gen = np.random.RandomState(11)
+    ref = sk.MiniBatchKMeans(n_clusters=K, batch_size=B, max_iter=4, n_init=1, max_no_improvement=mni, random_state=gen).fit(X)
+    assert ref.n_steps_ == a[1]
+    np.testing.assert_array_equal(gen.randint(0, 1 << 30, 4), a[3])
+    np.testing.assert_allclose(a[2], ref.inertia_, rtol=2e-3)
