@@ -24,11 +24,12 @@
 namespace msm {
 
 constexpr int PNT = 256;
-constexpr int PNB = 1024;  // scan blocks (= partial slots)
+constexpr int PNB = 1024;  // scan blocks (= partial slots), at most
+constexpr long long SCAN_ROWS = 1024;  // rows per chunk of the column scans
 
 struct ScanChunk {
     const void* base;
-    long long n;  // rows (<= 4096)
+    long long n;  // rows (<= SCAN_ROWS; the digit passes use 4096)
 };
 
 struct ScanArgs {
@@ -91,6 +92,23 @@ __global__ __launch_bounds__(PNT) void colstats_kernel(ScanArgs P)
                 const ScanChunk ch = P.chunks[c];
                 const global_ptr<T> X = as_global<T>(ch.base);
                 const bool al = vec && ((((uintptr_t)ch.base) & 15) == 0);
+                // One chunk (<= SCAN_ROWS rows, 1 / rl of them this thread's) per column as SHIFTED sums
+                // s1 = sum (x - K), s2 = sum (x - K)^2 in float64, K = the running mean (first chunk: the first value):
+                // 4 float64 operations per element and one division per chunk, where the first version (two-pass
+                // batches of 8 rows, one Chan merge with two divisions per batch) was VALU-bound at 2.7 TB/s.
+                // x - K is rounded once (float64); the cancellation in s2 - s1^2/n costs at most
+                // n_chunk * eps * (x - K)^2 <= 1024 * 2^-53 * range^2, against a total M2 >= range^2 / 2.
+                double K[CW], s1[CW], s2[CW];
+                int cnt[CW];
+                T lo[CW], hi[CW];
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    K[e] = run[e].mean;
+                    s1[e] = s2[e] = 0.0;
+                    cnt[e] = 0;
+                    lo[e] = (T)INFINITY;
+                    hi[e] = (T)-INFINITY;
+                }
                 for (long long k0 = tr; k0 < ch.n; k0 += (long long)rl * RU) {
                     T v[RU][CW];
 #pragma unroll
@@ -107,41 +125,39 @@ __global__ __launch_bounds__(PNT) void colstats_kernel(ScanArgs P)
                     }
 #pragma unroll
                     for (int e = 0; e < CW; ++e) {
-                        // batch of <= RU rows of one column: count the non-NaN ones, two-pass mean / M2.
-                        // NaN / inf tests, min and max stay in the input type (cheap), sums are float64.
-                        Stat b;
-                        stat_init(b);
-                        double sum = 0.0;
-                        int cnt = 0;
-                        T lo = (T)INFINITY, hi = (T)-INFINITY;
-                        unsigned okmask = 0;
+                        if (k0 == tr && run[e].n == 0.0) {  // nothing seen yet: shift by the first finite value
+                            const T x0 = v[0][e];
+                            K[e] = (x0 == x0 && x0 != (T)INFINITY && x0 != (T)-INFINITY) ? (double)x0 : 0.0;
+                        }
 #pragma unroll
                         for (int u = 0; u < RU; ++u) {
                             const T xt = v[u][e];
                             const bool ok = (k0 + (long long)u * rl < ch.n) && (xt == xt);  // NaN = missing
-                            okmask |= ok ? (1u << u) : 0u;
+                            const double d = (double)xt - K[e];
                             if (ok) {
-                                ++cnt;
-                                sum += (double)xt;
-                                lo = xt < lo ? xt : lo;
-                                hi = xt > hi ? xt : hi;
+                                ++cnt[e];
+                                s1[e] += d;
+                                s2[e] = fma(d, d, s2[e]);
+                                lo[e] = xt < lo[e] ? xt : lo[e];
+                                hi[e] = xt > hi[e] ? xt : hi[e];
                             }
-                        }
-                        if (cnt > 0) {
-                            inf_seen |= (lo == (T)-INFINITY || hi == (T)INFINITY) ? 1 : 0;
-                            b.n = (double)cnt;
-                            b.lo = (double)lo;
-                            b.hi = (double)hi;
-                            b.mean = sum / b.n;
-#pragma unroll
-                            for (int u = 0; u < RU; ++u) {
-                                const double d = (double)v[u][e] - b.mean;
-                                if (okmask & (1u << u)) b.m2 += d * d;
-                            }
-                            stat_merge(run[e], b);
                         }
                     }
                 }
+#pragma unroll
+                for (int e = 0; e < CW; ++e)
+                    if (cnt[e] > 0) {
+                        inf_seen |= (lo[e] == (T)-INFINITY || hi[e] == (T)INFINITY) ? 1 : 0;
+                        Stat b;
+                        b.n = (double)cnt[e];
+                        const double m = s1[e] / b.n;
+                        b.mean = K[e] + m;
+                        const double m2 = s2[e] - s1[e] * m;
+                        b.m2 = m2 > 0.0 ? m2 : 0.0;
+                        b.lo = (double)lo[e];
+                        b.hi = (double)hi[e];
+                        stat_merge(run[e], b);
+                    }
             }
         }
 #pragma unroll
@@ -476,15 +492,27 @@ int msm_colstats(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n
                 base = d;
                 off += ((size_t)n_rows[i] * row_bytes + 255) & ~(size_t)255;
             }
-            for (long long r0 = 0; r0 < n_rows[i]; r0 += 4096) {
+            for (long long r0 = 0; r0 < n_rows[i]; r0 += SCAN_ROWS) {
                 ScanChunk ch;
                 ch.base = base + (size_t)r0 * (size_t)group_ld * dtype_bytes;
-                ch.n = std::min<long long>(4096, n_rows[i] - r0);
+                ch.n = std::min<long long>(SCAN_ROWS, n_rows[i] - r0);
                 tab.push_back(ch);
             }
         }
         if (!tab.empty()) {
-            const int nb = (int)std::min<size_t>(tab.size(), (size_t)PNB);
+            // one resident round: with more workgroups than fit (first version: 1024 on 768 slots) the second round runs
+            // a third full, and chunks of 4096 rows left 2441 of them on 768 workgroups (3 or 4 each: 25 % tail)
+            static int slots[2] = {0, 0};
+            int& sl = slots[dtype_bytes == 4 ? 0 : 1];
+            if (!sl) {
+                int occ = 0;
+                if (dtype_bytes == 4)
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, colstats_kernel<float>, PNT, 0);
+                else
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, colstats_kernel<double>, PNT, 0);
+                sl = std::max(1, std::min(PNB, std::max(1, occ) * num_cus()));
+            }
+            const int nb = (int)std::min<size_t>(tab.size(), (size_t)sl);
             if ((rc = dTab.reserve(tab.size() * sizeof(ScanChunk) + 16))) return rc;
             if ((rc = dPart.reserve((size_t)nb * 5 * F * sizeof(double)))) return rc;
             if ((rc = dOut.reserve((size_t)5 * F * sizeof(double) + 16))) return rc;
