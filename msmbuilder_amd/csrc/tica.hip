@@ -754,7 +754,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) aH[bi][bj][r] = aD[bi][bj][r] = 0.f;
-    int rows_acc = 0;
+    int rows_acc = 0, chunks_done = 0;
     if (P.dbg && blockIdx.x == 0 && tid == 0) {
         P.dbg[0] = clock64();
         P.dbg[2] = wall_clock64();
@@ -838,6 +838,14 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     pu = npu; pd = npd; qu = nqu; qd = nqd;
         __syncthreads();  // every wave is done with both buffers (previous chunk)
         MSM_STAGE_EDGE(0, 0)
+        if (P.cosync && chunks_done > 0 && tid == 0) {  // cohort pacing (opt-in, see the C/G kernel): bounded wait
+            const unsigned target = (unsigned)P.ntiles * (unsigned)chunks_done;
+            const long long t0 = clock64();
+            while (__hip_atomic_load(P.cosync + cohort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (clock64() - t0 > 200000) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
         __syncthreads();
         PROF_MARK(0)
         const int fa = kl * TM + wr * 64 + 2 * cl, fb = kl * TM + wc * 64 + 2 * cl;  // floats
@@ -907,6 +915,10 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 #undef MSM_SYM_FRAGS
 #undef MSM_STORE_X
 #undef MSM_STORE_Y
+        if (P.cosync) {
+            ++chunks_done;
+            if (tid == 0) __hip_atomic_fetch_add(P.cosync + cohort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         rows_acc += ch.n;
         if (rows_acc + P.kc > KFLUSH_SYM || c + P.S >= P.nchunks) {
             rows_acc = 0;
@@ -1856,7 +1868,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipGetLastError());
     }
     // 2) the MFMA pass
-    MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(h->S + 1) * sizeof(unsigned), stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned), stream()));
     if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
     if (usesym) {
         if (h->F % TM == 0)
@@ -2016,7 +2028,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->packed, (FF2 + 2) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->flag, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->dbg, 64 * sizeof(long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->cosync, (size_t)(h->S + 1) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->cosync, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
