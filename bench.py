@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--clusters", type=int, default=200)
     ap.add_argument("--mode", default=os.environ.get("MSMBUILDER_AMD_TICA_MODE", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mbk", action="store_true", help="skip the untimed MiniBatchKMeans(k=1000) leg")
     args = ap.parse_args()
     os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
 
@@ -174,7 +175,7 @@ def main():
                 torch.cuda.synchronize()
                 record.setdefault("kcenters_predict", []).append(time.perf_counter() - t3)
                 record.setdefault("cluster", []).append(time.perf_counter() - t2)
-        return ev, labels, kc
+        return ev, labels, kc, Y
 
     for _ in range(args.warmup):
         step(None)
@@ -183,7 +184,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ev, labels, kc = step(times)
+        ev, labels, kc, Y = step(times)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -241,6 +242,22 @@ def main():
         pass_bytes = frames * (args.components * 8 + 16)          # read X row + distances_, update distances_/labels_
         out["clustering"] = {"kcenters_fit_frames_per_s": world * frames / fit_s, "assign_frames_per_s": world * frames / pred_s,
                              "kcenters_pass_TBps": args.clusters * pass_bytes / fit_s / 1e12, "hbm_peak_TBps": 8.0}
+        if world == 1 and not args.no_mbk:
+            # BASELINE configs[3] names MiniBatchKMeans(k=1000) as the clusterer of this shape: the same projection through
+            # it, once, OUTSIDE the timed steps (`value` stays the metric's tICA + KCenters pipeline)
+            from msmbuilder_amd import MiniBatchKMeans
+            Y32 = Y.float().contiguous()
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                mb = MiniBatchKMeans(n_clusters=1000, random_state=0).fit([Y32])
+            torch.cuda.synchronize()
+            tm = time.perf_counter() - tm
+            out["minibatchkmeans"] = {"n_clusters": 1000, "fit_ms": 1e3 * tm, "n_steps": int(mb.n_steps_),
+                                      "fit_frames_per_s": frames / tm, "inertia_per_frame": float(mb.inertia_) / frames,
+                                      "note": "MiniBatchKMeans(n_clusters=1000).fit on the [frames, %d] projection (fp32), "
+                                              "k-means++ seeding + mini-batch steps + labels_ of every frame" % args.components}
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             sample = [s.cpu().numpy() for s in seqs[:64]]
             out["cpu_baseline"] = cpu_baseline(sample, args.lag, args.components, args.clusters)

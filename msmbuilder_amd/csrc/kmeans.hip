@@ -519,7 +519,9 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 
 // per-row ||x - c_label||^2 (fp32 difference, fp64 accumulate), one wave per row;
 // per-block fp64 partial sums for the inertia.
-__global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* __restrict__ partial)
+// nsplit > 1 (centre-split labelling of a small batch): the row's label is first picked from the splits' candidates
+// (lowest value, then lowest index -- what kmeans_label_reduce_kernel does as a launch of its own) and written out.
+__global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* __restrict__ partial, int nsplit)
 {
     if (P.stop && *P.stop) return;  // uniform
     __shared__ double red[KNT / 64];
@@ -528,7 +530,24 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
     for (long long i = (long long)blockIdx.x * 4 + wave; i < P.n; i += (long long)gridDim.x * 4) {
         const long long r = P.rows ? P.rows[i] : i;
         const float* x = P.X + r * P.m;
-        const float* c = P.C + (long long)P.labels[i] * P.m;
+        int lab;
+        if (nsplit > 1) {  // uniform over the wave
+            float bv = P.pv[i];
+            int bi = P.pi[i];
+            for (int q = 1; q < nsplit; ++q) {
+                const float v = P.pv[(long long)q * P.n + i];
+                const int ix = P.pi[(long long)q * P.n + i];
+                if (v < bv || (v == bv && ix < bi)) {
+                    bv = v;
+                    bi = ix;
+                }
+            }
+            lab = bi;
+            if (lane == 0) P.labels[i] = bi;
+        } else {
+            lab = P.labels[i];
+        }
+        const float* c = P.C + (long long)lab * P.m;
         double s = 0.0;
         for (long long k = lane; k < P.m; k += 64) {
             const float d = x[k] - c[k];
@@ -543,6 +562,59 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// msm_mbk_run: end of one queued step.  Sums the inertia partials, then plays sklearn's _mini_batch_convergence
+// (_kmeans.py:1963-2027, tol = 0 and verbose = 0 branch) in float64 on the device so that the host does not have to
+// look at every step: st = {ewa, ewa_min, no_improvement, have_ewa, have_min, steps_done}.  Plain IEEE operations in
+// the host's order (no contraction: __dmul_rn / __dadd_rn).  Executed by the LAST workgroup of mbk_update_kernel to
+// finish (an arrival counter), not by a launch of its own: between dependent launches the GPU idles for ~10-15 us,
+// which at 85 us of work per step is what a launch costs.
+struct MbkConv {
+    const double* partial;  // inertia partials of the step
+    int nb;
+    double* st;             // nullptr: no convergence bookkeeping (plain msm_mbk_step)
+    int* stop;
+    double* inertias;
+    unsigned* done;         // arrival counter, zero between launches
+    long long step_index;
+    double batch_size, alpha;
+    long long max_no_improvement;
+};
+
+__device__ __forceinline__ void mbk_converge(const MbkConv& cv, double* red)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < cv.nb; i += KNT) s += cv.partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = KNT / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double* st = cv.st;
+    const double inertia = red[0];
+    cv.inertias[(long long)st[5]] = inertia;
+    st[5] += 1.0;
+    if (cv.step_index == 0) return;  // "ignore first iteration because it's inertia from initialization"
+    const double bi = inertia / cv.batch_size;
+    double ewa;
+    if (st[3] == 0.0) {
+        ewa = bi;
+        st[3] = 1.0;
+    } else {
+        ewa = __dadd_rn(__dmul_rn(st[0], __dadd_rn(1.0, -cv.alpha)), __dmul_rn(bi, cv.alpha));
+    }
+    st[0] = ewa;
+    if (st[4] == 0.0 || ewa < st[1]) {
+        st[2] = 0.0;
+        st[1] = ewa;
+        st[4] = 1.0;
+    } else {
+        st[2] += 1.0;
+    }
+    if (cv.max_no_improvement >= 0 && st[2] >= (double)cv.max_no_improvement) *cv.stop = 1;
+}
+
 // One workgroup per centre: find the centre's members in the batch (ordered compaction by the whole workgroup:
 // wave ballots + a 4-entry prefix; the first version let thread 0 walk the labels alone, 183 us per step at
 // K = 1000, B = 1024), visit them in batch order.
@@ -552,7 +624,7 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
 __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __restrict__ centers,
                                                          float* __restrict__ counts, float* __restrict__ cnorm,
                                                          double* __restrict__ sums,
-                                                         double* __restrict__ cnts, int apply)
+                                                         double* __restrict__ cnts, int apply, MbkConv cv)
 {
     if (P.stop && *P.stop) return;
     extern __shared__ int members[];  // compacted member positions of one chunk
@@ -619,6 +691,17 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
         for (int msk = 32; msk > 0; msk >>= 1) sq += __shfl_xor(sq, msk, 64);
         if (lane == 0) cnorm[j] = sq;
     }
+    if (cv.st) {  // uniform: the last workgroup to arrive closes the step
+        __shared__ int is_last;
+        __shared__ double cred[KNT];
+        __syncthreads();
+        if (tid == 0) is_last = (atomicAdd(cv.done, 1u) == gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        if (is_last) {
+            mbk_converge(cv, cred);
+            if (tid == 0) *cv.done = 0u;
+        }
+    }
 }
 
 // finish a centre-split labelling: lowest (value, index) over the splits
@@ -671,49 +754,6 @@ __global__ __launch_bounds__(KNT) void mbk_finish_kernel(const double* __restric
     }
     if (threadIdx.x == 0) *out_inertia = red[0];
     for (long long j = threadIdx.x; j < K; j += KNT) out_counts[j] = counts[j];
-}
-
-// msm_mbk_run: end of one queued step.  Sums the inertia partials, then plays sklearn's _mini_batch_convergence
-// (_kmeans.py:1963-2027, tol = 0 and verbose = 0 branch) in float64 on the device so that the host does not have to
-// look at every step: st = {ewa, ewa_min, no_improvement, have_ewa, have_min, steps_done}.  Plain IEEE operations in
-// the host's order (no contraction: the file's arithmetic here is written with __dmul_rn / __dadd_rn).
-__global__ __launch_bounds__(KNT) void mbk_converge_kernel(const double* __restrict__ partial, int nb, double* __restrict__ st,
-                                                           int* __restrict__ stop, double* __restrict__ inertias,
-                                                           long long step_index, double batch_size, double alpha,
-                                                           long long max_no_improvement)
-{
-    if (*stop) return;
-    __shared__ double red[KNT];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nb; i += KNT) s += partial[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int k = KNT / 2; k > 0; k >>= 1) {
-        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const double inertia = red[0];
-    inertias[(long long)st[5]] = inertia;
-    st[5] += 1.0;
-    if (step_index == 0) return;  // "ignore first iteration because it's inertia from initialization"
-    const double bi = inertia / batch_size;
-    double ewa;
-    if (st[3] == 0.0) {
-        ewa = bi;
-        st[3] = 1.0;
-    } else {
-        ewa = __dadd_rn(__dmul_rn(st[0], __dadd_rn(1.0, -alpha)), __dmul_rn(bi, alpha));
-    }
-    st[0] = ewa;
-    if (st[4] == 0.0 || ewa < st[1]) {
-        st[2] = 0.0;
-        st[1] = ewa;
-        st[4] = 1.0;
-    } else {
-        st[2] += 1.0;
-    }
-    if (max_no_improvement >= 0 && st[2] >= (double)max_no_improvement) *stop = 1;
 }
 
 // centres (+counts) <- (centres * w + batch sums) / (w + n) from all-reduced fp64 sums (multi-GPU)
@@ -794,7 +834,7 @@ static int km_label_and_inertia(KmArgs& P, double* inertia)
         DevBuf& dPart = pool(PS_PART);
         int rc = dPart.reserve((size_t)nb * sizeof(double));
         if (rc) return rc;
-        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, dPart.as<double>());
+        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, dPart.as<double>(), 1);
         MSM_HIP_CHECK(hipGetLastError());
         std::vector<double> h((size_t)nb);
         MSM_HIP_CHECK(hipMemcpyAsync(h.data(), dPart.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, stream()));
@@ -859,8 +899,9 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
         P.pv = h->pv.as<float>();
         P.pi = h->pi.as<int>();
         if ((rc = km_launch_label(P, dim3((unsigned)rowblocks, (unsigned)nsplit)))) return rc;
-        hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
-                           P.pv, P.pi, n, nsplit, labels_d, P.stop);
+        if (!inertia_dev_partial)  // else the inertia kernel below picks the labels from the candidates itself
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
+                               P.pv, P.pi, n, nsplit, labels_d, P.stop);
     } else {
         if ((rc = km_launch_label(P, dim3((unsigned)rowblocks)))) return rc;
     }
@@ -868,7 +909,7 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
     if (inertia_dev_partial) {
         const int nb = (int)std::min<long long>(ceil_div(n, 4), 1024);
         P.jspan = 0;
-        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial);
+        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial, nsplit);
         MSM_HIP_CHECK(hipGetLastError());
         *nb_out = nb;
     }
@@ -983,7 +1024,7 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
     P.labels = h->labels.as<int32_t>();
     hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
                        h->counts, h->cnorm, apply_update ? (double*)nullptr : h->packed,
-                       apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update);
+                       apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update, MbkConv{});
     MSM_HIP_CHECK(hipGetLastError());
     double* d_inertia = apply_update ? reinterpret_cast<double*>(h->outbuf) : h->packed + (size_t)h->K * h->m + h->K;
     hipLaunchKernelGGL(mbk_finish_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->counts, h->K,
@@ -1023,7 +1064,7 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
         MSM_HIP_CHECK(hipHostMalloc((void**)&h->pinned, need, hipHostMallocDefault));
         h->pinned_bytes = need;
     }
-    if (!h->stop) MSM_HIP_CHECK(hipMalloc((void**)&h->stop, sizeof(int)));
+    if (!h->stop) MSM_HIP_CHECK(hipMalloc((void**)&h->stop, 2 * sizeof(int)));  // {stop flag, arrival counter}
     if ((rc = h->idx.reserve(idx_bytes))) return rc;
     if ((rc = h->runbuf.reserve(st_bytes))) return rc;
     if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
@@ -1036,7 +1077,7 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
     for (int i = 0; i < 5; ++i) st0[i] = state6[i];
     st0[5] = 0.0;
     MSM_HIP_CHECK(hipMemcpyAsync(st, st0, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
-    MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, sizeof(int), stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, 2 * sizeof(int), stream()));
     for (msm_idx_t s = 0; s < S; ++s) {
         const msm_idx_t* rows_d = h->idx.as<msm_idx_t>() + (size_t)s * B;
         int nb = 0;
@@ -1050,10 +1091,19 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
         P.K = h->K;
         P.labels = h->labels.as<int32_t>();
         P.stop = h->stop;
+        MbkConv cv;
+        cv.partial = h->part.as<double>();
+        cv.nb = nb;
+        cv.st = st;
+        cv.stop = h->stop;
+        cv.inertias = st + 6;
+        cv.done = reinterpret_cast<unsigned*>(h->stop + 1);
+        cv.step_index = (long long)(first_step + s);
+        cv.batch_size = (double)B;
+        cv.alpha = alpha;
+        cv.max_no_improvement = (long long)max_no_improvement;
         hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
-                           h->counts, h->cnorm, (double*)nullptr, (double*)nullptr, 1);
-        hipLaunchKernelGGL(mbk_converge_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, st, h->stop,
-                           st + 6, (long long)(first_step + s), (double)B, alpha, (long long)max_no_improvement);
+                           h->counts, h->cnorm, (double*)nullptr, (double*)nullptr, 1, cv);
         MSM_HIP_CHECK(hipGetLastError());
     }
     // out: [state | inertias | stop | counts] through the pinned mirror, one synchronisation for the whole run
@@ -1257,7 +1307,7 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
         dCnts = dSums + (size_t)K * m;
     }
     hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)K), dim3(KNT), 4096 * sizeof(int), stream(), P,
-                       dCent, dW.as<float>(), (float*)nullptr, dSums, dCnts, apply_update);
+                       dCent, dW.as<float>(), (float*)nullptr, dSums, dCnts, apply_update, MbkConv{});
     MSM_HIP_CHECK(hipGetLastError());
     if (apply_update) {
         MSM_HIP_CHECK(hipMemcpyAsync(centers, dCent, (size_t)K * m * sizeof(float), hipMemcpyDeviceToHost, stream()));
