@@ -18,7 +18,10 @@ tICA lag 100):
 Scaling is weak: every rank holds its own 10M x 512 shard (20.5 GB of the 288 GB HBM), so
 `value` = N x frames-per-rank / max-over-ranks step time.  Data is generated on the
 device before timing (AR(1) slow modes mixed into 512 features).
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the contract's keys it carries `roofline` (dominant kernel: algorithmic and
+executed TFLOP/s against the fp32 MFMA peak, L2-fabric traffic), `clustering` (the HBM-bound half on its own),
+`cpu_baseline` (the oracle on the host cores, bounded sample; N = 1 only) and `minibatchkmeans` (configs[3]'s
+clusterer, MiniBatchKMeans(k=1000).fit on the same projection, run once OUTSIDE the timed steps; N = 1 only).
 """
 import argparse
 import ctypes as C

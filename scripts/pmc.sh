@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $CTRS --kernel-include-regex "msm::" --output-format csv -d $OUT -o pmc -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc $CTRS --kernel-include-regex "msm::" --output-format csv -d $OUT -o pmc -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-mbk "$@" > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-200
 f=$(find $OUT -name "*counter_collection.csv" | head -1)
 if [ -n "$f" ]; then

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-mbk "$@" > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-400
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -14 "$f"
