@@ -405,3 +405,34 @@ def test_project_matches_numpy(gpu, dtype, n, F, k):
     rc = _lib.lib().msm_tica_project(ax.vp, ax.dtype.itemsize, n, F, F, mu.ctypes.data, np.ascontiguousarray(V).ctypes.data, k,
                                      Arr(out, np.float64).vp, 0, 1)
     assert rc == _lib.MSM_ERR_NONFINITE
+
+
+@pytest.mark.parametrize("F", [132, 256, 388])
+def test_symmetric_kernel_half_step_edges(gpu, monkeypatch, F):
+    """Pair counts around the kernel's 16-frame half-steps and 32-frame steps, one trajectory each and all together
+    (chunks that start and end inside a step), against float64 numpy."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
+    lag = 3
+    rs = np.random.RandomState(F)
+    pairs = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 4095, 4096, 4097]
+    seqs = [(rs.randn(n + lag, F) * 2 + rs.randn(F)).astype(np.float32) for n in pairs]
+
+    def ref(ss):
+        C = np.zeros((F, F)); G = np.zeros((F, F))
+        for x in ss:
+            x = x.astype(np.float64)
+            a, b = x[:-lag], x[lag:]
+            C += a.T @ b; G += a.T @ a + b.T @ b
+        return 0.5 * (C + C.T), G
+
+    for group in [[s] for s in seqs[:14]] + [seqs]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(lag_time=lag).fit(group)
+        assert m._lagged_symmetrised
+        m._pull()
+        Cs, G = ref(group)
+        scale = max(np.abs(G).max(), 1e-30)
+        np.testing.assert_allclose(m._outer_gram_sum, G, rtol=0, atol=ATOL_SCALE["f32"] * scale)
+        np.testing.assert_allclose(m._outer_0_to_T_lagged, Cs, rtol=0, atol=ATOL_SCALE["f32"] * scale)
