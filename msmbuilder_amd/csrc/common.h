@@ -26,6 +26,12 @@ int fail(int code, const char* fmt, ...);
 hipStream_t stream();
 int num_cus();
 
+// Bulk upload of caller-owned PAGEABLE host memory, ordered like a hipMemcpyAsync on stream().  A plain
+// hipMemcpyAsync from pageable memory goes through the runtime's single-threaded bounce buffer (measured
+// 13.7 GB/s); this one has a few worker threads memcpy slices into a ring of pinned buffers while the DMA
+// engine ships the previous slice on a copy stream.  Small copies fall through to hipMemcpyAsync.
+int h2d_bulk(void* dst_device, const void* src_host, size_t bytes);
+
 // RAII device scratch used when the caller hands over host pointers.
 struct DevBuf {
     void* p = nullptr;

@@ -1086,7 +1086,7 @@ int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_id
         P.min_dist = min_dist;
     } else {
         if ((rc = dX.reserve((size_t)n_X * m * sizeof(T)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n_X * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n_X * m * sizeof(T)))) return rc;
         P.X = dX.p;
         if (X_indices) {
             if ((rc = dIdx.reserve((size_t)n * sizeof(msm_idx_t)))) return rc;
@@ -1130,7 +1130,7 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
     DevBuf &dX = pool(PS_X), &dY = pool(PS_Y), &dIdx = pool(PS_IDX), &dOut = pool(PS_OUT);
     int grid = (int)std::min<long long>(ceil_div(n, DT), 2048);
     if ((rc = dY.reserve((size_t)nb * m * sizeof(T)))) return rc;
-    MSM_HIP_CHECK(hipMemcpyAsync(dY.p, XB, (size_t)nb * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+    if ((rc = h2d_bulk(dY.p, XB, (size_t)nb * m * sizeof(T)))) return rc;
     PairArgs P;
     memset(&P, 0, sizeof(P));
     P.Y = dY.p;
@@ -1143,7 +1143,7 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
         P.out = out;
     } else {
         if ((rc = dX.reserve((size_t)na * m * sizeof(T)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, XA, (size_t)na * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        if ((rc = h2d_bulk(dX.p, XA, (size_t)na * m * sizeof(T)))) return rc;
         P.X = dX.p;
         if (X_indices) {
             if ((rc = dIdx.reserve((size_t)n * sizeof(msm_idx_t)))) return rc;
@@ -1196,7 +1196,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         if ((rc = dX.reserve((size_t)n * m * sizeof(T)))) return rc;
         if ((rc = dLab.reserve((size_t)n * sizeof(msm_idx_t)))) return rc;
         if ((rc = dDist.reserve((size_t)n * sizeof(double)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * m * sizeof(T)))) return rc;
         P.X = dX.p;
         P.labels = dLab.as<msm_idx_t>();
         P.dist = dDist.as<double>();
@@ -1248,7 +1248,7 @@ int pdist_impl(const T* X, const char* metric, msm_idx_t n, msm_idx_t m, const m
         P.out = out;
     } else {
         if ((rc = dX.reserve((size_t)n * m * sizeof(T)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * m * sizeof(T)))) return rc;
         P.X = dX.p;
         if (X_indices) {
             if ((rc = dIdx.reserve((size_t)nn * sizeof(msm_idx_t)))) return rc;
@@ -1292,7 +1292,7 @@ int sumdist_impl(const T* X, const char* metric, msm_idx_t n, msm_idx_t m, const
     } else {
         if ((rc = dX.reserve((size_t)n * m * sizeof(T)))) return rc;
         if ((rc = dIdx.reserve((size_t)p * 2 * sizeof(msm_idx_t)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * m * sizeof(T), hipMemcpyHostToDevice, stream()));
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * m * sizeof(T)))) return rc;
         MSM_HIP_CHECK(hipMemcpyAsync(dIdx.p, pairs, (size_t)p * 2 * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
         P.X = dX.p;
         P.pairs = dIdx.as<msm_idx_t>();

@@ -1201,7 +1201,7 @@ int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, do
     if (!on_device) {
         if ((rc = dX.reserve((size_t)n * h->m * sizeof(float)))) return rc;
         if ((rc = dL.reserve((size_t)n * sizeof(int32_t)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * h->m * sizeof(float), hipMemcpyHostToDevice, stream()));
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * h->m * sizeof(float)))) return rc;
         Xd = dX.as<float>();
         lab_d = dL.as<int32_t>();
     }
@@ -1247,7 +1247,7 @@ int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* 
     } else {
         if ((rc = dX.reserve((size_t)n * m * sizeof(float)))) return rc;
         if ((rc = dL.reserve((size_t)n * sizeof(int32_t)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dX.p, X, (size_t)n * m * sizeof(float), hipMemcpyHostToDevice, stream()));
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * m * sizeof(float)))) return rc;
         P.X = dX.as<float>();
         P.labels = dL.as<int32_t>();
     }

@@ -484,7 +484,7 @@ int msm_colstats(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n
                 char* d = dX.as<char>() + off;
                 if (n_rows[i] > 0) {
                     if (ld == F)
-                        MSM_HIP_CHECK(hipMemcpyAsync(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes, hipMemcpyHostToDevice, stream()));
+                        if ((rc = h2d_bulk(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes))) return rc;
                     else
                         MSM_HIP_CHECK(hipMemcpy2DAsync(d, row_bytes, X_ptrs[i], (size_t)ld * dtype_bytes, row_bytes,
                                                        (size_t)n_rows[i], hipMemcpyHostToDevice, stream()));
@@ -584,8 +584,12 @@ int msm_scale_apply(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t 
     if (!on_device) {
         if ((rc = dX.reserve((size_t)n_rows * row_bytes))) return rc;
         if ((rc = dO.reserve((size_t)n_rows * row_bytes))) return rc;
-        MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, row_bytes, X, (size_t)ld * dtype_bytes, row_bytes, (size_t)n_rows,
-                                       hipMemcpyHostToDevice, stream()));
+        if (ld == F) {
+            if ((rc = h2d_bulk(dX.p, X, (size_t)n_rows * row_bytes))) return rc;
+        } else {
+            MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, row_bytes, X, (size_t)ld * dtype_bytes, row_bytes, (size_t)n_rows,
+                                           hipMemcpyHostToDevice, stream()));
+        }
         xin = dX.p;
         xout = dO.p;
         ldi = ldo = F;

@@ -1,7 +1,12 @@
 // runtime.hip -- device selection, stream, error state, memory helpers of libmsmhip.
 #include "common.h"
 
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 namespace msm {
 
@@ -27,6 +32,135 @@ int fail(int code, const char* fmt, ...)
 }
 
 hipStream_t stream() { return g_stream; }
+
+// ---------------------------------------------------------------------------------------------------
+// h2d_bulk: pageable host memory -> HBM through pinned buffers filled by a small thread pool
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const char* src = nullptr;
+    char* dst = nullptr;
+    size_t len = 0;
+    unsigned long gen = 0;
+    int pending = 0;
+    bool quit = false;
+
+    explicit CopyPool(int n)
+    {
+        for (int i = 0; i < n; ++i) th.emplace_back([this, i] { run(i); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m);
+            quit = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void run(int id)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            const char* s = src;
+            char* d = dst;
+            const size_t n = len;
+            const size_t T = th.size();
+            l.unlock();
+            const size_t per = (((n + T - 1) / T) + 4095) & ~(size_t)4095;
+            const size_t o = (size_t)id * per;
+            if (o < n) memcpy(d + o, s + o, std::min(per, n - o));
+            l.lock();
+            if (--pending == 0) cv_done.notify_one();
+        }
+    }
+    void copy(char* d, const char* s, size_t n)  // blocking, all workers
+    {
+        std::unique_lock<std::mutex> l(m);
+        src = s;
+        dst = d;
+        len = n;
+        pending = (int)th.size();
+        ++gen;
+        cv.notify_all();
+        cv_done.wait(l, [&] { return pending == 0; });
+    }
+};
+
+struct BulkH2D {
+    static constexpr int NBUF = 4;
+    static constexpr size_t BUF = (size_t)32 << 20;
+    CopyPool pool;
+    char* pin[NBUF] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[NBUF] = {nullptr, nullptr, nullptr, nullptr};
+    bool used[NBUF] = {false, false, false, false};
+    int next = 0;  // ring position, kept across calls: a call's first memcpy overlaps the previous call's last DMA
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipStream_t cs = nullptr;
+    bool ok = false;
+
+    BulkH2D() : pool(pool_threads())
+    {
+        hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        for (int i = 0; i < NBUF && e == hipSuccess; ++i) {
+            e = hipHostMalloc((void**)&pin[i], BUF, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_out, hipEventDisableTiming);
+        ok = (e == hipSuccess);
+        if (!ok) (void)hipGetLastError();
+    }
+    static int pool_threads()
+    {
+        const char* env = getenv("MSM_H2D_THREADS");
+        if (env && atoi(env) > 0) return std::min(64, atoi(env));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::max(2u, std::min(8u, hw / 2));
+    }
+};
+
+}  // namespace
+
+int h2d_bulk(void* dst_device, const void* src_host, size_t bytes)
+{
+    static const bool disabled = [] { const char* e = getenv("MSM_H2D_BULK"); return e && atoi(e) == 0; }();
+    if (bytes < ((size_t)8 << 20) || disabled) {
+        MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));
+        return MSM_OK;
+    }
+    static BulkH2D* B = new BulkH2D();  // process lifetime (the pool's threads only ever memcpy)
+    if (!B->ok) {
+        MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));
+        return MSM_OK;
+    }
+    // the destination may still be read by work queued on the caller's stream
+    MSM_HIP_CHECK(hipEventRecord(B->ev_in, g_stream));
+    MSM_HIP_CHECK(hipStreamWaitEvent(B->cs, B->ev_in, 0));
+    const char* s = static_cast<const char*>(src_host);
+    char* d = static_cast<char*>(dst_device);
+    for (size_t off = 0; off < bytes; off += BulkH2D::BUF) {
+        const size_t len = std::min(BulkH2D::BUF, bytes - off);
+        const int slot = B->next;
+        B->next = (B->next + 1) % BulkH2D::NBUF;
+        if (B->used[slot]) MSM_HIP_CHECK(hipEventSynchronize(B->done[slot]));  // its previous DMA has drained
+        B->pool.copy(B->pin[slot], s + off, len);
+        MSM_HIP_CHECK(hipMemcpyAsync(d + off, B->pin[slot], len, hipMemcpyHostToDevice, B->cs));
+        MSM_HIP_CHECK(hipEventRecord(B->done[slot], B->cs));
+        B->used[slot] = true;
+    }
+    MSM_HIP_CHECK(hipEventRecord(B->ev_out, B->cs));
+    MSM_HIP_CHECK(hipStreamWaitEvent(g_stream, B->ev_out, 0));
+    return MSM_OK;
+}
 
 int num_cus()
 {

@@ -2104,7 +2104,8 @@ static int tica_accumulate_any(msm_tica_t* h, const void* const* X_ptrs, const m
             dptrs[(size_t)(i - s)] = d;
             if (n_rows[i] > 0) {
                 if (ld == h->F) {
-                    MSM_HIP_CHECK(hipMemcpyAsync(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes, hipMemcpyHostToDevice, stream()));
+                    int rcb = h2d_bulk(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes);
+                    if (rcb) return rcb;
                 } else {
                     MSM_HIP_CHECK(hipMemcpy2DAsync(d, row_bytes, X_ptrs[i], (size_t)ld * dtype_bytes, row_bytes,
                                                    (size_t)n_rows[i], hipMemcpyHostToDevice, stream()));
@@ -2307,8 +2308,12 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     if (!on_device) {
         if ((rc = dX.reserve((size_t)n_rows * n_features * dtype_bytes))) return rc;
         if ((rc = dOut.reserve((size_t)n_rows * k * sizeof(double)))) return rc;
-        MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, (size_t)n_features * dtype_bytes, X, (size_t)ld * dtype_bytes,
-                                       (size_t)n_features * dtype_bytes, (size_t)n_rows, hipMemcpyHostToDevice, stream()));
+        if (ld == n_features) {
+            if ((rc = h2d_bulk(dX.p, X, (size_t)n_rows * n_features * dtype_bytes))) return rc;
+        } else {
+            MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, (size_t)n_features * dtype_bytes, X, (size_t)ld * dtype_bytes,
+                                           (size_t)n_features * dtype_bytes, (size_t)n_rows, hipMemcpyHostToDevice, stream()));
+        }
         Xd = dX.p;
         outd = dOut.as<double>();
         ldd = n_features;

@@ -38,6 +38,7 @@ from .. import _lib
 from .._lib import Arr, check, is_device_array
 from ..base import BaseEstimator
 from ..utils import check_iter_of_sequences, array2d
+from ..utils.validation import _assert_all_finite
 from . import _moments
 from ._moments import rao_blackwell_ledoit_wolf  # noqa: F401  (public name in the reference module)
 
@@ -388,8 +389,11 @@ class tICA(BaseEstimator, TransformerMixin):
 
     def _prepare(self, X):
         """array2d + dtype rule: float32/float64 are consumed natively, anything else is
-        up-cast to float64 exactly like tica.py:402."""
-        X = array2d(X)
+        up-cast to float64 exactly like tica.py:402.  The finite check of array2d (validation.py:68-74) is NOT run
+        on the host for data that goes to the device: the column-sum kernel performs it on every frame it reads
+        and the call raises the same ValueError (a numpy reduction over the trajectories was 2/3 of a host-array
+        fit: 0.2 s per 4 GB against 0.1 s for upload + kernels)."""
+        X = array2d(X, force_all_finite=False)
         if is_device_array(X):
             import torch
             if X.dtype not in (torch.float32, torch.float64):
@@ -417,6 +421,8 @@ class tICA(BaseEstimator, TransformerMixin):
                     self.n_features, self.n_features, X.shape[1], X.shape[0]))
             # We don't need to scream and shout here. Just ignore this data.
             if not len(X) > self.lag_time:
+                if not is_device_array(X):
+                    _assert_all_finite(X)   # never reaches the device: keep the reference's check (tica.py:402 -> array2d)
                 warnings.warn("length of data (%d) is too short for the lag time (%d)"
                               % (len(X), self.lag_time))
                 continue
