@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 }
 
 // ---------------------------------------------------------------------------
-// Symmetric fp32 kernel (the default up to F = 1024): 20 instead of 26 tile products at F = 512.
+// Symmetric fp32 kernel (the fp32 default for 128 < F <= 3968): 20 instead of 26 tile products at F = 512.
 // Only the SYMMETRISED lagged moment is ever used (offset_correlation = (C + C^T) / 2N' - mu mu^T,
 // tica.py:234-241), and with the sum and difference frames of a pair, u = x_t + x_{t+tau},
 // d = x_t - x_{t+tau},
@@ -604,10 +604,10 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 // so G = (H + D) / 2 and C + C^T = (H - D) / 2: TWO symmetric matrices, T(T+1) upper tile products
 // instead of T^2 + T(T+1)/2, and no per-row weights {0,1,2} (a frame counts once per pair it is in).
 // A workgroup owns one upper tile (I <= J) and computes BOTH its H and its D block from the same four
-// loaded panels (x_t and x_{t+tau}, columns I and J): 128 MFMAs per wave and K-step, so the step boundary
-// is amortised twice as well; 128 accumulator registers (AGPRs), two workgroups per CU with ONE 64 KiB LDS
-// image each (interleaved (u, d) pairs).  The sums and differences are formed when a staged step is written
-// to LDS.  fp32 rounding of u and d is 2^-24 relative and zero-mean: its contribution to the sums is
+// loaded panels (x_t and x_{t+tau}, columns I and J): 128 accumulator registers per lane, two workgroups per
+// CU with 64 KiB of LDS each (two buffers of u/d planes, see the kernel).  The sums and differences are formed in
+// registers, inside the MFMA stream, before a staged half-step is written to LDS.
+// fp32 rounding of u and d is 2^-24 relative and zero-mean: its contribution to the sums is
 // ~eps/sqrt(N), far below the fp32 accumulation error, which is bounded by flushing to the fp64 slabs every
 // KFLUSH_SYM frames (|H| is up to twice |G|).  The raw, non-symmetrised C is not available in this mode:
 // the exported "C" is already (C + C^T) / 2, which is what every consumer of the handle forms anyway.
@@ -616,78 +616,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 // ---------------------------------------------------------------------------
 constexpr int KFLUSH_SYM = 4096;
 
-struct StageS {
-    float4 xa[4], xb[4], ya[4], yb[4];  // rows t / t+tau, columns I (x) and J (y)
-    float sc[4];                        // pair validity per row (edge steps only)
-};
-
-struct StageAddrS {
-    global_ptr<char> pa, pb;
-    unsigned oxa[4], oxb[4], oya[4], oyb[4];
-};
-
-__device__ __forceinline__ void stage_addr_sym(StageAddrS& sa, StageS& st, int& uniform, const ChunkCtx& cx,
-                                               const LaneOffs& lo, int F, int k0, int I0, int J0, int tid)
-{
-    sa.pa = cx.base;
-    sa.pb = cx.baseB;
-    if (step_interior(cx, k0, 0)) {
-        sa.pa += (size_t)k0 * cx.ldb;  // scalar
-        sa.pb += (size_t)k0 * cx.ldb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sa.oxa[j] = sa.oxb[j] = lo.a[j];
-            sa.oya[j] = sa.oyb[j] = lo.b[j];
-        }
-        uniform = 1;
-    } else {
-        const int c4 = (tid & 31) * 4;
-        const int rr0 = tid >> 5;
-        const unsigned ca = 4u * (unsigned)(I0 + c4 < F ? I0 + c4 : F - 4), cb = 4u * (unsigned)(J0 + c4 < F ? J0 + c4 : F - 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kr = k0 + rr0 + 8 * j;
-            const int ra = kr < cx.nmax ? kr : cx.nmax;
-            const int rb = kr < cx.nmaxB ? kr : cx.nmaxB;
-            sa.oxa[j] = (unsigned)ra * cx.ldb + ca;
-            sa.oxb[j] = (unsigned)rb * cx.ldb + ca;
-            sa.oya[j] = (unsigned)ra * cx.ldb + cb;
-            sa.oyb[j] = (unsigned)rb * cx.ldb + cb;
-            st.sc[j] = (kr < cx.hi) ? 1.f : 0.f;
-        }
-        uniform = 0;
-    }
-}
-
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 m) { return make_float4(a.x * m.x, a.y * m.y, a.z * m.z, a.w * m.w); }
-
-// edge steps / partial tiles: fold the pair validity into x (both rows of an invalid pair -> 0, so u = d = 0)
-// and the column masks into x and y, in registers
-template <bool PARTIAL>
-__device__ __forceinline__ void stage_scale_sym(StageS& st, int uniform, float4 ma, float4 mb)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float sc = uniform ? 1.f : st.sc[j];
-        const float4 wa = PARTIAL ? make_float4(sc * ma.x, sc * ma.y, sc * ma.z, sc * ma.w) : make_float4(sc, sc, sc, sc);
-        st.xa[j] = f4mul(st.xa[j], wa);
-        st.xb[j] = f4mul(st.xb[j], wa);
-        if (PARTIAL) {
-            st.ya[j] = f4mul(st.ya[j], mb);
-            st.yb[j] = f4mul(st.yb[j], mb);
-        }
-    }
-}
-
-// one row's four columns of (u, d) = (a + b, a - b), interleaved: 32 contiguous bytes, two ds_write_b128
-__device__ __forceinline__ void sym_store(float __attribute__((ext_vector_type(2)))* dst, float4 a, float4 b)
-{
-    float4* p = reinterpret_cast<float4*>(dst);
-    p[0] = make_float4(a.x + b.x, a.x - b.x, a.y + b.y, a.y - b.y);
-    p[1] = make_float4(a.z + b.z, a.z - b.z, a.w + b.w, a.w - b.w);
-}
 
 // a - b on four floats as two v_pk_add_f32 with the negate modifiers on the second source (the compiler splits a
 // vector fsub into scalar v_sub_f32: there is no v_pk_sub_f32)
