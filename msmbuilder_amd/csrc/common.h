@@ -31,6 +31,8 @@ int num_cus();
 // 13.7 GB/s); this one has a few worker threads memcpy slices into a ring of pinned buffers while the DMA
 // engine ships the previous slice on a copy stream.  Small copies fall through to hipMemcpyAsync.
 int h2d_bulk(void* dst_device, const void* src_host, size_t bytes);
+// The other direction, BLOCKING: returns when dst_host holds the data (results produced on stream()).
+int d2h_bulk(void* dst_host, const void* src_device, size_t bytes);
 
 // RAII device scratch used when the caller hands over host pointers.
 struct DevBuf {

@@ -1260,7 +1260,7 @@ int pdist_impl(const T* X, const char* metric, msm_idx_t n, msm_idx_t m, const m
     }
     launch_pd<T, 0>(mid, (int)std::min<long long>(nn - 1, 4096), P);
     MSM_HIP_CHECK(hipGetLastError());
-    if (!on_device) MSM_HIP_CHECK(hipMemcpyAsync(out, P.out, npairs * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (!on_device && (rc = d2h_bulk(out, P.out, npairs * sizeof(double)))) return rc;
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
 }

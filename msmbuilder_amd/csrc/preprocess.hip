@@ -483,11 +483,12 @@ int msm_colstats(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n
             if (!on_device) {
                 char* d = dX.as<char>() + off;
                 if (n_rows[i] > 0) {
-                    if (ld == F)
+                    if (ld == F) {
                         if ((rc = h2d_bulk(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes))) return rc;
-                    else
+                    } else {
                         MSM_HIP_CHECK(hipMemcpy2DAsync(d, row_bytes, X_ptrs[i], (size_t)ld * dtype_bytes, row_bytes,
                                                        (size_t)n_rows[i], hipMemcpyHostToDevice, stream()));
+                    }
                 }
                 base = d;
                 off += ((size_t)n_rows[i] * row_bytes + 255) & ~(size_t)255;
@@ -607,9 +608,14 @@ int msm_scale_apply(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t 
         hipLaunchKernelGGL(scale_apply_kernel<double>, dim3(grid), dim3(PNT), 0, stream(), (const double*)xin, (long long)n_rows,
                            F, ldi, dshift, dscale, (double*)xout, ldo, vec, mode);
     MSM_HIP_CHECK(hipGetLastError());
-    if (!on_device)
-        MSM_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ld_out * dtype_bytes, xout, row_bytes, row_bytes, (size_t)n_rows,
-                                       hipMemcpyDeviceToHost, stream()));
+    if (!on_device) {
+        if (ld_out == F) {
+            if ((rc = d2h_bulk(out, xout, (size_t)n_rows * row_bytes))) return rc;
+        } else {
+            MSM_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)ld_out * dtype_bytes, xout, row_bytes, row_bytes, (size_t)n_rows,
+                                           hipMemcpyDeviceToHost, stream()));
+        }
+    }
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // shift/scale staging and scratch are reused
     return MSM_OK;
 }

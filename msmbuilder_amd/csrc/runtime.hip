@@ -128,6 +128,12 @@ struct BulkH2D {
     }
 };
 
+BulkH2D* bulk_instance()
+{
+    static BulkH2D* inst = new BulkH2D();  // process lifetime (the pool's threads only ever memcpy)
+    return inst;
+}
+
 }  // namespace
 
 int h2d_bulk(void* dst_device, const void* src_host, size_t bytes)
@@ -137,7 +143,7 @@ int h2d_bulk(void* dst_device, const void* src_host, size_t bytes)
         MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));
         return MSM_OK;
     }
-    static BulkH2D* B = new BulkH2D();  // process lifetime (the pool's threads only ever memcpy)
+    BulkH2D* B = bulk_instance();
     if (!B->ok) {
         MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));
         return MSM_OK;
@@ -159,6 +165,47 @@ int h2d_bulk(void* dst_device, const void* src_host, size_t bytes)
     }
     MSM_HIP_CHECK(hipEventRecord(B->ev_out, B->cs));
     MSM_HIP_CHECK(hipStreamWaitEvent(g_stream, B->ev_out, 0));
+    return MSM_OK;
+}
+
+int d2h_bulk(void* dst_host, const void* src_device, size_t bytes)
+{
+    static const bool disabled = [] { const char* e = getenv("MSM_H2D_BULK"); return e && atoi(e) == 0; }();
+    BulkH2D* B = nullptr;
+    if (bytes >= ((size_t)8 << 20) && !disabled) {
+        BulkH2D* inst = bulk_instance();
+        if (inst->ok) B = inst;
+    }
+    if (!B) {
+        MSM_HIP_CHECK(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, g_stream));
+        MSM_HIP_CHECK(hipStreamSynchronize(g_stream));
+        return MSM_OK;
+    }
+    MSM_HIP_CHECK(hipEventRecord(B->ev_in, g_stream));
+    MSM_HIP_CHECK(hipStreamWaitEvent(B->cs, B->ev_in, 0));
+    const char* s = static_cast<const char*>(src_device);
+    char* d = static_cast<char*>(dst_host);
+    // DMA of slice i+1 into the next pinned buffer while the workers copy slice i out of its buffer
+    int prev_slot = -1;
+    size_t prev_off = 0, prev_len = 0;
+    for (size_t off = 0; off < bytes; off += BulkH2D::BUF) {
+        const size_t len = std::min(BulkH2D::BUF, bytes - off);
+        const int slot = B->next;
+        B->next = (B->next + 1) % BulkH2D::NBUF;
+        if (B->used[slot]) MSM_HIP_CHECK(hipEventSynchronize(B->done[slot]));
+        MSM_HIP_CHECK(hipMemcpyAsync(B->pin[slot], s + off, len, hipMemcpyDeviceToHost, B->cs));
+        MSM_HIP_CHECK(hipEventRecord(B->done[slot], B->cs));
+        B->used[slot] = true;
+        if (prev_slot >= 0) {
+            MSM_HIP_CHECK(hipEventSynchronize(B->done[prev_slot]));
+            B->pool.copy(d + prev_off, B->pin[prev_slot], prev_len);
+        }
+        prev_slot = slot;
+        prev_off = off;
+        prev_len = len;
+    }
+    MSM_HIP_CHECK(hipEventSynchronize(B->done[prev_slot]));
+    B->pool.copy(d + prev_off, B->pin[prev_slot], prev_len);
     return MSM_OK;
 }
 

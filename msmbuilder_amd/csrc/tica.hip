@@ -2275,8 +2275,10 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
                                    outd, dflag);
         }
         MSM_HIP_CHECK(hipGetLastError());
-        if (!on_device)
-            MSM_HIP_CHECK(hipMemcpyAsync(out, outd, (size_t)n_rows * k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        if (!on_device) {
+            int rcd = d2h_bulk(out, outd, (size_t)n_rows * k * sizeof(double));
+            if (rcd) return rcd;
+        }
         int f2 = 0;
         if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f2, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // `vp` and the scratch buffers die with this frame
@@ -2306,8 +2308,10 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
 #undef MSM_PROJ_T
 #undef MSM_PROJ
     MSM_HIP_CHECK(hipGetLastError());
-    if (!on_device)
-        MSM_HIP_CHECK(hipMemcpyAsync(out, outd, (size_t)n_rows * k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (!on_device) {
+        int rcd = d2h_bulk(out, outd, (size_t)n_rows * k * sizeof(double));
+        if (rcd) return rcd;
+    }
     int f = 0;
     if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // scratch buffers die with this frame

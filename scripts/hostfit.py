@@ -15,3 +15,11 @@ if os.environ.get("PROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable(); tICA(n_components=10, lag_time=100).fit(seqs).n_observations_; pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(8)
+from msmbuilder_amd.preprocessing import StandardScaler
+sc = StandardScaler().fit(seqs)
+for it in range(2):
+    t = time.perf_counter(); out = sc.transform(seqs); dt = time.perf_counter() - t
+    print("host StandardScaler.transform %.1f ms  %.1f GB/s in + %.1f GB/s out" % (1e3 * dt, X.nbytes / dt / 1e9, X.nbytes / dt / 1e9))
+for it in range(2):
+    t = time.perf_counter(); Y = m.transform(seqs); dt = time.perf_counter() - t
+    print("host tICA.transform %.1f ms  %.2fM frames/s" % (1e3 * dt, n_seq * T / dt / 1e6))
