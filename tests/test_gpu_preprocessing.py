@@ -163,3 +163,33 @@ def test_robust_scaler_matches_sklearn(gpu, dtype):
         assert np.array_equal(md.scale_, ref.scale_)
     even = [np.arange(10, dtype=dtype).reshape(10, 1)[::-1].copy()]      # even count: mean of the middle pair
     assert np.array_equal(RobustScaler().fit(even).center_, Ref().fit(even[0]).center_)
+
+
+def test_colstats_and_scale_apply_strided_host_rows(gpu):
+    """C ABI with a row pitch larger than n_features on HOST memory (the Python wrappers always pass contiguous arrays):
+    the staging copy has to be a 2-D one."""
+    import ctypes as C
+    L = gpu.lib()
+    rs = np.random.RandomState(4)
+    F, ld = 37, 48
+    blocks = [rs.randn(n, ld).astype(np.float32) * 3 + 1 for n in (700, 1, 2600)]
+    ptrs = (C.c_void_p * 3)(*[b.ctypes.data for b in blocks])
+    rows = (C.c_int64 * 3)(*[len(b) for b in blocks])
+    out = np.empty((5, F))
+    has_inf = C.c_int(0)
+    gpu.check(L.msm_colstats(ptrs, rows, 3, 4, F, ld, 0, out.ctypes.data, C.byref(has_inf)))
+    X = np.concatenate([b[:, :F] for b in blocks]).astype(np.float64)
+    assert has_inf.value == 0 and np.all(out[0] == len(X))
+    np.testing.assert_allclose(out[1], X.mean(0), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out[2], ((X - X.mean(0)) ** 2).sum(0), rtol=1e-10)
+    np.testing.assert_array_equal(out[3], X.min(0))
+    np.testing.assert_array_equal(out[4], X.max(0))
+    shift, scale = X.mean(0), X.std(0)
+    b = blocks[2]
+    res = np.full((len(b), 40), -7.0, dtype=np.float32)
+    gpu.check(L.msm_scale_apply(C.c_void_p(b.ctypes.data), 4, len(b), F, ld, C.c_void_p(shift.ctypes.data),
+                                C.c_void_p(scale.ctypes.data), 0, C.c_void_p(res.ctypes.data), 40, 0))
+    want = (b[:, :F].astype(np.float64) - shift).astype(np.float32)     # numpy's in-place X -= mean; X /= scale on float32:
+    want = (want.astype(np.float64) / scale).astype(np.float32)         # each step rounded to the array dtype
+    np.testing.assert_array_equal(res[:, :F], want)
+    assert np.all(res[:, F:] == -7.0)
