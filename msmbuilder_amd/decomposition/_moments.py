@@ -124,16 +124,21 @@ _controller = None
 
 
 def _blas_limit(n_threads):
-    """threadpoolctl context limiting BLAS threads.  The controller is built ONCE: constructing it
-    walks every loaded shared object (1.3 ms per solve when done per call)."""
+    """threadpoolctl context LOWERING the BLAS thread count to ``n_threads``.  The controller is built ONCE:
+    constructing it walks every loaded shared object (1.3 ms per solve when done per call).  The count is never
+    raised: under ``torchrun`` every rank starts with OMP_NUM_THREADS=1, OpenBLAS sizes its per-thread buffers for
+    that, and asking it for 4 threads afterwards crashed dsygvx with SIGSEGV on both ranks of a 2-rank bench."""
     global _controller
+    import contextlib
     try:
         if _controller is None:
             from threadpoolctl import ThreadpoolController
             _controller = ThreadpoolController()
-        return _controller.limit(limits=n_threads, user_api="blas")
+        current = [int(lib.num_threads) for lib in _controller.lib_controllers if lib.user_api == "blas"]
+        if not current or min(current) <= int(n_threads):
+            return contextlib.nullcontext()
+        return _controller.limit(limits=int(n_threads), user_api="blas")
     except Exception:  # threadpoolctl missing: solve with whatever BLAS does
-        import contextlib
         return contextlib.nullcontext()
 
 

@@ -202,3 +202,24 @@ def test_split_frames_covers_every_usable_row_once():
         for i, n in enumerate(lengths):
             assert (seen[i] == (1 if n > lag else 0)).all()
         assert max(loads) - min(loads) <= 1
+
+
+def test_eigensolve_survives_torchrun_thread_settings():
+    """torchrun starts every rank with OMP_NUM_THREADS=1; raising OpenBLAS's thread count afterwards (the solve asks
+    for a handful of threads, the k-means++ seeding for 8) crashed dsygvx with SIGSEGV.  The limiter must only lower."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from msmbuilder_amd.decomposition import _moments\n"
+        "from msmbuilder_amd.cluster.minibatchkmeans import kmeans_plusplus\n"
+        "rs = np.random.RandomState(0)\n"
+        "A = rs.randn(512, 512); A = A + A.T\n"
+        "B = rs.randn(700, 512); B = B.T @ B\n"
+        "vals, vecs = _moments.top_generalized_eigenpairs(A, B, 5)\n"
+        "assert vals.shape == (5,) and np.all(np.diff(vals) <= 0)\n"
+        "c = kmeans_plusplus(rs.randn(400, 16).astype(np.float32), 12, np.random.RandomState(1))\n"
+        "assert c.shape == (12, 16)\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.returncode, out.stderr[-2000:])
