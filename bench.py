@@ -31,6 +31,12 @@ import sys
 import time
 import warnings
 
+# torchrun exports OMP_NUM_THREADS=1 to every rank unless the user set it ("please further tune the variable"): the
+# host eigensolve of a step would then run on one BLAS thread at N > 1 but on four at N = 1.  OpenBLAS sizes its
+# buffers from this variable when numpy / scipy are first imported, so it has to be raised HERE, before that import.
+if "LOCAL_RANK" in os.environ and os.environ.get("OMP_NUM_THREADS") == "1":
+    os.environ["OMP_NUM_THREADS"] = "8"
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
