@@ -1,11 +1,10 @@
-"""List-of-sequences adaptor for clusterers (reference: msmbuilder/cluster/base.py:17-173).
+"""List-of-sequences adaptor for clusterers (reference behaviour: msmbuilder/cluster/base.py:17-173).
 
-Single-array estimators (``fit(X)`` / ``predict(X)`` on one [n, F] array) become
-MSMBuilder estimators (``fit(list_of_sequences)``): the sequences are joined into one
-array -- ``np.concatenate`` on the host, ``torch.cat`` for device-resident trajectories,
-which stays in HBM -- the wrapped ``fit`` runs once, and ``labels_`` is cut back into
-per-sequence pieces using the remembered lengths.  mdtraj trajectories (the RMSD
-metric) are outside this package's scope.
+MSMBuilder estimators take a LIST of trajectories; the clustering kernels take one [n, F] array.  This mixin sits
+between the two: it joins the trajectories (``torch.cat`` for device-resident ones, so they never leave HBM;
+``numpy.concatenate`` for host arrays), lets the wrapped single-array estimator run once, and cuts ``labels_`` back
+into one piece per trajectory with the remembered lengths.  ``predict`` / ``transform`` work trajectory by trajectory.
+mdtraj trajectories (RMSD metric) are outside this package's scope.
 """
 import numpy as np
 
@@ -15,77 +14,79 @@ from ..utils import check_iter_of_sequences
 __all__ = ['MultiSequenceClusterMixin']
 
 
+def _join(sequences):
+    """One array holding every frame, on the side (host / device) the first trajectory lives on."""
+    if not len(sequences):
+        raise TypeError('sequences must be a list of numpy arrays (or torch CUDA tensors)')
+    head = sequences[0]
+    if isinstance(head, np.ndarray):
+        return np.ascontiguousarray(np.concatenate(sequences))
+    if is_device_array(head):
+        import torch
+        return torch.cat(list(sequences), dim=0).contiguous()
+    raise TypeError('sequences must be a list of numpy arrays (or torch CUDA tensors)')
+
+
 class MultiSequenceClusterMixin(object):
     _allow_trajectory = False
 
+    # ------------------------------------------------------------------ bookkeeping
+    def _concat(self, sequences):
+        self._seq_lengths = [len(s) for s in sequences]
+        joined = _join(sequences)
+        if len(joined) != sum(self._seq_lengths):
+            raise ValueError('sequences must be a list of sequences')
+        return joined
+
+    def _split(self, joined):
+        """Per-trajectory views of an array indexed like the joined frames."""
+        out, start = [], 0
+        for n in self._seq_lengths:
+            out.append(joined[start:start + n])
+            start += n
+        return out
+
+    def _split_indices(self, joined_positions):
+        """(trajectory index, frame index) for positions in the joined array."""
+        bounds = np.concatenate(([0], np.cumsum(self._seq_lengths)))
+        pos = np.asarray(joined_positions)
+        traj = np.searchsorted(bounds, pos, side='right') - 1
+        return np.stack([traj, pos - bounds[traj]], axis=-1).astype(int)
+
+    # ------------------------------------------------------------------ estimator protocol
     def fit(self, sequences, y=None):
-        """Cluster the frames of all sequences; ``labels_`` becomes a list with one
-        integer array per input sequence."""
+        """Cluster the frames of all trajectories; ``labels_`` becomes a list with one integer array each."""
         check_iter_of_sequences(sequences, allow_trajectory=self._allow_trajectory)
         super(MultiSequenceClusterMixin, self).fit(self._concat(sequences))
-
         if hasattr(self, 'labels_'):
             self.labels_ = self._split(self.labels_)
-
         return self
 
-    def _concat(self, sequences):
-        self.__lengths = [len(s) for s in sequences]
-        if len(sequences) > 0 and isinstance(sequences[0], np.ndarray):
-            concat = np.ascontiguousarray(np.concatenate(sequences))
-        elif len(sequences) > 0 and is_device_array(sequences[0]):
-            import torch
-            concat = torch.cat(list(sequences), dim=0).contiguous()
-        else:
-            raise TypeError('sequences must be a list of numpy arrays '
-                            '(or torch CUDA tensors)')
-
-        assert sum(self.__lengths) == len(concat)
-        return concat
-
-    def _split(self, concat):
-        ends = np.cumsum(self.__lengths)
-        return [concat[e - l: e] for (e, l) in zip(ends, self.__lengths)]
-
-    def _split_indices(self, concat_inds):
-        """Positions in the concatenated array -> (sequence index, frame index) pairs."""
-        starts = np.append([0], np.cumsum(self.__lengths))
-        table = np.zeros((starts[-1], 2), dtype=int)
-        for traj_i, (a, b) in enumerate(zip(starts[:-1], starts[1:])):
-            table[a:b, 0] = traj_i
-            table[a:b, 1] = np.arange(b - a)
-        return table[concat_inds]
+    def partial_predict(self, X, y=None):
+        """Nearest-centre index for every frame of ONE trajectory."""
+        return super(MultiSequenceClusterMixin, self).predict(X)
 
     def predict(self, sequences, y=None):
-        """Nearest-centre index for every frame of every sequence (a list of arrays)."""
+        """Nearest-centre index for every frame of every trajectory (a list of arrays)."""
         check_iter_of_sequences(sequences, allow_trajectory=self._allow_trajectory)
         return [self.partial_predict(X) for X in sequences]
 
-    def partial_predict(self, X, y=None):
-        """Nearest-centre index for every frame of one sequence."""
-        return super(MultiSequenceClusterMixin, self).predict(X)
-
     def fit_predict(self, sequences, y=None):
-        """``fit`` then return the training labels, one array per sequence."""
-        if hasattr(super(MultiSequenceClusterMixin, self), 'fit_predict'):
+        """``fit``, then the training labels, one array per trajectory."""
+        wrapped = super(MultiSequenceClusterMixin, self)
+        if hasattr(wrapped, 'fit_predict'):
             check_iter_of_sequences(sequences, allow_trajectory=self._allow_trajectory)
-            labels = super(MultiSequenceClusterMixin, self).fit_predict(sequences)
+            labels = wrapped.fit_predict(sequences)
         else:
-            self.fit(sequences)
-            labels = self.predict(sequences)
+            labels = self.fit(sequences).predict(sequences)
+        return labels if isinstance(labels, list) else self._split(labels)
 
-        if not isinstance(labels, list):
-            labels = self._split(labels)
-        return labels
-
+    # the reference exposes the same three operations under transformer names
     def transform(self, sequences):
-        """Alias for predict"""
         return self.predict(sequences)
 
     def partial_transform(self, X):
-        """Alias for partial_predict"""
         return self.partial_predict(X)
 
     def fit_transform(self, sequences, y=None):
-        """Alias for fit_predict"""
         return self.fit_predict(sequences, y)
