@@ -223,3 +223,32 @@ def test_eigensolve_survives_torchrun_thread_settings():
     env = dict(os.environ, OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, (out.returncode, out.stderr[-2000:])
+
+
+def _header_arities():
+    """{function name: number of parameters} parsed from include/msmhip.h (plain C declarations)."""
+    txt = open(os.path.join(ROOT, "include", "msmhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    out = {}
+    for name, params in re.findall(r"\b(msm_\w+)\s*\(([^()]*)\)\s*;", txt):
+        params = params.strip()
+        out[name] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_ctypes_prototypes_match_the_header():
+    """Every prototype the Python host declares must have as many arguments as the C declaration in include/msmhip.h:
+    a drifted ctypes signature passes garbage in registers instead of failing."""
+    from msmbuilder_amd import _lib
+    L = _lib.lib()
+    arity = _header_arities()
+    assert len(arity) >= 60
+    checked = 0
+    for name, n in sorted(arity.items()):
+        fn = getattr(L, name)
+        if fn.argtypes is None:     # exported and declared in the header, not bound by the Python host
+            continue
+        assert len(fn.argtypes) == n, "%s: header declares %d parameters, _lib.py binds %d" % (name, n, len(fn.argtypes))
+        checked += 1
+    assert checked >= 50
