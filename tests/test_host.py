@@ -252,3 +252,19 @@ def test_ctypes_prototypes_match_the_header():
         assert len(fn.argtypes) == n, "%s: header declares %d parameters, _lib.py binds %d" % (name, n, len(fn.argtypes))
         checked += 1
     assert checked >= 50
+
+
+@pytest.mark.parametrize("n,F,k", [(500, 8, 10), (3072, 64, 50), (1000, 3, 25)])
+def test_kmeans_plusplus_draws_scikit_learns_seeds(n, F, k):
+    """The host k-means++ seeding walks scikit-learn's RandomState call sequence and the same float32 arithmetic
+    (||x||^2 - 2 x.c + ||c||^2 with a BLAS sgemm): the SAME rows are chosen, bit for bit, and the generator ends in the
+    same state (MiniBatchKMeans then draws the same minibatches)."""
+    sk = pytest.importorskip("sklearn.cluster")
+    from msmbuilder_amd.cluster.minibatchkmeans import kmeans_plusplus
+    rs = np.random.RandomState(n + k)
+    X = (rs.randn(n, F) * rs.uniform(0.5, 3, F) + rs.randn(F)).astype(np.float32)
+    g_mine, g_ref = np.random.RandomState(7), np.random.RandomState(7)
+    mine = kmeans_plusplus(X, k, g_mine)
+    ref, _ = sk.kmeans_plusplus(X, k, random_state=g_ref)
+    np.testing.assert_array_equal(mine, ref)
+    np.testing.assert_array_equal(g_mine.randint(0, 1 << 30, 5), g_ref.randint(0, 1 << 30, 5))
