@@ -268,3 +268,34 @@ def test_kmeans_plusplus_draws_scikit_learns_seeds(n, F, k):
     ref, _ = sk.kmeans_plusplus(X, k, random_state=g_ref)
     np.testing.assert_array_equal(mine, ref)
     np.testing.assert_array_equal(g_mine.randint(0, 1 << 30, 5), g_ref.randint(0, 1 << 30, 5))
+
+
+def test_minibatch_host_bookkeeping_matches_scikit_learn():
+    """The host restatement of scikit-learn's per-step bookkeeping (_mini_batch_convergence, _random_reassign:
+    sklearn/cluster/_kmeans.py:1963-2043) against the private methods themselves, on synthetic inertia sequences."""
+    sk = pytest.importorskip("sklearn.cluster")
+    from msmbuilder_amd.cluster.minibatchkmeans import _MiniBatchKMeans
+    rs = np.random.RandomState(0)
+    for trial in range(20):
+        mni = [None, 3, 10][trial % 3]
+        kw = dict(n_clusters=20, batch_size=64, max_no_improvement=mni, tol=0.0)
+        mine, ref = _MiniBatchKMeans(**kw), sk.MiniBatchKMeans(**kw)
+        for m in (mine, ref):
+            m._batch_size, m._tol = 64, 0.0
+            m._ewa_inertia = m._ewa_inertia_min = None
+            m._no_improvement = 0
+            m._n_since_last_reassign = 0
+            m._counts = np.zeros(20, dtype=np.float32)
+        base = rs.uniform(50, 500)
+        n_samples = int(rs.randint(500, 50000))
+        for step in range(200):
+            inertia = base * (0.9 ** min(step, 20)) * rs.uniform(0.97, 1.03) * 64
+            a = mine._mini_batch_convergence(step, 200, n_samples, 0, inertia)
+            b = ref._mini_batch_convergence(step, 200, n_samples, 0, inertia)
+            assert a == b and mine._ewa_inertia == ref._ewa_inertia and mine._no_improvement == ref._no_improvement
+            counts = rs.randint(0 if step < 3 else 1, 9, 20).astype(np.float32)
+            mine._counts, ref._counts = counts.copy(), counts.copy()
+            assert mine._random_reassign() == ref._random_reassign()
+            assert mine._n_since_last_reassign == ref._n_since_last_reassign
+            if a:
+                break
