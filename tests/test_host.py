@@ -299,3 +299,42 @@ def test_minibatch_host_bookkeeping_matches_scikit_learn():
             assert mine._n_since_last_reassign == ref._n_since_last_reassign
             if a:
                 break
+
+
+def test_dir_npy_dataset_host_protocol(tmp_path):
+    """The dir-npy container without a device: file naming, key order, modes, provenance chain, mmap reads and the
+    estimator hooks (reference behaviour: msmbuilder/dataset.py:30-97, 158-237, 290-331)."""
+    from msmbuilder_amd.dataset import dataset, NumpyDirDataset
+    rs = np.random.RandomState(1)
+    arrays = [rs.randn(n, 5).astype(np.float32) for n in (40, 1, 300)]
+    path = str(tmp_path / "trajs")
+    with dataset(path, mode="w", fmt="dir-npy") as ds:
+        assert isinstance(ds, NumpyDirDataset)
+        for i, a in enumerate(arrays):
+            ds[i] = a
+    with pytest.raises(ValueError):
+        dataset(path, mode="w", fmt="dir-npy")              # exists
+    ro = dataset(path, mode="r")
+    assert list(ro.keys()) == [0, 1, 2] and len(ro) == 3
+    assert sorted(os.listdir(path)) == ["00000000.npy", "00000001.npy", "00000002.npy", "PROVENANCE.txt"]
+    for a, b in zip(arrays, ro):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ro.get(2, mmap=True)[7], arrays[2][7])
+    with pytest.raises(IndexError):
+        ro[5]
+    with pytest.raises(IOError):
+        ro[0] = arrays[0]
+
+    class Halver(object):
+        def fit(self, sequences):
+            self.n_ = sum(len(s) for s in sequences)
+            return self
+
+        def partial_transform(self, X):
+            return X[:, :2] * 0.5
+
+    est = Halver()
+    out = ro.fit_transform_with(est, str(tmp_path / "halved"), fmt="dir-npy")
+    assert est.n_ == 341 and list(out.keys()) == [0, 1, 2]
+    np.testing.assert_array_equal(out[2], arrays[2][:, :2] * 0.5)
+    assert "Derived from" in out.provenance and path in out.provenance
