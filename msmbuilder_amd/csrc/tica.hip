@@ -59,6 +59,7 @@ struct TicaArgs {
     int* flag;        // sticky non-finite flag
     unsigned* cosync; // [S] per-cohort arrival counters (zeroed per launch): keeps a cohort's workgroups within one chunk of each other
     long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
+    const float* shift; // [F] per-column reference row r (or nullptr): the fp32 / bf16 kernels accumulate (x - r), see "mean shift"
 };
 
 __device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
@@ -370,20 +371,43 @@ __device__ __forceinline__ float4 stage_ld(global_ptr<char> base, unsigned off, 
     return load_row4<false>(base, off, col, F);
 }
 
-// apply the per-row weight (edge steps) and the column masks (partial tiles) to a loaded stage in place
+// shift (x - r), then apply the per-row weight (edge steps) and the column masks (partial tiles) to a loaded stage
+// in place.  Interior steps of full tiles do not come here: their shift is applied inside the MFMA stream.
 template <bool VEC4, bool PARTIAL>
-__device__ __forceinline__ void stage_scale32(Stage32<VEC4>& st, int uniform, float4 ma, float4 mb)
+__device__ __forceinline__ void stage_scale32(Stage32<VEC4>& st, int uniform, float4 ma, float4 mb, float4 ra, float4 rb)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float sc = uniform ? 1.f : st.sc[j];
+        const float4 a = make_float4(st.a[j].x - ra.x, st.a[j].y - ra.y, st.a[j].z - ra.z, st.a[j].w - ra.w);
+        const float4 b = make_float4(st.b[j].x - rb.x, st.b[j].y - rb.y, st.b[j].z - rb.z, st.b[j].w - rb.w);
         if (PARTIAL) {
-            st.a[j] = make_float4(st.a[j].x * (sc * ma.x), st.a[j].y * (sc * ma.y), st.a[j].z * (sc * ma.z), st.a[j].w * (sc * ma.w));
-            st.b[j] = make_float4(st.b[j].x * mb.x, st.b[j].y * mb.y, st.b[j].z * mb.z, st.b[j].w * mb.w);
+            st.a[j] = make_float4(a.x * (sc * ma.x), a.y * (sc * ma.y), a.z * (sc * ma.z), a.w * (sc * ma.w));
+            st.b[j] = make_float4(b.x * mb.x, b.y * mb.y, b.z * mb.z, b.w * mb.w);
         } else {
-            st.a[j] = make_float4(st.a[j].x * sc, st.a[j].y * sc, st.a[j].z * sc, st.a[j].w * sc);
+            st.a[j] = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
+            st.b[j] = b;
         }
     }
+}
+
+// x - f * r with f in {0, 1} (wave-uniform): exact product, so this is x - r or x bit for bit.  Two v_pk_fma_f32.
+__device__ __forceinline__ float4 shift_fma4(float4 x, float4 r, float nf)
+{
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const f2v n2 = {nf, nf};
+    f2v lo, hi;  // (the builtin elementwise fma is split into scalar v_fma_f32)
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(n2), "v"(f2v{r.x, r.y}), "v"(f2v{x.x, x.y}));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(n2), "v"(f2v{r.z, r.w}), "v"(f2v{x.z, x.w}));
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// this thread's four columns of the reference row (clamped like the data loads; zeros without a shift)
+__device__ __forceinline__ float4 load_shift4(const float* shift, int col, int F)
+{
+    if (!shift) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return make_float4(shift[col + 0 < F ? col + 0 : F - 1], shift[col + 1 < F ? col + 1 : F - 1],
+                       shift[col + 2 < F ? col + 2 : F - 1], shift[col + 3 < F ? col + 3 : F - 1]);
 }
 
 template <bool VEC4, bool PARTIAL>
@@ -435,6 +459,9 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
     const float4 mb = make_float4(J0 + c4 + 0 < P.F ? 1.f : 0.f, J0 + c4 + 1 < P.F ? 1.f : 0.f,
                                   J0 + c4 + 2 < P.F ? 1.f : 0.f, J0 + c4 + 3 < P.F ? 1.f : 0.f);
 
+    // mean shift: this thread's staging columns of the reference row r; both panels hold (x - r)
+    const float4 ra = load_shift4(P.shift, I0 + c4, P.F), rb = load_shift4(P.shift, J0 + c4, P.F);
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
@@ -472,7 +499,8 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
         int un0 = 0, un1 = 0;
         const LaneOffs lofs = make_lane_offs<VEC4>(cx, P.F, I0, J0, tid);
         stage_load32x<VEC4>(st0, un0, cx, lofs, P.F, 0, isG, tauB, I0, J0, tid);
-        stage_store32x<VEC4, PARTIAL>(st0, un0, As, Bs, tid, ma, mb);
+        stage_scale32<VEC4, PARTIAL>(st0, un0, ma, mb, ra, rb);
+        stage_store32x<VEC4, false>(st0, 1, As, Bs, tid, ma, mb);  // already shifted, weighted and masked
         stage_load32x<VEC4>(st0, un0, cx, lofs, P.F, BK32, isG, tauB, I0, J0, tid);
         if (P.cosync && chunks_done > 0) {
             if (tid == 0) {
@@ -497,7 +525,9 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
             StageAddr sa;                                                                         \
             stage_addr32<VEC4>(sa, SLOAD, ULOAD, cx, lofs, P.F, (s + 2) * BK32, isG, I0, J0, tid); \
             /* step s+1's panel becomes what LDS must hold: weights / masks applied in registers */ \
-            if (PARTIAL || !UNEXT) stage_scale32<VEC4, PARTIAL>(SNEXT, UNEXT, ma, mb);            \
+            /* (shifted there too; interior steps of full tiles are shifted inside the stream)   */ \
+            if (PARTIAL || !UNEXT) stage_scale32<VEC4, PARTIAL>(SNEXT, UNEXT, ma, mb, ra, rb);    \
+            const float nfs = (PARTIAL || !UNEXT) ? 0.f : -1.f;                                   \
             PROF_MARK(1) /* step head */                                                          \
             /* fully unrolled: an inner loop makes the compiler's vmcnt bookkeeping give up and     */ \
             /* wait vmcnt(0) at the top of every step, which cuts the register pipeline to 1 step */ \
@@ -514,6 +544,10 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
                 if (kk < 4) { /* step s+2 -> registers */                                         \
                     SLOAD.a[kk] = stage_ld<VEC4>(sa.pa, sa.oa[kk], P.F, I0 + scol);               \
                     SLOAD.b[kk] = stage_ld<VEC4>(sa.pb, sa.ob[kk], P.F, J0 + scol);               \
+                }                                                                                 \
+                if (kk >= 7 && kk < 15 && (kk & 1) == 1) { /* shift one k-pair ahead of its store */ \
+                    SNEXT.a[(kk - 7) / 2] = shift_fma4(SNEXT.a[(kk - 7) / 2], ra, nfs);           \
+                    SNEXT.b[(kk - 7) / 2] = shift_fma4(SNEXT.b[(kk - 7) / 2], rb, nfs);           \
                 }                                                                                 \
                 if (kk >= 8 && (kk & 1) == 0) { /* step s+1 -> the other LDS buffer */            \
                     *reinterpret_cast<float4*>(Aw + ((kk - 8) / 2) * 8 * TM) = SNEXT.a[(kk - 8) / 2]; \
@@ -639,9 +673,16 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
     typedef float f2v __attribute__((ext_vector_type(2)));
     typedef float f4v __attribute__((ext_vector_type(4)));
 #define MSM_F2(O) (*reinterpret_cast<const f2v*>(lds + (O)))
-#define MSM_SYM_UD(A, B)                                                                               \
+    // (x_t, x_{t+tau}) -> (u, d) of the SHIFTED frames y = x - r (R: this thread's four columns of r; W: row weight x
+    // column mask, applied only where USEW): y is exact or rounded at its own (sigma-sized) scale, so the fp32 products
+    // never see the column means
+#define MSM_SYM_UD(A, B, R, W, USEW)                                                                   \
     {                                                                                                  \
-        const f4v a_ = *reinterpret_cast<const f4v*>(&(A)), b_ = *reinterpret_cast<const f4v*>(&(B));  \
+        f4v a_ = pk_sub4(*reinterpret_cast<const f4v*>(&(A)), R), b_ = pk_sub4(*reinterpret_cast<const f4v*>(&(B)), R); \
+        if (USEW) {                                                                                    \
+            a_ *= *reinterpret_cast<const f4v*>(&(W));                                                 \
+            b_ *= *reinterpret_cast<const f4v*>(&(W));                                                 \
+        }                                                                                              \
         const f4v u_ = a_ + b_, d_ = pk_sub4(a_, b_);                                                  \
         A = *reinterpret_cast<const float4*>(&u_);                                                     \
         B = *reinterpret_cast<const float4*>(&d_);                                                     \
@@ -675,6 +716,17 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                                   I0 + c4 + 2 < P.F ? 1.f : 0.f, I0 + c4 + 3 < P.F ? 1.f : 0.f);
     const float4 mb = make_float4(J0 + c4 + 0 < P.F ? 1.f : 0.f, J0 + c4 + 1 < P.F ? 1.f : 0.f,
                                   J0 + c4 + 2 < P.F ? 1.f : 0.f, J0 + c4 + 3 < P.F ? 1.f : 0.f);
+
+    // mean shift: the reference row r of this tile's I and J columns lives in LDS behind the panels ([2][TM] floats;
+    // the kernel has no registers to spare) and is read, 16 bytes per thread, inside the MFMA stream one k-pair
+    // before the packed subtractions that use it.  No shift = zeros (x - 0 is exact: bit-identical sums).
+    float* rs = lds + 2 * 4 * PAN;
+    if (tid < 64) {
+        const int col = (tid < 32 ? I0 : J0) + (tid & 31) * 4;
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.shift) rv = *reinterpret_cast<const float4*>(P.shift + (col < P.F ? col : P.F - 4));
+        *reinterpret_cast<float4*>(rs + tid * 4) = rv;
+    }
 
     f32x16 aH[2][2], aD[2][2];
 #pragma unroll
@@ -733,17 +785,12 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                 yb[j] = load16_global<char>(cx.baseB + (rb + cb));                                     \
                 sc_[j] = (kr < cx.hi) ? 1.f : 0.f;                                                     \
             }                                                                                          \
+            const f4v rx_ = *reinterpret_cast<const f4v*>(rs + scol), ry_ = *reinterpret_cast<const f4v*>(rs + TM + scol); \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
                 const float4 wa = PARTIAL ? make_float4(sc_[j] * ma.x, sc_[j] * ma.y, sc_[j] * ma.z, sc_[j] * ma.w) \
                                           : make_float4(sc_[j], sc_[j], sc_[j], sc_[j]);               \
-                xa[j] = f4mul(xa[j], wa);                                                              \
-                xb[j] = f4mul(xb[j], wa);                                                              \
-                if (PARTIAL) {                                                                         \
-                    ya[j] = f4mul(ya[j], mb);                                                          \
-                    yb[j] = f4mul(yb[j], mb);                                                          \
-                }                                                                                      \
-                MSM_SYM_UD(xa[j], xb[j])                                                               \
-                MSM_SYM_UD(ya[j], yb[j])                                                               \
+                MSM_SYM_UD(xa[j], xb[j], rx_, wa, true)                                                \
+                MSM_SYM_UD(ya[j], yb[j], ry_, mb, PARTIAL)                                             \
             }                                                                                          \
             MSM_STORE_X(BUF)                                                                           \
             MSM_STORE_Y(BUF)                                                                           \
@@ -793,6 +840,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                 const unsigned ox = fast ? offx : ca, oy = fast ? offy : cb;
                 f2v pu = MSM_F2(b * 4 * PAN + 0 * PAN + fa), pd = MSM_F2(b * 4 * PAN + 1 * PAN + fa);
                 f2v qu = MSM_F2(b * 4 * PAN + 2 * PAN + fb), qd = MSM_F2(b * 4 * PAN + 3 * PAN + fb);
+                f4v rsh;
                 PROF_MARK(1)
 #pragma unroll
                 for (int kk = 0; kk < HK / 2; ++kk) {
@@ -809,25 +857,16 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                             ya[j] = load16_global<char>(pa + j * r8 + oy);
                             yb[j] = load16_global<char>(pb + j * r8 + oy);
                         }
+                    } else if (kk == 4) {
+                        rsh = *reinterpret_cast<const f4v*>(rs + scol);  // r, I columns (waited on with the fragments)
                     } else if (kk == 5) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (PARTIAL) {
-                                xa[j] = f4mul(xa[j], ma);
-                                xb[j] = f4mul(xb[j], ma);
-                            }
-                            MSM_SYM_UD(xa[j], xb[j])
-                        }
+                        for (int j = 0; j < 2; ++j) MSM_SYM_UD(xa[j], xb[j], rsh, ma, PARTIAL)
+                        rsh = *reinterpret_cast<const f4v*>(rs + TM + scol);  // r, J columns
                     } else if (kk == 6) {
                         MSM_STORE_X(b ^ 1)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (PARTIAL) {
-                                ya[j] = f4mul(ya[j], mb);
-                                yb[j] = f4mul(yb[j], mb);
-                            }
-                            MSM_SYM_UD(ya[j], yb[j])
-                        }
+                        for (int j = 0; j < 2; ++j) MSM_SYM_UD(ya[j], yb[j], rsh, mb, PARTIAL)
                     } else if (kk == 7) {
                         MSM_STORE_Y(b ^ 1)
                     }
@@ -1132,17 +1171,19 @@ __device__ __forceinline__ void stageB_load(float4 (&v)[8], float (&sc)[8], cons
 
 template <bool X3>
 __device__ __forceinline__ void stageB_store(const float4 (&v)[8], const float (&sc)[8], bf16x8* hi, bf16x8* mid,
-                                             float4 colmask, int tid)
+                                             float4 colmask, float4 shift, int tid)
 {
     const int c4 = (tid & 31) * 4;
     const int kg = (tid >> 5) & 3;
     const float m4[4] = {colmask.x, colmask.y, colmask.z, colmask.w};
+    const float r4[4] = {shift.x, shift.y, shift.z, shift.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         bf16x8 h, m;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const float x = (q == 0 ? v[r].x : q == 1 ? v[r].y : q == 2 ? v[r].z : v[r].w) * (sc[r] * m4[q]);
+            // mean shift BEFORE the bf16 rounding: 8 (16) significant bits are spent on x - r, not on the column mean
+            const float x = ((q == 0 ? v[r].x : q == 1 ? v[r].y : q == 2 ? v[r].z : v[r].w) - r4[q]) * (sc[r] * m4[q]);
             const __bf16 xh = (__bf16)x;
             h[r] = xh;
             if (X3) m[r] = (__bf16)(x - (float)xh);
@@ -1179,6 +1220,8 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_bf16_kernel(TicaArgs P)
     const float4 cm = make_float4(col0 + c4 + 0 < P.F ? 1.f : 0.f, col0 + c4 + 1 < P.F ? 1.f : 0.f,
                                   col0 + c4 + 2 < P.F ? 1.f : 0.f, col0 + c4 + 3 < P.F ? 1.f : 0.f);
 
+    const float4 rsh = load_shift4(P.shift, col0 + c4, P.F);
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
@@ -1196,7 +1239,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_bf16_kernel(TicaArgs P)
 
         StageB<X3> s0, s1;
         stageB_load<VEC4>(s0.v, s0.sc, cx, P.F, 0, isG, col0, isB, tid);
-        stageB_store<X3>(s0.v, s0.sc, L + (isB ? PK : 0), L + (isB ? PK : 0) + 2 * PK, cm, tid);
+        stageB_store<X3>(s0.v, s0.sc, L + (isB ? PK : 0), L + (isB ? PK : 0) + 2 * PK, cm, rsh, tid);
         stageB_load<VEC4>(s0.v, s0.sc, cx, P.F, BKB, isG, col0, isB, tid);
         __syncthreads();
 #define MSM_TICA_STEPB(SNEXT, SLOAD, BUF)                                                         \
@@ -1233,7 +1276,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_bf16_kernel(TicaArgs P)
             }                                                                                     \
             if (s + 1 < nsteps) {                                                                 \
                 bf16x8* dst = L + ((BUF) ^ 1) * IMG + (isB ? PK : 0);                             \
-                stageB_store<X3>(SNEXT.v, SNEXT.sc, dst, dst + 2 * PK, cm, tid);                  \
+                stageB_store<X3>(SNEXT.v, SNEXT.sc, dst, dst + 2 * PK, cm, rsh, tid);             \
             }                                                                                     \
             __syncthreads();                                                                      \
         }
@@ -1370,6 +1413,81 @@ __global__ void tica_colmerge_kernel(double* __restrict__ dst, double* __restric
         dst[i] += tmp[i];
         tmp[i] = 0.0;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Mean shift.  The covariance is G / 2N - mu mu^T (tica.py:228-259): an error of eps * |G| in an fp32-accumulated
+// G is a RELATIVE covariance error of eps * (mu / sigma)^2, i.e. 1e-3 for features whose mean is 100 standard
+// deviations (contact and atom-pair distances), where the reference -- float64 throughout, tica.py:402 -- loses nothing.
+// So the fp32 and bf16 kernels accumulate the moments of y = x - r for a per-handle reference row r (fp32, the column
+// mean of the first launch: the column-sum pass runs before the MFMA pass anyway), whose entries are sigma-sized, and
+// the raw moments are restored in fp64 at export time from the exact fp64 column sums:
+//     C = C' + A' r^T + r B'^T + n r r^T          A' = A - n r,  B' = B - n r      (A, B: sums of the left / right frames
+//     G = G' + W' r^T + r W'^T + nW r r^T         W' = W - nW r                     of the n shifted pairs; W, nW: weighted
+// frame sum and total weight of the Gram term -- A + B and 2n except when a trajectory is split over ranks, where the
+// C/G kernel's Gram tiles own FRAMES, not pairs).  r never changes while a handle accumulates, so launches add up.
+// ---------------------------------------------------------------------------
+// part: the [NCB][2][F] column-sum partials (a = "s0" half, b = "stau" half) of ONE column-sum launch; `what` says where
+// they go: SH_A_a: A += a, SH_B_b: B += b, SH_W_ab: W += a + b, SH_B_a: B += a, SH_W_a: W += a.
+//   whole trajectories                       A|B_b|W_ab   (left sums, right sums, both)
+//   segments, owned rows, C/G or bf16 kernel A|W_ab       (the Gram tiles weight the OWNED frames)
+//   segments, owned rows, H/D kernel         A|W_a        (its Gram is over owned PAIRS: W = A + B)
+//   segments, the pairs' right rows          B_a (|W_a for the H/D kernel)
+enum { SH_A_a = 1, SH_B_b = 2, SH_W_ab = 4, SH_B_a = 8, SH_W_a = 16 };
+__global__ __launch_bounds__(256) void tica_shift_kernel(const double* __restrict__ part, double* __restrict__ shsum,
+                                                         float* __restrict__ r, int F, double inv_n, int set_r, int what)
+{
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x, col = blockIdx.x * 64 + (tid & 63), rl = tid >> 6;
+    double a = 0.0, b = 0.0;
+    if (col < F)
+        for (int k = rl; k < NCB; k += 4) {
+            a += part[(size_t)k * 2 * F + col];
+            b += part[(size_t)k * 2 * F + F + col];
+        }
+    red[0][tid] = a;
+    red[1][tid] = b;
+    __syncthreads();
+    if (rl == 0 && col < F) {
+        a += red[0][tid + 64] + red[0][tid + 128] + red[0][tid + 192];
+        b += red[1][tid + 64] + red[1][tid + 128] + red[1][tid + 192];
+        if (set_r) r[col] = (float)((a + b) * inv_n);
+        if (what & SH_A_a) shsum[col] += a;
+        if (what & SH_B_b) shsum[F + col] += b;
+        if (what & SH_B_a) shsum[F + col] += a;
+        if (what & SH_W_ab) shsum[2 * F + col] += a + b;
+        if (what & SH_W_a) shsum[2 * F + col] += a;
+    }
+}
+
+__global__ void tica_unshift_kernel(double* __restrict__ packed, const double* __restrict__ shsum,
+                                    const float* __restrict__ r, double n, double nW, int F, int sym)
+{
+    const size_t FF = (size_t)F * F;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * FF) return;
+    const int type = idx >= FF;
+    const size_t e = idx - (type ? FF : 0);
+    int i = (int)(e / F), j = (int)(e % F);
+    if ((type || sym) && i > j) {  // symmetric corrections: evaluate the mirrored element with the SAME operand order, so
+        const int t = i;           // the result is symmetric bit for bit whatever the compiler contracts into FMAs
+        i = j;
+        j = t;
+    }
+    const double ri = (double)r[i], rj = (double)r[j];
+    double v;
+    if (type) {
+        const double wi = shsum[2 * F + i] - nW * ri, wj = shsum[2 * F + j] - nW * rj;
+        v = (ri * wj + wi * rj) + nW * ri * rj;
+    } else {
+        const double ai = shsum[i] - n * ri, aj = shsum[j] - n * rj;
+        const double bi = shsum[F + i] - n * ri, bj = shsum[F + j] - n * rj;
+        if (sym)
+            v = 0.5 * ((ai * rj + aj * ri) + (ri * bj + rj * bi)) + n * ri * rj;
+        else
+            v = (ai * rj + ri * bj) + n * ri * rj;
+    }
+    packed[idx] += v;
 }
 
 // packed[C | G | s0 | stau | n_obs | n_seq] = base + sum over slabs / column partials
@@ -1629,10 +1747,14 @@ struct msm_tica {
     int* flag = nullptr;        // [2]: [0] sticky, [1] per-call
     long long* dbg = nullptr;   // [4] profiling clocks
     unsigned* cosync = nullptr; // [S] cohort pacing counters
+    float* shift = nullptr;     // [F] reference row r of the mean shift (fp32 / bf16 kernels); valid once have_shift
+    double* shsum = nullptr;    // [3F] raw column sums [A | B | W] of everything accumulated under the shift
+    bool shift_on = true, have_shift = false;
+    long long n_sh = 0, nw_sh = 0;  // shifted pairs, and the total weight of their Gram terms (2 n_sh for whole trajectories)
     long long n_obs = 0, n_seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
     bool timed = false;
-    DevBuf table, staging;
+    DevBuf table, table2, staging;
     size_t packed_len() const { return 2 * (size_t)F * F + 2 * (size_t)F + 2; }
 };
 
@@ -1649,7 +1771,7 @@ int query_slots(K kernel, size_t lds, int* slots)
 }
 
 constexpr size_t LDS32 = 2 * 2 * BK32 * TM * sizeof(float);  // 64 KiB
-constexpr size_t LDSSYM = 4 * BK32 * TM * sizeof(float);  // 64 KiB: the (u, d) images for columns I and J
+constexpr size_t LDSSYM = 4 * BK32 * TM * sizeof(float) + 2 * TM * sizeof(float);  // 64 KiB: the (u, d) images for columns I and J, + 1 KiB: the shift row
 constexpr size_t LDSB = 2 * 2 * 4 * TM * 16;                  // 32 KiB: [2 bufs][A,B][4 groups][128] 16-byte packets
 constexpr size_t LDSB3 = 2 * 4 * 4 * TM * 16;                 // 64 KiB: + mid images
 constexpr size_t LDS64 = 2 * 2 * BK64 * P64 * sizeof(double);  // 72 KiB (double-buffered, pitch 144)
@@ -1664,6 +1786,13 @@ int tica_zero(msm_tica* h)
     MSM_HIP_CHECK(hipMemsetAsync(h->colpart, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, 2 * sizeof(int), stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->shsum, 0, 3 * (size_t)h->F * sizeof(double), stream()));
+    h->have_shift = false;
+    h->n_sh = h->nw_sh = 0;
+    {
+        const char* sh_env = getenv("MSM_TICA_SHIFT");  // 0: accumulate raw moments (A/B switch for the tests); read per reset
+        h->shift_on = !(sh_env && atoi(sh_env) == 0);
+    }
     h->n_obs = 0;
     h->n_seq = 0;
     return MSM_OK;
@@ -1790,11 +1919,73 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
         }
     }
+    // 1b) mean shift bookkeeping (fp32 / bf16 kernels): the raw column sums of what this launch accumulates under the
+    //     shift, and -- first shifted launch of the handle -- the reference row r = this launch's column means
+    const bool shifted = h->shift_on && (use32 || useb);
+    long long n_call = 0, nw_call = 0, nmean = 0;
+    if (shifted) {
+        for (msm_idx_t s = 0; s < n_seq; ++s) {
+            const SegInfo g = seg_of(s);
+            if (g.len <= h->lag || g.oe <= g.ob) continue;
+            const long long n0 = std::max<long long>(0, std::min<long long>(g.oe, g.len - h->lag) - g.ob);
+            const long long nt = std::max<long long>(0, g.oe - std::max<long long>(g.ob, h->lag));
+            n_call += n0;
+            nmean += n0 + nt;
+            nw_call += (segs && !usesym) ? n0 + nt : 2 * n0;
+        }
+        const int what = !segs ? (SH_A_a | SH_B_b | SH_W_ab) : usesym ? (SH_A_a | SH_W_a) : (SH_A_a | SH_W_ab);
+        hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(256), 0, stream(), h->coltmp,
+                           h->shsum, h->shift, h->F, 1.0 / (double)std::max<long long>(1, nmean), h->have_shift ? 0 : 1, what);
+        MSM_HIP_CHECK(hipGetLastError());
+        h->have_shift = true;
+        h->n_sh += n_call;
+        h->nw_sh += nw_call;
+        P.shift = h->shift;
+    }
     {
         const size_t n = (size_t)NCB * 2 * h->F;
         hipLaunchKernelGGL(tica_colmerge_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
                            h->colpart, h->coltmp, n);
         MSM_HIP_CHECK(hipGetLastError());
+    }
+    if (shifted && segs) {
+        // a trajectory split over ranks: the RIGHT frames of the owned pairs, rows [own_begin + lag, min(own_end, len - lag)
+        // + lag), are not the owned rows the pass above summed -- one more column-sum pass over exactly those rows (into
+        // the temporary partials, which the merge above has just zeroed; they are zeroed again afterwards)
+        std::vector<TicaChunk> tab;
+        for (msm_idx_t s = 0; s < n_seq; ++s) {
+            const SegInfo g = seg_of(s);
+            if (g.len <= h->lag || g.oe <= g.ob) continue;
+            const long long b0 = g.ob + h->lag, b1 = std::min<long long>(g.oe, g.len - h->lag) + h->lag;
+            for (long long r0 = b0; r0 < b1; r0 += kc) {
+                TicaChunk ch;
+                ch.base = (const char*)ptrs[s] - (ptrdiff_t)g.off * (ptrdiff_t)ld * dtype_bytes;
+                ch.row0 = r0;
+                ch.len = (long long)1 << 60;  // every row counts (as "s0")
+                ch.n = (int)std::min<long long>(kc, b1 - r0);
+                ch.pad = 0;
+                ch.last = g.off + n_rows[s] - 1;
+                tab.push_back(ch);
+            }
+        }
+        if (!tab.empty()) {
+            int rc = h->table2.reserve(tab.size() * sizeof(TicaChunk));
+            if (rc) return rc;
+            MSM_HIP_CHECK(hipMemcpyAsync(h->table2.p, tab.data(), tab.size() * sizeof(TicaChunk), hipMemcpyHostToDevice, stream()));
+            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+            TicaArgs Q = P;
+            Q.chunks = h->table2.as<TicaChunk>();
+            Q.nchunks = (long long)tab.size();
+            Q.flag = h->flag + 1;  // these rows were (or will be) checked by the launch that owns them
+            if (dtype_bytes == 4)
+                hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), Q);
+            else
+                hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), Q);
+            hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(256), 0, stream(), h->coltmp,
+                               h->shsum, h->shift, h->F, 0.0, 0, usesym ? (SH_B_a | SH_W_a) : SH_B_a);
+            MSM_HIP_CHECK(hipGetLastError());
+            MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
+        }
     }
     // 2) the MFMA pass
     MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned), stream()));
@@ -1852,6 +2043,12 @@ int tica_export_device(msm_tica* h)
         const size_t ff2 = 2 * (size_t)h->F * h->F;
         hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->slabs_sym,
                            h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    if (h->have_shift) {  // restore the raw moments from the shifted ones (fp64)
+        const size_t ff2 = 2 * (size_t)h->F * h->F;
+        hipLaunchKernelGGL(tica_unshift_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->packed,
+                           h->shsum, h->shift, (double)h->n_sh, (double)h->nw_sh, h->F, h->sym);
         MSM_HIP_CHECK(hipGetLastError());
     }
     const double cnt[2] = {(double)h->n_obs, (double)h->n_seq};
@@ -1958,6 +2155,8 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->flag, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->dbg, 64 * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void**)&h->cosync, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->shift, (size_t)h->F * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->shsum, 3 * (size_t)h->F * sizeof(double));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -1986,6 +2185,8 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->flag) (void)hipFree(h->flag);
     if (h->dbg) (void)hipFree(h->dbg);
     if (h->cosync) (void)hipFree(h->cosync);
+    if (h->shift) (void)hipFree(h->shift);
+    if (h->shsum) (void)hipFree(h->shsum);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
