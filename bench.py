@@ -4,24 +4,31 @@
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over the rank's HBM-resident synthetic shard
-(BASELINE.json configs[3]: 10,000,000 x 512 fp32 as 1,000 trajectories x 10,000 frames,
-tICA lag 100):
+One "step" = one pass of the hot path over the HBM-resident synthetic data set of BASELINE.json configs[3]
+(10,000,000 x 512 fp32 as 1,000 trajectories x 10,000 frames, tICA lag 100):
 
-    tICA.fit        MFMA covariance accumulation of every frame  (dominant kernel)
-    allreduce       one RCCL all-reduce of the packed fp64 accumulators (N > 1)
-    solve           finalise + generalized eigensolve (host scipy, F x F)
-    transform       fused projection to n_components = 10 (fp64 out, stays in HBM)
-    KCenters.fit    K = 200 fused k-centers passes on the projected frames (exact arithmetic)
-    KCenters.predict  assign_nearest of every frame (exact arithmetic, bit-identical labels)
+    fit               tICA.fit: column sums + MFMA covariance accumulation of every frame   (dominant kernel)
+    allreduce         one RCCL all-reduce of the packed fp64 accumulators                    (N > 1)
+    solve             finalise + generalized eigensolve, top n_components = 10
+    transform         fused projection (fp64 out, stays in HBM)
+    kcenters_fit      K = 200 fused k-centers passes on the projected frames (exact arithmetic)
+    kcenters_predict  assign_nearest of every frame (exact arithmetic, bit-identical labels)
 
-Scaling is weak: every rank holds its own 10M x 512 shard (20.5 GB of the 288 GB HBM), so
-`value` = N x frames-per-rank / max-over-ranks step time.  Data is generated on the
-device before timing (AR(1) slow modes mixed into 512 features).
-Prints ONE JSON line on rank 0.  Besides the contract's keys it carries `roofline` (dominant kernel: algorithmic and
-executed TFLOP/s against the fp32 MFMA peak, L2-fabric traffic), `clustering` (the HBM-bound half on its own),
-`cpu_baseline` (the oracle on the host cores, bounded sample; N = 1 only) and `minibatchkmeans` (configs[3]'s
-clusterer, MiniBatchKMeans(k=1000).fit on the same projection, run once OUTSIDE the timed steps; N = 1 only).
+Scaling.  N = 1: the whole problem on one GPU.  N > 1 defaults to STRONG scaling -- the same 10M x 512 problem, its
+trajectories dealt out over the ranks (`frames // N` per GPU), which is what BASELINE's metric and configs[3] describe;
+`--scaling weak` gives every rank its own 10M x 512 shard instead.  `value` = total frames / max-over-ranks step time.
+Data is generated on the device before timing (AR(1) slow modes mixed into 512 features).
+
+Prints ONE JSON line on rank 0.  Besides the contract's keys:
+  roofline      dominant kernel (the MFMA accumulation): `achieved` = the MFMA flop it EXECUTES / its HIP-event duration,
+                `frac` = achieved / dense fp32-MFMA peak (pipe utilisation); `algorithmic` = SURVEY 8(d)'s 4 F^2 flop per
+                frame / the same duration (can exceed the peak: the sum/difference kernel needs 0.625 of those flops)
+  phases_ms     per-phase wall times (host clock around synchronised phases), summing to the step
+  self_check    the HIP path and the float64 oracle fitted on the same 64 trajectories (eigenvalues, rtol 1e-5), and the
+                full run's leading eigenvalues against that sample (loose)
+  cpu_baseline  the oracle on the host cores (bounded sample): all-threads and 1-thread BLAS tICA, single-thread and
+                row-parallel exact KCenters, scikit-learn's own MiniBatchKMeans(k=1000)
+  f64, config2, config5_width, minibatchkmeans, strong_scaling_model   untimed secondary legs (N = 1 only)
 """
 import argparse
 import ctypes as C
@@ -32,7 +39,7 @@ import time
 import warnings
 
 # torchrun exports OMP_NUM_THREADS=1 to every rank unless the user set it ("please further tune the variable"): the
-# host eigensolve of a step would then run on one BLAS thread at N > 1 but on four at N = 1.  OpenBLAS sizes its
+# host part of the eigensolve would then run on one BLAS thread at N > 1 but on four at N = 1.  OpenBLAS sizes its
 # buffers from this variable when numpy / scipy are first imported, so it has to be raised HERE, before that import.
 if "LOCAL_RANK" in os.environ and os.environ.get("OMP_NUM_THREADS") == "1":
     os.environ["OMP_NUM_THREADS"] = "8"
@@ -43,19 +50,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
-PEAK_F64_MFMA_TFLOPS = 78.6
+# /opt/skills/guides/MI355X_MICROARCH.md, dense peaks
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0, "bf16x2": 2500.0}
 PEAK_HBM_GBS = 8000.0
 
 
-def synth(torch, n_seq, n_frames, F, seed, device, n_slow=16):
+def synth(torch, n_seq, n_frames, F, seed, device, n_slow=16, mean_scale=1.0):
     """AR(1) slow modes -> F features, generated on the device.  Returns [n_seq*n_frames, F] f32."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     gm = torch.Generator(device="cpu")
     gm.manual_seed(4321)
     M = (torch.randn(n_slow, F, generator=gm) / np.sqrt(n_slow)).to(device)
-    b = (torch.rand(F, generator=gm) * 2 - 1).to(device)
+    b = ((torch.rand(F, generator=gm) * 2 - 1) * mean_scale).to(device)
     ts = torch.logspace(np.log10(20.0), np.log10(5000.0), n_slow)
     a = torch.exp(-1.0 / ts).to(device)
     sig = torch.sqrt(1 - a * a)
@@ -80,12 +87,29 @@ def synth(torch, n_seq, n_frames, F, seed, device, n_slow=16):
     return X
 
 
-def cpu_baseline(X_host_list, lag, k_comp, k_clusters, budget_s=12.0):
-    """The CPU checker timed on the host cores on a bounded sample of the same workload:
-    oracle tICA (the reference's op sequence: f64 up-cast + 3 dgemm, tica.py:402-422),
-    eigensolve, projection, then the C restatement of KCenters.fit + assign_nearest."""
+def executed_flop_per_frame(F, sym):
+    """MFMA flop the accumulation kernel issues per frame, in 128 x 128 tile products: all T^2 lagged tiles + the
+    T(T+1)/2 upper Gram tiles, or -- fp32 sum/difference kernel -- the H and the D block of the upper tiles only."""
+    nt = (F + 127) // 128
+    tiles = nt * (nt + 1) if sym else nt * nt + nt * (nt + 1) // 2
+    return 2.0 * 128 * 128 * tiles, tiles
+
+
+def kernel_ms_of(tica, _lib):
+    ms = C.c_float(0.0)
+    _lib.check(_lib.lib().msm_tica_last_kernel_ms(tica._handle, C.byref(ms)))
+    return float(ms.value)
+
+
+def cpu_baseline(X_host_list, lag, k_comp, k_clusters, budget_s=10.0):
+    """The CPU checker timed on the host cores on a bounded sample of the same workload (SURVEY 8(d) i-iii):
+    (i) oracle tICA = the reference's op sequence (f64 up-cast + 3 dgemm, tica.py:402-422) on all BLAS threads and on
+    one; (ii) the C restatement of KCenters.fit + assign_nearest single-threaded (the reference has no threads there)
+    and assign_nearest row-parallel over all cores; (iii) scikit-learn's MiniBatchKMeans(k=1000) itself."""
     from oracle.tica_oracle import TicaOracle
     from oracle.libdistance_oracle import Oracle
+    from concurrent.futures import ThreadPoolExecutor
+    ncpu = os.cpu_count() or 1
     o = TicaOracle(n_components=k_comp, lag_time=lag)
     t0 = time.perf_counter()
     used = []
@@ -97,21 +121,66 @@ def cpu_baseline(X_host_list, lag, k_comp, k_clusters, budget_s=12.0):
             if time.perf_counter() - t0 > budget_s:
                 break
     t_fit = time.perf_counter() - t0
+    # (i) one BLAS thread, on as many of the same trajectories as ~3 s allow
+    t_fit1, n1 = None, 0
+    try:
+        from threadpoolctl import threadpool_limits
+        o1 = TicaOracle(n_components=k_comp, lag_time=lag)
+        with threadpool_limits(1, "blas"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t1 = time.perf_counter()
+            for X in used:
+                o1.partial_fit(X)
+                n1 += len(X)
+                if time.perf_counter() - t1 > 3.0:
+                    break
+            t_fit1 = time.perf_counter() - t1
+    except Exception:
+        pass
     t1 = time.perf_counter()
     Y = np.concatenate(o.transform(used))
     t_proj = time.perf_counter() - t1
     lo = Oracle()
     t2 = time.perf_counter()
     ids, labels, dist = lo.kcenters_fit(Y, k_clusters, "euclidean", 0)
-    lab, _ = lo.assign_nearest(Y, np.ascontiguousarray(Y[ids]), "euclidean")
+    centers = np.ascontiguousarray(Y[ids])
+    t2b = time.perf_counter()
+    lab, _ = lo.assign_nearest(Y, centers, "euclidean")
     t_clu = time.perf_counter() - t2
+    t_assign1 = time.perf_counter() - t2b
+    # (ii) row-parallel variant of the same scalar routine (ctypes releases the GIL)
+    nth = min(ncpu, 64)
+    bounds = np.linspace(0, len(Y), nth + 1).astype(np.int64)
+    t3 = time.perf_counter()
+    with ThreadPoolExecutor(nth) as ex:
+        parts = list(ex.map(lambda i: lo.assign_nearest(np.ascontiguousarray(Y[bounds[i]:bounds[i + 1]]), centers, "euclidean")[0],
+                            range(nth)))
+    t_assign_par = time.perf_counter() - t3
+    assert np.array_equal(np.concatenate(parts), lab)
     n = sum(len(x) for x in used)
     total = t_fit + t_proj + t_clu
-    return dict(value=n / total, unit="frames/s", cores=os.cpu_count(), kind="port",
-                sample="%d trajectories x %d frames x %d f32 of the same synthetic data (oracle tICA via numpy BLAS "
-                       "on all host threads %.2fs + projection %.2fs + single-thread C KCenters K=%d fit+assign %.2fs)"
-                       % (len(used), len(used[0]), used[0].shape[1], t_fit, t_proj, k_clusters, t_clu),
-                tica_fit_frames_per_s=n / t_fit)
+    out = dict(value=n / total, unit="frames/s", cores=ncpu, kind="port",
+               sample="%d trajectories x %d frames x %d f32 of the same synthetic data: oracle tICA (numpy BLAS, all host "
+                      "threads) %.2fs + projection %.2fs + single-thread C KCenters K=%d fit+assign %.2fs"
+                      % (len(used), len(used[0]), used[0].shape[1], t_fit, t_proj, k_clusters, t_clu),
+               tica_fit_frames_per_s=n / t_fit,
+               tica_fit_1thread_frames_per_s=(n1 / t_fit1) if t_fit1 else None,
+               assign_1thread_frames_per_s=n / t_assign1,
+               assign_row_parallel_frames_per_s=n / t_assign_par, assign_row_parallel_threads=nth)
+    # (iii) scikit-learn's MiniBatchKMeans on the projected sample
+    try:
+        from sklearn.cluster import MiniBatchKMeans as SkMBK
+        Y32 = Y.astype(np.float32)
+        t4 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk = SkMBK(n_clusters=1000, random_state=0, n_init=1).fit(Y32)
+        t_sk = time.perf_counter() - t4
+        out["sklearn_minibatchkmeans"] = dict(n_clusters=1000, frames=len(Y32), fit_s=t_sk, n_steps=int(sk.n_steps_),
+                                              fit_frames_per_s=len(Y32) / t_sk)
+    except Exception as e:  # baseline only
+        out["sklearn_minibatchkmeans"] = dict(error=str(e)[:100])
+    return out, o, used
 
 
 def main():
@@ -119,15 +188,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=10_000_000, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=10_000_000, help="frames of the whole problem (strong) / per GPU (weak)")
     ap.add_argument("--features", type=int, default=512)
     ap.add_argument("--traj-len", type=int, default=10_000)
     ap.add_argument("--lag", type=int, default=100)
     ap.add_argument("--components", type=int, default=10)
     ap.add_argument("--clusters", type=int, default=200)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--mode", default=os.environ.get("MSMBUILDER_AMD_TICA_MODE", "f32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mbk", action="store_true", help="skip the untimed MiniBatchKMeans(k=1000) leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed f64 / config2 / config5 / model legs")
     args = ap.parse_args()
     os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
 
@@ -144,113 +215,142 @@ def main():
     _lib.set_stream(torch.cuda.current_stream().cuda_stream)
 
     F, T = args.features, args.traj_len
-    n_seq = max(1, args.frames // T)
+    n_seq_total = max(1, args.frames // T)
+    if args.scaling == "strong":   # the same problem dealt out over the ranks, whole trajectories
+        n_seq = n_seq_total // world + (1 if rank < n_seq_total % world else 0)
+        total_frames = n_seq_total * T
+    else:
+        n_seq = n_seq_total
+        total_frames = n_seq_total * T * world
     frames = n_seq * T
     X = synth(torch, n_seq, T, F, 1234 + rank, dev)
     seqs = list(X.view(n_seq, T, F).unbind(0))
     torch.cuda.synchronize()
 
-    times = {}
-
-    def step(record):
+    def step(record, seqs, X):
+        def mark(name, t_prev):
+            if record is None:
+                return t_prev
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            record.setdefault(name, []).append(now - t_prev)
+            return now
         t = time.perf_counter()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             tica = tICA(n_components=args.components, lag_time=args.lag)
             tica.fit(seqs)
             if record is not None:
-                ms = C.c_float(0.0)
-                _lib.check(_lib.lib().msm_tica_last_kernel_ms(tica._handle, C.byref(ms)))
-                record.setdefault("mfma_ms", []).append(ms.value)
+                record.setdefault("mfma_ms", []).append(kernel_ms_of(tica, _lib))
                 record["sym"] = tica._lagged_symmetrised
-                torch.cuda.synchronize()
-                record.setdefault("fit", []).append(time.perf_counter() - t)
+            t = mark("fit", t)
             if world > 1:
                 tica.allreduce()
-            ev = tica.eigenvalues_          # finalise + eigensolve (host)
-            t1 = time.perf_counter()
+                t = mark("allreduce", t)
+            ev = tica.eigenvalues_          # finalise + eigensolve
+            comps = tica.components_
+            t = mark("solve", t)
             Y = tica.transform([X])[0]      # [frames, k] float64, device resident
-            if record is not None:
-                torch.cuda.synchronize()
-                record.setdefault("transform", []).append(time.perf_counter() - t1)
-            t2 = time.perf_counter()
+            t = mark("transform", t)
             kc = KCenters(n_clusters=args.clusters, random_state=0).fit([Y])
-            if record is not None:
-                torch.cuda.synchronize()
-                t3 = time.perf_counter()
-                record.setdefault("kcenters_fit", []).append(t3 - t2)
+            t = mark("kcenters_fit", t)
             labels = kc.predict([Y])[0]
-            if record is not None:
-                torch.cuda.synchronize()
-                record.setdefault("kcenters_predict", []).append(time.perf_counter() - t3)
-                record.setdefault("cluster", []).append(time.perf_counter() - t2)
-        return ev, labels, kc, Y
+            t = mark("kcenters_predict", t)
+        return ev, labels, kc, Y, tica
 
-    for _ in range(args.warmup):
-        step(None)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ev, labels, kc, Y = step(times)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = float(parallel.allreduce_array(np.array([elapsed]), op="max")[0])
+    def timed(record, seqs, X, warmup, steps):
+        res = None
+        for _ in range(warmup):
+            step(None, seqs, X)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step(record, seqs, X)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            el = float(parallel.allreduce_array(np.array([el]), op="max")[0])
+        return el, res
 
+    times = {}
+    elapsed, (ev, labels, kc, Y, tica) = timed(times, seqs, X, args.warmup, args.steps)
+
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_extras:
+        # the other reading of "N GPUs", untimed secondary leg: every rank its own full-size shard (weak scaling)
+        del labels, kc, Y, tica, seqs, X
+        torch.cuda.empty_cache()
+        Xw = synth(torch, n_seq_total, T, F, 1234 + rank, dev)
+        seqsw = list(Xw.view(n_seq_total, T, F).unbind(0))
+        rec_w = {}
+        el_w, _r = timed(rec_w, seqsw, Xw, 1, 2)
+        del _r
+        rec_w.pop("sym", None)
+        weak = {"frames_per_gpu": n_seq_total * T, "ms_per_step": 1e3 * el_w / 2,
+                "value": world * n_seq_total * T / (el_w / 2), "unit": "frames/s",
+                "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in rec_w.items() if k != "mfma_ms"}}
+        del Xw, seqsw
+        labels = kc = Y = tica = seqs = X = None
+
+    exit_code = 0
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * frames / (elapsed / args.steps)
+        value = total_frames / (elapsed / args.steps)
         mfma_ms = float(np.mean(times["mfma_ms"]))
         sym = bool(times.pop("sym", False))
-        flops = 4.0 * F * F * frames                     # algorithmic: 2 dense F x F rank-1 updates per frame
-        # MFMA flops the kernel really issues per frame, in 128 x 128 tiles: G upper tiles + all C tiles, or -- fp32
-        # sum/difference kernel -- the H and the D block of the upper tiles only
-        nt = (F + 127) // 128
-        tiles = nt * (nt + 1) if sym else nt * nt + nt * (nt + 1) // 2
-        executed = 2.0 * 128 * 128 * tiles * frames
+        alg_flop = 4.0 * F * F                      # two dense F x F rank-1 updates per frame
+        exe_flop, tiles = executed_flop_per_frame(F, sym)
         kernel = "tica_sym_f32_kernel" if sym else "tica_mfma_%s_kernel" % args.mode
-        achieved = flops / (mfma_ms * 1e-3) / 1e12
-        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f64": PEAK_F64_MFMA_TFLOPS}.get(args.mode, 2500.0)  # bf16 dense MFMA
-        traffic = None   # PMC counters need their own rocprofv3 pass: read the committed measurement
+        peak = PEAK_TFLOPS.get(args.mode, 157.3)
+        executed = exe_flop * frames / (mfma_ms * 1e-3) / 1e12
+        algorithmic = alg_flop * frames / (mfma_ms * 1e-3) / 1e12
+        traffic, traffic_source = None, None   # PMC counters need their own rocprofv3 passes (scripts/pmc.sh)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
             if tj["workload"].startswith("%dx%d " % (frames, F)):
                 traffic = tj["bytes_per_launch"]
+                traffic_source = "committed profile, not this run: " + tj["source"]
         except Exception:
             pass
         out = {
             "metric": "frames/sec tICA fit + KCenters assign, 10M x 512 feats",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.mode, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3] shape per GPU: %d x %d fp32 as %d trajectories x %d, "
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
+            "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: %d x %d fp32 as %d trajectories x %d (%d frames on each of %d GPU%s), "
                                    "tICA(n_components=%d, lag_time=%d) fit+solve+transform -> KCenters(k=%d) fit+predict"
-                                   % (frames, F, n_seq, T, args.components, args.lag, args.clusters),
-                       "frames_per_gpu": frames, "n_features": F, "lag_time": args.lag,
+                                   % (total_frames, F, total_frames // T, T, frames, world, "s" if world > 1 else "",
+                                      args.components, args.lag, args.clusters),
+                       "total_frames": total_frames, "frames_per_gpu": frames, "n_features": F, "lag_time": args.lag,
                        "n_components": args.components, "n_clusters": args.clusters,
-                       "parallelism": "frames sharded x%d, 1 all-reduce" % world},
-            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "executed": executed / (mfma_ms * 1e-3) / 1e12, "executed_frac": executed / (mfma_ms * 1e-3) / 1e12 / peak,
-                         "frac_note": "achieved = SURVEY 8d's algorithmic 4 F^2 flop/frame / kernel time; executed = the MFMA flops "
-                                      "actually issued (%d tile products of 128x128 per frame). The symmetric kernel needs fewer "
-                                      "flops than 4 F^2, so achieved/peak can exceed 1; executed_frac is the pipe utilisation" % tiles,
-                         "traffic_note": "bytes/launch at the L2 fabric side (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC pass, "
-                                         "profiles/traffic.json); includes Infinity-Cache hits; algorithmic bytes/launch = %d" % (frames * F * 4),
-                         "kernel_ms": mfma_ms, "algorithmic_flop_per_frame": 4 * F * F,
+                       "parallelism": "whole trajectories dealt over %d rank%s, 1 all-reduce (tICA) + 1 all-gather per centre (KCenters)"
+                                      % (world, "s" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": executed, "peak": peak, "unit": "TFLOP/s",
+                         "frac": executed / peak, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic": algorithmic, "algorithmic_frac": algorithmic / peak,
+                         "frac_note": "achieved = MFMA flop the kernel executes (%d tile products of 128x128 per frame = %.0f flop) / "
+                                      "HIP-event kernel time; algorithmic = SURVEY 8d's 4 F^2 = %.0f flop per frame / the same time (the "
+                                      "sum/difference kernel needs fewer flops than 4 F^2, so algorithmic_frac can exceed 1)"
+                                      % (tiles, exe_flop, alg_flop),
+                         "traffic_note": "bytes/launch at the L2 fabric side (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes); "
+                                         "includes Infinity-Cache hits; algorithmic bytes/launch = %d" % (frames * F * 4),
+                         "kernel_ms": mfma_ms, "frames_per_launch": frames,
                          "tica_accumulate_frames_per_s": frames / (mfma_ms * 1e-3)},
             "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k not in ("mfma_ms", "sym")},
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
-        # the clustering half of the metric on its own: HBM-bound exact-arithmetic scans of the [frames, k] float64 projection
+        if weak is not None:
+            out["weak_scaling"] = weak
         fit_s, pred_s = float(np.mean(times["kcenters_fit"])), float(np.mean(times["kcenters_predict"]))
         pass_bytes = frames * (args.components * 8 + 16)          # read X row + distances_, update distances_/labels_
-        out["clustering"] = {"kcenters_fit_frames_per_s": world * frames / fit_s, "assign_frames_per_s": world * frames / pred_s,
-                             "kcenters_pass_TBps": args.clusters * pass_bytes / fit_s / 1e12, "hbm_peak_TBps": 8.0}
+        out["clustering"] = {"kcenters_fit_frames_per_s": total_frames / fit_s, "assign_frames_per_s": total_frames / pred_s,
+                             "kcenters_pass_TBps_per_gpu": args.clusters * pass_bytes / fit_s / 1e12, "hbm_peak_TBps": 8.0}
+
+        extras = world == 1 and not args.no_extras
         if world == 1 and not args.no_mbk:
             # BASELINE configs[3] names MiniBatchKMeans(k=1000) as the clusterer of this shape: the same projection through
             # it, once, OUTSIDE the timed steps (`value` stays the metric's tICA + KCenters pipeline)
@@ -267,13 +367,125 @@ def main():
                                       "fit_frames_per_s": frames / tm, "inertia_per_frame": float(mb.inertia_) / frames,
                                       "note": "MiniBatchKMeans(n_clusters=1000).fit on the [frames, %d] projection (fp32), "
                                               "k-means++ seeding + mini-batch steps + labels_ of every frame" % args.components}
+            del Y32, mb
+        del labels, kc, Y
+
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             sample = [s.cpu().numpy() for s in seqs[:64]]
-            out["cpu_baseline"] = cpu_baseline(sample, args.lag, args.components, args.clusters)
+            base, oracle, used = cpu_baseline(sample, args.lag, args.components, args.clusters)
+            out["cpu_baseline"] = base
+            # self-check: the HIP path against the float64 oracle on the SAME trajectories, at the stated tolerance
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m_s = tICA(n_components=args.components, lag_time=args.lag).fit(seqs[:len(used)])
+                e_hip, e_ref = np.asarray(m_s.eigenvalues_), np.asarray(oracle.eigenvalues_)
+            rel = float(np.abs(e_hip / e_ref - 1).max())
+            full_vs_sample = float(np.abs(np.asarray(ev[:3]) / e_ref[:3] - 1).max())
+            tol = {"f32": 1e-5, "f64": 1e-9, "bf16x2": 1e-5, "bf16": 5e-3}.get(args.mode, 1e-5)
+            ok = bool(rel <= tol and full_vs_sample <= 0.25)
+            out["self_check"] = {"sample_trajectories": len(used), "hip_vs_oracle_eigenvalue_max_rel_err": rel, "rtol": tol,
+                                 "full_run_top3_vs_sample_max_rel_diff": full_vs_sample, "loose_bound": 0.25, "ok": ok}
+            if not ok:
+                exit_code = 1
+            del m_s, sample, used
+
+        if extras:
+            ev32 = np.asarray(ev, dtype=np.float64)
+            # --- f64 mode: the reference's own arithmetic (fp64 MFMA on widened inputs) on the same data
+            os.environ["MSMBUILDER_AMD_TICA_MODE"] = "f64"
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(2):
+                    m64 = tICA(n_components=args.components, lag_time=args.lag).fit(seqs)
+                ms64 = kernel_ms_of(m64, _lib)
+                ev64 = np.asarray(m64.eigenvalues_)
+            e64, _t = executed_flop_per_frame(F, False)
+            out["f64"] = {"kernel": "tica_mfma_f64_kernel", "kernel_ms": ms64,
+                          "executed_TFLOPs": e64 * frames / ms64 / 1e9, "frac_of_fp64_mfma_peak": e64 * frames / ms64 / 1e9 / PEAK_TFLOPS["f64"],
+                          "algorithmic_TFLOPs": alg_flop * frames / ms64 / 1e9, "frames_per_s": frames / ms64 * 1e3,
+                          "eigenvalues_max_rel_diff_vs_%s_run" % args.mode: float(np.abs(ev32 / ev64 - 1).max()),
+                          "top_eigenvalues": [float(x) for x in ev64[:3]]}
+            del m64
+            os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
+            # --- strong-scaling model: what ONE rank of an 8-GPU run of this problem executes (1/8 of the trajectories),
+            # measured on this GPU without the collectives
+            n8 = max(1, n_seq // 8)
+            X8 = X[: n8 * T]
+            seqs8 = seqs[:n8]
+            rec8 = {}
+            step(None, seqs8, X8)
+            for _ in range(3):
+                step(rec8, seqs8, X8)
+            rec8.pop("sym", None)
+            ph8 = {k: 1e3 * float(np.mean(v)) for k, v in rec8.items() if k != "mfma_ms"}
+            step8 = sum(ph8.values())
+            comm_us = {"allreduce_4MB": 150.0, "allgather_per_centre": 25.0}   # assumed RCCL latencies over xGMI (not measured here)
+            comm_ms = (comm_us["allreduce_4MB"] + args.clusters * comm_us["allgather_per_centre"]) / 1e3
+            serial = ph8.get("solve", 0.0) + comm_ms
+            out["strong_scaling_model"] = {
+                "what": "one rank's share at N=8 (%d of %d trajectories) run alone on this GPU: per-phase ms measured, collectives "
+                        "modelled" % (n8, n_seq),
+                "phases_ms": ph8, "mfma_ms": float(np.mean(rec8["mfma_ms"])), "measured_step_ms": step8,
+                "assumed_comm_us": comm_us, "modelled_step_ms": step8 + comm_ms,
+                "modelled_speedup_at_8": ms_per_step / (step8 + comm_ms),
+                "serial_fraction_of_n1_step": serial / ms_per_step}
+            del X8, seqs8
+        del X, seqs
+        if extras:
+            torch.cuda.empty_cache()
+            # --- BASELINE configs[1]: 1M x 128, lag 100, ONE trajectory (single-tile C/G kernel)
+            X2 = synth(torch, 1, 1_000_000, 128, 99, dev)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(3):
+                    m2 = tICA(n_components=args.components, lag_time=100).fit([X2])
+                ms2 = kernel_ms_of(m2, _lib)
+                t2 = time.perf_counter()
+                m2 = tICA(n_components=args.components, lag_time=100).fit([X2])
+                e2 = m2.eigenvalues_
+                torch.cuda.synchronize()
+                t2 = time.perf_counter() - t2
+            ex2, _t = executed_flop_per_frame(128, False)
+            out["config2"] = {"workload": "1,000,000 x 128 fp32, one trajectory, lag 100", "kernel": "tica_mfma_f32_kernel",
+                              "kernel_ms": ms2, "executed_TFLOPs": ex2 * 1e6 / ms2 / 1e9, "frac": ex2 * 1e6 / ms2 / 1e9 / PEAK_TFLOPS["f32"],
+                              "accumulate_frames_per_s": 1e6 / ms2 * 1e3, "fit_plus_solve_ms": 1e3 * t2,
+                              "top_eigenvalues": [float(x) for x in e2[:3]]}
+            del X2, m2
+            # --- BASELINE configs[4] width: F = 2048, fp32 vs bf16x2 vs bf16 MFMA
+            n5 = 100
+            X5 = synth(torch, n5, T, 2048, 7, dev)
+            seqs5 = list(X5.view(n5, T, 2048).unbind(0))
+            c5 = {"workload": "%d x 2048 fp32 as %d trajectories x %d, lag %d" % (n5 * T, n5, T, args.lag), "modes": {}}
+            ref5 = None
+            for mode in ("f32", "bf16x2", "bf16"):
+                os.environ["MSMBUILDER_AMD_TICA_MODE"] = mode
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    for _ in range(2):
+                        m5 = tICA(n_components=args.components, lag_time=args.lag).fit(seqs5)
+                    ms5 = kernel_ms_of(m5, _lib)
+                    sym5 = m5._lagged_symmetrised
+                    e5 = np.asarray(m5.eigenvalues_)
+                if ref5 is None:
+                    ref5 = e5
+                ex5, _t = executed_flop_per_frame(2048, sym5)
+                if mode == "bf16x2":
+                    ex5 *= 4          # four bf16 products per fp32-equivalent product
+                c5["modes"][mode] = {"kernel_ms": ms5, "frames_per_s": n5 * T / ms5 * 1e3,
+                                     "executed_TFLOPs": ex5 * n5 * T / ms5 / 1e9,
+                                     "frac_of_its_mfma_peak": ex5 * n5 * T / ms5 / 1e9 / PEAK_TFLOPS[mode],
+                                     "algorithmic_TFLOPs": 4.0 * 2048 * 2048 * n5 * T / ms5 / 1e9,
+                                     "eigenvalues_max_rel_diff_vs_f32": float(np.abs(e5 / ref5 - 1).max())}
+                del m5
+            os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
+            out["config5_width"] = c5
+            del X5, seqs5
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -148,6 +148,31 @@ msm_idx_t msm_tica_packed_size(msm_tica_t* h); /* number of doubles */
 int msm_tica_export_packed(msm_tica_t* h, double* buf, int on_device);
 int msm_tica_import_packed(msm_tica_t* h, const double* buf, int on_device);
 
+/* s0 / stau alone (host, F doubles each): the means without the two F x F downloads. */
+int msm_tica_export_sums(msm_tica_t* h, double* s0, double* stau);
+
+/* Device-resident finalisation + solve of the generalized eigenproblem of tica.py:167-259 (replaces the host-side
+ * `_solve` body: offset_correlation_, covariance_ incl. the Rao-Blackwell Ledoit-Wolf shrinkage of tica.py:492-524,
+ * and scipy.linalg.eigh(lhs, b=rhs, eigvals=(F-k, F-1)) of tica.py:188-194).  Nothing F x F crosses PCIe except, in
+ * the hybrid form, the one reduced matrix.
+ *   shrinkage < 0 (or NaN): the RBLW estimate with n = n_rblw (= n_observations_); otherwise the given intensity.
+ *   scale: NULL, or F host doubles s of a folded input scaling x' = (x - m) / s (moments scale by 1 / (s_i s_j)).
+ *   mu (host, F): the RAW means (s0 + stau) / 2N'.   info (host, 8 doubles, nullable): {rho, tr S, potrf info,
+ *   syevd info, OC non-finite, S non-finite}.
+ * Errors: MSM_ERR_NONFINITE with the reference's RuntimeError texts ("... is not symmetric") when a moment is not
+ * finite; MSM_ERR_INVALID with LAPACK's "leading minor ... not positive definite" text; MSM_ERR_STATE before any data.
+ *
+ * msm_tica_reduce: B = L L^T, Cs = L^-1 OC L^-T on the device; Cs (host, F x F, symmetric up to rounding) is returned
+ * for a top-k standard eigensolver on the host (LAPACK dsyevr: its tridiagonalisation is latency-bound on a GPU at
+ * F = 512); msm_tica_backsolve then maps k eigenvectors y of Cs (rows of Y, host k x F) to v = L^-T y (rows of V),
+ * B-orthonormal like LAPACK's dsygvx.  msm_tica_solve_device does everything on the device (rocSOLVER dsyevd; wins
+ * from F ~ 1024) and returns the k largest eigenvalues (descending) and their eigenvectors as rows. */
+int msm_tica_reduce(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* Cs, double* mu,
+                    double* info);
+int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V);
+int msm_tica_solve_device(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k,
+                          double* vals, double* vecs, double* mu, double* info);
+
 /* out[n, k] (float64) = (X - mean) @ comps.T, comps is k x F row-major, mean/comps host
  * float64 (tica.py:329-333; any kinetic/commute column scaling is folded into comps by
  * the caller).  X / out follow on_device.  check_finite as above. */

@@ -87,6 +87,10 @@ def _declare(lib):
     f("msm_tica_export_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_import_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_project", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, _i64, _p, C.c_int, C.c_int)
+    f("msm_tica_export_sums", C.c_int, _p, _p, _p)
+    f("msm_tica_reduce", C.c_int, _p, C.c_double, _i64, _p, _p, _p, _p)
+    f("msm_tica_backsolve", C.c_int, _p, _p, _i64, _p)
+    f("msm_tica_solve_device", C.c_int, _p, C.c_double, _i64, _p, _i64, _p, _p, _p, _p)
 
     f("msm_label_range", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64p, _i64p, _i64p)
     f("msm_label_histogram", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _i64, _p)

@@ -36,29 +36,29 @@ def _as_float(X):
 
 
 class _KCenters(ClusterMixin, TransformerMixin):
-    """Single-array K-Centers; see :class:`KCenters` for the sequence-list estimator.
+    """Farthest-point clustering of ONE array (the sequence-list estimator is :class:`KCenters`).
+
+    Starting from a randomly drawn row, every further centre is the row that is currently farthest from
+    all centres chosen so far; each row is labelled with its nearest centre.
 
     Parameters
     ----------
-    n_clusters : int, optional, default: 8
-        The number of clusters to form as well as the number of centroids to generate.
-    metric : {"euclidean", "sqeuclidean", "cityblock", "chebyshev", "canberra",
-              "braycurtis", "hamming", "jaccard", "cityblock"}
-        The distance metric to use ("rmsd" needs mdtraj and is not supported here).
-    random_state : integer or numpy.RandomState, optional
-        Seeds the choice of the first centre, exactly as the reference does
-        (``check_random_state(random_state).randint(0, n_samples)``).
+    n_clusters : int (default 8)
+        How many centres to pick.
+    metric : str (default "euclidean")
+        One of libdistance's vector metrics: euclidean, sqeuclidean, cityblock, chebyshev, canberra,
+        braycurtis, hamming, jaccard.  (The reference's "rmsd" needs mdtraj trajectories and is out of scope.)
+    random_state : int, numpy RandomState or None
+        Source of the first centre: ``check_random_state(random_state).randint(0, n_samples)``, the same
+        draw as the reference's, so equal seeds give equal clusterings.
 
     Attributes
     ----------
-    cluster_ids_ : list, [n_clusters]
-        Index of the data point that each cluster label corresponds to.
-    cluster_centers_ : array, [n_clusters, n_features]
-    labels_ : array, [n_samples,]
-    distances_ : array, [n_samples,]
-        Distance from each sample to the cluster center it is assigned to.
-    inertia_ : float
-        Sum of distances of samples to their closest cluster center.
+    cluster_ids_ : list of n_clusters row indices, in the order the centres were chosen
+    cluster_centers_ : (n_clusters, n_features) the rows themselves
+    labels_ : (n_samples,) int64, index into cluster_ids_ of the nearest centre
+    distances_ : (n_samples,) float64, distance to that centre
+    inertia_ : float, sum of distances_
     """
 
     def __init__(self, n_clusters=8, metric='euclidean', random_state=None):
@@ -182,16 +182,9 @@ class KCenters(MultiSequenceClusterMixin, _KCenters, BaseEstimator):
         '''
     Attributes
     ----------
-    `cluster_centers_` : array, [n_clusters, n_features]
-        Coordinates of cluster centers
-
-    `labels_` : list of arrays, each of shape [sequence_length, ]
-        `labels_[i]` holds the label (an integer in [0, n_clusters)) of each
-        point of sequence `i`.
-
-    `distances_` : list of arrays, each of shape [sequence_length, ]
-        `distances_[i]` holds the distance from each point of sequence `i` to the
-        cluster center it is assigned to.
+    cluster_centers_ : (n_clusters, n_features)
+    labels_ : list with one int array per input sequence (label of every frame)
+    distances_ : list with one float64 array per input sequence (distance of every frame to its centre)
     '''
 
     def fit(self, sequences, y=None):

@@ -66,6 +66,11 @@ int metric_id(const char* name);  // -1 if unknown
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// eigsolve.hip: rocSOLVER / rocBLAS building blocks (dlopen'ed at first use) on stream(), nothing synchronised
+int sygv_reduce_device(double* A, double* B, int n, int* dinfo);   // B = L L^T (lower, col-major), A <- L^-1 A L^-T
+int sygv_back_device(const double* L, double* Y, int n, int k);    // Y[n x k col-major] <- L^-T Y
+int syevd_device(double* A, int n, double* D, double* E, int* dinfo);
+
 // A data pointer that was itself LOADED from memory (e.g. out of a descriptor table) is a
 // generic pointer to the compiler, which then emits flat_load: slower, and because FLAT counts on
 // both vmcnt and lgkmcnt every counted wait degenerates to vmcnt(0).  Re-type it as global.

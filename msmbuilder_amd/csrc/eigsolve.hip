@@ -71,6 +71,46 @@ __global__ void top_pairs_kernel(const double* __restrict__ Z, const double* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) vals[j] = D[n - 1 - j];
 }
 
+// ---- building blocks shared with tica.hip's device-resident solve (declared in common.h) -----------------------
+// B = L L^T in place (lower, column-major == upper of the row-major symmetric buffer), then A <- L^-1 A L^-T.
+// Nothing is synchronised: *dinfo (device int) receives potrf's info and is read by the caller with its results.
+int sygv_reduce_device(double* A, double* B, int n, int* dinfo)
+{
+    Solver& s = solver();
+    if (!s.error.empty()) return fail(MSM_ERR_STATE, "device eigensolver unavailable: %s", s.error.c_str());
+    if (s.set_stream(s.handle, stream()) != 0) return fail(MSM_ERR_HIP, "rocblas_set_stream failed");
+    const double one = 1.0;
+    int st = s.dpotrf(s.handle, 122, n, B, n, dinfo);
+    if (st != 0) return fail(MSM_ERR_HIP, "rocsolver_dpotrf failed with rocblas_status %d", st);
+    st = s.dtrsm(s.handle, 141, 122, 111, 131, n, n, &one, B, n, A, n);               // X = L^-1 A
+    if (st == 0) st = s.dtrsm(s.handle, 142, 122, 112, 131, n, n, &one, B, n, A, n);  // C = X L^-T
+    if (st != 0) return fail(MSM_ERR_HIP, "rocblas_dtrsm failed with rocblas_status %d", st);
+    return MSM_OK;
+}
+
+// Y (n x k, column-major: k eigenvectors of the reduced problem as contiguous columns) <- L^-T Y
+int sygv_back_device(const double* L, double* Y, int n, int k)
+{
+    Solver& s = solver();
+    if (!s.error.empty()) return fail(MSM_ERR_STATE, "device eigensolver unavailable: %s", s.error.c_str());
+    if (s.set_stream(s.handle, stream()) != 0) return fail(MSM_ERR_HIP, "rocblas_set_stream failed");
+    const double one = 1.0;
+    const int st = s.dtrsm(s.handle, 141, 122, 112, 131, n, k, &one, L, n, Y, n);
+    if (st != 0) return fail(MSM_ERR_HIP, "rocblas_dtrsm failed with rocblas_status %d", st);
+    return MSM_OK;
+}
+
+// all eigenpairs of the symmetric A (in place: columns = eigenvectors, D ascending); E: n doubles of workspace
+int syevd_device(double* A, int n, double* D, double* E, int* dinfo)
+{
+    Solver& s = solver();
+    if (!s.error.empty()) return fail(MSM_ERR_STATE, "device eigensolver unavailable: %s", s.error.c_str());
+    if (s.set_stream(s.handle, stream()) != 0) return fail(MSM_ERR_HIP, "rocblas_set_stream failed");
+    const int st = s.dsyevd(s.handle, 211, 122, n, A, n, D, E, dinfo);
+    if (st != 0) return fail(MSM_ERR_HIP, "rocsolver_dsyevd failed with rocblas_status %d", st);
+    return MSM_OK;
+}
+
 }  // namespace msm
 
 using namespace msm;

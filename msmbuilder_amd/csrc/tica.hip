@@ -1730,6 +1730,114 @@ __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __r
     if (bad) atomicOr(flag, 1);
 }
 
+// ---------------------------------------------------------------------------
+// Device-resident finalisation (tica.py:228-259, 492-524): from the packed raw moments [C | G | s0 | stau] to
+//     mu = (s0 + stau) / 2N',   OC = (C + C^T) / 2N' - mu mu^T,   S = G / 2N' - mu mu^T      (each scaled by 1 / (sc_i sc_j)
+// when an input scaling is folded in), per-block partials of tr S and sum S^2 for the Rao-Blackwell Ledoit-Wolf
+// intensity, then  B = (1 - rho) S + rho (tr S / p) I.  Operation for operation what decomposition/_moments.py does on
+// the host in numpy (division by 2N', outer product subtracted, scaling, shrink), so the two paths agree to rounding.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tica_finalise_kernel(const double* __restrict__ packed, const double* __restrict__ scale,
+                                                            double two_n, int F, double* __restrict__ A, double* __restrict__ B,
+                                                            double* __restrict__ mu, double* __restrict__ part, int* __restrict__ flags)
+{
+    __shared__ double red[2][256];
+    const size_t FF = (size_t)F * F;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double tr = 0.0, sq = 0.0;
+    if (idx < FF) {
+        const int i = (int)(idx / F), j = (int)(idx % F);
+        const double* s0 = packed + 2 * FF;
+        const double* st = s0 + F;
+        const double mi = (s0[i] + st[i]) / two_n, mj = (s0[j] + st[j]) / two_n;
+        double oc = (packed[idx] + packed[(size_t)j * F + i]) / two_n - mi * mj;
+        double sv = packed[FF + idx] / two_n - mi * mj;
+        if (scale) {
+            const double d = scale[i] * scale[j];
+            oc /= d;
+            sv /= d;
+        }
+        A[idx] = oc;
+        B[idx] = sv;
+        if (!isfinite(oc)) atomicOr(flags, 1);
+        if (!isfinite(sv)) atomicOr(flags + 1, 1);
+        if (i == 0) mu[j] = mj;
+        if (i == j) tr = sv;
+        sq = sv * sv;
+    }
+    red[0][threadIdx.x] = tr;
+    red[1][threadIdx.x] = sq;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = red[0][0];
+        part[2 * blockIdx.x + 1] = red[1][0];
+    }
+}
+
+// scal[0] = rho, scal[1] = tr S, scal[2] = rho tr S / p  (one workgroup; fixed summation order)
+__global__ __launch_bounds__(256) void tica_rblw_kernel(const double* __restrict__ part, int nblocks, double shrinkage, double n, int p,
+                                                        double* __restrict__ scal)
+{
+    __shared__ double red[2][256];
+    double tr = 0.0, sq = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        tr += part[2 * b];
+        sq += part[2 * b + 1];
+    }
+    red[0][threadIdx.x] = tr;
+    red[1][threadIdx.x] = sq;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tr = red[0][0];
+        sq = red[1][0];
+        double rho = shrinkage;
+        if (!(shrinkage >= 0.0)) {  // tica.py:492-524 (Chen, Wiesel, Hero), n = n_observations
+            const double alpha = (n - 2.0) / (n * (n + 2.0));
+            const double beta = ((p + 1.0) * n - 2.0) / (n * (n + 2.0));
+            const double U = (double)p * sq / (tr * tr) - 1.0;
+            rho = alpha + beta / U;
+            if (!(rho < 1.0)) rho = 1.0;
+        }
+        scal[0] = rho;
+        scal[1] = tr;
+        scal[2] = rho * tr / (double)p;
+    }
+}
+
+__global__ void tica_shrink_kernel(double* __restrict__ B, const double* __restrict__ scal, int F)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)F * F) return;
+    const int i = (int)(idx / F), j = (int)(idx % F);
+    double v = (1.0 - scal[0]) * B[idx];
+    if (i == j) v += scal[2];
+    B[idx] = v;
+}
+
+// vecs[j][:] = column (n - 1 - j) of the column-major Z (eigenvector of the j-th LARGEST eigenvalue), vals[j] = D[n - 1 - j]
+__global__ void tica_top_pairs_kernel(const double* __restrict__ Z, const double* __restrict__ D, int n, int k,
+                                      double* __restrict__ vecs, double* __restrict__ vals)
+{
+    const int j = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        vecs[(size_t)j * n + i] = Z[(size_t)(n - 1 - j) * n + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) vals[j] = D[n - 1 - j];
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -1755,6 +1863,8 @@ struct msm_tica {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
     bool timed = false;
     DevBuf table, table2, staging;
+    DevBuf solve;                // device-resident solve: [A (F*F) | B (F*F) | mu F | D F | E F | scal 4 | part 2*nblk | scale F | Y k*F | vals F | ints]
+    bool reduced = false;        // solve.A / solve.B hold the reduced matrix and the Cholesky factor of the current state
     size_t packed_len() const { return 2 * (size_t)F * F + 2 * (size_t)F + 2; }
 };
 
@@ -1788,6 +1898,7 @@ int tica_zero(msm_tica* h)
     MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, 2 * sizeof(int), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->shsum, 0, 3 * (size_t)h->F * sizeof(double), stream()));
     h->have_shift = false;
+    h->reduced = false;
     h->n_sh = h->nw_sh = 0;
     {
         const char* sh_env = getenv("MSM_TICA_SHIFT");  // 0: accumulate raw moments (A/B switch for the tests); read per reset
@@ -1831,6 +1942,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     }
     if (n_skipped) *n_skipped = skipped;
     if (nvalid == 0) return MSM_OK;
+    h->reduced = false;
 
     // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
     const bool use32 = (h->mode == MSM_TICA_F32 && dtype_bytes == 4);
@@ -2406,6 +2518,176 @@ int msm_tica_import(msm_tica_t* h, const double* C, const double* G, const doubl
     h->n_seq = n_sequences;
     return MSM_OK;
 }
+
+}  // extern "C"
+
+// ---- device-resident finalise + solve ------------------------------------------------------------------------
+namespace {
+
+struct SolveBufs {
+    double *A, *B, *mu, *D, *E, *scal, *part, *scale, *Y, *vals;
+    int* ints;  // [0..1] non-finite flags (OC, S), [2] potrf info, [3] syevd info
+    int nblk;
+};
+
+int solve_bufs(msm_tica* h, SolveBufs* b)
+{
+    const size_t F = (size_t)h->F, FF = F * F;
+    const int nblk = (int)ceil_div((int64_t)FF, 256);
+    const size_t nd = 3 * FF + 5 * F + 4 + 2 * (size_t)nblk;
+    int rc = h->solve.reserve(nd * sizeof(double) + 8 * sizeof(int));
+    if (rc) return rc;
+    double* p = h->solve.as<double>();
+    b->A = p;
+    b->B = b->A + FF;
+    b->Y = b->B + FF;
+    b->mu = b->Y + FF;
+    b->D = b->mu + F;
+    b->E = b->D + F;
+    b->scale = b->E + F;
+    b->vals = b->scale + F;
+    b->scal = b->vals + F;
+    b->part = b->scal + 4;
+    b->ints = reinterpret_cast<int*>(b->part + 2 * (size_t)nblk);
+    b->nblk = nblk;
+    return MSM_OK;
+}
+
+// export -> finalise -> shrink -> B = L L^T -> A <- L^-1 A L^-T, all queued on the stream (no synchronisation)
+int tica_reduce_device(msm_tica* h, double shrinkage, long long n_rblw, const double* scale_host, SolveBufs* b)
+{
+    int rc = solve_bufs(h, b);
+    if (rc) return rc;
+    const long long npairs = h->n_obs - (long long)h->lag * h->n_seq;
+    if (h->n_obs <= 0 || npairs <= 0) return fail(MSM_ERR_STATE, "the model must be fit() before use");
+    // the packed raw moments (slab sums, un-shifted) stay on the device
+    const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
+    hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
+                       h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
+    if (h->sym) {
+        const size_t ff2 = 2 * (size_t)h->F * h->F;
+        hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->slabs_sym,
+                           h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
+    }
+    if (h->have_shift) {
+        const size_t ff2 = 2 * (size_t)h->F * h->F;
+        hipLaunchKernelGGL(tica_unshift_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->packed,
+                           h->shsum, h->shift, (double)h->n_sh, (double)h->nw_sh, h->F, h->sym);
+    }
+    MSM_HIP_CHECK(hipGetLastError());
+    MSM_HIP_CHECK(hipMemsetAsync(b->ints, 0, 8 * sizeof(int), stream()));
+    if (scale_host) MSM_HIP_CHECK(hipMemcpyAsync(b->scale, scale_host, h->F * sizeof(double), hipMemcpyHostToDevice, stream()));
+    hipLaunchKernelGGL(tica_finalise_kernel, dim3((unsigned)b->nblk), dim3(256), 0, stream(), h->packed,
+                       scale_host ? b->scale : (const double*)nullptr, 2.0 * (double)npairs, h->F, b->A, b->B, b->mu, b->part, b->ints);
+    hipLaunchKernelGGL(tica_rblw_kernel, dim3(1), dim3(256), 0, stream(), b->part, b->nblk, shrinkage, (double)n_rblw, h->F, b->scal);
+    hipLaunchKernelGGL(tica_shrink_kernel, dim3((unsigned)b->nblk), dim3(256), 0, stream(), b->B, b->scal, h->F);
+    MSM_HIP_CHECK(hipGetLastError());
+    if ((rc = sygv_reduce_device(b->A, b->B, h->F, b->ints + 2))) return rc;
+    h->reduced = true;
+    return MSM_OK;
+}
+
+// status of the queued reduction, after the stream was synchronised: info = {rho, tr S, flags...}
+int tica_reduce_status(const double scal[4], const int ints[8], double* info)
+{
+    if (info) {
+        info[0] = scal[0];
+        info[1] = scal[1];
+        info[2] = (double)ints[2];
+        info[3] = (double)ints[3];
+        info[4] = (double)ints[0];
+        info[5] = (double)ints[1];
+    }
+    if (ints[0]) return fail(MSM_ERR_NONFINITE, "offset correlation matrix is not symmetric");
+    if (ints[1]) return fail(MSM_ERR_NONFINITE, "correlation matrix is not symmetric");
+    if (ints[2] != 0)
+        return fail(MSM_ERR_INVALID, "The leading minor of order %d of B is not positive definite. The factorization of B "
+                    "could not be completed and no eigenvalues or eigenvectors were computed.", ints[2]);
+    return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msm_tica_reduce(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* Cs, double* mu, double* info)
+{
+    if (!h || !Cs || !mu) return fail(MSM_ERR_STATE, "msm_tica_reduce: null argument");
+    SolveBufs b;
+    int rc = tica_reduce_device(h, shrinkage, n_rblw, scale, &b);
+    if (rc) return rc;
+    const size_t FF = (size_t)h->F * h->F;
+    double scal[4];
+    int ints[8];
+    MSM_HIP_CHECK(hipMemcpyAsync(Cs, b.A, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, h->F * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return tica_reduce_status(scal, ints, info);
+}
+
+int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V)
+{
+    if (!h || !Y || !V) return fail(MSM_ERR_STATE, "msm_tica_backsolve: null argument");
+    if (!h->reduced) return fail(MSM_ERR_STATE, "msm_tica_backsolve: no reduced problem (call msm_tica_reduce first)");
+    if (k < 1 || k > h->F) return fail(MSM_ERR_INVALID, "msm_tica_backsolve: need 1 <= k <= n_features");
+    SolveBufs b;
+    int rc = solve_bufs(h, &b);
+    if (rc) return rc;
+    const size_t bytes = (size_t)k * h->F * sizeof(double);
+    MSM_HIP_CHECK(hipMemcpyAsync(b.Y, Y, bytes, hipMemcpyHostToDevice, stream()));
+    if ((rc = sygv_back_device(b.B, b.Y, h->F, (int)k))) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(V, b.Y, bytes, hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_tica_solve_device(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k,
+                          double* vals, double* vecs, double* mu, double* info)
+{
+    if (!h || !vals || !vecs || !mu) return fail(MSM_ERR_STATE, "msm_tica_solve_device: null argument");
+    if (k < 1 || k > h->F) return fail(MSM_ERR_INVALID, "msm_tica_solve_device: need 1 <= k <= n_features");
+    SolveBufs b;
+    int rc = tica_reduce_device(h, shrinkage, n_rblw, scale, &b);
+    if (rc) return rc;
+    const int n = h->F;
+    if ((rc = syevd_device(b.A, n, b.D, b.E, b.ints + 3))) return rc;
+    if ((rc = sygv_back_device(b.B, b.A + (size_t)(n - k) * n, n, (int)k))) return rc;
+    hipLaunchKernelGGL(tica_top_pairs_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream(), b.A, b.D, n,
+                       (int)k, b.Y, b.vals);
+    MSM_HIP_CHECK(hipGetLastError());
+    double scal[4];
+    int ints[8];
+    MSM_HIP_CHECK(hipMemcpyAsync(vecs, b.Y, (size_t)k * n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(vals, b.vals, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    h->reduced = false;  // A was overwritten by the eigenvectors
+    rc = tica_reduce_status(scal, ints, info);
+    if (rc) return rc;
+    if (ints[3] != 0) return fail(MSM_ERR_INVALID, "eigenvalue iteration did not converge (info = %d)", ints[3]);
+    return MSM_OK;
+}
+
+/* s0 / stau alone (F doubles each, host): the column sums without the F x F moments */
+int msm_tica_export_sums(msm_tica_t* h, double* s0, double* stau)
+{
+    if (!h || !s0 || !stau) return fail(MSM_ERR_STATE, "null argument");
+    int rc = tica_export_device(h);
+    if (rc) return rc;
+    const size_t FF = (size_t)h->F * h->F;
+    MSM_HIP_CHECK(hipMemcpyAsync(s0, h->packed + 2 * FF, h->F * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(stau, h->packed + 2 * FF + h->F, h->F * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features,
                      msm_idx_t ld, const double* mean, const double* comps, msm_idx_t k,

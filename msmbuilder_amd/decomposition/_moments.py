@@ -79,7 +79,7 @@ def _blas_threads(F):
     return 4 if F <= 768 else 8
 
 
-DEVICE_SOLVE_MIN_FEATURES = 1024   # measured crossover (host dsygvx 42 ms vs device dsygvd 31 ms at F = 1024)
+DEVICE_SOLVE_MIN_FEATURES = 1536   # measured: F = 1024 hybrid 25.3 ms vs all-device 26.8 ms (host dsygvx 49.6); F = 2048 all-device 62 ms vs host 175 ms
 
 
 def _use_device_solve(F):
@@ -89,6 +89,34 @@ def _use_device_solve(F):
     if env in ("0", "1"):
         return env == "1"
     return F >= DEVICE_SOLVE_MIN_FEATURES
+
+
+def solve_mode(F):
+    """Where ``tICA._solve`` runs: "hybrid" (device finalise + Cholesky reduction + back-substitution, host dsyevr on
+    the reduced matrix; default below DEVICE_SOLVE_MIN_FEATURES), "device" (rocSOLVER dsyevd as well; default from
+    there), or "host" (round 1's numpy finalisation + dsygvx).  MSMBUILDER_AMD_DEVICE_SOLVE = 0 -> host, 1 -> device,
+    hybrid -> hybrid."""
+    import os
+    env = os.environ.get("MSMBUILDER_AMD_DEVICE_SOLVE", "auto")
+    if env == "0":
+        return "host"
+    if env == "1":
+        return "device"
+    if env == "hybrid":
+        return "hybrid"
+    return "device" if F >= DEVICE_SOLVE_MIN_FEATURES else "hybrid"
+
+
+def top_standard_eigenpairs(Cs, k):
+    """k largest eigenpairs of the symmetric ``Cs`` (destroyed), eigenvalues descending, eigenvectors as ROWS of a
+    C-contiguous k x F array.  LAPACK dsyevr on ONE thread: at F = 512 the call is its memory-bound tridiagonalisation
+    (5.7 ms; 6.9 ms on 4 threads, measured on the GPU boxes' hosts)."""
+    F = Cs.shape[0]
+    with _blas_limit(1 if F <= 768 else _blas_threads(F)):
+        vals, vecs = scipy.linalg.eigh(Cs, subset_by_index=[F - k, F - 1], driver="evr", overwrite_a=True,
+                                       check_finite=False)
+    order = np.argsort(vals)[::-1]
+    return vals[order], np.ascontiguousarray(vecs[:, order].T)
 
 
 def device_generalized_eigenpairs(lhs, rhs, k):

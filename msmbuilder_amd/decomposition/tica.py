@@ -83,34 +83,38 @@ def _mode_from_env():
 
 
 class tICA(BaseEstimator, TransformerMixin):
-    """Time-structure Independent Component Analysis (tICA)
+    """tICA: the linear combinations of the input features that decorrelate most slowly.
 
-    Linear dimensionality reduction using an eigendecomposition of the
-    time-lag correlation matrix and covariance matrix of the data, keeping
-    only the vectors which decorrelate slowest to project the data into a
-    lower dimensional space.
+    The estimator accumulates, over all pairs of frames ``lag_time`` apart, the symmetrised time-lagged
+    second moment and the instantaneous covariance of the features, and solves the generalized symmetric
+    eigenproblem between the two.  The eigenvectors with the largest eigenvalues (autocorrelations at the lag)
+    are the slow coordinates; ``transform`` projects mean-free frames onto the first ``n_components`` of them.
+    Constructor arguments, fitted attributes, warnings and exceptions are those of the reference class
+    (/root/reference/msmbuilder/decomposition/tica.py:26-148); the work runs in libmsmhip.
 
     Parameters
     ----------
-    n_components : int, None
-        Number of components to keep.
+    n_components : int or None
+        How many slow coordinates to keep; ``None`` keeps as many as there are features.
     lag_time : int
-        Delay time forward or backward in the input data. The time-lagged
-        correlations is computed between datas X[t] and X[t+lag_time].
-    shrinkage : float, default=None
-        The covariance shrinkage intensity (range 0-1). If shrinkage is not
-        specified (the default) it is estimated using an analytic formula
-        (the Rao-Blackwellized Ledoit-Wolf estimator).
-    kinetic_mapping : bool, default=False
-        If True, weigh the projections by the tICA eigenvalues.
-    commute_mapping : bool, default=False
-        If True, scale by the regularized timescales (commute map).
+        Offset, in frames, between the two members of a pair (x_t, x_{t+lag_time}).
+    shrinkage : float in [0, 1] or None
+        Weight of the scaled identity mixed into the covariance estimate.  ``None`` (default) computes it from
+        the data with the Rao-Blackwellised Ledoit-Wolf formula.
+    kinetic_mapping : bool
+        Multiply every projected coordinate by its eigenvalue, so Euclidean distances approximate kinetic ones.
+    commute_mapping : bool
+        Multiply every projected coordinate by sqrt(t_reg / 2), t_reg a regularised implied timescale (commute
+        distances).  Mutually exclusive with ``kinetic_mapping``.
 
     Attributes
     ----------
-    components_, offset_correlation_, eigenvalues_, eigenvectors_, means_,
-    n_observations_, n_sequences_, timescales_, covariance_, shrinkage_, score_
-        exactly as in the reference (tica.py:52-82).
+    components_ : (n_components, n_features)   rows are the slow directions
+    eigenvalues_, eigenvectors_, timescales_   top ``n_components`` solutions, eigenvalues descending
+    means_, covariance_, offset_correlation_   the centred moments the eigenproblem is built from
+    shrinkage_                                 the intensity actually used
+    n_observations_, n_sequences_              frames and trajectories seen so far
+    score_                                     sum of the kept eigenvalues
     """
 
     def __init__(self, n_components=None, lag_time=1, shrinkage=None,
@@ -241,29 +245,75 @@ class tICA(BaseEstimator, TransformerMixin):
 
     # --------------------------------------------------------------------- solve
     def _solve(self):
+        """Top ``n_components`` generalized eigenpairs of (offset_correlation_, covariance_), cached until the
+        accumulators change (tica.py:167-199).  The finalisation of the moments, the shrinkage estimate, the Cholesky
+        reduction and the back-substitution run on the device (``msm_tica_reduce`` / ``msm_tica_backsolve``); only the
+        reduced F x F standard problem visits the host for LAPACK's dsyevr (its tridiagonalisation is latency-bound on
+        a GPU at F = 512), and from F = 1024 the device does that too (``msm_tica_solve_device``).
+        ``MSMBUILDER_AMD_DEVICE_SOLVE=0`` restores the all-host numpy / dsygvx path of round 1."""
         if not self._is_dirty:
-            # someone might have changed n_components
+            # n_components may have been raised since the last solve
             if len(self._eigenvalues_) >= self.n_components:
                 return
 
-        # just check to make sure we've actually seen some data
         if not self.n_observations_:
             raise RuntimeError('The model must be fit() before use.')
 
-        lhs = self.offset_correlation_
-        rhs = self.covariance_
-
-        if not _moments.is_symmetric(lhs):
-            raise RuntimeError('offset correlation matrix is not symmetric')
-        if not _moments.is_symmetric(rhs):
-            raise RuntimeError('correlation matrix is not symmetric')
-
-        vals, vecs = _moments.top_generalized_eigenpairs(lhs, rhs, self.n_components)
+        mode = _moments.solve_mode(self.n_features)
+        if mode == "host":
+            lhs = self.offset_correlation_
+            rhs = self.covariance_
+            if not _moments.is_symmetric(lhs):
+                raise RuntimeError('offset correlation matrix is not symmetric')
+            if not _moments.is_symmetric(rhs):
+                raise RuntimeError('correlation matrix is not symmetric')
+            vals, vecs = _moments.top_generalized_eigenpairs(lhs, rhs, self.n_components)
+        else:
+            vals, vecs = self._solve_on_device(mode)
 
         self._eigenvalues_ = vals
         self._eigenvectors_ = vecs
 
         self._is_dirty = False
+
+    def _solve_on_device(self, mode):
+        self._ensure_handle()
+        L = _lib.lib()
+        F, k = int(self.n_features), int(self.n_components)
+        if k > F:
+            raise ValueError("Requested eigenvalue indices are not valid. Valid range is [0, %d] and start <= end, but "
+                             "start=%d, end=%d is given" % (F - 1, F - k, F - 1))
+        shrink = -1.0 if self.shrinkage is None else float(self.shrinkage)
+        scale = getattr(self, "_input_scale", None)
+        scale_p = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+        mu = np.empty(F)
+        info = np.zeros(8)
+
+        def run(rc):
+            if rc == _lib.MSM_ERR_NONFINITE:
+                raise RuntimeError(_lib.last_error())      # the reference's np.allclose(lhs, lhs.T) checks, tica.py:183-186
+            if rc == _lib.MSM_ERR_INVALID and "positive definite" in _lib.last_error():
+                raise np.linalg.LinAlgError(_lib.last_error())
+            check(rc)
+
+        if mode == "device":
+            vals = np.empty(k)
+            vecs = np.empty((k, F))
+            run(L.msm_tica_solve_device(self._handle, shrink, int(self.n_observations_),
+                                        None if scale_p is None else scale_p.ctypes.data, k, vals.ctypes.data,
+                                        vecs.ctypes.data, mu.ctypes.data, info.ctypes.data))
+            V = vecs
+        else:
+            Cs = np.empty((F, F))
+            run(L.msm_tica_reduce(self._handle, shrink, int(self.n_observations_),
+                                  None if scale_p is None else scale_p.ctypes.data, Cs.ctypes.data, mu.ctypes.data,
+                                  info.ctypes.data))
+            vals, Y = _moments.top_standard_eigenpairs(Cs, k)       # Y: k x F, rows = eigenvectors of the reduced problem
+            V = np.empty((k, F))
+            check(L.msm_tica_backsolve(self._handle, Y.ctypes.data, k, V.ctypes.data))
+        self.shrinkage_ = float(info[0]) if self.shrinkage is None else self.shrinkage
+        self._mu_raw = mu
+        return vals, np.ascontiguousarray(V.T)
 
     @property
     def score_(self):
@@ -312,6 +362,13 @@ class tICA(BaseEstimator, TransformerMixin):
         return self
 
     def _raw_means(self):
+        if not self._is_dirty and getattr(self, "_mu_raw", None) is not None:
+            return self._mu_raw                 # left behind by the device-side solve of the current state
+        if self._host_stale and self._handle is not None:
+            # the two column sums alone: no need to download the F x F moments for a mean
+            s0, st = np.empty(self.n_features), np.empty(self.n_features)
+            check(_lib.lib().msm_tica_export_sums(self._handle, s0.ctypes.data, st.ctypes.data))
+            return _moments.mean_vector(s0, st, self._n_pairs)
         self._pull()
         return _moments.mean_vector(self._sum_0_to_TminusTau, self._sum_tau_to_T, self._n_pairs)
 
@@ -345,22 +402,11 @@ class tICA(BaseEstimator, TransformerMixin):
 
     # ----------------------------------------------------------------------- fit
     def fit(self, sequences, y=None):
-        """Fit the model with a collection of sequences.
-
-        This method is not online.  Any state accumulated from previous calls to
-        fit() or partial_fit() will be cleared. For online learning, use
-        `partial_fit`.
-
-        Parameters
-        ----------
-        sequences: list of array-like, each of shape (n_samples_i, n_features)
-        y : None
-            Ignored
-
-        Returns
-        -------
-        self
-        """
+        """Forget everything seen before, then accumulate every trajectory of ``sequences`` (a list, or a lazily
+        loading iterable, of (n_frames_i, n_features) arrays; numpy arrays are staged over PCIe, torch CUDA tensors
+        are read in place).  Trajectories not longer than ``lag_time`` are skipped with a warning; if none is long
+        enough a ValueError is raised.  ``y`` is ignored.  Use ``partial_fit`` to add data to an existing model.
+        Returns ``self``."""
         self._initialized = False
         check_iter_of_sequences(sequences, max_iter=3)  # we might be lazy-loading
         # host trajectories are shipped over PCIe in groups of ~1 GiB; device-resident ones
@@ -557,16 +603,9 @@ class tICA(BaseEstimator, TransformerMixin):
         return np.ascontiguousarray(self._raw_means(), dtype=np.float64), np.ascontiguousarray(comps)
 
     def transform(self, sequences):
-        """Apply the dimensionality reduction on X.
-
-        Parameters
-        ----------
-        sequences: list of array-like, each of shape (n_samples_i, n_features)
-
-        Returns
-        -------
-        sequence_new : list of array-like, each of shape (n_samples_i, n_components)
-        """
+        """Project every trajectory onto the slow coordinates: one (n_frames_i, n_components) float64 array per input
+        (tica.py:329-352), on the device when the input is.  The kinetic / commute scalings are folded into the
+        projection matrix."""
         check_iter_of_sequences(sequences, max_iter=3)  # we might be lazy-loading
         sequences_new = []
         mean, comps = None, None
@@ -600,26 +639,26 @@ class tICA(BaseEstimator, TransformerMixin):
 
     # ---------------------------------------------------------------------- score
     def score(self, sequences, y=None):
-        """Score the model on new data using the generalized matrix Rayleigh quotient
-        (tica.py:426-467)."""
+        """Generalized matrix Rayleigh quotient of this model's slow directions on OTHER data (tica.py:426-467):
+        fit a second model to ``sequences``, express its lagged and instantaneous moments in the basis V of this
+        model's eigenvectors, and return trace((V^T OC' V) (V^T Sigma' V)^-1) -- the sum of this model's
+        eigenvalues if the new data had exactly the training statistics, lower when the directions do not
+        transfer.  NaN when the projected covariance is singular."""
         assert self._initialized
         V = self.eigenvectors_
 
-        m2 = self.__class__(shrinkage=self.shrinkage, n_components=self.n_components,
-                            lag_time=self.lag_time)
+        other = self.__class__(n_components=self.n_components, lag_time=self.lag_time, shrinkage=self.shrinkage)
         for X in sequences:
-            m2.partial_fit(X)
+            other.partial_fit(X)
         if getattr(self, "_input_scale", None) is not None:
-            m2.set_input_scaling(self._input_shift, self._input_scale)
+            other.set_input_scaling(self._input_shift, self._input_scale)
 
-        numerator = V.T.dot(m2.offset_correlation_).dot(V)
-        denominator = V.T.dot(m2.covariance_).dot(V)
-
+        lagged = V.T @ other.offset_correlation_ @ V
+        instantaneous = V.T @ other.covariance_ @ V
         try:
-            trace = np.trace(numerator.dot(np.linalg.inv(denominator)))
+            return np.trace(lagged @ np.linalg.inv(instantaneous))
         except np.linalg.LinAlgError:
-            trace = np.nan
-        return trace
+            return np.nan
 
     def summarize(self):
         """Some summary information."""
