@@ -85,6 +85,25 @@ int msm_event_record(void* ev);
 int msm_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int msm_event_destroy(void* ev);
 
+/* ---- communicator: RCCL over xGMI, one process per GPU ---------------
+ * The reference is a single process (no collective exists in /root/reference); these are the exchange steps the
+ * sharded hot path adds: msm_tica_allreduce, msm_kcenters_fit_sharded_*, msm_mbk_allreduce / msm_mbk_run.
+ * Bootstrap: rank 0 calls msm_comm_unique_id and ships the 128 bytes to the other ranks by any means (parallel.py:
+ * a torch.distributed broadcast); every rank then calls msm_comm_init_rccl AFTER msm_init(device).  The collectives
+ * run on the library stream on device buffers.
+ * msm_comm_init_host installs a host-side transport instead (buffers are staged through pinned memory and
+ * fn(op, send, recv, nbytes) is called: op 0 = all-reduce(sum) of nbytes/8 doubles in place (send == recv), op 1 =
+ * all-gather of nbytes from every rank into recv[world][nbytes]; non-zero return = failure).  It exists for runs
+ * where RCCL cannot form a communicator -- several ranks on ONE GPU, gloo-only test runs. */
+typedef int (*msm_host_collective_fn)(int op, void* send, void* recv, int64_t nbytes);
+int msm_comm_unique_id(char* id128);
+int msm_comm_init_rccl(const char* id128, int rank, int world);
+int msm_comm_init_host(msm_host_collective_fn fn, int rank, int world);
+int msm_comm_destroy(void);
+int msm_comm_info(int* rank, int* world, int* kind); /* kind: 0 none, 1 RCCL, 2 host callback */
+int msm_comm_allreduce_f64(double* dbuf, msm_idx_t n);                    /* device buffer, in place; synchronises */
+int msm_comm_allgather(const void* dsend, void* drecv, msm_idx_t bytes);  /* device buffers; synchronises */
+
 /* ---- tICA second-moment accumulation ---------------------------------- */
 typedef struct msm_tica msm_tica_t;
 
@@ -173,6 +192,12 @@ int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V);
 int msm_tica_solve_device(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k,
                           double* vals, double* vecs, double* mu, double* info);
 
+/* Sum the accumulators over all ranks of the library communicator: ONE all-reduce of the packed float64
+ * [C | G | s0 | stau | n_obs | n_seq] (4.2 MB at F = 512), device to device; every rank ends with the global model.
+ * Without a communicator (or with one rank) it is a no-op. */
+int msm_tica_allreduce(msm_tica_t* h);
+int msm_tica_counts(msm_tica_t* h, msm_idx_t* n_observations, msm_idx_t* n_sequences); /* frames / trajectories seen */
+
 /* out[n, k] (float64) = (X - mean) @ comps.T, comps is k x F row-major, mean/comps host
  * float64 (tica.py:329-333; any kinetic/commute column scaling is folded into comps by
  * the caller).  X / out follow on_device.  check_finite as above. */
@@ -257,6 +282,20 @@ int msm_kcenters_select_f32(const double* cands_dev, msm_idx_t world, msm_idx_t 
 int msm_kcenters_select_f64(const double* cands_dev, msm_idx_t world, msm_idx_t m, double* y_dev, double* centers_dev,
                             msm_idx_t* ids_dev, msm_idx_t slot);
 
+/* The whole row-sharded k-centers fit in one call (every rank of the library communicator calls it with ITS block of
+ * rows; ranks own consecutive blocks of the global array, this one starting at global row row_offset): per centre one
+ * pass kernel, one candidate record, ONE all-gather of the world's records (RCCL on the library stream) and one select
+ * kernel -- nothing returns to the host inside the loop.  seed_index is the GLOBAL row of centre 0.  labels / distances
+ * (device, n_local) stay sharded; ids (host, K global rows), centers (host, K x m) and *inertia (sum over ALL rows) are
+ * the same on every rank and equal the single-process fit of the concatenated array bit for bit (ties go to the lowest
+ * global row, numpy's argmax: kcenters.py:91-97). */
+int msm_kcenters_fit_sharded_f32(const float* X, msm_idx_t n_local, msm_idx_t m, msm_idx_t n_clusters, const char* metric,
+                                 msm_idx_t seed_index, msm_idx_t row_offset, msm_idx_t* labels, double* distances,
+                                 msm_idx_t* ids, float* centers, double* inertia);
+int msm_kcenters_fit_sharded_f64(const double* X, msm_idx_t n_local, msm_idx_t m, msm_idx_t n_clusters, const char* metric,
+                                 msm_idx_t seed_index, msm_idx_t row_offset, msm_idx_t* labels, double* distances,
+                                 msm_idx_t* ids, double* centers, double* inertia);
+
 /* ---- k-means labelling / mini-batch step (fp32, GEMM form on MFMA) ---- */
 /* labels[i] = argmin_j ||X[i]-C[j]||^2 computed as ||c||^2 - 2 x.c (+||x||^2 for the
  * inertia), fp32 like scikit-learn's _labels_inertia; centers host [K, m].
@@ -304,6 +343,12 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
 msm_idx_t msm_mbk_packed_size(msm_mbk_t* h);
 int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device);
 int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int on_device);
+/* Sharded step over the library communicator: every rank runs msm_mbk_step(apply_update = 0) on the batch rows it
+ * owns (msm_mbk_zero_packed if it owns none), then msm_mbk_allreduce: ONE all-reduce of the device-resident
+ * [K*m sums | K counts | inertia] (RCCL on the library stream, nothing staged through the host) and the identical
+ * update on every rank.  *batch_inertia = global batch inertia, counts_out (host, K) = updated cumulative counts. */
+int msm_mbk_zero_packed(msm_mbk_t* h);
+int msm_mbk_allreduce(msm_mbk_t* h, double* batch_inertia, float* counts_out);
 int msm_mbk_reassign(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
                      msm_idx_t n_reassign, float new_count, int on_device);
 int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device);

@@ -100,14 +100,13 @@ class _KCenters(ClusterMixin, TransformerMixin):
         return self
 
     def _fit_sharded(self, X, metric):
-        """Row-sharded k-centers (one process per GPU): X is THIS rank's block of rows, ranks own
-        consecutive blocks of the global array.  Every pass runs locally on each rank; ONE
-        all-gather per centre exchanges the candidate records ``[max distance | global row | that
-        row's coordinates]`` and every rank picks the same winner on the device
-        (``msm_kcenters_pass_dev`` / ``msm_kcenters_select``): the centre loop never touches the
-        host, so the K launches and collectives queue up asynchronously on the stream.  Results
-        equal the single-process fit of the concatenated data bit for bit (ties go to the lowest
-        GLOBAL row, numpy's argmax).  labels_/distances_ stay sharded."""
+        """Row-sharded k-centers (one process per GPU): X is THIS rank's block of rows, ranks own consecutive blocks
+        of the global array.  The whole fit is ONE library call, ``msm_kcenters_fit_sharded_*``: per centre a pass
+        kernel, the shard's candidate record ``[max distance | global row | that row's coordinates]``, one
+        all-gather over the library communicator (RCCL over xGMI on the library stream) and a select kernel that
+        picks the same winner on every rank -- nothing returns to the host or to Python inside the centre loop.
+        Results equal the single-process fit of the concatenated data bit for bit (ties go to the lowest GLOBAL row,
+        numpy's argmax).  labels_/distances_ stay sharded."""
         from .. import parallel
         import torch
         if isinstance(X, np.ndarray):
@@ -116,48 +115,26 @@ class _KCenters(ClusterMixin, TransformerMixin):
         n_local, m = ax.shape
         shard = parallel.RowShard(n_local)
         kind = "f64" if ax.dtype == np.float64 else "f32"
-        tdt = torch.float64 if kind == "f64" else torch.float32
         K = int(self.n_clusters)
-        world, rank = parallel.world_size(), parallel.rank()
-        dev = ax.keep.device
+        rank = parallel.rank()
         # rank 0's draw decides (random_state=None would differ per process)
         seed = check_random_state(self.random_state).randint(0, shard.n_total)
         seed = int(parallel.allreduce_array(np.array([float(seed) if rank == 0 else 0.0]))[0])
         labels = empty_like_placement(ax, (n_local,), np.int64)
         distances = empty_like_placement(ax, (n_local,), np.float64)
         al, ad = Arr(labels, np.int64), Arr(distances, np.float64)
-        L = _lib.lib()
-        fpass = getattr(L, "msm_kcenters_pass_dev_" + kind)
-        fsel = getattr(L, "msm_kcenters_select_" + kind)
-        cand = torch.zeros(2 + m, dtype=torch.float64, device=dev)
-        cands = torch.zeros(world, 2 + m, dtype=torch.float64, device=dev)
-        y = torch.zeros(m, dtype=tdt, device=dev)
-        centers = torch.zeros(K, m, dtype=tdt, device=dev)
-        ids = torch.zeros(K, dtype=torch.int64, device=dev)
-
-        def exchange(slot):
-            parallel.all_gather_rows(cands, cand)
-            _lib.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            check(fsel(C.c_void_p(cands.data_ptr()), world, m, C.c_void_p(y.data_ptr()),
-                       C.c_void_p(centers.data_ptr()), C.c_void_p(ids.data_ptr()), slot))
-
-        # centre 0: the rank that owns the seed row publishes it through the same exchange
-        cand[0], cand[1] = -1.0, -1.0
-        if shard.offset <= seed < shard.offset + n_local:
-            cand[0], cand[1] = 1.0, float(seed)
-            cand[2:] = ax.keep[seed - shard.offset].to(torch.float64)
-        exchange(0)
-        for it in range(K):
-            check(fpass(ax.vp, n_local, m, C.c_void_p(y.data_ptr()), it, metric.encode(), al.vp, ad.vp,
-                        shard.offset, C.c_void_p(cand.data_ptr())))
-            if it + 1 < K:
-                exchange(it + 1)
+        parallel.library_comm()
+        ids = np.zeros(K, dtype=np.int64)
+        centers = np.zeros((K, m), dtype=ax.dtype)
+        inertia = C.c_double(0.0)
+        fn = getattr(_lib.lib(), "msm_kcenters_fit_sharded_" + kind)
+        check(fn(ax.vp, n_local, m, K, metric.encode(), seed, shard.offset, al.vp, ad.vp, ids.ctypes.data,
+                 centers.ctypes.data, C.byref(inertia)))
         self.labels_ = labels
         self.distances_ = distances
-        self.cluster_ids_ = [int(i) for i in ids.cpu().numpy()]
-        self.cluster_centers_ = centers.cpu().numpy()
-        local_sum = float(distances.sum().item()) if n_local else 0.0
-        self.inertia_ = float(parallel.allreduce_array(np.array([local_sum]))[0])
+        self.cluster_ids_ = [int(i) for i in ids]
+        self.cluster_centers_ = centers
+        self.inertia_ = float(inertia.value)
         return self
 
     def predict(self, X):

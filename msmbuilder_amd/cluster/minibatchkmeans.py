@@ -242,17 +242,19 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         inertia = C.c_double(0.0)
         L = _lib.lib()
         if parallel.active():
+            # the rows of the batch this rank owns -> [K*F sums | K counts | inertia] in the handle's DEVICE buffer; one
+            # all-reduce over the library communicator (msm_mbk_allreduce: RCCL on the library stream, in place) and the
+            # identical update on every rank.  Only the batch's row numbers go in and [inertia | counts] come out.
+            parallel.library_comm()
             _, sub = shard.local(batch_idx)
             sub = np.ascontiguousarray(sub, dtype=np.int64)
-            n_packed = int(L.msm_mbk_packed_size(self._mbk))
-            packed = np.zeros(n_packed, dtype=np.float64)
             if len(sub):
                 check(L.msm_mbk_step(self._mbk, ax.vp, ax.shape[0], sub.ctypes.data, len(sub), C.byref(inertia),
                                      None, 0, ax.on_device))
-                check(L.msm_mbk_export_packed(self._mbk, packed.ctypes.data, 0))
-            packed = np.ascontiguousarray(parallel.allreduce_array(packed))
-            inertia_v = float(packed[-1])
-            check(L.msm_mbk_apply_packed(self._mbk, packed.ctypes.data, self._counts.ctypes.data, 0))
+            else:
+                check(L.msm_mbk_zero_packed(self._mbk))
+            check(L.msm_mbk_allreduce(self._mbk, C.byref(inertia), self._counts.ctypes.data))
+            inertia_v = float(inertia.value)
         else:
             check(L.msm_mbk_step(self._mbk, ax.vp, ax.shape[0], batch_idx.ctypes.data, B, C.byref(inertia),
                                  self._counts.ctypes.data, 1, ax.on_device))
@@ -369,11 +371,28 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         shard = RowShard(ax.shape[0])  # single process: the whole array
         n_samples, n_features = shard.n_total, ax.shape[1]
         self._check_params_vs_input(n_samples)
-        random_state = check_random_state(self.random_state)
+        from .. import parallel as _par
+        if _par.active() and not isinstance(self.random_state, (int, np.integer)):
+            # every rank must draw the SAME validation / init / batch indices: with random_state=None (or a shared
+            # RandomState object that differs per process) rank 0's draw seeds them all
+            seed0 = check_random_state(self.random_state).randint(0, 2 ** 31 - 1) if _par.rank() == 0 else 0
+            seed0 = int(_par.allreduce_array(np.array([float(seed0)]))[0])
+            random_state = np.random.RandomState(seed0)
+        else:
+            random_state = check_random_state(self.random_state)
         self.n_features_in_ = n_features
 
         if self.tol > 0:
-            if ax.on_device:
+            if _par.active():
+                # the variance of ALL rows (so every rank makes the same stop decision): all-reduced moments
+                Xl = ax.keep.double() if ax.on_device else np.asarray(ax.keep, dtype=np.float64)
+                s1 = np.asarray((Xl.sum(0).cpu().numpy() if ax.on_device else Xl.sum(0)), dtype=np.float64)
+                s2 = np.asarray(((Xl * Xl).sum(0).cpu().numpy() if ax.on_device else (Xl * Xl).sum(0)), dtype=np.float64)
+                red = _par.allreduce_array(np.concatenate([s1, s2]))
+                mean = red[:n_features] / n_samples
+                var = red[n_features:] / n_samples - mean * mean
+                self._tol = float(np.mean(var)) * self.tol
+            elif ax.on_device:
                 self._tol = float(ax.keep.var(dim=0, unbiased=False).mean().item()) * self.tol
             else:
                 self._tol = float(np.mean(np.var(ax.keep, axis=0))) * self.tol

@@ -1,0 +1,238 @@
+// comm.hip -- the library's own communicator: RCCL over xGMI, one process per GPU.
+//
+// The exchange steps of the hot path -- the all-reduce of the packed tICA accumulators, the per-centre all-gather of the
+// k-centers candidate records, the per-step all-reduce of the MiniBatchKMeans centroid sums -- are issued by the library
+// itself on its own stream, between its own kernels, on device buffers: nothing is staged through the host and no
+// Python runs inside a centre / step loop.  The reference has no collective at all (single process, single thread), so
+// there is no call pattern to follow; these are sized for point-to-point xGMI: ONE 4 MB all-reduce per tICA fit, and
+// latency-bound 100-byte records per k-centers centre.
+//
+// Two transports behind the same two primitives (comm_allreduce_f64, comm_allgather):
+//   * RCCL (`msm_comm_init_rccl`): librccl is dlopen'ed (the copy PyTorch loaded when there is one); the 128-byte
+//     unique id is created on rank 0 (`msm_comm_unique_id`) and handed to the other ranks by whatever bootstrap the
+//     host program has (msmbuilder_amd/parallel.py broadcasts it through torch.distributed).
+//   * host callback (`msm_comm_init_host`): the library stages the buffer through pinned host memory and calls a
+//     function of the host program (gloo in the CPU-only / single-GPU test runs, where RCCL cannot form a communicator
+//     because several ranks share one device).  Same code path above the primitive, so the multi-rank logic of the
+//     centre and step loops is exercised by world_size-2 tests on one GPU.
+#include "common.h"
+
+#include <dlfcn.h>
+
+#include <mutex>
+#include <string>
+
+namespace msm {
+
+namespace {
+
+typedef struct { char internal[128]; } nccl_uid;
+typedef void* nccl_comm;
+typedef int (*fn_get_uid)(nccl_uid*);
+typedef int (*fn_init_rank)(nccl_comm*, int, nccl_uid, int);
+typedef int (*fn_destroy)(nccl_comm);
+typedef const char* (*fn_errstr)(int);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
+constexpr int NCCL_CHAR = 0, NCCL_F64 = 8, NCCL_SUM = 0;
+
+struct Rccl {
+    void* lib = nullptr;
+    fn_get_uid get_uid = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_errstr errstr = nullptr;
+    fn_allreduce allreduce = nullptr;
+    fn_allgather allgather = nullptr;
+    std::string error;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        r.lib = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);  // PyTorch's copy, if it is in the process
+        for (int i = 0; !r.lib && i < 3; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) {
+            r.error = "librccl.so not found";
+            return;
+        }
+        r.get_uid = (fn_get_uid)dlsym(r.lib, "ncclGetUniqueId");
+        r.init_rank = (fn_init_rank)dlsym(r.lib, "ncclCommInitRank");
+        r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
+        r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
+        r.allreduce = (fn_allreduce)dlsym(r.lib, "ncclAllReduce");
+        r.allgather = (fn_allgather)dlsym(r.lib, "ncclAllGather");
+        if (!r.get_uid || !r.init_rank || !r.destroy || !r.allreduce || !r.allgather) r.error = "RCCL entry points not found in librccl";
+    });
+    return r;
+}
+
+struct Comm {
+    int kind = 0;  // 0 none, 1 RCCL, 2 host callback
+    int rank = 0, world = 1;
+    nccl_comm comm = nullptr;
+    msm_host_collective_fn cb = nullptr;
+    void* pinned = nullptr;  // host-callback staging
+    size_t pinned_cap = 0;
+};
+Comm g_comm;
+
+int pinned_reserve(size_t bytes)
+{
+    if (bytes <= g_comm.pinned_cap) return MSM_OK;
+    if (g_comm.pinned) (void)hipHostFree(g_comm.pinned);
+    g_comm.pinned = nullptr;
+    g_comm.pinned_cap = 0;
+    MSM_HIP_CHECK(hipHostMalloc(&g_comm.pinned, bytes, hipHostMallocDefault));
+    g_comm.pinned_cap = bytes;
+    return MSM_OK;
+}
+
+const char* nccl_err(int st)
+{
+    Rccl& r = rccl();
+    return r.errstr ? r.errstr(st) : "?";
+}
+
+}  // namespace
+
+bool comm_active() { return g_comm.kind != 0; }  // a communicator is installed (a world of one still runs the collectives)
+int comm_rank() { return g_comm.kind ? g_comm.rank : 0; }
+int comm_world() { return g_comm.kind ? g_comm.world : 1; }
+
+// in place, device buffer, ordered on stream(); returns without synchronising (RCCL) or synchronised (host callback)
+int comm_allreduce_f64(double* dbuf, size_t n)
+{
+    if (g_comm.kind == 0 || n == 0) return MSM_OK;
+    if (g_comm.kind == 1) {
+        const int st = rccl().allreduce(dbuf, dbuf, n, NCCL_F64, NCCL_SUM, g_comm.comm, stream());
+        if (st != 0) return fail(MSM_ERR_HIP, "ncclAllReduce failed: %s", nccl_err(st));
+        return MSM_OK;
+    }
+    int rc = pinned_reserve(n * sizeof(double));
+    if (rc) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(g_comm.pinned, dbuf, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    if (g_comm.cb(0, g_comm.pinned, g_comm.pinned, (int64_t)(n * sizeof(double))) != 0)
+        return fail(MSM_ERR_STATE, "host collective callback failed (all-reduce)");
+    MSM_HIP_CHECK(hipMemcpyAsync(dbuf, g_comm.pinned, n * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+// drecv[r * bytes ...] = rank r's dsend[0 .. bytes); device buffers, ordered on stream()
+int comm_allgather(const void* dsend, void* drecv, size_t bytes)
+{
+    if (bytes == 0) return MSM_OK;
+    if (g_comm.kind == 0) {
+        if (dsend != drecv) MSM_HIP_CHECK(hipMemcpyAsync(drecv, dsend, bytes, hipMemcpyDeviceToDevice, stream()));
+        return MSM_OK;
+    }
+    if (g_comm.kind == 1) {
+        const int st = rccl().allgather(dsend, drecv, bytes, NCCL_CHAR, g_comm.comm, stream());
+        if (st != 0) return fail(MSM_ERR_HIP, "ncclAllGather failed: %s", nccl_err(st));
+        return MSM_OK;
+    }
+    const size_t W = (size_t)g_comm.world;
+    int rc = pinned_reserve((W + 1) * bytes);
+    if (rc) return rc;
+    char* hs = static_cast<char*>(g_comm.pinned);
+    char* hr = hs + bytes;
+    MSM_HIP_CHECK(hipMemcpyAsync(hs, dsend, bytes, hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    if (g_comm.cb(1, hs, hr, (int64_t)bytes) != 0) return fail(MSM_ERR_STATE, "host collective callback failed (all-gather)");
+    MSM_HIP_CHECK(hipMemcpyAsync(drecv, hr, W * bytes, hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" {
+
+int msm_comm_unique_id(char* id128)
+{
+    if (!id128) return fail(MSM_ERR_INVALID, "msm_comm_unique_id: null pointer");
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(MSM_ERR_STATE, "RCCL unavailable: %s", r.error.c_str());
+    nccl_uid id;
+    const int st = r.get_uid(&id);
+    if (st != 0) return fail(MSM_ERR_HIP, "ncclGetUniqueId failed: %s", nccl_err(st));
+    memcpy(id128, id.internal, 128);
+    return MSM_OK;
+}
+
+int msm_comm_init_rccl(const char* id128, int rank, int world)
+{
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(MSM_ERR_INVALID, "msm_comm_init_rccl: bad argument");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(MSM_ERR_STATE, "RCCL unavailable: %s", r.error.c_str());
+    msm_comm_destroy();
+    nccl_uid id;
+    memcpy(id.internal, id128, 128);
+    nccl_comm c = nullptr;
+    const int st = r.init_rank(&c, world, id, rank);  // uses the calling thread's current device (msm_init)
+    if (st != 0) return fail(MSM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, nccl_err(st));
+    g_comm.kind = 1;
+    g_comm.rank = rank;
+    g_comm.world = world;
+    g_comm.comm = c;
+    return MSM_OK;
+}
+
+int msm_comm_init_host(msm_host_collective_fn fn, int rank, int world)
+{
+    if (!fn || world < 1 || rank < 0 || rank >= world) return fail(MSM_ERR_INVALID, "msm_comm_init_host: bad argument");
+    msm_comm_destroy();
+    g_comm.kind = 2;
+    g_comm.rank = rank;
+    g_comm.world = world;
+    g_comm.cb = fn;
+    return MSM_OK;
+}
+
+int msm_comm_destroy(void)
+{
+    if (g_comm.kind == 1 && g_comm.comm) {
+        (void)hipStreamSynchronize(stream());
+        (void)rccl().destroy(g_comm.comm);
+    }
+    if (g_comm.pinned) (void)hipHostFree(g_comm.pinned);
+    g_comm = Comm();
+    return MSM_OK;
+}
+
+int msm_comm_info(int* rank, int* world, int* kind)
+{
+    if (rank) *rank = comm_rank();
+    if (world) *world = comm_world();
+    if (kind) *kind = g_comm.kind;
+    return MSM_OK;
+}
+
+/* test / bootstrap helpers on caller-owned DEVICE buffers */
+int msm_comm_allreduce_f64(double* dbuf, msm_idx_t n)
+{
+    if (!dbuf || n < 0) return fail(MSM_ERR_INVALID, "msm_comm_allreduce_f64: bad argument");
+    int rc = comm_allreduce_f64(dbuf, (size_t)n);
+    if (rc) return rc;
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_comm_allgather(const void* dsend, void* drecv, msm_idx_t bytes)
+{
+    if (!dsend || !drecv || bytes < 0) return fail(MSM_ERR_INVALID, "msm_comm_allgather: bad argument");
+    int rc = comm_allgather(dsend, drecv, (size_t)bytes);
+    if (rc) return rc;
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+}  // extern "C"

@@ -66,6 +66,14 @@ int metric_id(const char* name);  // -1 if unknown
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// comm.hip: the library's communicator (RCCL over xGMI, or a host callback in gloo test runs).  Device buffers,
+// ordered on stream(); no-ops (all-gather: a copy) without a communicator.
+bool comm_active();
+int comm_rank();
+int comm_world();
+int comm_allreduce_f64(double* dbuf, size_t n);                     // sum, in place
+int comm_allgather(const void* dsend, void* drecv, size_t bytes);   // drecv[r * bytes ...] = rank r's dsend
+
 // eigsolve.hip: rocSOLVER / rocBLAS building blocks (dlopen'ed at first use) on stream(), nothing synchronised
 int sygv_reduce_device(double* A, double* B, int n, int* dinfo);   // B = L L^T (lower, col-major), A <- L^-1 A L^-T
 int sygv_back_device(const double* L, double* Y, int n, int k);    // Y[n x k col-major] <- L^-T Y

@@ -1409,6 +1409,71 @@ int kcenters_select_impl(const double* cands_dev, msm_idx_t world, msm_idx_t m, 
     return MSM_OK;
 }
 
+// centre 0 of a sharded fit: the rank that owns the seed row publishes it through the same record exchange
+template <typename T>
+__global__ __launch_bounds__(DT) void kc_seed_candidate_kernel(const T* __restrict__ X, long long m, long long local_row,
+                                                               long long global_row, double* __restrict__ cand)
+{
+    if (threadIdx.x == 0) {
+        cand[0] = local_row >= 0 ? 1.0 : -1.0;
+        cand[1] = local_row >= 0 ? (double)global_row : -1.0;
+    }
+    for (long long f = threadIdx.x; f < m; f += DT) cand[2 + f] = local_row >= 0 ? (double)X[local_row * m + f] : 0.0;
+}
+
+// The whole row-sharded fit: K x (pass, candidate record, all-gather over the library communicator, select), all
+// queued on the stream -- the host enqueues and synchronises once at the end.
+template <typename T>
+int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char* metric, msm_idx_t seed,
+                              msm_idx_t row_offset, msm_idx_t* labels, double* distances, msm_idx_t* ids, T* centers,
+                              double* inertia)
+{
+    const int mid = metric_id(metric);
+    if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
+    if (!ids || !centers || (n > 0 && (!X || !labels || !distances))) return fail(MSM_ERR_INVALID, "kcenters_fit_sharded: null pointer");
+    if (n < 0 || m < 1 || K < 1 || seed < 0 || row_offset < 0) return fail(MSM_ERR_INVALID, "kcenters_fit_sharded: bad shape");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    const int world = comm_world();
+    const size_t rec = (size_t)(2 + m);
+    // [cand rec | cands world*rec | sums 1024 + 1] doubles, [y m | centers K*m] T, [ids K] int64
+    DevBuf& dS = pool(PS_S);
+    const size_t nd = rec + (size_t)world * rec + 1032;
+    const size_t bytes = nd * sizeof(double) + ((size_t)(K + 1) * m * sizeof(T) + 15) / 16 * 16 + (size_t)K * sizeof(msm_idx_t);
+    int rc = dS.reserve(bytes);
+    if (rc) return rc;
+    double* cand = dS.as<double>();
+    double* cands = cand + rec;
+    double* sums = cands + (size_t)world * rec;
+    T* y = reinterpret_cast<T*>(sums + 1032);
+    T* cen = y + m;
+    msm_idx_t* dids = reinterpret_cast<msm_idx_t*>(reinterpret_cast<char*>(y) + ((size_t)(K + 1) * m * sizeof(T) + 15) / 16 * 16);
+    const long long local_seed = (seed >= row_offset && seed < row_offset + n) ? (long long)(seed - row_offset) : -1;
+    hipLaunchKernelGGL((kc_seed_candidate_kernel<T>), dim3(1), dim3(DT), 0, stream(), X, (long long)m, local_seed, (long long)seed, cand);
+    MSM_HIP_CHECK(hipGetLastError());
+    if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
+    if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, 0))) return rc;
+    for (msm_idx_t it = 0; it < K; ++it) {
+        if ((rc = kcenters_pass_dev_impl<T>(X, n, m, y, it, metric, labels, distances, row_offset, cand))) return rc;
+        if (it + 1 < K) {
+            if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
+            if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, it + 1))) return rc;
+        }
+    }
+    // inertia = sum of ALL ranks' distances_: local fp64 tree sum, then one all-reduce of a single double
+    const int nblk = (int)std::min<long long>(std::max<long long>(ceil_div(std::max<long long>(n, 1), DT), 1), 1024);
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nblk), dim3(DT), 0, stream(), distances, (long long)n, sums);
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(1), dim3(DT), 0, stream(), sums, (long long)nblk, sums + 1024);
+    MSM_HIP_CHECK(hipGetLastError());
+    if ((rc = comm_allreduce_f64(sums + 1024, 1))) return rc;
+    double tot = 0.0;
+    MSM_HIP_CHECK(hipMemcpyAsync(&tot, sums + 1024, sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(ids, dids, (size_t)K * sizeof(msm_idx_t), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(centers, cen, (size_t)K * m * sizeof(T), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    if (inertia) *inertia = tot;
+    return MSM_OK;
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -1519,6 +1584,22 @@ int msm_assign_nearest_f64(const double* X, const double* Y, const char* metric,
 {
     return assign_nearest_impl<double>(X, Y, metric, X_indices, n_X, n_Y, n_features, n_X_indices,
                                        assignments, min_dist, inertia, on_device);
+}
+
+int msm_kcenters_fit_sharded_f32(const float* X, msm_idx_t n_local, msm_idx_t m, msm_idx_t n_clusters, const char* metric,
+                                 msm_idx_t seed_index, msm_idx_t row_offset, msm_idx_t* labels, double* distances,
+                                 msm_idx_t* ids, float* centers, double* inertia)
+{
+    return kcenters_fit_sharded_impl<float>(X, n_local, m, n_clusters, metric, seed_index, row_offset, labels, distances, ids,
+                                            centers, inertia);
+}
+
+int msm_kcenters_fit_sharded_f64(const double* X, msm_idx_t n_local, msm_idx_t m, msm_idx_t n_clusters, const char* metric,
+                                 msm_idx_t seed_index, msm_idx_t row_offset, msm_idx_t* labels, double* distances,
+                                 msm_idx_t* ids, double* centers, double* inertia)
+{
+    return kcenters_fit_sharded_impl<double>(X, n_local, m, n_clusters, metric, seed_index, row_offset, labels, distances, ids,
+                                             centers, inertia);
 }
 
 int msm_kcenters_fit_f32(const float* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters,

@@ -1147,6 +1147,33 @@ int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int
     return MSM_OK;
 }
 
+/* sharded step, exchange half: msm_mbk_step(apply_update = 0) left this rank's [K*m sums | K counts | inertia] of ITS
+ * batch rows in the handle's device buffer (msm_mbk_zero_packed for a rank that owns none of them); one all-reduce over
+ * the library communicator (RCCL on the library stream, device buffer, in place) and the reduced buffer is applied
+ * identically on every rank.  *batch_inertia / counts_out (host, K): the global batch inertia and the updated counts. */
+int msm_mbk_zero_packed(msm_mbk_t* h)
+{
+    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_zero_packed: null handle");
+    MSM_HIP_CHECK(hipMemsetAsync(h->packed, 0, (size_t)msm_mbk_packed_size(h) * sizeof(double), stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_allreduce(msm_mbk_t* h, double* batch_inertia, float* counts_out)
+{
+    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_allreduce: null handle");
+    int rc = comm_allreduce_f64(h->packed, (size_t)msm_mbk_packed_size(h));
+    if (rc) return rc;
+    hipLaunchKernelGGL(mbk_apply_kernel, dim3((unsigned)h->K), dim3(256), 0, stream(), h->centers, h->counts, h->packed, h->K, h->m);
+    MSM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (batch_inertia)
+        MSM_HIP_CHECK(hipMemcpyAsync(batch_inertia, h->packed + (size_t)h->K * h->m + h->K, sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (counts_out) MSM_HIP_CHECK(hipMemcpyAsync(counts_out, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
 int msm_mbk_reassign(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
                      msm_idx_t n_reassign, float new_count, int on_device)
 {

@@ -2672,6 +2672,25 @@ int msm_tica_solve_device(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, con
     return MSM_OK;
 }
 
+int msm_tica_counts(msm_tica_t* h, msm_idx_t* n_observations, msm_idx_t* n_sequences)
+{
+    if (!h) return fail(MSM_ERR_STATE, "null tica handle");
+    if (n_observations) *n_observations = h->n_obs;
+    if (n_sequences) *n_sequences = h->n_seq;
+    return MSM_OK;
+}
+
+/* one all-reduce of the packed accumulators over the library communicator, device to device */
+int msm_tica_allreduce(msm_tica_t* h)
+{
+    if (!h) return fail(MSM_ERR_STATE, "null tica handle");
+    if (!comm_active()) return MSM_OK;
+    int rc = tica_export_device(h);  // h->packed = [C | G | s0 | stau | n_obs | n_seq], raw (un-shifted) moments
+    if (rc) return rc;
+    if ((rc = comm_allreduce_f64(h->packed, h->packed_len()))) return rc;
+    return msm_tica_import_packed(h, h->packed, 1);  // resets the local state, keeps the reduced sums as the base
+}
+
 /* s0 / stau alone (F doubles each, host): the column sums without the F x F moments */
 int msm_tica_export_sums(msm_tica_t* h, double* s0, double* stau)
 {

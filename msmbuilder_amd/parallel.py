@@ -69,6 +69,106 @@ def init_from_env(backend=None):
     return r, world, local
 
 
+# ---------------------------------------------------------------------------------------------------
+# The library's own communicator (csrc/comm.hip): the collectives of the hot path -- tICA's all-reduce, the
+# per-centre all-gather of k-centers, MiniBatchKMeans' per-step all-reduce -- are issued by libmsmhip itself on
+# its stream between its kernels.  torch.distributed is only the bootstrap (rendezvous + one broadcast of RCCL's
+# 128-byte unique id).  With the gloo backend (CPU-only test runs, several ranks sharing one GPU) RCCL cannot
+# form a communicator, so the library is given a host-side transport instead: same library code above it.
+# ---------------------------------------------------------------------------------------------------
+_lib_comm_kind = None      # None | "rccl" | "host"
+_host_cb_keepalive = None
+
+
+def _host_collective(op, send, recv, nbytes):
+    """msm_host_collective_fn: op 0 = all-reduce(sum) of nbytes/8 doubles in place, op 1 = all-gather of nbytes."""
+    import ctypes as C
+    try:
+        import torch
+        dist = _dist()
+        nccl = _backend_is_nccl()
+        if op == 0:
+            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(nbytes // 8,))
+            t = torch.from_numpy(a)
+            if nccl:
+                d = t.cuda()
+                dist.all_reduce(d, op=dist.ReduceOp.SUM)
+                t.copy_(d.cpu())
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            w = dist.get_world_size()
+            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+            o = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(w, nbytes))
+            t = torch.from_numpy(a)
+            outs = [torch.from_numpy(o[r]) for r in range(w)]
+            if nccl:
+                douts = [x.cuda() for x in outs]
+                dist.all_gather(douts, t.cuda())
+                for x, d in zip(outs, douts):
+                    x.copy_(d.cpu())
+            else:
+                dist.all_gather(outs, t)
+        return 0
+    except Exception:   # never let an exception cross the C boundary
+        import traceback
+        traceback.print_exc()
+        return 1
+
+
+def library_comm():
+    """Make sure libmsmhip has a communicator for the current torch.distributed world (collective call: every
+    rank reaches it from the same SPMD entry point).  Returns "rccl", "host" or None (single process)."""
+    global _lib_comm_kind, _host_cb_keepalive
+    if not active():
+        return None
+    if _lib_comm_kind is not None:
+        return _lib_comm_kind
+    import ctypes as C
+    import torch
+    from . import _lib
+    dist = _dist()
+    L = _lib.lib()
+    r, w = dist.get_rank(), dist.get_world_size()
+    want = os.environ.get("MSMBUILDER_AMD_COMM", "auto")     # auto | rccl | host
+    kind = None
+    if want != "host" and _backend_is_nccl():
+        _lib.ensure_device()
+        uid = (C.c_char * 128)()
+        ok = 1
+        if r == 0:
+            ok = 1 if L.msm_comm_unique_id(uid) == 0 else 0
+        t = torch.tensor(list(bytes(uid)) + [ok], dtype=torch.uint8, device="cuda")
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().numpy().tolist())
+        if raw[128]:
+            rc = L.msm_comm_init_rccl(raw[:128], r, w)
+            flag = torch.tensor([1.0 if rc == 0 else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() > 0:
+                kind = "rccl"
+            else:
+                L.msm_comm_destroy()
+        if kind is None and want == "rccl":
+            raise RuntimeError("libmsmhip could not create its RCCL communicator: " + _lib.last_error())
+    if kind is None:
+        cbt = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+        _host_cb_keepalive = cbt(_host_collective)
+        _lib.check(L.msm_comm_init_host(C.cast(_host_cb_keepalive, C.c_void_p), r, w))
+        kind = "host"
+    _lib_comm_kind = kind
+    return kind
+
+
+def library_comm_shutdown():
+    global _lib_comm_kind, _host_cb_keepalive
+    if _lib_comm_kind is not None:
+        from . import _lib
+        _lib.lib().msm_comm_destroy()
+    _lib_comm_kind = None
+    _host_cb_keepalive = None
+
+
 def shard_sequences(sequences, rank_=None, world=None):
     """Greedy longest-first assignment of WHOLE trajectories to ranks (balanced frame
     counts, zero halo).  Returns the indices this rank owns."""
@@ -138,35 +238,25 @@ def all_gather_rows(out2d, row, group=None):
 
 
 def allreduce_tica(model, group=None):
-    """All-reduce(sum) a fitted local tICA's accumulators in place."""
+    """All-reduce(sum) a fitted local tICA's accumulators in place: ``msm_tica_allreduce`` -- the packed fp64
+    buffer is exported, reduced over the library communicator (RCCL over xGMI) and re-imported device to device."""
     if not active():
         return model
-    import ctypes as C
-    import torch
     from . import _lib
-    dist = _dist()
     L = _lib.lib()
     if not model._initialized:
         raise RuntimeError("allreduce() before any data was seen on this rank")
     model._ensure_handle()
-    n = int(L.msm_tica_packed_size(model._handle))
-    if _backend_is_nccl(group):
-        buf = torch.empty(n, dtype=torch.float64, device="cuda")
+    library_comm()
+    import torch
+    if torch.cuda.is_available():
         _lib.set_stream(torch.cuda.current_stream().cuda_stream)
-        _lib.check(L.msm_tica_export_packed(model._handle, C.c_void_p(buf.data_ptr()), 1))
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        torch.cuda.current_stream().synchronize()
-        _lib.check(L.msm_tica_import_packed(model._handle, C.c_void_p(buf.data_ptr()), 1))
-        counts = buf[-2:].cpu().numpy()
-    else:
-        host = np.empty(n, dtype=np.float64)
-        _lib.check(L.msm_tica_export_packed(model._handle, C.c_void_p(host.ctypes.data), 0))
-        t = torch.from_numpy(host)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        _lib.check(L.msm_tica_import_packed(model._handle, C.c_void_p(host.ctypes.data), 0))
-        counts = host[-2:]
-    model.n_observations_ = int(round(counts[0]))
-    model.n_sequences_ = int(round(counts[1]))
+    _lib.check(L.msm_tica_allreduce(model._handle))
+    import ctypes as C
+    nobs, nseq = C.c_int64(0), C.c_int64(0)
+    _lib.check(L.msm_tica_counts(model._handle, C.byref(nobs), C.byref(nseq)))
+    model.n_observations_ = int(nobs.value)
+    model.n_sequences_ = int(nseq.value)
     model._host_stale = True
     model._is_dirty = True
     return model

@@ -46,6 +46,20 @@ np.testing.assert_allclose(ms.eigenvalues_, rl.eigenvalues_, rtol=1e-11)
 np.testing.assert_allclose(ms.offset_correlation_, rl.offset_correlation_, rtol=1e-10, atol=1e-13)
 np.testing.assert_allclose(ms.covariance_, rl.covariance_, rtol=1e-10, atol=1e-13)
 
+assert parallel._lib_comm_kind == "host"      # the library ran the exchange itself (host transport under gloo)
+
+# ---- tICA, default f32 mode on UN-CENTRED features (|mean|/std = 50): every rank has its own shift row r; the raw
+# moments are restored before the all-reduce, so the sum is the unsplit fit's
+os.environ["MSMBUILDER_AMD_TICA_MODE"] = "f32"
+unc = [(rs.randn(int(n), 12) + 50.0 * np.sign(rs.randn(12))).astype(np.float32) for n in (700, 900, 650, 1200)]
+mu_ = tICA(n_components=3, lag_time=5).fit([unc[i] for i in parallel.shard_sequences(unc)]).allreduce()
+os.environ["MSMBUILDER_AMD_TICA_MODE"] = "f64"
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "0"
+ru = tICA(n_components=3, lag_time=5).fit(unc)
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "1"
+np.testing.assert_allclose(mu_.eigenvalues_, ru.eigenvalues_, rtol=1e-5)
+np.testing.assert_allclose(mu_.covariance_, ru.covariance_, rtol=0, atol=1e-5 * np.abs(ru.covariance_).max())
+
 # ---- KCenters: consecutive row blocks per rank
 X = np.concatenate(seqs).astype(np.float64)
 X[40:44] = X[3]                                   # duplicates: argmax ties across the shard boundary
@@ -89,9 +103,61 @@ assert mb.n_steps_ == mref.n_steps_
 np.testing.assert_allclose(mb.cluster_centers_, mref.cluster_centers_, rtol=1e-5, atol=1e-6)
 np.testing.assert_allclose(mb.inertia_, mref.inertia_, rtol=1e-5)
 assert (mb.labels_[0] != mref.labels_[0][lo:hi]).mean() < 5e-3
+# random_state=None: rank 0's draw seeds every rank (ADVICE r1) -- the ranks must agree on every centre
+mn = MiniBatchKMeans(n_clusters=5, batch_size=150, max_iter=2, n_init=1, tol=1e-4).fit([blockf])
+spread = parallel.allreduce_array(mn.cluster_centers_.astype(np.float64).ravel(), op="max") + \
+    parallel.allreduce_array(-mn.cluster_centers_.astype(np.float64).ravel(), op="max")
+assert np.all(spread == 0.0), spread.max()
 dist.barrier()
+parallel.library_comm_shutdown()
 dist.destroy_process_group()
 print("rank", rank, "ok")
+'''
+
+_RCCL1 = r'''
+import os, sys, warnings, ctypes as C
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch
+from msmbuilder_amd import tICA, KCenters, _lib
+from msmbuilder_amd._lib import Arr
+warnings.simplefilter("ignore")
+_lib.ensure_device(0)
+L = _lib.lib()
+uid = (C.c_char * 128)()
+_lib.check(L.msm_comm_unique_id(uid))
+_lib.check(L.msm_comm_init_rccl(bytes(uid), 0, 1))        # a world of one: RCCL itself runs every collective
+r, w, k = C.c_int(), C.c_int(), C.c_int()
+L.msm_comm_info(C.byref(r), C.byref(w), C.byref(k))
+assert (r.value, w.value, k.value) == (0, 1, 1)
+t = torch.arange(1000, dtype=torch.float64, device="cuda")
+_lib.check(L.msm_comm_allreduce_f64(C.c_void_p(t.data_ptr()), 1000))
+assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+o = torch.zeros(1000, dtype=torch.float64, device="cuda")
+_lib.check(L.msm_comm_allgather(C.c_void_p(t.data_ptr()), C.c_void_p(o.data_ptr()), 8000))
+assert torch.equal(o, t)
+# tICA all-reduce through RCCL (device to device)
+rs = np.random.RandomState(2)
+seqs = [(rs.randn(800, 40) + 20.0).astype(np.float32) for _ in range(3)]
+m = tICA(n_components=3, lag_time=4).fit(seqs)
+e0 = m.eigenvalues_.copy()
+_lib.check(L.msm_tica_allreduce(m._handle))
+m._is_dirty = True; m._host_stale = True
+np.testing.assert_allclose(m.eigenvalues_, e0, rtol=1e-12)
+# sharded k-centers loop with RCCL all-gathers == the single-process fit
+X = torch.from_numpy(rs.randn(5000, 10)).cuda()
+ref = KCenters(n_clusters=30, random_state=3).fit([X])
+ax = Arr(X)
+lab = torch.empty(5000, dtype=torch.int64, device="cuda"); dist_ = torch.empty(5000, dtype=torch.float64, device="cuda")
+ids = np.zeros(30, dtype=np.int64); cen = np.zeros((30, 10)); inertia = C.c_double()
+_lib.check(L.msm_kcenters_fit_sharded_f64(ax.vp, 5000, 10, 30, b"euclidean", ref.cluster_ids_[0], 0, C.c_void_p(lab.data_ptr()),
+                                          C.c_void_p(dist_.data_ptr()), ids.ctypes.data, cen.ctypes.data, C.byref(inertia)))
+assert list(ids) == ref.cluster_ids_
+assert torch.equal(lab, ref.labels_[0]) and torch.equal(dist_, ref.distances_[0])
+assert np.array_equal(cen, ref.cluster_centers_.cpu().numpy() if hasattr(ref.cluster_centers_, "cpu") else ref.cluster_centers_)
+assert abs(inertia.value - ref.inertia_) <= 1e-12 * ref.inertia_
+L.msm_comm_destroy()
+print("rccl world-of-one ok")
 '''
 
 
@@ -105,3 +171,13 @@ def test_two_ranks_match_single_process(gpu, tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
         assert "ok" in o
+
+
+def test_library_rccl_world_of_one(gpu, tmp_path):
+    """The RCCL transport of csrc/comm.hip on the one GPU a test box has: a communicator of a single rank still
+    goes through ncclCommInitRank / ncclAllReduce / ncclAllGather on the library stream (dlopen, prototypes, stream
+    ordering), under the tICA all-reduce and the sharded k-centers loop."""
+    script = tmp_path / "rccl1.py"
+    script.write_text(_RCCL1.format(root=ROOT))
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl world-of-one ok" in p.stdout, p.stdout[-3000:]
