@@ -1,0 +1,150 @@
+"""BASELINE.json configs that round 1 left untested (VERDICT r1 "close the test holes"):
+
+* configs[0] shape -- 10 trajectories x 9,999 frames x 4 features (sin/cos of phi, psi), tICA(n_components=2,
+  lag_time=1) -- f32 and f64 against the oracle;
+* the BENCH shape itself, 10M x 512 fp32, lag 100: accumulators against an independent float64 contraction (torch, on the
+  device), eigenvalues against a float64 solve of those moments at the stated rtol 1e-5;
+* the sum/difference kernel's widths [512, lag 100] and [2048, lag 20]: eigenvalues against the ORACLE at rtol 1e-5 on
+  well-sampled data (round 1 compared them with the other HIP kernel at atol 5e-5);
+* MiniBatchKMeans(n_clusters=1000).fit on 100k x 512 against scikit-learn itself (n_steps_ equal, centres and inertia
+  rtol 1e-4)."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit(seqs, mode, monkeypatch, **kw):
+    from msmbuilder_amd import tICA
+    from oracle.tica_oracle import TicaOracle
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return tICA(**kw).fit(seqs), TicaOracle(**kw).fit(seqs)
+
+
+@pytest.mark.parametrize("mode,rtol", [("f32", 1e-5), ("f64", 1e-10)])
+def test_config1_alanine_dipeptide_shape(gpu, monkeypatch, mode, rtol):
+    """SURVEY 8(d) "C1-synthetic": two slowly diffusing dihedral angles -> [sin phi, cos phi, sin psi, cos psi]."""
+    rs = np.random.RandomState(1234)
+    seqs = []
+    for _ in range(10):
+        ang = np.cumsum(rs.randn(9999, 2) * 0.08, axis=0) + rs.uniform(-np.pi, np.pi, size=2)
+        seqs.append(np.stack([np.sin(ang[:, 0]), np.cos(ang[:, 0]), np.sin(ang[:, 1]), np.cos(ang[:, 1])], axis=1).astype(np.float32))
+    m, o = _fit(seqs, mode, monkeypatch, n_components=2, lag_time=1)
+    assert (m.n_observations_, m.n_sequences_, m.n_features) == (99990, 10, 4)
+    np.testing.assert_allclose(m.eigenvalues_, o.eigenvalues_, rtol=rtol)
+    np.testing.assert_allclose(m.timescales_, o.timescales_, rtol=rtol * 200)      # -1 / ln(lambda), lambda ~ 0.99
+    np.testing.assert_allclose(m.means_, o.means_, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m.covariance_, o.covariance_, rtol=0, atol=rtol * np.abs(o.covariance_).max())
+    np.testing.assert_allclose(m.offset_correlation_, o.offset_correlation_, rtol=0, atol=rtol * np.abs(o.offset_correlation_).max())
+    Y, Yo = m.transform(seqs[:2]), o.transform(seqs[:2])
+    for a, b in zip(Y, Yo):
+        sign = np.sign((a * b).sum(0))
+        np.testing.assert_allclose(a * sign, b, rtol=1e-3, atol=1e-4)
+        assert a.shape == (9999, 2) and a.dtype == np.float64
+
+
+def test_bench_shape_10M_x_512_against_fp64_contraction(gpu, monkeypatch):
+    """The headline run's own shape and data recipe (bench.synth): 1,000 x 10,000 x 512 fp32, lag 100, default f32 mode
+    (sum/difference kernel).  Reference: per-trajectory float64 matmuls in torch on the device (an independent
+    contraction: different kernels, different summation order), finalised and solved on the host by the oracle's
+    formulas."""
+    import torch
+    import scipy.linalg
+    import bench
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
+    n_seq, T, F, lag, k = 1000, 10_000, 512, 100, 10
+    X = bench.synth(torch, n_seq, T, F, 1234, torch.device("cuda"))
+    seqs = list(X.view(n_seq, T, F).unbind(0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = tICA(n_components=k, lag_time=lag).fit(seqs)
+        ev = np.asarray(m.eigenvalues_)
+    assert m._lagged_symmetrised and m.n_observations_ == n_seq * T
+    C = torch.zeros(F, F, dtype=torch.float64, device="cuda")
+    G = torch.zeros_like(C)
+    s0 = torch.zeros(F, dtype=torch.float64, device="cuda")
+    st = torch.zeros_like(s0)
+    for s in range(0, n_seq, 20):
+        V = X.view(n_seq, T, F)[s:s + 20].double()
+        A, B = V[:, :-lag].reshape(-1, F), V[:, lag:].reshape(-1, F)
+        C += A.T @ B
+        G += A.T @ A + B.T @ B
+        s0 += A.sum(0)
+        st += B.sum(0)
+        del V, A, B
+    C, G, s0, st = C.cpu().numpy(), G.cpu().numpy(), s0.cpu().numpy(), st.cpu().numpy()
+    m._pull()
+    two_n = 2.0 * n_seq * (T - lag)
+    mu = (s0 + st) / two_n
+    S = G / two_n - np.outer(mu, mu)
+    OC = (C + C.T) / two_n - np.outer(mu, mu)
+    # accumulators: fp32-class error relative to the CENTRED moment (the mean shift), fp64 rounding of the raw totals
+    atol = 1e-6 * two_n * np.abs(S).max() + 1e-11 * np.abs(G).max()
+    np.testing.assert_allclose(m._outer_gram_sum, G, rtol=0, atol=atol)
+    np.testing.assert_allclose(m._outer_0_to_T_lagged, 0.5 * (C + C.T), rtol=0, atol=atol)
+    np.testing.assert_allclose(m._sum_0_to_TminusTau, s0, rtol=1e-11)
+    np.testing.assert_allclose(m._sum_tau_to_T, st, rtol=1e-11)
+    from oracle.tica_oracle import rao_blackwell_ledoit_wolf
+    Sig, rho = rao_blackwell_ledoit_wolf(S, n_seq * T)
+    ref = scipy.linalg.eigh(OC, b=Sig, subset_by_index=[F - k, F - 1])[0][::-1]
+    np.testing.assert_allclose(ev, ref, rtol=1e-5)
+    assert abs(m.shrinkage_ - rho) <= 1e-6 * rho
+    np.testing.assert_allclose(m.covariance_, Sig, rtol=0, atol=1e-5 * np.abs(Sig).max())
+
+
+@pytest.mark.parametrize("F,lag,n_seq,T", [(512, 100, 12, 12000), (2048, 20, 6, 10000)])
+def test_sum_difference_kernel_eigenvalues_vs_oracle(gpu, monkeypatch, F, lag, n_seq, T):
+    """Well-sampled (>= 25 frames per feature), slow modes much longer than the lag: the leading eigenvalues are
+    separated, and the f32 default must reproduce the float64 oracle to the STATED rtol 1e-5."""
+    rs = np.random.RandomState(F + lag)
+    k = 8
+    M = rs.randn(k, F) / np.sqrt(k)
+    a = np.exp(-1.0 / (lag * np.array([40.0, 25.0, 15.0, 9.0, 5.0, 3.0, 2.0, 1.2])))
+    seqs = []
+    for _ in range(n_seq):
+        e = rs.randn(T, k)
+        z = np.empty((T, k))
+        z[0] = e[0]
+        for t in range(1, T):
+            z[t] = a * z[t - 1] + np.sqrt(1 - a * a) * e[t]
+        seqs.append((z @ M + 0.4 * rs.randn(T, F) + rs.uniform(-3, 3, size=F)).astype(np.float32))
+    m, o = _fit(seqs, "f32", monkeypatch, n_components=4, lag_time=lag)
+    assert m._lagged_symmetrised
+    np.testing.assert_allclose(m.eigenvalues_, o.eigenvalues_, rtol=1e-5)
+    np.testing.assert_allclose(m.covariance_, o.covariance_, rtol=0, atol=1e-5 * np.abs(o.covariance_).max())
+    np.testing.assert_allclose(m.offset_correlation_, o.offset_correlation_, rtol=0, atol=1e-5 * np.abs(o.offset_correlation_).max())
+
+
+@pytest.mark.parametrize("reassignment_ratio", [0.0, 0.01])
+def test_config4_minibatchkmeans_k1000_fit_vs_sklearn(gpu, reassignment_ratio):
+    """configs[3]'s clusterer at its K: MiniBatchKMeans(n_clusters=1000).fit on 100k x 512 against scikit-learn itself on
+    the same init and the same RNG stream: equal step counts (same mini-batches, same early-stopping decisions), centres and
+    inertia to rtol 1e-4, labels equal up to fp32 near-ties.  The data are 1000 separated blobs seeded with one member each, so
+    that no label hangs on an fp32 near-tie (one flipped label changes a count, a count changes a reassignment draw, and
+    from there the two RNG streams -- and fits -- legitimately diverge: that is sklearn's algorithm, not an error)."""
+    sk = pytest.importorskip("sklearn.cluster")
+    import torch
+    from msmbuilder_amd import MiniBatchKMeans
+    rs = np.random.RandomState(17)
+    K, F, N = 1000, 512, 100_000
+    cent = rs.randn(K, F).astype(np.float32) * 1.5
+    member = rs.permutation(np.repeat(np.arange(K), N // K))
+    X = (cent[member] + 0.5 * rs.randn(N, F).astype(np.float32)).astype(np.float32)
+    first = np.array([np.nonzero(member == c)[0][0] for c in range(K)])
+    init = X[first].copy()
+    kw = dict(n_clusters=K, init=init, n_init=1, batch_size=1024, max_iter=2, random_state=5,
+              reassignment_ratio=reassignment_ratio)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = sk.MiniBatchKMeans(**kw).fit(X)
+        mine = MiniBatchKMeans(**kw).fit([torch.from_numpy(X).cuda()])
+    assert mine.n_steps_ == ref.n_steps_
+    np.testing.assert_allclose(mine.cluster_centers_, ref.cluster_centers_, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(mine.inertia_, ref.inertia_, rtol=1e-4)
+    lab = mine.labels_[0].cpu().numpy()
+    assert (lab != ref.labels_).mean() < 1e-3
