@@ -252,7 +252,7 @@ int msm_transition_counts(const msm_idx_t* const* y_ptrs, const msm_idx_t* n_row
     int rc = check_seqs(y_ptrs, n_rows, n_seq, "msm_transition_counts");
     if (rc) return rc;
     if (lag_time < 1) return fail(MSM_ERR_INVALID, "msm_transition_counts: lag_time must be >= 1");
-    if (n_states < 0 || n_states > 46340 || n_bins < 0 || n_bins > ((msm_idx_t)1 << 31) - 1 || (n_states > 0 && !counts))
+    if (n_states < 0 || n_states > ((msm_idx_t)1 << 20) || n_bins < 0 || n_bins > ((msm_idx_t)1 << 31) - 1 || (n_states > 0 && !counts))
         return fail(MSM_ERR_INVALID, "msm_transition_counts: bad table size");
     if (!remap && n_bins != n_states) return fail(MSM_ERR_INVALID, "msm_transition_counts: n_bins must equal n_states without a remap table");
     if (n_states == 0) return MSM_OK;

@@ -294,6 +294,112 @@ __global__ __launch_bounds__(DT) void pair_small_kernel(PairArgs P)
     }
 }
 
+// assign_nearest for short rows (m <= FC, contiguous, no X_indices), the KCenters.predict shape: VALU-bound exact
+// arithmetic, so the kernel is built around the fp64 issue rate.
+//  * TWO rows per lane share every centre-element read from LDS (a broadcast ds_read feeds 2 x 3 fp64 operations; with
+//    one row per lane the LDS pipe, not the VALU, was the limit: 4 waves x 4 clk per b64 read against 12 VALU cycles);
+//  * a whole tile of centres (all of them when K m fits 32 KiB) is staged once per workgroup: no barrier inside the
+//    centre loop;
+//  * euclidean: the reference compares sqrt(a) (distance_kernels.h:67-77, assign.hpp:22-31), and so does this kernel --
+//    but it only EVALUATES a square root when the comparison could depend on its rounding.  sqrt is monotone and
+//    correctly rounded, so a candidate with a >= a_best can never win the strict `<`; one with a < a_best (1 - 2^-48)
+//    wins for certain (the exact roots differ by more than 2 ulp); only candidates inside that sliver -- exact
+//    near-ties -- take both roots and compare them.  One sqrt per row at the end gives min_dist.  Bit-identical
+//    labels and distances (tests/test_gpu_libdistance.py, incl. constructed ties), ~1/4 fewer fp64 cycles per pair at m = 10.
+template <typename T, int M>
+__global__ __launch_bounds__(DT) void assign_small2_kernel(PairArgs P)
+{
+    constexpr int FC = FeatChunk<T>::FC;
+    constexpr int YCAP = 32768 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) T Ys[YCAP];
+    __shared__ double red[DT];
+    const T* X = static_cast<const T*>(P.X);
+    const T* Y = static_cast<const T*>(P.Y);
+    const int tid = threadIdx.x;
+    const int m = (int)P.m;
+    const int mp = (m + 3) & ~3;          // centre pitch: whole groups of 4, zero padded (exact for every metric)
+    const int KT = YCAP / mp;             // centres per LDS tile
+    double inertia = 0.0;
+    const long long ntile = (P.n + 2 * DT - 1) / (2 * DT);
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long long i0 = t * (2 * DT) + tid, i1 = i0 + DT;
+        T x0[FC], x1[FC];
+        load_row_regs<T>(x0, X + (i0 < P.n ? i0 : P.n - 1) * P.m, m, P.vecw);
+        load_row_regs<T>(x1, X + (i1 < P.n ? i1 : P.n - 1) * P.m, m, P.vecw);
+        // euclidean: (best squared distance, certain-win threshold); other metrics: best distance
+        double best0 = INFINITY, best1 = INFINITY, thr0 = INFINITY, thr1 = INFINITY;
+        if (M != M_EUCLIDEAN) best0 = best1 = 1.7976931348623157e308;  // DBL_MAX, assign.hpp:20
+        int lab0 = -1, lab1 = -1;
+        for (long long j0 = 0; j0 < P.K; j0 += KT) {
+            const int kt = (int)((P.K - j0) < KT ? (P.K - j0) : KT);
+            __syncthreads();
+            for (int e = tid; e < kt * mp; e += DT) {
+                const int c = e / mp, ff = e - c * mp;
+                Ys[e] = ff < m ? Y[(j0 + c) * P.m + ff] : (T)0;
+            }
+            __syncthreads();
+            for (int c = 0; c < kt; ++c) {
+                const T* yc = Ys + c * mp;
+                double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int g = 0; g < FC / 4; ++g)
+                    if (g * 4 < m) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const T y = yc[g * 4 + q];
+                            m_update<T, M>(a0, b0, x0[g * 4 + q], y);
+                            m_update<T, M>(a1, b1, x1[g * 4 + q], y);
+                        }
+                    }
+                const int j = (int)(j0 + c);
+                if (M == M_EUCLIDEAN) {
+                    if (a0 < thr0 || (a0 < best0 && sqrt(a0) < sqrt(best0))) {
+                        best0 = a0;
+                        thr0 = a0 * (1.0 - 0x1p-48);
+                        lab0 = j;
+                    }
+                    if (a1 < thr1 || (a1 < best1 && sqrt(a1) < sqrt(best1))) {
+                        best1 = a1;
+                        thr1 = a1 * (1.0 - 0x1p-48);
+                        lab1 = j;
+                    }
+                } else {
+                    const double d0 = m_final<M>(a0, b0, P.m), d1 = m_final<M>(a1, b1, P.m);
+                    if (d0 < best0) {
+                        best0 = d0;
+                        lab0 = j;
+                    }
+                    if (d1 < best1) {
+                        best1 = d1;
+                        lab1 = j;
+                    }
+                }
+            }
+        }
+        // no centre ever compared smaller (NaN rows, K = 0): label 0 and DBL_MAX, as the reference's initial values
+        double d0 = 1.7976931348623157e308, d1 = 1.7976931348623157e308;
+        if (lab0 >= 0) d0 = (M == M_EUCLIDEAN) ? sqrt(best0) : best0;
+        if (lab1 >= 0) d1 = (M == M_EUCLIDEAN) ? sqrt(best1) : best1;
+        if (i0 < P.n) {
+            P.labels[i0] = lab0 < 0 ? 0 : lab0;
+            if (P.min_dist) P.min_dist[i0] = d0;
+            inertia += d0;
+        }
+        if (i1 < P.n) {
+            P.labels[i1] = lab1 < 0 ? 0 : lab1;
+            if (P.min_dist) P.min_dist[i1] = d1;
+            inertia += d1;
+        }
+    }
+    red[tid] = inertia;
+    __syncthreads();
+    for (int s = DT / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) P.partial[blockIdx.x] = red[0];
+}
+
 // ---------------------------------------------------------------------------
 // One k-centers pass (kcenters.py:91-97), fused: (prologue) global argmax of the
 // previous pass's per-block partials -> new centre index c; d = metric(X, X[c]);
@@ -320,7 +426,23 @@ struct KcArgs {
     int vecw;               // > 0: rows in registers (m <= FC), vector width in bytes
     const void* ycenter;    // non-null: explicit centre coordinates (device, m values) instead of X[argmax];
                             // used by the sharded driver, where the centre may live on another rank
+    const void* centers;    // sharded driver: coordinates of the centres chosen so far, device [it + 1][m] (else X[ids[j]])
+    int prune;              // triangle-inequality pruning of rows that cannot change (register path, norm metrics)
 };
+
+// Exact pruning of a k-centers pass.  A row i at distance dist_i from its centre c_l cannot move to the new centre c when
+// d(c, c_l) >= 2 dist_i: then d(x_i, c) >= d(c, c_l) - d(x_i, c_l) >= dist_i and the reference's strict `d < dist_i`
+// (kcenters.py:93) is false.  Such a row needs neither its coordinates nor the distance evaluation -- only distances_[i]
+// and labels_[i] (16 B instead of 16 + m sizeof(T)).  Trajectory frames are time-ordered, so neighbouring rows sit in the
+// same cluster and whole wavefronts skip together: the untouched 64-byte sectors never leave HBM.  The comparison carries a
+// safety factor far above the rounding of the computed distances (fp64 accumulation: ~m 2^-53; float inputs subtract in
+// fp32: 2^-24), so a skipped row is PROVABLY one the reference would not update -- labels_/distances_ stay bit-identical.
+// Norm metrics only (euclidean, cityblock, chebyshev): the others are not metrics or are not worth it.
+constexpr int KC_PRUNE_MAX = 2048;  // previous centres whose distance to the new one is tabulated per block (16 KiB of LDS)
+template <typename T> struct PruneMargin;
+template <> struct PruneMargin<double> { static constexpr double F = 2.0 * (1.0 + 1e-9); };
+template <> struct PruneMargin<float> { static constexpr double F = 2.0 * (1.0 + 1e-5); };
+template <int M> struct IsNormMetric { static constexpr bool V = (M == M_EUCLIDEAN || M == M_CITYBLOCK || M == M_CHEBYSHEV); };
 
 __device__ __forceinline__ bool kc_better(double v, long long i, double bv, long long bi)
 {
@@ -374,15 +496,56 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
     double bv = -1.0;
     long long bi = -1;
     const long long ntile = (P.n + DT - 1) / DT;
+    __shared__ double Dc[IsNormMetric<M>::V ? KC_PRUNE_MAX : 1];  // d(new centre, centre j) for the pruning test
+    const bool prune = IsNormMetric<M>::V && P.prune && P.vecw > 0 && P.it > 0;
+    const int nprev = P.it < KC_PRUNE_MAX ? P.it : KC_PRUNE_MAX;
     if (P.vecw > 0) {  // centre row once per block, broadcast from LDS
         __syncthreads();
         if (tid < FC) ys[tid] = tid < P.m ? y[tid] : (T)0;
         __syncthreads();
+        if (prune) {
+            for (int j = tid; j < nprev; j += DT) {
+                const T* cj = P.centers ? static_cast<const T*>(P.centers) + (long long)j * P.m : X + P.ids[j] * P.m;
+                double a = 0.0, b = 0.0;
+                for (int f = 0; f < (int)P.m; ++f) m_update<T, M>(a, b, cj[f], ys[f]);
+                Dc[j] = m_final<M>(a, b, P.m);
+            }
+            __syncthreads();
+        }
     }
     for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
         const long long row0 = t * DT;
         const long long i = row0 + tid;
         double a = 0.0, b = 0.0;
+        if (P.vecw > 0 && prune) {
+            // register path with pruning: everything per row in one place (the common code below is skipped)
+            if (i < P.n) {
+                double cur = P.dist[i];
+                const long long lab = P.labels[i];
+                const bool skip = lab < nprev && Dc[(IsNormMetric<M>::V && lab < nprev) ? lab : 0] >= PruneMargin<T>::F * cur;
+                if (!skip) {
+                    T x[FC];
+                    load_row_regs<T>(x, X + i * P.m, (int)P.m, P.vecw);
+#pragma unroll
+                    for (int g = 0; g < FC / 4; ++g)
+                        if (g * 4 < P.m) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) m_update<T, M>(a, b, x[g * 4 + q], ys[g * 4 + q]);
+                        }
+                    const double d = m_final<M>(a, b, P.m);
+                    if (d < cur) {   // strict, kcenters.py:93
+                        cur = d;
+                        P.dist[i] = d;
+                        P.labels[i] = P.it;
+                    }
+                }
+                if (bi < 0 || kc_better(cur, i, bv, bi)) {
+                    bv = cur;
+                    bi = i;
+                }
+            }
+            continue;
+        }
         if (P.vecw > 0) {
             T x[FC];
             load_row_regs<T>(x, X + (i < P.n ? i : P.n - 1) * P.m, (int)P.m, P.vecw);
@@ -465,7 +628,7 @@ __device__ __forceinline__ void wide_tile_end(const WideArgs& A, long long i, lo
 // MODE 0 assign_nearest, 1 cdist/dist, 2 one k-centers pass (NC == 1).
 // ---------------------------------------------------------------------------
 constexpr int WP = 36;   // staged row pitch in 32-bit words (128 B of data + 16 B pad)
-constexpr int WNC = 8;   // centres per register tile in MODE 0/1
+constexpr int WNC = 16;  // centres per register tile in MODE 0/1 (8: every X tile was re-fetched K/8 times -- 5.5 TB/s of L2/MALL traffic at the VALU-bound rate)
 
 struct WideArgs {
     PairArgs pa;   // MODE 0/1
@@ -919,6 +1082,12 @@ __global__ __launch_bounds__(DT) void sum_partial_kernel(const double* __restric
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+static int kc_prune_enabled()
+{
+    static const int on = !(getenv("MSM_KC_PRUNE") && atoi(getenv("MSM_KC_PRUNE")) == 0);  // A/B switch for scripts / tests
+    return on;
+}
+
 // ---- host-side dispatch ----------------------------------------------------
 // widest aligned per-lane vector load for a [*, m] row-major array, 0 if the fast path does not apply
 template <typename T>
@@ -966,12 +1135,15 @@ template <typename T, int MODE>
 void launch_pair(int metric, int grid, const PairArgs& P)
 {
     const bool wide = wide_ok<T>(P.X, P.Y, P.m, P.X_indices != nullptr);
+    static const bool small1 = getenv("MSM_DIST_SMALL1") != nullptr;  // A/B switch: one row per lane (round 1's kernel)
     WideArgs A;
     memset(&A, 0, sizeof(A));
     A.pa = P;
 #define MSM_CASE(MM)                                                                              \
     case MM:                                                                                      \
-        if (P.vecw > 0)                                                                           \
+        if (P.vecw > 0 && MODE == 0 && !small1)                                                   \
+            hipLaunchKernelGGL((assign_small2_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P); /* every block writes its partial */ \
+        else if (P.vecw > 0)                                                                      \
             hipLaunchKernelGGL((pair_small_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P); \
         else if (wide)                                                                            \
             launch_wide<T, MM, MODE>(grid, A);                                                    \
@@ -1188,6 +1360,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     P.seed = seed;
     P.nblk = nblk;
     P.ids = dIds.as<msm_idx_t>();
+    P.prune = kc_prune_enabled();
     if (on_device) {
         P.X = X;
         P.labels = labels;
@@ -1359,7 +1532,8 @@ int kcenters_pass_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y, msm_idx
 // one pass + candidate record, everything on the stream, no synchronisation
 template <typename T>
 int kcenters_pass_dev_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y_dev, msm_idx_t it, const char* metric,
-                           msm_idx_t* labels, double* distances, msm_idx_t row_offset, double* cand_dev)
+                           msm_idx_t* labels, double* distances, msm_idx_t row_offset, double* cand_dev,
+                           const T* centers_dev = nullptr)
 {
     const int mid = metric_id(metric);
     if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
@@ -1382,6 +1556,8 @@ int kcenters_pass_dev_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y_dev,
     P.labels = labels;
     P.ids = dIds.as<msm_idx_t>();
     P.ycenter = y_dev;
+    P.centers = centers_dev;                        // centres 0 .. it of the fit (pruning table); null: no pruning
+    P.prune = centers_dev ? kc_prune_enabled() : 0;
     if (n > 0) {
         P.vecw = row_vecw<T>(P.X, m, false);
         if (P.vecw == 0 && wide_ok<T>(P.X, P.ycenter, m, false)) nblk = std::min(nblk, wide_grid(n));
@@ -1453,7 +1629,7 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
     if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
     if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, 0))) return rc;
     for (msm_idx_t it = 0; it < K; ++it) {
-        if ((rc = kcenters_pass_dev_impl<T>(X, n, m, y, it, metric, labels, distances, row_offset, cand))) return rc;
+        if ((rc = kcenters_pass_dev_impl<T>(X, n, m, y, it, metric, labels, distances, row_offset, cand, cen))) return rc;
         if (it + 1 < K) {
             if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
             if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, it + 1))) return rc;

@@ -114,10 +114,12 @@ struct msm_npy_loader {
         int fd;
         long long file_off, n;
         char* dst;
+        hipEvent_t fence;  // recorded on the consumer's stream at submit time: the copy must not start before it
     };
     struct JobState {
         int fd = -1;
         long long remaining = 0;
+        hipEvent_t fence = nullptr;
     };
     size_t buf_bytes = 0;
     std::vector<char*> bufs;  // pinned, one per reader
@@ -158,6 +160,11 @@ struct msm_npy_loader {
                 if (k <= 0) err = "short read in .npy payload";
                 else got += k;
             }
+            // The destination usually comes from a stream-ordered caching allocator (torch): the block may have been
+            // handed back by a tensor that kernels queued on the consumer's stream are still reading.  The reader's own
+            // stream therefore waits for the fence recorded on that stream when the job was submitted.
+            if (err.empty() && pc.n > 0 && pc.fence && hipStreamWaitEvent(streams[r], pc.fence, 0) != hipSuccess)
+                err = "hipStreamWaitEvent on the submit fence failed";
             if (err.empty() && pc.n > 0 &&
                 (hipMemcpyAsync(pc.dst, bufs[r], (size_t)pc.n, hipMemcpyHostToDevice, streams[r]) != hipSuccess ||
                  hipStreamSynchronize(streams[r]) != hipSuccess))
@@ -169,6 +176,8 @@ struct msm_npy_loader {
                 if (js && --js->remaining == 0) {
                     close(js->fd);
                     js->fd = -1;
+                    if (js->fence) (void)hipEventDestroy(js->fence);
+                    js->fence = nullptr;
                     while (!jobs.empty() && jobs.front().second.remaining == 0) jobs.pop_front();
                 }
             }
@@ -242,11 +251,19 @@ int msm_npy_loader_submit(msm_npy_loader_t* h, const char* path, void* dptr, msm
         close(fd);
         return rc;
     }
+    // fence: everything queued so far on the library stream (= the consumer's stream, e.g. torch's current stream)
+    hipEvent_t fence = nullptr;
+    if (hipEventCreateWithFlags(&fence, hipEventDisableTiming) != hipSuccess || hipEventRecord(fence, stream()) != hipSuccess) {
+        if (fence) (void)hipEventDestroy(fence);
+        close(fd);
+        return fail(MSM_ERR_HIP, "msm_npy_loader_submit: could not record the submit fence");
+    }
     {
         std::lock_guard<std::mutex> lk(h->mu);
         const long long id = h->next_id++;
         msm_npy_loader::JobState js;
         js.fd = fd;
+        js.fence = fence;
         js.remaining = std::max<long long>(1, ceil_div(nbytes, (long long)h->buf_bytes));
         h->jobs.emplace_back(id, js);
         long long off = 0;
@@ -257,6 +274,7 @@ int msm_npy_loader_submit(msm_npy_loader_t* h, const char* path, void* dptr, msm
             pc.file_off = info.data_offset + off;
             pc.n = std::min<long long>((long long)h->buf_bytes, nbytes - off);
             pc.dst = static_cast<char*>(dptr) + off;
+            pc.fence = fence;
             h->queue.push_back(pc);
             off += pc.n;
         } while (off < nbytes);
@@ -289,8 +307,10 @@ int msm_npy_loader_destroy(msm_npy_loader_t* h)
     h->cv_piece.notify_all();
     for (auto& t : h->readers)
         if (t.joinable()) t.join();  // readers drain the queue first: no copy is left in flight
-    for (auto& j : h->jobs)
+    for (auto& j : h->jobs) {
         if (j.second.fd >= 0) close(j.second.fd);
+        if (j.second.fence) (void)hipEventDestroy(j.second.fence);
+    }
     for (char* p : h->bufs) (void)hipHostFree(p);
     for (hipStream_t st : h->streams) (void)hipStreamDestroy(st);
     delete h;

@@ -60,6 +60,7 @@ struct TicaArgs {
     unsigned* cosync; // [S] per-cohort arrival counters (zeroed per launch): keeps a cohort's workgroups within one chunk of each other
     long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
     const float* shift; // [F] per-column reference row r (or nullptr): the fp32 / bf16 kernels accumulate (x - r), see "mean shift"
+    int kflush;         // sum/difference kernel: frames accumulated in fp32 registers before the fp64 slab merge
 };
 
 __device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
             if (tid == 0) __hip_atomic_fetch_add(P.cosync + cohort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         rows_acc += ch.n;
-        if (rows_acc + P.kc > KFLUSH_SYM || c + P.S >= P.nchunks) {
+        if (rows_acc + P.kc > P.kflush || c + P.S >= P.nchunks) {
             rows_acc = 0;
             // accumulator register r of block (bi, bj), lane (kl, cl) = tile row wr*64 + 2*rho + bi with
             // rho = (r & 3) + 8 (r >> 2) + 4 kl, tile column wc*64 + 2*cl + bj: the two bj of a lane are adjacent doubles
@@ -1969,6 +1970,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     P.colpart = h->coltmp;
     P.flag = h->flag;
     P.dbg = h->dbg;
+    {
+        // fp32 partial sums of the SHIFTED frames are sigma^2-sized, so two chunks (8192 frames) can share a merge; raw
+        // moments (no shift) keep the 4096-frame partials of round 1
+        static const char* kf = getenv("MSM_TICA_KFLUSH");
+        P.kflush = kf ? atoi(kf) : (h->shift_on ? 2 * KFLUSH_SYM : KFLUSH_SYM);
+    }
     {
         // measured (10M x 512): pacing cuts the L2 fabric-side fetch from 207 GB to 79-82 GB per launch but
         // makes the kernel 4 % slower (78.4 -> 81.7 ms), so it is opt-in

@@ -196,7 +196,9 @@ class _DeviceView(object):
         return path, dt, tuple(shape[i] for i in range(nd.value))
 
     def __getitem__(self, i):
-        for x in self._stream(self._keys[i:i + 1] if isinstance(i, int) else self._keys[i]):
+        if isinstance(i, slice):
+            return list(self._stream(self._keys[i]))
+        for x in self._stream([self._keys[i]]):      # list semantics: negative indices count from the end, IndexError beyond
             return x
 
     def __iter__(self):
@@ -218,6 +220,9 @@ class _DeviceView(object):
                     return False
                 path, dt, shape = self._info(key)
                 t = torch.empty(shape, dtype=getattr(torch, dt), device=dev)
+                # `t` may re-use a block that kernels queued on torch's stream are still reading (a trajectory the consumer
+                # has already dropped): submit() records a fence on the library stream, which must be that stream
+                _lib.set_stream(torch.cuda.current_stream(dev).cuda_stream)
                 job = C.c_int64(0)
                 check(L.msm_npy_loader_submit(h, path, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), C.byref(job)))
                 pending.append((job.value, t))

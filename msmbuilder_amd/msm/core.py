@@ -156,7 +156,8 @@ def _generic_path(sequences, lag_time, label_dtype=None):
         code = np.full(len(y), -1, dtype=np.int64)
         if n_states and y.dtype.kind in "fiuUS":      # sorted classes: one vectorised lookup
             valid = ~np.isnan(y) if y.dtype.kind == "f" else np.ones(len(y), dtype=bool)
-            code[valid] = np.searchsorted(np.asarray(classes), y[valid])
+            cls = np.asarray(classes)
+            code[valid] = np.searchsorted(cls, y[valid].astype(cls.dtype, copy=False))   # mixed str / int inputs: compare in the classes' dtype
         elif n_states:
             for i, v in enumerate(y):
                 if v is None or (isinstance(v, (float, np.floating)) and np.isnan(v)):
