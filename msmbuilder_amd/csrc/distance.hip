@@ -428,6 +428,17 @@ struct KcArgs {
                             // used by the sharded driver, where the centre may live on another rank
     const void* centers;    // sharded driver: coordinates of the centres chosen so far, device [it + 1][m] (else X[ids[j]])
     int prune;              // triangle-inequality pruning of rows that cannot change (register path, norm metrics)
+    // Fused sharded pass (register path only): the all-gathered candidate records of the previous pass are reduced to this
+    // pass's centre in the PROLOGUE (every block redundantly; block 0 stores it to sel_centers[it] / sel_ids[it]), and the
+    // shard's candidate record for the next pass is produced in the EPILOGUE by the last block to finish -- one kernel
+    // and one all-gather per centre.
+    const double* sel_cands;  // [sel_world][2 + m]
+    int sel_world;
+    void* sel_centers;        // T [K][m]
+    msm_idx_t* sel_ids;       // [K]
+    double* cand_out;         // [2 + m]
+    long long row_offset;
+    unsigned* counter;        // zero before the first pass; the last block resets it
 };
 
 // Exact pruning of a k-centers pass.  A row i at distance dist_i from its centre c_l cannot move to the new centre c when
@@ -463,7 +474,28 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
 
     // ---- prologue: centre of this pass ----
     long long cidx = 0;
-    if (P.ycenter) {
+    __shared__ int sel_win;
+    if (P.sel_cands) {
+        // fused select: largest distance wins, ties to the lowest GLOBAL row (numpy's argmax over the concatenated array)
+        const long long rec = 2 + P.m;
+        if (tid == 0) {
+            int w = -1;
+            for (int r = 0; r < P.sel_world; ++r) {
+                const double v = P.sel_cands[r * rec], g = P.sel_cands[r * rec + 1];
+                if (g < 0.0) continue;
+                if (w < 0 || v > P.sel_cands[w * rec] || (v == P.sel_cands[w * rec] && g < P.sel_cands[w * rec + 1])) w = r;
+            }
+            sel_win = w;
+            if (blockIdx.x == 0) P.sel_ids[P.it] = w >= 0 ? (msm_idx_t)P.sel_cands[w * rec + 1] : -1;
+        }
+        __syncthreads();
+        if (tid < FC) {
+            const T v = (tid < P.m && sel_win >= 0) ? (T)P.sel_cands[sel_win * rec + 2 + tid] : (T)0;
+            ys[tid] = v;
+            if (blockIdx.x == 0 && tid < P.m) static_cast<T*>(P.sel_centers)[(long long)P.it * P.m + tid] = v;
+        }
+        __syncthreads();
+    } else if (P.ycenter) {
         // centre supplied by the host (multi-rank driver): nothing to reduce
     } else if (P.it == 0) {
         cidx = P.seed;
@@ -490,8 +522,8 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         cidx = ri[0];
         __syncthreads();
     }
-    if (!P.ycenter && blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
-    const T* y = P.ycenter ? static_cast<const T*>(P.ycenter) : X + cidx * P.m;
+    if (!P.ycenter && !P.sel_cands && blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
+    const T* y = P.ycenter ? static_cast<const T*>(P.ycenter) : X + cidx * P.m;  // (unused by the fused select: ys is set)
 
     double bv = -1.0;
     long long bi = -1;
@@ -500,9 +532,11 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
     const bool prune = IsNormMetric<M>::V && P.prune && P.vecw > 0 && P.it > 0;
     const int nprev = P.it < KC_PRUNE_MAX ? P.it : KC_PRUNE_MAX;
     if (P.vecw > 0) {  // centre row once per block, broadcast from LDS
-        __syncthreads();
-        if (tid < FC) ys[tid] = tid < P.m ? y[tid] : (T)0;
-        __syncthreads();
+        if (!P.sel_cands) {
+            __syncthreads();
+            if (tid < FC) ys[tid] = tid < P.m ? y[tid] : (T)0;
+            __syncthreads();
+        }
         if (prune) {
             for (int j = tid; j < nprev; j += DT) {
                 const T* cj = P.centers ? static_cast<const T*>(P.centers) + (long long)j * P.m : X + P.ids[j] * P.m;
@@ -598,6 +632,47 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         q.v = rv[0];
         q.i = ri[0];
         P.next[blockIdx.x] = q;
+    }
+    if (P.cand_out) {
+        // fused candidate record: the last block to arrive reduces all partials (agent-scope release on the way in,
+        // acquire for the block that reads the others' partials)
+        __shared__ int am_last;
+        if (tid == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            am_last = prev == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (am_last) {
+            double cv = -1.0;
+            long long ci = -1;
+            for (int k = tid; k < (int)gridDim.x; k += DT) {
+                const KcPartial q = P.next[k];
+                if (q.i >= 0 && (ci < 0 || kc_better(q.v, q.i, cv, ci))) {
+                    cv = q.v;
+                    ci = q.i;
+                }
+            }
+            rv[tid] = cv;
+            ri[tid] = ci;
+            __syncthreads();
+            for (int s = DT / 2; s > 0; s >>= 1) {
+                if (tid < s) {
+                    const long long oi = ri[tid + s];
+                    if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + s], oi, rv[tid], ri[tid]))) {
+                        rv[tid] = rv[tid + s];
+                        ri[tid] = oi;
+                    }
+                }
+                __syncthreads();
+            }
+            const long long w = ri[0];
+            if (tid == 0) {
+                P.cand_out[0] = w >= 0 ? rv[0] : -1.0;
+                P.cand_out[1] = w >= 0 ? (double)(P.row_offset + w) : -1.0;
+                __hip_atomic_store(P.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (long long f = tid; f < P.m; f += DT) P.cand_out[2 + f] = w >= 0 ? (double)X[w * P.m + f] : 0.0;
+        }
     }
 }
 
@@ -1627,12 +1702,49 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
     hipLaunchKernelGGL((kc_seed_candidate_kernel<T>), dim3(1), dim3(DT), 0, stream(), X, (long long)m, local_seed, (long long)seed, cand);
     MSM_HIP_CHECK(hipGetLastError());
     if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
-    if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, 0))) return rc;
-    for (msm_idx_t it = 0; it < K; ++it) {
-        if ((rc = kcenters_pass_dev_impl<T>(X, n, m, y, it, metric, labels, distances, row_offset, cand, cen))) return rc;
-        if (it + 1 < K) {
-            if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
-            if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, it + 1))) return rc;
+    static const bool unfused = getenv("MSM_KC_UNFUSED") != nullptr;  // A/B switch: pass + candidate + select kernels
+    const bool fused = !unfused && n > 0 && row_vecw<T>(X, m, false) > 0;  // register path (m <= FC): one kernel per centre
+    if (fused) {
+        // every rank must take the same path or the all-gathers would not match: rows are a property of the data type and
+        // width only, except for an EMPTY shard -- which therefore runs the generic kernels but keeps the exchange pattern
+        DevBuf &dPart = pool(PS_PART);
+        const int nblk = (int)std::min<long long>(ceil_div(n, DT), KC_MAXBLK);
+        if ((rc = dPart.reserve((size_t)nblk * sizeof(KcPartial) + 16))) return rc;
+        unsigned* counter = reinterpret_cast<unsigned*>(dPart.as<KcPartial>() + nblk);
+        MSM_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned), stream()));
+        KcArgs P;
+        memset(&P, 0, sizeof(P));
+        P.X = X;
+        P.n = n;
+        P.m = m;
+        P.nblk = nblk;
+        P.next = dPart.as<KcPartial>();
+        P.dist = distances;
+        P.labels = labels;
+        P.vecw = row_vecw<T>(X, m, false);
+        P.centers = cen;
+        P.prune = kc_prune_enabled();
+        P.sel_cands = cands;
+        P.sel_world = world;
+        P.sel_centers = cen;
+        P.sel_ids = dids;
+        P.cand_out = cand;
+        P.row_offset = row_offset;
+        P.counter = counter;
+        for (msm_idx_t it = 0; it < K; ++it) {
+            P.it = (int)it;
+            launch_kc<T>(mid, nblk, P);
+            if (it + 1 < K && (rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
+        }
+        MSM_HIP_CHECK(hipGetLastError());
+    } else {
+        if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, 0))) return rc;
+        for (msm_idx_t it = 0; it < K; ++it) {
+            if ((rc = kcenters_pass_dev_impl<T>(X, n, m, y, it, metric, labels, distances, row_offset, cand, cen))) return rc;
+            if (it + 1 < K) {
+                if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
+                if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, it + 1))) return rc;
+            }
         }
     }
     // inertia = sum of ALL ranks' distances_: local fp64 tree sum, then one all-reduce of a single double
