@@ -116,6 +116,8 @@ int msm_tica_reset(msm_tica_t* h); /* zero all accumulators and counters */
  * (tica.py:410-412).  check_finite != 0: the call synchronises and returns
  * MSM_ERR_NONFINITE, state unchanged, if X holds NaN/Inf; check_finite == 0: fully
  * asynchronous, a sticky flag is kept (msm_tica_nonfinite). */
+/* dtype_bytes = 2: bfloat16-STORED trajectories (BASELINE configs[4]: half the bytes per frame), accepted by the
+ * MSM_TICA_BF16 / MSM_TICA_BF16X2 modes (MSM_ERR_INVALID otherwise), device-resident or host. */
 int msm_tica_accumulate(msm_tica_t* h, const void* X, int dtype_bytes, msm_idx_t n_rows,
                         msm_idx_t ld, int on_device, int check_finite, int* skipped);
 /* Many trajectories in one launch: X_ptrs[s] -> n_rows[s] x n_features, common ld.
@@ -143,6 +145,8 @@ int msm_tica_lagged_symmetrised(msm_tica_t* h, int* flag);
 /* HIP-event duration (ms) of the most recent MFMA accumulation launch of this handle,
  * measured on the stream it ran on (bench.py's roofline leg); synchronises on it. */
 int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
+/* bf16 modes: duration (ms) of the packed-image pre-pass that preceded that MFMA launch (0 when there was none) */
+int msm_tica_last_prepass_ms(msm_tica_t* h, float* ms);
 /* profiling: {shader-clock start, end, 100 MHz wall-clock start, end} of workgroup 0 of that launch */
 int msm_tica_debug_clocks(msm_tica_t* h, long long* out4);
 /* profiling builds (csrc built with -DMSM_TICA_PROFILE) only: out64[8 + 8*slot + i] = shader cycles wave 0 of

@@ -45,6 +45,7 @@ struct TicaChunk {
     int pad;
     long long last;    // last ADDRESSABLE row of the trajectory's storage (len - 1, or the end of the
                        // slice a rank holds when one long trajectory is split over ranks)
+    long long g0;      // bf16 image path: first 8-pair group of this chunk in the packed image
 };
 
 struct TicaArgs {
@@ -1314,10 +1315,283 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_bf16_kernel(TicaArgs P)
 }
 
 // ---------------------------------------------------------------------------
+// bf16 image path (modes `bf16` / `bf16x2`, BASELINE configs[4]): the sum/difference form of 3.1b on the bf16 matrix
+// pipe, in two kernels.
+//
+//  1. tica_img_kernel: ONE streaming pass turns the frame-major trajectories into a packed bf16 IMAGE of the
+//     pair frames u = (x_t - r) + (x_{t+tau} - r) and d = x_t - x_{t+tau} (formed in fp32; r = mean shift row), laid out as
+//     the bf16 MFMA wants its operands: 16-byte packets [8 consecutive pairs] of one feature, [pair group][feature][8].
+//     The lag, the trajectory edges (a trajectory's pairs are padded with zero packets to a whole K-step), the shift, the
+//     fp32 -> bf16 rounding (RNE; bf16x2: hi + mid = 16 significant bits, mid image alongside) and partial feature tiles
+//     (the image is zero-padded to a multiple of 256 features) are all handled HERE, once per element.  bf16-STORED
+//     trajectories (dtype_bytes = 2) enter through the same kernel.  Traffic: F sizeof(T) read (+ the lagged row, an
+//     L2 hit) and 4 B (bf16x2: 8 B) written per pair and feature.
+//  2. tica_img_mfma_kernel: H = sum u u^T and D = sum d d^T on the upper tiles, v_mfma_f32_32x32x16_bf16, straight from
+//     the image: both operands of a product come from the SAME image at the SAME pair index, so there is no lag, no
+//     edge, no mask and no conversion left in the hot loop -- 16-byte packets go global -> (registers) -> LDS unchanged and
+//     come back as conflict-free ds_read_b128 fragments.  A workgroup is 8 waves and owns a 256 x 256 tile of H or of D
+//     (wave: 64 x 128 outputs, 128 fp32 accumulators): per 32-pair K-step it stages 32 KiB for 128 MFMAs, HALF the
+//     L2 -> LDS bytes per flop of the 128 x 128 tiles of round 1 (whose bf16 kernel sat at 0.11 of the bf16 peak, bound by
+//     exactly that traffic plus the in-register transpose).  bf16x2 forms hi.hi + hi.mid + mid.hi + mid.mid per 16 pairs.
+//     fp32 partials go to the fp64 slabs of the sum/difference layout every <= 8192 pairs; export and un-shift are 3.1b's.
+// ---------------------------------------------------------------------------
+struct ImgArgs {
+    const TicaChunk* chunks;
+    long long nchunks;
+    long long ld;
+    int F, Fp, lag, dtype_bytes;
+    const float* shift;
+    bf16x8* u_hi;   // [G][Fp] packets
+    bf16x8* d_hi;
+    bf16x8* u_mid;  // bf16x2 only
+    bf16x8* d_mid;
+};
+
+// thread -> 4 consecutive features (one 16-byte load per row for float32, 8 bytes for bfloat16) x the 8 pairs of one group:
+// 16 row loads in flight, an 8 x 4 transpose in registers, four 16-byte packets per image written back to back (a wave
+// writes 4 KiB contiguous).  A workgroup handles one K-step (4 groups) of a 256-feature block per iteration.
+template <bool X2>
+__global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
+{
+    const TicaChunk ch = P.chunks[blockIdx.x];
+    const int fq = threadIdx.x & 63, gq = threadIdx.x >> 6;   // feature quad, group within the K-step
+    const int f0 = blockIdx.y * 256 + fq * 4;                 // < Fp
+    const bool vec = (P.F % 4 == 0) && (P.ld % 4 == 0) && ((((uintptr_t)ch.base) & 15) == 0);
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = (P.shift && f0 + q < P.F) ? P.shift[f0 + q] : 0.f;
+    long long nv = ch.len - P.lag - ch.row0;   // valid pairs of this chunk: left frames row0 .. with t < len - lag
+    if (nv > ch.n) nv = ch.n;
+    if (nv < 0) nv = 0;
+    const long long nsteps = (nv + 31) / 32;   // whole K-steps of 32 pairs, zero padded
+    const size_t esz = (size_t)P.dtype_bytes;
+    const global_ptr<char> base = as_global<char>(ch.base);
+    const int fc = f0 < P.F ? f0 : (P.F >= 4 ? P.F - 4 : 0);  // clamped column of the vector loads
+    for (long long st = 0; st < nsteps; ++st) {
+        const long long gi = st * 4 + gq;
+        float a[8][4], b[8][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long long pidx = gi * 8 + e;
+            const long long t = ch.row0 + (pidx < nv ? pidx : 0);
+            const global_ptr<char> rowa = base + (size_t)t * (size_t)P.ld * esz;
+            const global_ptr<char> rowb = rowa + (size_t)P.lag * (size_t)P.ld * esz;
+            if (P.dtype_bytes == 4 && vec) {
+                const raw_f32x4 va = *(global_ptr<raw_f32x4>)(rowa + (size_t)fc * 4), vb = *(global_ptr<raw_f32x4>)(rowb + (size_t)fc * 4);
+                a[e][0] = va.x; a[e][1] = va.y; a[e][2] = va.z; a[e][3] = va.w;
+                b[e][0] = vb.x; b[e][1] = vb.y; b[e][2] = vb.z; b[e][3] = vb.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t col = (size_t)(f0 + q < P.F ? f0 + q : P.F - 1);   // clamped: masked below
+                    if (P.dtype_bytes == 4) {
+                        a[e][q] = *(global_ptr<float>)(rowa + col * 4);
+                        b[e][q] = *(global_ptr<float>)(rowb + col * 4);
+                    } else {
+                        a[e][q] = (float)*(global_ptr<__bf16>)(rowa + col * 2);
+                        b[e][q] = (float)*(global_ptr<__bf16>)(rowb + col * 2);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 uh, dh, um, dm;
+            const bool inF = f0 + q < P.F;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = inF && (gi * 8 + e) < nv;
+                const float ya = ok ? a[e][q] - r[q] : 0.f, yb = ok ? b[e][q] - r[q] : 0.f;
+                const float u = ya + yb, d = ya - yb;
+                const __bf16 u1 = (__bf16)u, d1 = (__bf16)d;
+                uh[e] = u1;
+                dh[e] = d1;
+                if (X2) {
+                    um[e] = (__bf16)(u - (float)u1);
+                    dm[e] = (__bf16)(d - (float)d1);
+                }
+            }
+            const size_t o = (size_t)(ch.g0 + gi) * (size_t)P.Fp + (size_t)(f0 + q);
+            P.u_hi[o] = uh;
+            P.d_hi[o] = dh;
+            if (X2) {
+                P.u_mid[o] = um;
+                P.d_mid[o] = dm;
+            }
+        }
+    }
+}
+
+struct ImgMfmaArgs {
+    const bf16x8* u_hi;
+    const bf16x8* d_hi;
+    const bf16x8* u_mid;
+    const bf16x8* d_mid;
+    long long nsteps;  // K-steps in the image (bf16: 4 groups = 32 pairs each; bf16x2: 2 groups = 16 pairs each)
+    int Fp, T, T2, ntiles_sym, ntile2, S, kflush_steps;
+    double* slabs;     // sum/difference layout: [S * ntiles_sym][2][TM * TM]
+};
+
+constexpr int IMG_NT = 512;                       // 8 waves: 4 (rows) x 2 (columns), each 64 x 128 outputs
+constexpr size_t IMG_LDS = 2 * 2 * 4 * 256 * 16;  // 64 KiB: [2 buffers][A, B][4 packet rows][256 features] 16-byte packets
+
+template <bool X2>
+__global__ __launch_bounds__(IMG_NT, 1) void tica_img_mfma_kernel(ImgMfmaArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16x8* L = reinterpret_cast<bf16x8*>(smem);   // [2][2][4][256]
+    constexpr int PAN = 4 * 256;                   // packets per panel
+    const int tid = threadIdx.x;
+    const int p = xcd_linear_id();
+    const int cohort = p / P.ntile2, tile = p % P.ntile2;
+    const int which = tile & 1;                    // 0: H = sum u u^T, 1: D = sum d d^T
+    int I = 0, uix = tile >> 1;
+    while (uix >= P.T2 - I) {
+        uix -= P.T2 - I;
+        ++I;
+    }
+    const int J = I + uix;
+    const bf16x8* hi = which ? P.d_hi : P.u_hi;
+    const bf16x8* mid = which ? P.d_mid : P.u_mid;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kl = lane >> 5, cl = lane & 31;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+
+    // this cohort's contiguous share of the K-steps
+    const long long s0 = P.nsteps * cohort / P.S, s1 = P.nsteps * (cohort + 1) / P.S;
+    // staging: panel = 4 packet rows x 256 features; thread -> packets tid and tid + 512 of A and of B
+    //   bf16  : packet rows = pair groups 4 s .. 4 s + 3 of the hi image
+    //   bf16x2: rows 0-1 = groups 2 s, 2 s + 1 of the hi image, rows 2-3 = the same groups of the mid image
+    const int c0 = tid & 255, q0 = tid >> 8;  // q0 in {0, 1}: packet rows q0 and q0 + 2
+    raw_f32x4 ra[2], rb[2], na[2], nb[2];
+#define MSM_IMG_LOAD(RA, RB, S_)                                                                   \
+    {                                                                                              \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                            \
+            const int row = q0 + 2 * h;                                                            \
+            const bf16x8* src = (X2 && row >= 2) ? mid : hi;                                       \
+            const long long g = X2 ? (S_) * 2 + (row & 1) : (S_) * 4 + row;                        \
+            const global_ptr<raw_f32x4> base = as_global<raw_f32x4>(src + (size_t)g * (size_t)P.Fp); \
+            RA[h] = base[I * 256 + c0];                                                            \
+            RB[h] = base[J * 256 + c0];                                                            \
+        }                                                                                          \
+    }
+#define MSM_IMG_STORE(RA, RB, BUF)                                                                 \
+    {                                                                                              \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                            \
+            const int row = q0 + 2 * h;                                                            \
+            *reinterpret_cast<raw_f32x4*>(L + (BUF) * 2 * PAN + row * 256 + c0) = RA[h];           \
+            *reinterpret_cast<raw_f32x4*>(L + (BUF) * 2 * PAN + PAN + row * 256 + c0) = RB[h];     \
+        }                                                                                          \
+    }
+    if (s1 > s0) {
+        MSM_IMG_LOAD(ra, rb, s0)
+        MSM_IMG_STORE(ra, rb, 0)
+        MSM_IMG_LOAD(ra, rb, (s0 + 1 < s1 ? s0 + 1 : s0))
+    }
+    __syncthreads();
+    int steps_acc = 0;
+    for (long long s = s0; s < s1; ++s) {
+        const int buf = (int)((s - s0) & 1);
+        {   // K-step s + 2 -> the other register set (clamped to the last step: never out of the image)
+            const long long sn = s + 2 < s1 ? s + 2 : s1 - 1;
+            MSM_IMG_LOAD(na, nb, sn)
+        }
+        const bf16x8* Ah = L + buf * 2 * PAN;
+        const bf16x8* Bh = Ah + PAN;
+        if (!X2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {      // two k-halves of 16 pairs
+                const int kg = 2 * q + kl;
+                bf16x8 a[2], b[4];
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi) a[bi] = Ah[kg * 256 + wr * 64 + bi * 32 + cl];
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj) b[bj] = Bh[kg * 256 + wc * 128 + bj * 32 + cl];
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int bj = 0; bj < 4; ++bj)
+                        acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[bi], b[bj], acc[bi][bj], 0, 0, 0);
+            }
+        } else {
+            bf16x8 ah[2], am[2], bh[4], bm[4];
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                ah[bi] = Ah[kl * 256 + wr * 64 + bi * 32 + cl];
+                am[bi] = Ah[(2 + kl) * 256 + wr * 64 + bi * 32 + cl];
+            }
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) {
+                bh[bj] = Bh[kl * 256 + wc * 128 + bj * 32 + cl];
+                bm[bj] = Bh[(2 + kl) * 256 + wc * 128 + bj * 32 + cl];
+            }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj) {
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[bi], bm[bj], acc[bi][bj], 0, 0, 0);
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[bi], bm[bj], acc[bi][bj], 0, 0, 0);
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[bi], bh[bj], acc[bi][bj], 0, 0, 0);
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[bi], bh[bj], acc[bi][bj], 0, 0, 0);
+                }
+        }
+        if (s + 1 < s1) MSM_IMG_STORE(ra, rb, buf ^ 1)
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ra[h] = na[h];
+            rb[h] = nb[h];
+        }
+        // fp64 merge into the private slabs of the four 128 x 128 sub-tiles (upper ones only)
+        if (++steps_acc >= P.kflush_steps || s + 1 == s1) {
+            steps_acc = 0;
+            const int ti = 2 * I + (wr >> 1), tj = 2 * J + wc;   // 128-blocks of this wave's outputs
+            if (ti <= tj && tj < P.T) {
+                const int st = ti * P.T - ti * (ti - 1) / 2 + (tj - ti);
+                double* slab = P.slabs + ((size_t)cohort * P.ntiles_sym + st) * (2 * TM * TM) + (size_t)which * (TM * TM);
+                unsigned toff = (unsigned)(((wr & 1) * 64 + 4 * kl) * TM + cl);
+                asm volatile("" : "+v"(toff));
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                    for (int bj = 0; bj < 4; ++bj) {
+                        double old[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) old[r] = (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff] = old[r] + (double)acc[bi][bj][r];
+                    }
+            }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+        }
+    }
+#undef MSM_IMG_LOAD
+#undef MSM_IMG_STORE
+}
+
+// ---------------------------------------------------------------------------
 // Column sums s0 / stau (tica.py:418-419) + the finite check of
 // utils/validation.py:68-74, one streaming pass, fp64 accumulation.
 // Block b owns partial slot b and walks chunks b, b+grid, ...
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ double to_f64(float v) { return (double)v; }
+__device__ __forceinline__ double to_f64(double v) { return v; }
+__device__ __forceinline__ double to_f64(__bf16 v) { return (double)(float)v; }
+
 template <typename TIn>
 __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
 {
@@ -1352,7 +1626,7 @@ __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
                         const int kr = k0 + u * rl;
                         const long long r = ch.row0 + kr;
 #pragma unroll
-                        for (int e = 0; e < CW; ++e) v[u][e] = (TIn)0;
+                        for (int e = 0; e < CW; ++e) v[u][e] = (TIn)0.f;
                         if (kr < ch.n) {
                             const global_ptr<TIn> p = X + r * P.ld + col;
                             if (al) {
@@ -1372,7 +1646,7 @@ __global__ __launch_bounds__(NT) void tica_colsum_kernel(TicaArgs P)
                         const bool in1 = (kr < ch.n) && (r >= P.lag);
 #pragma unroll
                         for (int e = 0; e < CW; ++e) {
-                            const double x = (double)v[u][e];
+                            const double x = to_f64(v[u][e]);
                             bad |= !isfinite(x);
                             if (in0) s0[e] += x;
                             if (in1) st[e] += x;
@@ -1862,8 +2136,11 @@ struct msm_tica {
     long long n_sh = 0, nw_sh = 0;  // shifted pairs, and the total weight of their Gram terms (2 n_sh for whole trajectories)
     long long n_obs = 0, n_seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
-    bool timed = false;
+    hipEvent_t evp = nullptr;                 // bf16 image path: start of the image pre-pass (ev0 then sits between the two kernels)
+    bool timed = false, timed_pre = false;
     DevBuf table, table2, staging;
+    DevBuf img;                  // bf16 image path: [u_hi | d_hi | (u_mid | d_mid)] packets, grow-only
+    int img_on = 0, T2 = 0, ntile2 = 0, S_img = 0;  // 256-wide tiles per side, H and D tiles of the upper triangle, cohorts
     DevBuf solve;                // device-resident solve: [A (F*F) | B (F*F) | mu F | D F | E F | scal 4 | part 2*nblk | scale F | Y k*F | vals F | ints]
     bool reduced = false;        // solve.A / solve.B hold the reduced matrix and the Cholesky factor of the current state
     size_t packed_len() const { return 2 * (size_t)F * F + 2 * (size_t)F + 2; }
@@ -1947,10 +2224,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
 
     // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
     const bool use32 = (h->mode == MSM_TICA_F32 && dtype_bytes == 4);
-    const bool useb = (h->mode == MSM_TICA_BF16 || h->mode == MSM_TICA_BF16X2) && dtype_bytes == 4;
-    const int bk = (use32 || useb) ? BK32 : BK64;
-    const bool usesym = use32 && h->sym && aligned;  // H/D kernel: 16-byte aligned rows only
-    const int S = usesym ? h->S_sym : use32 ? h->S32 : useb ? (h->mode == MSM_TICA_BF16 ? h->SB : h->SB3) : h->S64;  // one resident round
+    const bool bfmode = (h->mode == MSM_TICA_BF16 || h->mode == MSM_TICA_BF16X2);
+    const bool useimg = bfmode && h->img_on && (dtype_bytes == 4 || dtype_bytes == 2);  // packed bf16 image + 256 x 256 tiles
+    const bool useb = bfmode && dtype_bytes == 4 && !useimg;                            // round 1's in-register transpose kernels
+    const int bk = (use32 || useb || useimg) ? BK32 : BK64;
+    const bool usesym = (use32 && h->sym && aligned) || useimg;  // pair semantics: sum/difference slabs (H/D kernel: 16-byte aligned rows only)
+    const int S = useimg ? h->S_img : usesym ? h->S_sym : use32 ? h->S32 : useb ? (h->mode == MSM_TICA_BF16 ? h->SB : h->SB3) : h->S64;  // one resident round
     const int G = S * (usesym ? h->ntiles_sym : h->ntiles);
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
@@ -1983,7 +2262,8 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         P.cosync = (e && atoi(e)) ? h->cosync : nullptr;
     }
 
-    if (nvalid == 1 && n_seq == 1 && !segs) {
+    long long img_groups = 0;  // bf16 image path: 8-pair groups of the packed image (whole K-steps per chunk)
+    if (nvalid == 1 && n_seq == 1 && !segs && !useimg) {
         P.chunks = nullptr;
         P.single.base = ptrs[0];
         P.single.row0 = 0;
@@ -2010,6 +2290,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
                 ch.n = (int)((g.oe - r0) < piece ? (g.oe - r0) : piece);
                 ch.pad = 0;
                 ch.last = g.off + n_rows[s] - 1;
+                ch.g0 = img_groups;
+                if (useimg) {
+                    long long nv = std::min<long long>(ch.n, g.len - h->lag - r0);
+                    if (nv < 0) nv = 0;
+                    img_groups += ceil_div(nv, 32) * 4;
+                }
                 tab.push_back(ch);
             }
         }
@@ -2025,6 +2311,8 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // 1) column sums + finite check into the temporary partials
     if (dtype_bytes == 4)
         hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), P);
+    else if (dtype_bytes == 2)
+        hipLaunchKernelGGL(tica_colsum_kernel<__bf16>, dim3(NCB), dim3(NT), 0, stream(), P);
     else
         hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), P);
     MSM_HIP_CHECK(hipGetLastError());
@@ -2040,7 +2328,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     }
     // 1b) mean shift bookkeeping (fp32 / bf16 kernels): the raw column sums of what this launch accumulates under the
     //     shift, and -- first shifted launch of the handle -- the reference row r = this launch's column means
-    const bool shifted = h->shift_on && (use32 || useb);
+    const bool shifted = h->shift_on && (use32 || useb || useimg);
     long long n_call = 0, nw_call = 0, nmean = 0;
     if (shifted) {
         for (msm_idx_t s = 0; s < n_seq; ++s) {
@@ -2098,6 +2386,8 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             Q.flag = h->flag + 1;  // these rows were (or will be) checked by the launch that owns them
             if (dtype_bytes == 4)
                 hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), Q);
+            else if (dtype_bytes == 2)
+                hipLaunchKernelGGL(tica_colsum_kernel<__bf16>, dim3(NCB), dim3(NT), 0, stream(), Q);
             else
                 hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), Q);
             hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(256), 0, stream(), h->coltmp,
@@ -2108,8 +2398,66 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     }
     // 2) the MFMA pass
     MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned), stream()));
-    if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
-    if (usesym) {
+    h->timed_pre = false;
+    if (useimg && h->evp) {
+        MSM_HIP_CHECK(hipEventRecord(h->evp, stream()));
+        h->timed_pre = true;
+    } else if (h->ev0) {
+        MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
+    }
+    if (useimg) {
+        const bool x2 = h->mode == MSM_TICA_BF16X2;
+        const int Fp = h->T2 * 256;
+        const size_t one = (size_t)std::max<long long>(img_groups, 4) * (size_t)Fp * 16;  // bytes of one image
+        int rc = h->img.reserve(one * (x2 ? 4 : 2));
+        if (rc) return rc;
+        ImgArgs IA;
+        memset(&IA, 0, sizeof(IA));
+        IA.chunks = P.chunks;
+        IA.nchunks = P.nchunks;
+        IA.ld = ld;
+        IA.F = h->F;
+        IA.Fp = Fp;
+        IA.lag = h->lag;
+        IA.dtype_bytes = dtype_bytes;
+        IA.shift = P.shift;
+        char* ib = h->img.as<char>();
+        IA.u_hi = reinterpret_cast<bf16x8*>(ib);
+        IA.d_hi = reinterpret_cast<bf16x8*>(ib + one);
+        IA.u_mid = x2 ? reinterpret_cast<bf16x8*>(ib + 2 * one) : nullptr;
+        IA.d_mid = x2 ? reinterpret_cast<bf16x8*>(ib + 3 * one) : nullptr;
+        if (img_groups > 0) {
+            const dim3 g1((unsigned)P.nchunks, (unsigned)h->T2);
+            if (x2)
+                hipLaunchKernelGGL(tica_img_kernel<true>, g1, dim3(256), 0, stream(), IA);
+            else
+                hipLaunchKernelGGL(tica_img_kernel<false>, g1, dim3(256), 0, stream(), IA);
+            MSM_HIP_CHECK(hipGetLastError());
+            if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
+            ImgMfmaArgs MA;
+            memset(&MA, 0, sizeof(MA));
+            MA.u_hi = IA.u_hi;
+            MA.d_hi = IA.d_hi;
+            MA.u_mid = IA.u_mid;
+            MA.d_mid = IA.d_mid;
+            MA.nsteps = x2 ? img_groups / 2 : img_groups / 4;
+            MA.Fp = Fp;
+            MA.T = h->T;
+            MA.T2 = h->T2;
+            MA.ntiles_sym = h->ntiles_sym;
+            MA.ntile2 = h->ntile2;
+            MA.S = h->S_img;
+            MA.kflush_steps = std::max(1, P.kflush / (x2 ? 16 : 32));
+            MA.slabs = h->slabs_sym;
+            const unsigned g2 = (unsigned)(h->S_img * h->ntile2);
+            if (x2)
+                hipLaunchKernelGGL(tica_img_mfma_kernel<true>, dim3(g2), dim3(IMG_NT), IMG_LDS, stream(), MA);
+            else
+                hipLaunchKernelGGL(tica_img_mfma_kernel<false>, dim3(g2), dim3(IMG_NT), IMG_LDS, stream(), MA);
+        } else if (h->ev0) {
+            MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
+        }
+    } else if (usesym) {
         if (h->F % TM == 0)
             hipLaunchKernelGGL((tica_sym_f32_kernel<false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
         else
@@ -2261,6 +2609,23 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
             h->sym = h->S_sym >= 1;  // at least one whole cohort resident (F <= 3968 on 256 CUs), else the C/G kernel
         }
     }
+    {
+        // bf16 image path (256 x 256 tiles of H and D on the upper triangle, one 8-wave workgroup per CU)
+        const char* img_env = getenv("MSM_TICA_BF16_IMG");
+        const bool img_off = img_env && atoi(img_env) == 0;   // A/B switch: round 1's bf16 kernels
+        h->T2 = (int)ceil_div(n_features, 256);
+        h->ntile2 = h->T2 * (h->T2 + 1);
+        if ((mode == MSM_TICA_BF16 || mode == MSM_TICA_BF16X2) && !img_off && h->ntile2 <= num_cus()) {
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_mfma_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_mfma_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_LDS));
+            h->img_on = 1;
+            h->S_img = num_cus() / h->ntile2;
+            h->sym = 1;                 // the exported lagged moment is the symmetrised one
+            h->S_sym = h->S_img;
+        }
+    }
     h->S = std::max(std::max(h->S32, h->S64), std::max(h->SB, h->SB3));  // slabs exist for the largest; unused ones stay zero
     h->G = h->S * h->ntiles;
     const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
@@ -2278,6 +2643,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->shsum, 3 * (size_t)h->F * sizeof(double));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&h->evp);
     if (e != hipSuccess) {
         msm_tica_destroy(h);
         return fail(MSM_ERR_HIP, "msm_tica_create: hipMalloc failed: %s", hipGetErrorString(e));
@@ -2308,6 +2674,7 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->shsum) (void)hipFree(h->shsum);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->evp) (void)hipEventDestroy(h->evp);
     delete h;
     return MSM_OK;
 }
@@ -2324,7 +2691,9 @@ static int tica_accumulate_any(msm_tica_t* h, const void* const* X_ptrs, const m
 {
     if (!h) return fail(MSM_ERR_STATE, "null tica handle");
     if (n_seq < 0 || (n_seq > 0 && (!X_ptrs || !n_rows))) return fail(MSM_ERR_INVALID, "bad sequence table");
-    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (dtype_bytes != 4 && dtype_bytes != 8 && dtype_bytes != 2) return fail(MSM_ERR_INVALID, "dtype_bytes must be 2 (bfloat16), 4 or 8");
+    if (dtype_bytes == 2 && !h->img_on)
+        return fail(MSM_ERR_INVALID, "bfloat16 trajectories need MSM_TICA_BF16 / MSM_TICA_BF16X2 mode (got mode %d)", h->mode);
     if (ld < h->F) return fail(MSM_ERR_INVALID, "ld=%lld < n_features=%d", (long long)ld, h->F);
     for (msm_idx_t s = 0; s < n_seq; ++s)
         if (n_rows[s] < 0 || (n_rows[s] > 0 && !X_ptrs[s])) return fail(MSM_ERR_INVALID, "bad sequence %lld", (long long)s);
@@ -2441,6 +2810,16 @@ int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms)
     if (!h->timed) return fail(MSM_ERR_STATE, "no accumulation launch recorded yet");
     MSM_HIP_CHECK(hipEventSynchronize(h->ev1));
     MSM_HIP_CHECK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MSM_OK;
+}
+
+int msm_tica_last_prepass_ms(msm_tica_t* h, float* ms)
+{
+    if (!h || !ms) return fail(MSM_ERR_STATE, "null argument");
+    *ms = 0.f;
+    if (!h->timed_pre) return MSM_OK;  // no image pre-pass in the most recent launch
+    MSM_HIP_CHECK(hipEventSynchronize(h->ev0));
+    MSM_HIP_CHECK(hipEventElapsedTime(ms, h->evp, h->ev0));
     return MSM_OK;
 }
 

@@ -433,7 +433,7 @@ class tICA(BaseEstimator, TransformerMixin):
         self._fit(X)
         return self
 
-    def _prepare(self, X):
+    def _prepare(self, X, keep_bf16=False):
         """array2d + dtype rule: float32/float64 are consumed natively, anything else is
         up-cast to float64 exactly like tica.py:402.  The finite check of array2d (validation.py:68-74) is NOT run
         on the host for data that goes to the device: the column-sum kernel performs it on every frame it reads
@@ -442,7 +442,12 @@ class tICA(BaseEstimator, TransformerMixin):
         X = array2d(X, force_all_finite=False)
         if is_device_array(X):
             import torch
-            if X.dtype not in (torch.float32, torch.float64):
+            if X.dtype == torch.bfloat16:
+                # bf16-STORED trajectories (BASELINE configs[4]: half the bytes) feed the bf16 modes as they are;
+                # the other modes take them as float32 (an exact widening)
+                if not (keep_bf16 and _mode_from_env() in (_lib.TICA_BF16, _lib.TICA_BF16X2)):
+                    X = X.to(torch.float32)
+            elif X.dtype not in (torch.float32, torch.float64):
                 X = X.to(torch.float64)
             return X.contiguous()
         if X.dtype not in (np.float32, np.float64):
@@ -456,7 +461,7 @@ class tICA(BaseEstimator, TransformerMixin):
         """One launch for a group of trajectories (tica.py:401-424 per trajectory)."""
         prepared = []
         for X in Xs:
-            X = self._prepare(X)
+            X = self._prepare(X, keep_bf16=True)
             if X.shape[1] > X.shape[0]:
                 warnings.warn("The number of features (%d) is greater than the length of the data (%d). "
                               "The covariance matrix is not guaranteed to be positive definite."
@@ -479,7 +484,7 @@ class tICA(BaseEstimator, TransformerMixin):
         # one launch per (placement, dtype) class, preserving the reference's skip semantics
         classes = {}
         for X in prepared:
-            key = (is_device_array(X), 8 if str(X.dtype).endswith("64") else 4)
+            key = (is_device_array(X), 8 if str(X.dtype).endswith("64") else 2 if str(X.dtype).endswith("bfloat16") else 4)
             classes.setdefault(key, []).append(X)
         L = _lib.lib()
         for (on_dev, nbytes), arrs in classes.items():
@@ -488,7 +493,9 @@ class tICA(BaseEstimator, TransformerMixin):
                 # one Arr() for the device/stream binding, raw pointers for the rest (1000 trajectories
                 # per call: per-item wrappers cost more than the launch)
                 views = arrs
-                Arr(arrs[0])
+                import torch
+                _lib.ensure_device(arrs[0].device.index)
+                _lib.set_stream(torch.cuda.current_stream(arrs[0].device).cuda_stream)
                 ptrs = (C.c_void_p * n)(*[a.data_ptr() for a in arrs])
             else:
                 views = [Arr(a) for a in arrs]

@@ -148,3 +148,42 @@ def test_config4_minibatchkmeans_k1000_fit_vs_sklearn(gpu, reassignment_ratio):
     np.testing.assert_allclose(mine.inertia_, ref.inertia_, rtol=1e-4)
     lab = mine.labels_[0].cpu().numpy()
     assert (lab != ref.labels_).mean() < 1e-3
+
+
+@pytest.mark.parametrize("mode,rtol,ctol", [("bf16x2", 1e-5, 1e-5), ("bf16", 1e-3, 5e-3)])
+@pytest.mark.parametrize("F,lag", [(2048, 20), (300, 7)])
+def test_config5_bf16_image_path_vs_oracle(gpu, monkeypatch, mode, rtol, ctol, F, lag):
+    """configs[4]'s width against the float64 ORACLE (round 1 compared bf16 only with the fp32 HIP path): the packed bf16
+    sum/difference image + 256 x 256-tile MFMA kernel, un-centred features (the mean shift precedes the rounding), ragged
+    trajectories, a width that is not a multiple of the 256-feature tiles, float32 and bfloat16-STORED input."""
+    import torch
+    rs = np.random.RandomState(F)
+    k = 8
+    M = rs.randn(k, F) / np.sqrt(k)
+    a = np.exp(-1.0 / (lag * np.array([40.0, 25.0, 15.0, 9.0, 5.0, 3.0, 2.0, 1.2])))
+    seqs = []
+    for T in (12000, 9001, 4100 + lag, lag + 1, lag):
+        e = rs.randn(T, k)
+        z = np.empty((T, k))
+        z[0] = e[0]
+        for t in range(1, T):
+            z[t] = a * z[t - 1] + np.sqrt(1 - a * a) * e[t]
+        seqs.append((z @ M + 0.4 * rs.randn(T, F) + 8.0 * np.sign(rs.randn(F))).astype(np.float32))
+    m, o = _fit(seqs, mode, monkeypatch, n_components=4, lag_time=lag)
+    assert m._lagged_symmetrised and (m.n_observations_, m.n_sequences_) == (o.n_observations_, o.n_sequences_)
+    np.testing.assert_allclose(m.eigenvalues_, o.eigenvalues_, rtol=rtol)
+    np.testing.assert_allclose(m.means_, o.means_, rtol=1e-10)
+    np.testing.assert_allclose(m.covariance_, o.covariance_, rtol=0, atol=ctol * np.abs(o.covariance_).max())
+    np.testing.assert_allclose(m.offset_correlation_, o.offset_correlation_, rtol=0, atol=ctol * np.abs(o.offset_correlation_).max())
+    # bfloat16-stored trajectories: the oracle sees exactly the stored values
+    from msmbuilder_amd import tICA
+    from oracle.tica_oracle import TicaOracle
+    dev = [torch.from_numpy(x).cuda().to(torch.bfloat16) for x in seqs]
+    host = [x.float().cpu().numpy() for x in dev]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mb = tICA(n_components=4, lag_time=lag).fit(dev)
+        ob = TicaOracle(n_components=4, lag_time=lag).fit(host)
+    np.testing.assert_allclose(mb.eigenvalues_, ob.eigenvalues_, rtol=rtol)
+    np.testing.assert_allclose(mb.means_, ob.means_, rtol=1e-10)
+    np.testing.assert_allclose(mb.covariance_, ob.covariance_, rtol=0, atol=ctol * np.abs(ob.covariance_).max())
