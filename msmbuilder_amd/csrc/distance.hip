@@ -461,11 +461,14 @@ __device__ __forceinline__ bool kc_better(double v, long long i, double bv, long
     return (v > bv) || (v == bv && i < bi);
 }
 
-template <typename T, int M>
+// REG: rows live in registers (m <= FC, P.vecw > 0) -- the clustering-in-tICA-space shape.  A separate instantiation
+// so that the LDS row tile of the generic path (34 KiB) does not cap the occupancy of the streaming path: with it (and
+// the 16 KiB pruning table) only two workgroups fitted a CU, i.e. 8 waves to cover HBM latency.
+template <typename T, int M, bool REG>
 __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
 {
     constexpr int FC = FeatChunk<T>::FC;
-    __shared__ T Xs[DT * (FC + 1)];
+    __shared__ T Xs[REG ? 1 : DT * (FC + 1)];
     __shared__ T ys[FC];
     __shared__ double rv[DT];
     __shared__ long long ri[DT];
@@ -528,10 +531,10 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
     double bv = -1.0;
     long long bi = -1;
     const long long ntile = (P.n + DT - 1) / DT;
-    __shared__ double Dc[IsNormMetric<M>::V ? KC_PRUNE_MAX : 1];  // d(new centre, centre j) for the pruning test
-    const bool prune = IsNormMetric<M>::V && P.prune && P.vecw > 0 && P.it > 0;
+    __shared__ double Dc[(IsNormMetric<M>::V && REG) ? KC_PRUNE_MAX : 1];  // d(new centre, centre j) for the pruning test
+    const bool prune = REG && IsNormMetric<M>::V && P.prune && P.it > 0;
     const int nprev = P.it < KC_PRUNE_MAX ? P.it : KC_PRUNE_MAX;
-    if (P.vecw > 0) {  // centre row once per block, broadcast from LDS
+    if (REG) {  // centre row once per block, broadcast from LDS
         if (!P.sel_cands) {
             __syncthreads();
             if (tid < FC) ys[tid] = tid < P.m ? y[tid] : (T)0;
@@ -551,12 +554,12 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         const long long row0 = t * DT;
         const long long i = row0 + tid;
         double a = 0.0, b = 0.0;
-        if (P.vecw > 0 && prune) {
+        if (REG && prune) {
             // register path with pruning: everything per row in one place (the common code below is skipped)
             if (i < P.n) {
                 double cur = P.dist[i];
                 const long long lab = P.labels[i];
-                const bool skip = lab < nprev && Dc[(IsNormMetric<M>::V && lab < nprev) ? lab : 0] >= PruneMargin<T>::F * cur;
+                const bool skip = lab < nprev && Dc[(IsNormMetric<M>::V && REG && lab < nprev) ? lab : 0] >= PruneMargin<T>::F * cur;
                 if (!skip) {
                     T x[FC];
                     load_row_regs<T>(x, X + i * P.m, (int)P.m, P.vecw);
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
             }
             continue;
         }
-        if (P.vecw > 0) {
+        if (REG) {
             T x[FC];
             load_row_regs<T>(x, X + (i < P.n ? i : P.n - 1) * P.m, (int)P.m, P.vecw);
 #pragma unroll
@@ -1249,8 +1252,10 @@ void launch_kc(int metric, int grid, const KcArgs& P)
     case MM:                                                                                      \
         if (wide)                                                                                 \
             launch_wide<T, MM, 2>(grid, A);                                                       \
+        else if (P.vecw > 0)                                                                      \
+            hipLaunchKernelGGL((kcenters_pass_kernel<T, MM, true>), dim3(grid), dim3(DT), 0, stream(), P); \
         else                                                                                      \
-            hipLaunchKernelGGL((kcenters_pass_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P); \
+            hipLaunchKernelGGL((kcenters_pass_kernel<T, MM, false>), dim3(grid), dim3(DT), 0, stream(), P); \
         break;
     switch (metric) {
         MSM_CASE(M_EUCLIDEAN)
