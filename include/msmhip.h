@@ -192,6 +192,15 @@ int msm_tica_export_sums(msm_tica_t* h, double* s0, double* stau);
  * from F ~ 1024) and returns the k largest eigenvalues (descending) and their eigenvectors as rows. */
 int msm_tica_reduce(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* Cs, double* mu,
                     double* info);
+/* msm_tica_reduce followed by the Householder tridiagonalisation of the reduced matrix ON THE DEVICE (msm_sytrd's
+ * cooperative kernel, n_features <= 1024): the host receives LAPACK dsytrd(lower) outputs d[F], e[F-1], tau[F-1] and the
+ * reflectors V[(F-1)*(F-1)] (the block A(2:n, 1:n-1), column-major: dormqr's argument) and finishes with dstemr (selected eigenpairs of the tridiagonal) and dormqr
+ * (reflectors applied to the k vectors) before msm_tica_backsolve.  *status = 1: the cooperative kernel could not keep
+ * its workgroups resident -- Cs (host, F x F) then holds the reduced matrix for the msm_tica_reduce route. */
+int msm_tica_reduce_tridiag(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* d, double* e,
+                            double* tau, double* V, double* Cs, double* mu, double* info, int* status);
+/* The tridiagonalisation on its own: symmetric A (n x n, host or device per on_device), n <= 1024. */
+int msm_sytrd(const double* A, msm_idx_t n, double* d, double* e, double* tau, double* V, int* status, int on_device);
 int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V);
 int msm_tica_solve_device(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k,
                           double* vals, double* vecs, double* mu, double* info);

@@ -78,6 +78,9 @@ int comm_allgather(const void* dsend, void* drecv, size_t bytes);   // drecv[r *
 int sygv_reduce_device(double* A, double* B, int n, int* dinfo);   // B = L L^T (lower, col-major), A <- L^-1 A L^-T
 int sygv_back_device(const double* L, double* Y, int n, int k);    // Y[n x k col-major] <- L^-T Y
 int syevd_device(double* A, int n, double* D, double* E, int* dinfo);
+// sytrd.hip: cooperative Householder tridiagonalisation (n <= 1024), queued on stream(); work8n: 8n doubles of
+// exchange records; *status (device int) = 1 if the kernel gave up
+int sytrd_device(const double* A, int n, double* d, double* e, double* tau, double* V, double* work8n, int* status);
 
 // A data pointer that was itself LOADED from memory (e.g. out of a descriptor table) is a
 // generic pointer to the compiler, which then emits flat_load: slower, and because FLAT counts on

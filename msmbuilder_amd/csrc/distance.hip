@@ -317,8 +317,10 @@ __global__ __launch_bounds__(DT) void assign_small2_kernel(PairArgs P)
     const T* Y = static_cast<const T*>(P.Y);
     const int tid = threadIdx.x;
     const int m = (int)P.m;
-    const int mp = (m + 3) & ~3;          // centre pitch: whole groups of 4, zero padded (exact for every metric)
-    const int KT = YCAP / mp;             // centres per LDS tile
+    constexpr int GS = 16 / (int)sizeof(T);  // features per group = one 16-byte LDS read: 4 floats / 2 doubles (m = 10
+                                             // doubles is 5 exact groups; groups of 4 computed 12 elements for 10)
+    const int mp = (m + GS - 1) / GS * GS;   // centre pitch: whole groups, zero padded (exact for every metric)
+    const int KT = YCAP / mp;                // centres per LDS tile
     double inertia = 0.0;
     const long long ntile = (P.n + 2 * DT - 1) / (2 * DT);
     for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
@@ -338,30 +340,37 @@ __global__ __launch_bounds__(DT) void assign_small2_kernel(PairArgs P)
                 Ys[e] = ff < m ? Y[(j0 + c) * P.m + ff] : (T)0;
             }
             __syncthreads();
+#pragma unroll 2
             for (int c = 0; c < kt; ++c) {
                 const T* yc = Ys + c * mp;
                 double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
 #pragma unroll
-                for (int g = 0; g < FC / 4; ++g)
-                    if (g * 4 < m) {
+                for (int g = 0; g < FC / GS; ++g)
+                    if (g * GS < m) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const T y = yc[g * 4 + q];
-                            m_update<T, M>(a0, b0, x0[g * 4 + q], y);
-                            m_update<T, M>(a1, b1, x1[g * 4 + q], y);
+                        for (int q = 0; q < GS; ++q) {
+                            const T y = yc[g * GS + q];
+                            m_update<T, M>(a0, b0, x0[g * GS + q], y);
+                            m_update<T, M>(a1, b1, x1[g * GS + q], y);
                         }
                     }
                 const int j = (int)(j0 + c);
                 if (M == M_EUCLIDEAN) {
-                    if (a0 < thr0 || (a0 < best0 && sqrt(a0) < sqrt(best0))) {
-                        best0 = a0;
-                        thr0 = a0 * (1.0 - 0x1p-48);
-                        lab0 = j;
+                    // one comparison on the common path (a >= best: cannot win); inside, the certain win or the rare
+                    // exact near-tie that needs both roots
+                    if (a0 < best0) {
+                        if (a0 < thr0 || sqrt(a0) < sqrt(best0)) {
+                            best0 = a0;
+                            thr0 = a0 * (1.0 - 0x1p-48);
+                            lab0 = j;
+                        }
                     }
-                    if (a1 < thr1 || (a1 < best1 && sqrt(a1) < sqrt(best1))) {
-                        best1 = a1;
-                        thr1 = a1 * (1.0 - 0x1p-48);
-                        lab1 = j;
+                    if (a1 < best1) {
+                        if (a1 < thr1 || sqrt(a1) < sqrt(best1)) {
+                            best1 = a1;
+                            thr1 = a1 * (1.0 - 0x1p-48);
+                            lab1 = j;
+                        }
                     }
                 } else {
                     const double d0 = m_final<M>(a0, b0, P.m), d1 = m_final<M>(a1, b1, P.m);

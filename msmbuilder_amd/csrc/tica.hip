@@ -2911,8 +2911,8 @@ int msm_tica_import(msm_tica_t* h, const double* C, const double* G, const doubl
 namespace {
 
 struct SolveBufs {
-    double *A, *B, *mu, *D, *E, *scal, *part, *scale, *Y, *vals;
-    int* ints;  // [0..1] non-finite flags (OC, S), [2] potrf info, [3] syevd info
+    double *A, *B, *mu, *D, *E, *scal, *part, *scale, *Y, *vals, *trdw;
+    int* ints;  // [0..1] non-finite flags (OC, S), [2] potrf info, [3] syevd info; [8 ..] sytrd barrier flags + status
     int nblk;
 };
 
@@ -2920,8 +2920,8 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
 {
     const size_t F = (size_t)h->F, FF = F * F;
     const int nblk = (int)ceil_div((int64_t)FF, 256);
-    const size_t nd = 3 * FF + 5 * F + 4 + 2 * (size_t)nblk;
-    int rc = h->solve.reserve(nd * sizeof(double) + 8 * sizeof(int));
+    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk;
+    int rc = h->solve.reserve(nd * sizeof(double) + (8 + F / 16 + 4) * sizeof(int));
     if (rc) return rc;
     double* p = h->solve.as<double>();
     b->A = p;
@@ -2934,7 +2934,8 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
     b->vals = b->scale + F;
     b->scal = b->vals + F;
     b->part = b->scal + 4;
-    b->ints = reinterpret_cast<int*>(b->part + 2 * (size_t)nblk);
+    b->trdw = b->part + 2 * (size_t)nblk;   // 8F doubles of sytrd exchange records
+    b->ints = reinterpret_cast<int*>(b->trdw + 8 * F);
     b->nblk = nblk;
     return MSM_OK;
 }
@@ -3010,6 +3011,37 @@ int msm_tica_reduce(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const dou
     MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return tica_reduce_status(scal, ints, info);
+}
+
+int msm_tica_reduce_tridiag(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* d, double* e,
+                            double* tau, double* V, double* Cs, double* mu, double* info, int* status)
+{
+    if (!h || !d || !e || !tau || !V || !Cs || !mu || !status) return fail(MSM_ERR_STATE, "msm_tica_reduce_tridiag: null argument");
+    if (h->F > 1024) return fail(MSM_ERR_INVALID, "msm_tica_reduce_tridiag: n_features > 1024");
+    SolveBufs b;
+    int rc = tica_reduce_device(h, shrinkage, n_rblw, scale, &b);
+    if (rc) return rc;
+    const int n = h->F;
+    const size_t FF = (size_t)n * n;
+    // A holds Cs = L^-1 OC L^-T (both triangles, equal up to rounding); reflectors go to the Y slot
+    if ((rc = sytrd_device(b.A, n, b.D, b.E, b.vals, b.Y, b.trdw, b.ints + 8))) return rc;
+    double scal[4];
+    int ints[8], st = 0;
+    MSM_HIP_CHECK(hipMemcpyAsync(d, b.D, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (n > 1) MSM_HIP_CHECK(hipMemcpyAsync(e, b.E, (n - 1) * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (n > 1) MSM_HIP_CHECK(hipMemcpyAsync(tau, b.vals, (n - 1) * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (n > 1) MSM_HIP_CHECK(hipMemcpyAsync(V, b.Y, (size_t)(n - 1) * (n - 1) * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(&st, b.ints + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    *status = st;
+    if (st) {  // the cooperative kernel gave up: hand the reduced matrix to the host route
+        MSM_HIP_CHECK(hipMemcpyAsync(Cs, b.A, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    }
     return tica_reduce_status(scal, ints, info);
 }
 

@@ -119,6 +119,36 @@ def top_standard_eigenpairs(Cs, k):
     return vals[order], np.ascontiguousarray(vecs[:, order].T)
 
 
+def use_device_tridiagonalisation(F):
+    """Hybrid solve: tridiagonalise the reduced matrix on the device (csrc/sytrd.hip, F <= 1024) instead of inside the host's
+    dsyevr.  MSMBUILDER_AMD_DEVICE_TRD=0 keeps it on the host."""
+    import os
+    return F <= 1024 and os.environ.get("MSMBUILDER_AMD_DEVICE_TRD", "1") != "0"
+
+
+def eigenpairs_from_tridiagonal(d, e, tau, V, k):
+    """k largest eigenpairs of the symmetric matrix whose LAPACK dsytrd(lower) factors are (d, e, tau, V = the reflector
+    block A(2:n, 1:n-1), flat column-major): dstemr on the tridiagonal for the selected pairs (O(k n)), then Q = H(0) ... H(n-2) applied to the k vectors with
+    dormqr (dormtr's lower case: the reflectors act on rows 1 .. n-1).  Eigenvalues descending, eigenvectors as ROWS."""
+    import scipy.linalg.lapack as lp
+    n = len(d)
+    with _blas_limit(1):
+        if n == 1:
+            return np.array([d[0]]), np.ones((1, 1))
+        w, z = scipy.linalg.eigh_tridiagonal(d, e, select='i', select_range=(n - k, n - 1), lapack_driver='stemr',
+                                             check_finite=False)
+        z = np.asfortranarray(z)
+        if n > 2:
+            a = V[:(n - 1) * (n - 1)].reshape((n - 1, n - 1), order='F')   # LAPACK's A(2:n, 1:n-1) as the kernel packed it
+            c = np.asfortranarray(z[1:, :])
+            cq, _work, info = lp.dormqr('L', 'N', a, np.ascontiguousarray(tau[:n - 1]), c, max(1, c.shape[1]) * 64)
+            if info != 0:
+                raise np.linalg.LinAlgError("dormqr failed (info = %d)" % info)
+            z[1:, :] = cq
+    order = np.argsort(w)[::-1]
+    return w[order], np.ascontiguousarray(z[:, order].T)
+
+
 def device_generalized_eigenpairs(lhs, rhs, k):
     """The same k largest eigenpairs through ``msm_sygv_top`` (rocSOLVER dsygvd on the GPU)."""
     import ctypes as C

@@ -305,10 +305,25 @@ class tICA(BaseEstimator, TransformerMixin):
             V = vecs
         else:
             Cs = np.empty((F, F))
-            run(L.msm_tica_reduce(self._handle, shrink, int(self.n_observations_),
-                                  None if scale_p is None else scale_p.ctypes.data, Cs.ctypes.data, mu.ctypes.data,
-                                  info.ctypes.data))
-            vals, Y = _moments.top_standard_eigenpairs(Cs, k)       # Y: k x F, rows = eigenvectors of the reduced problem
+            done = False
+            if _moments.use_device_tridiagonalisation(F):
+                # the reduced matrix is tridiagonalised on the device too (cooperative Householder kernel, sytrd.hip);
+                # the host only runs dstemr on the tridiagonal and applies the reflectors to the k vectors
+                d, e, tau, Vr = np.empty(F), np.empty(max(F - 1, 1)), np.empty(max(F - 1, 1)), np.empty(max(F - 1, 1) ** 2)
+                status = C.c_int(0)
+                run(L.msm_tica_reduce_tridiag(self._handle, shrink, int(self.n_observations_),
+                                              None if scale_p is None else scale_p.ctypes.data, d.ctypes.data, e.ctypes.data,
+                                              tau.ctypes.data, Vr.ctypes.data, Cs.ctypes.data, mu.ctypes.data,
+                                              info.ctypes.data, C.byref(status)))
+                if status.value == 0:
+                    vals, Y = _moments.eigenpairs_from_tridiagonal(d, e[:F - 1], tau[:F - 1], Vr, k)
+                    done = True
+            else:
+                run(L.msm_tica_reduce(self._handle, shrink, int(self.n_observations_),
+                                      None if scale_p is None else scale_p.ctypes.data, Cs.ctypes.data, mu.ctypes.data,
+                                      info.ctypes.data))
+            if not done:   # host dsyevr on the reduced matrix (also the fallback when the cooperative kernel gave up)
+                vals, Y = _moments.top_standard_eigenpairs(Cs, k)   # Y: k x F, rows = eigenvectors of the reduced problem
             V = np.empty((k, F))
             check(L.msm_tica_backsolve(self._handle, Y.ctypes.data, k, V.ctypes.data))
         self.shrinkage_ = float(info[0]) if self.shrinkage is None else self.shrinkage

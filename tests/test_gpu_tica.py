@@ -436,3 +436,53 @@ def test_symmetric_kernel_half_step_edges(gpu, monkeypatch, F):
         scale = max(np.abs(G).max(), 1e-30)
         np.testing.assert_allclose(m._outer_gram_sum, G, rtol=0, atol=ATOL_SCALE["f32"] * scale)
         np.testing.assert_allclose(m._outer_0_to_T_lagged, Cs, rtol=0, atol=ATOL_SCALE["f32"] * scale)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 256, 300, 512, 1000])
+def test_device_tridiagonalisation_vs_lapack(gpu, n):
+    """csrc/sytrd.hip (cooperative Householder kernel, one grid barrier per column) finished with dstemr + dormqr on the host
+    against LAPACK's dsyevr on the same matrix: eigenvalues, residuals, orthonormality."""
+    import ctypes as C
+    import scipy.linalg
+    from msmbuilder_amd import _lib
+    from msmbuilder_amd.decomposition import _moments
+    rs = np.random.RandomState(n)
+    M = rs.randn(n, n)
+    A = (M + M.T) / 2 + np.diag(rs.randn(n) * 3)
+    d, e, tau, V = np.empty(n), np.empty(max(n - 1, 1)), np.empty(max(n - 1, 1)), np.empty(max(n - 1, 1) ** 2)
+    st = C.c_int(0)
+    _lib.check(_lib.lib().msm_sytrd(A.ctypes.data, n, d.ctypes.data, e.ctypes.data, tau.ctypes.data, V.ctypes.data,
+                                    C.byref(st), 0))
+    assert st.value == 0
+    k = min(n, 10)
+    w, Y = _moments.eigenpairs_from_tridiagonal(d, e[:n - 1], tau[:n - 1], V, k)
+    wr = scipy.linalg.eigh(A, subset_by_index=[n - k, n - 1])[0][::-1]
+    scale = np.abs(A).max() * n
+    np.testing.assert_allclose(w, wr, rtol=0, atol=1e-14 * scale)
+    assert np.abs(A @ Y.T - Y.T * w).max() <= 1e-14 * scale
+    assert np.abs(Y @ Y.T - np.eye(k)).max() <= 1e-12
+    # the tridiagonal has the same spectrum as A (all of it)
+    if n > 1:
+        np.testing.assert_allclose(scipy.linalg.eigvalsh_tridiagonal(d, e[:n - 1]), scipy.linalg.eigvalsh(A), rtol=0, atol=1e-14 * scale)
+
+
+def test_solve_paths_agree(gpu, monkeypatch):
+    """host (numpy + dsygvx), hybrid with host dsyevr, hybrid with the device tridiagonalisation, all-device: one model."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    seqs = _ar1(5, 6, 3000, 200)
+    out = {}
+    for name, env in (("host", {"MSMBUILDER_AMD_DEVICE_SOLVE": "0"}),
+                      ("evr", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "0"}),
+                      ("trd", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1"}),
+                      ("dev", {"MSMBUILDER_AMD_DEVICE_SOLVE": "1"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        m = tICA(n_components=6, lag_time=9).fit(seqs)
+        out[name] = (m.eigenvalues_.copy(), m.eigenvectors_.copy(), m.shrinkage_, m.means_.copy())
+    for name in ("evr", "trd", "dev"):
+        np.testing.assert_allclose(out[name][0], out["host"][0], rtol=1e-11)
+        sg = np.sign((out[name][1] * out["host"][1]).sum(0))
+        np.testing.assert_allclose(out[name][1] * sg, out["host"][1], rtol=0, atol=1e-8 * np.abs(out["host"][1]).max())
+        assert abs(out[name][2] - out["host"][2]) <= 1e-12 * abs(out["host"][2])
+        np.testing.assert_allclose(out[name][3], out["host"][3], rtol=1e-13)
