@@ -24,131 +24,9 @@
 #include <cstdlib>
 #include <vector>
 
+#include "distance_dev.h"
+
 namespace msm {
-
-constexpr int DT = 256;  // threads = rows per tile
-constexpr int CJ = 8;    // centres per register tile
-constexpr int KC_MAXBLK = 1024;
-
-template <typename T> struct FeatChunk;
-template <> struct FeatChunk<float> { static constexpr int FC = 32; };
-template <> struct FeatChunk<double> { static constexpr int FC = 16; };
-
-// ---- per-element update / finalisation: distance_kernels.h:41-243 ---------
-template <typename T, int M>
-__device__ __forceinline__ void m_update(double& a, double& b, const T u, const T v)
-{
-    if (M == M_EUCLIDEAN || M == M_SQEUCLIDEAN) {
-        const T df = u - v;
-        const double d = (double)df;
-        a = a + d * d;
-    } else if (M == M_CITYBLOCK) {
-        const T df = u - v;
-        a = a + fabs((double)df);
-    } else if (M == M_CHEBYSHEV) {
-        const T df = u - v;
-        const double d = fabs((double)df);
-        if (d > a) a = d;
-    } else if (M == M_CANBERRA) {
-        const T df = u - v;
-        const double snum = fabs((double)df);
-        const double sdenom = fabs((double)u) + fabs((double)v);
-        if (sdenom > 0.0) a = a + snum / sdenom;
-    } else if (M == M_BRAYCURTIS) {
-        const T df = u - v;
-        const T sf = u + v;
-        a = a + fabs((double)df);
-        b = b + fabs((double)sf);
-    } else if (M == M_HAMMING) {
-        a = a + (double)(u != v);
-    } else if (M == M_JACCARD) {
-        const int nz = (u != (T)0) | (v != (T)0);
-        a = a + (double)((u != v) & nz);
-        b = b + (double)nz;
-    }
-}
-
-template <int M>
-__device__ __forceinline__ double m_final(double a, double b, long long n)
-{
-    if (M == M_EUCLIDEAN) return sqrt(a);
-    if (M == M_BRAYCURTIS || M == M_JACCARD) return a / b;
-    if (M == M_HAMMING) return a / (double)n;
-    return a;
-}
-
-template <typename T>
-__device__ __forceinline__ void stage_rows(T* Xs, const T* __restrict__ X,
-                                           const msm_idx_t* __restrict__ X_indices, long long row0,
-                                           long long n, long long m, int f0, int fw, int tid)
-{
-    constexpr int FC = FeatChunk<T>::FC;  // power of two: lane -> (row, feature) needs no division
-    constexpr int RPP = DT / FC;          // rows covered per pass of the workgroup
-    const int ff = tid & (FC - 1);
-    const int rr0 = tid / FC;
-    if (ff >= fw) {
-        // nothing to load for this lane in a partial last chunk; the tile columns >= fw are never read
-        return;
-    }
-#pragma unroll 4
-    for (int rr = rr0; rr < DT; rr += RPP) {
-        const long long i = row0 + rr;
-        T v = (T)0;
-        if (i < n) {
-            const long long r = X_indices ? X_indices[i] : i;
-            v = X[r * m + f0 + ff];
-        }
-        Xs[rr * (FC + 1) + ff] = v;
-    }
-}
-
-// Small-m fast path (m <= FC, e.g. clustering in tICA space): each lane keeps its whole row
-// in registers, fetched with the widest aligned vector loads the row size allows; a wave's 64
-// rows are contiguous in memory, so HBM still sees a linear stream.  No LDS round trip.
-template <typename T>
-__device__ __forceinline__ void load_row_regs(T (&x)[FeatChunk<T>::FC], const T* __restrict__ p, int m, int vecw)
-{
-    constexpr int FC = FeatChunk<T>::FC;
-#pragma unroll
-    for (int f = 0; f < FC; ++f) x[f] = (T)0;
-    if (vecw == 16) {
-        constexpr int E = 16 / sizeof(T);
-#pragma unroll
-        for (int v = 0; v < FC / E; ++v)
-            if (v * E < m) {
-                const float4 q = *reinterpret_cast<const float4*>(p + v * E);
-                const T* qe = reinterpret_cast<const T*>(&q);
-#pragma unroll
-                for (int e = 0; e < E; ++e) x[v * E + e] = qe[e];
-            }
-    } else if (vecw == 8) {
-        constexpr int E = 8 / sizeof(T);
-#pragma unroll
-        for (int v = 0; v < FC / E; ++v)
-            if (v * E < m) {
-                const float2 q = *reinterpret_cast<const float2*>(p + v * E);
-                const T* qe = reinterpret_cast<const T*>(&q);
-#pragma unroll
-                for (int e = 0; e < E; ++e) x[v * E + e] = qe[e];
-            }
-    } else {
-#pragma unroll
-        for (int f = 0; f < FC; ++f)
-            if (f < m) x[f] = p[f];
-    }
-}
-
-struct PairArgs {
-    const void* X;
-    const msm_idx_t* X_indices;
-    const void* Y;        // device [K, m]
-    long long n, K, m;
-    msm_idx_t* labels;    // assign
-    double* min_dist;     // assign (nullable)
-    double* partial;      // assign: per-block inertia partials
-    double* out;          // cdist / dist
-    int vecw;             // fast path: vector width in bytes of the per-lane row loads (0 = LDS path)
-};
 
 // MODE 0: assign_nearest (assign.hpp:6-91), MODE 1: cdist (cdist.hpp) / dist (K == 1)
 template <typename T, int M, int MODE>
@@ -408,6 +286,7 @@ __global__ __launch_bounds__(DT) void assign_small2_kernel(PairArgs P)
     }
     if (tid == 0) P.partial[blockIdx.x] = red[0];
 }
+
 
 // ---------------------------------------------------------------------------
 // One k-centers pass (kcenters.py:91-97), fused: (prologue) global argmax of the
@@ -715,6 +594,8 @@ __device__ __forceinline__ void wide_tile_end(const WideArgs& A, long long i, lo
 // MODE 0 assign_nearest, 1 cdist/dist, 2 one k-centers pass (NC == 1).
 // ---------------------------------------------------------------------------
 constexpr int WP = 36;   // staged row pitch in 32-bit words (128 B of data + 16 B pad)
+constexpr int WRD = 4;    // centre-fragment reads in flight ahead of the arithmetic
+constexpr int WSTEP = 2;  // pairs between scheduling barriers
 constexpr int WNC = 16;  // centres per register tile in MODE 0/1 (8: every X tile was re-fetched K/8 times -- 5.5 TB/s of L2/MALL traffic at the VALU-bound rate)
 
 struct WideArgs {
@@ -853,23 +734,31 @@ __global__ __launch_bounds__(DT, 2) void wide_kernel(WideArgs A)
     {                                                                                             \
         WIDE_LOAD(SLOAD)                                                                          \
         const T* xr = reinterpret_cast<const T*>(Xs + (BUF) * (DT * WP) + tid * WP);              \
-        const T* yr = reinterpret_cast<const T*>(Ys + (BUF) * (WNC * 32));                        \
-        _Pragma("unroll") for (int v = 0; v < 8; ++v) {                                           \
-            const raw_f32x4 xq = *reinterpret_cast<const raw_f32x4*>(xr + v * E);                 \
-            const T* xe = reinterpret_cast<const T*>(&xq);                                        \
-            _Pragma("unroll") for (int q = 0; q < NC; ++q) {                                      \
-                const raw_f32x4 yq = *reinterpret_cast<const raw_f32x4*>(yr + q * FC + v * E);    \
-                const T* ye = reinterpret_cast<const T*>(&yq);                                    \
-                _Pragma("unroll") for (int e = 0; e < E; ++e) m_update<T, M>(a[q], b[q], xe[e], ye[e]); \
-            }                                                                                     \
-            /* pin the accumulators here: otherwise all 64 centre-fragment reads of a chunk are  */ \
-            /* hoisted above the arithmetic (256 live values -> the staged loads go to scratch)  */ \
-            if (NC > 1) {                                                                         \
-                _Pragma("unroll") for (int q = 0; q < NC; ++q) asm volatile("" : "+v"(a[q]) : : "memory"); \
-                if (M == M_BRAYCURTIS || M == M_JACCARD) {                                        \
-                    _Pragma("unroll") for (int q = 0; q < NC; ++q) asm volatile("" : "+v"(b[q]) : : "memory"); \
-                }                                                                                 \
-            }                                                                                     \
+        /* the centre tile's address is uniform; left in SGPRs every fragment read needs its own  */ \
+        /* v_mov (and the 128 addresses spill to VGPR lanes): one opaque VGPR base + immediates   */ \
+        unsigned yo = (BUF) * (WNC * 32) * 4;                                                     \
+        asm volatile("" : "+v"(yo));                                                              \
+        const T* yr = reinterpret_cast<const T*>(reinterpret_cast<const char*>(Ys) + yo);         \
+        /* flat over the 8 x NC (row fragment, centre fragment) pairs of the chunk, fully unrolled, with the centre   */ \
+        /* fragments read WRD pairs ahead and the row fragment one group ahead: with 2 waves per SIMD a read issued  */ \
+        /* right before its use is a stall per 4 pair-elements.  A scheduling barrier every WSTEP pairs keeps that   */ \
+        /* distance (the machine scheduler otherwise sinks each read to its use -- or, unpinned, hoists all 128      */ \
+        /* above the arithmetic and spills); within a step the pairs' dependent fma chains interleave.               */ \
+        raw_f32x4 xq = *reinterpret_cast<const raw_f32x4*>(xr), xn = xq;                          \
+        raw_f32x4 yb[WRD];                                                                        \
+        _Pragma("unroll") for (int d = 0; d < WRD; ++d)                                           \
+            yb[d] = *reinterpret_cast<const raw_f32x4*>(yr + (d % NC) * FC + (d / NC) * E);       \
+        _Pragma("unroll") for (int idx = 0; idx < 8 * NC; ++idx) {                                \
+            const int v = idx / NC, q = idx % NC;                                                 \
+            if (q == 0 && v + 1 < 8) xn = *reinterpret_cast<const raw_f32x4*>(xr + (v + 1) * E);  \
+            const raw_f32x4 yq = yb[idx % WRD];                                                   \
+            if (idx + WRD < 8 * NC)                                                               \
+                yb[idx % WRD] = *reinterpret_cast<const raw_f32x4*>(yr + ((idx + WRD) % NC) * FC + ((idx + WRD) / NC) * E); \
+            m_update_frag<T, M>(a[q], b[q], xq, yq);                                              \
+            asm volatile("" : "+v"(a[q]));  /* the sums are formed here, not sunk to the end of the chunk */ \
+            if (M == M_BRAYCURTIS || M == M_JACCARD) asm volatile("" : "+v"(b[q]));               \
+            if (idx % WSTEP == WSTEP - 1) __builtin_amdgcn_sched_barrier(0);                      \
+            if (q == NC - 1) xq = xn;                                                             \
         }                                                                                         \
         if (u + 1 < total) WIDE_STORE(SNEXT, (BUF) ^ 1)                                           \
         __syncthreads();                                                                          \
@@ -1223,12 +1112,15 @@ void launch_pair(int metric, int grid, const PairArgs& P)
 {
     const bool wide = wide_ok<T>(P.X, P.Y, P.m, P.X_indices != nullptr);
     static const bool small1 = getenv("MSM_DIST_SMALL1") != nullptr;  // A/B switch: one row per lane (round 1's kernel)
+    static const bool small2 = getenv("MSM_DIST_SMALL2") != nullptr;  // A/B switch: generic two-rows kernel for the euclidean family too
     WideArgs A;
     memset(&A, 0, sizeof(A));
     A.pa = P;
 #define MSM_CASE(MM)                                                                              \
     case MM:                                                                                      \
-        if (P.vecw > 0 && MODE == 0 && !small1)                                                   \
+        if (P.vecw > 0 && MODE == 0 && !small1 && !small2 && (MM == M_EUCLIDEAN || MM == M_SQEUCLIDEAN) &&  \
+            (sizeof(T) == 4 ? launch_small3_f32(MM, grid, P) : launch_small3_f64(MM, grid, P))) { \
+        } else if (P.vecw > 0 && MODE == 0 && !small1)                                            \
             hipLaunchKernelGGL((assign_small2_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P); /* every block writes its partial */ \
         else if (P.vecw > 0)                                                                      \
             hipLaunchKernelGGL((pair_small_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P); \

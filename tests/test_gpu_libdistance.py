@@ -47,7 +47,9 @@ def test_golden_vectors(gpu, golden_dir, metric, dtype):
 @pytest.mark.parametrize("metric", METRICS)
 @pytest.mark.parametrize("n,k,f", [(1, 1, 1), (300, 9, 3), (1000, 37, 10), (777, 200, 45), (513, 17, 130),
                                    # wide-row streaming path (16-byte aligned rows longer than one chunk)
-                                   (777, 200, 44), (513, 17, 132), (2100, 8, 64), (300, 1, 36), (70000, 3, 40)])
+                                   (777, 200, 44), (513, 17, 132), (2100, 8, 64), (300, 1, 36), (70000, 3, 40),
+                                   # two rows per lane (more than 32 centres): several 512-row tiles, partial last chunk / group
+                                   (1500, 70, 132), (1030, 33, 48)])
 def test_bit_exact_vs_oracle(gpu, oracle, metric, dtype, n, k, f):
     from msmbuilder_amd import libdistance as ld
     rs = np.random.RandomState(n + k + f)
