@@ -577,6 +577,11 @@ __device__ __forceinline__ void wide_group_end(const WideArgs& A, double (&a)[NC
 template <typename T, int M, int MODE>
 __device__ __forceinline__ void wide_tile_end(const WideArgs& A, long long i, long long n, double& min_d,
                                               long long& lab, double& inertia, double& bv, long long& bi);
+template <typename T, int M, int MODE, int NC>
+__device__ __forceinline__ void wide_group_end_split(const WideArgs& A, double (&a)[NC], double (&b)[NC], long long i,
+                                                     long long j0, int hh, long long n, long long m, long long K,
+                                                     double& min_d, long long& lab, double& min_d2, long long& lab2,
+                                                     double* rv, long long* ri);
 
 // ---------------------------------------------------------------------------
 // Wide-row streaming path (m > FC, rows 16-byte aligned, no X_indices): the HBM-bound scans
@@ -719,9 +724,19 @@ __global__ __launch_bounds__(DT, 2) void wide_kernel(WideArgs A)
     for (int q = 0; q < NC; ++q) a[q] = b[q] = 0.0;
     double min_d = 1.7976931348623157e308;  // assign.hpp:20
     long long lab = 0;
+    double min_d2 = 1.7976931348623157e308;  // SPLIT: the lane's second row
+    long long lab2 = 0;
     double inertia = 0.0;
     double bv = -1.0;    // k-centers: this block's (max distance, lowest row)
     long long bi = -1;
+    // MODE 0/1: a lane owns TWO rows (rl, rl + 128) and HALF of the centre group (hh): every centre fragment read from
+    // LDS then serves two rows -- 10 reads per 16 (row fragment, centre fragment) pairs instead of 17.  With one row per
+    // lane the broadcast centre reads kept the CU's LDS return path (8 cycles per ds_read_b128) busier than the VALU
+    // for float64 rows and ~80% as busy for float32 ones.  Same registers (2 x 8 sums), same tile in LDS.
+    constexpr bool SPLIT = MODE != 2;
+    constexpr int HQ = SPLIT ? NC / 2 : NC;  // centres per lane
+    const int rl = SPLIT ? (tid & (DT / 2 - 1)) : tid;
+    const int hh = SPLIT ? (tid / (DT / 2)) : 0;
 
     WideStage st0, st1;
     if (total > 0) {
@@ -733,40 +748,64 @@ __global__ __launch_bounds__(DT, 2) void wide_kernel(WideArgs A)
 #define WIDE_STEP(SNEXT, SLOAD, BUF)                                                              \
     {                                                                                             \
         WIDE_LOAD(SLOAD)                                                                          \
-        const T* xr = reinterpret_cast<const T*>(Xs + (BUF) * (DT * WP) + tid * WP);              \
+        const T* xr = reinterpret_cast<const T*>(Xs + (BUF) * (DT * WP) + rl * WP);               \
+        const T* xr2 = reinterpret_cast<const T*>(Xs + (BUF) * (DT * WP) + (rl + DT / 2) * WP);   \
         /* the centre tile's address is uniform; left in SGPRs every fragment read needs its own  */ \
         /* v_mov (and the 128 addresses spill to VGPR lanes): one opaque VGPR base + immediates   */ \
-        unsigned yo = (BUF) * (WNC * 32) * 4;                                                     \
+        unsigned yo = (BUF) * (WNC * 32) * 4 + hh * (HQ * 128);                                   \
         asm volatile("" : "+v"(yo));                                                              \
         const T* yr = reinterpret_cast<const T*>(reinterpret_cast<const char*>(Ys) + yo);         \
-        /* flat over the 8 x NC (row fragment, centre fragment) pairs of the chunk, fully unrolled, with the centre   */ \
-        /* fragments read WRD pairs ahead and the row fragment one group ahead: with 2 waves per SIMD a read issued  */ \
-        /* right before its use is a stall per 4 pair-elements.  A scheduling barrier every WSTEP pairs keeps that   */ \
-        /* distance (the machine scheduler otherwise sinks each read to its use -- or, unpinned, hoists all 128      */ \
-        /* above the arithmetic and spills); within a step the pairs' dependent fma chains interleave.               */ \
+        /* flat over the 8 x HQ (row fragment, centre fragment) pairs of the chunk, fully unrolled, with the centre   */ \
+        /* fragments read WRD pairs ahead and the row fragments one group ahead: a read issued right before its use   */ \
+        /* is a stall per 4 pair-elements.  A scheduling barrier every WSTEP pairs keeps that distance (the machine   */ \
+        /* scheduler otherwise sinks each read to its use -- or, unpinned, hoists all of them above the arithmetic    */ \
+        /* and spills); within a step the pairs' dependent fma chains interleave.                                     */ \
         raw_f32x4 xq = *reinterpret_cast<const raw_f32x4*>(xr), xn = xq;                          \
+        raw_f32x4 xq2 = xq, xn2 = xq;                                                             \
+        if (SPLIT) xq2 = xn2 = *reinterpret_cast<const raw_f32x4*>(xr2);                          \
         raw_f32x4 yb[WRD];                                                                        \
         _Pragma("unroll") for (int d = 0; d < WRD; ++d)                                           \
-            yb[d] = *reinterpret_cast<const raw_f32x4*>(yr + (d % NC) * FC + (d / NC) * E);       \
-        _Pragma("unroll") for (int idx = 0; idx < 8 * NC; ++idx) {                                \
-            const int v = idx / NC, q = idx % NC;                                                 \
-            if (q == 0 && v + 1 < 8) xn = *reinterpret_cast<const raw_f32x4*>(xr + (v + 1) * E);  \
+            yb[d] = *reinterpret_cast<const raw_f32x4*>(yr + (d % HQ) * FC + (d / HQ) * E);       \
+        _Pragma("unroll") for (int idx = 0; idx < 8 * HQ; ++idx) {                                \
+            const int v = idx / HQ, q = idx % HQ;                                                 \
+            if (q == 0 && v + 1 < 8) {                                                            \
+                xn = *reinterpret_cast<const raw_f32x4*>(xr + (v + 1) * E);                       \
+                if (SPLIT) xn2 = *reinterpret_cast<const raw_f32x4*>(xr2 + (v + 1) * E);          \
+            }                                                                                     \
             const raw_f32x4 yq = yb[idx % WRD];                                                   \
-            if (idx + WRD < 8 * NC)                                                               \
-                yb[idx % WRD] = *reinterpret_cast<const raw_f32x4*>(yr + ((idx + WRD) % NC) * FC + ((idx + WRD) / NC) * E); \
+            if (idx + WRD < 8 * HQ)                                                               \
+                yb[idx % WRD] = *reinterpret_cast<const raw_f32x4*>(yr + ((idx + WRD) % HQ) * FC + ((idx + WRD) / HQ) * E); \
             m_update_frag<T, M>(a[q], b[q], xq, yq);                                              \
+            if (SPLIT) m_update_frag<T, M>(a[HQ + q], b[HQ + q], xq2, yq);                        \
             asm volatile("" : "+v"(a[q]));  /* the sums are formed here, not sunk to the end of the chunk */ \
-            if (M == M_BRAYCURTIS || M == M_JACCARD) asm volatile("" : "+v"(b[q]));               \
+            if (SPLIT) asm volatile("" : "+v"(a[HQ + q]));                                        \
+            if (M == M_BRAYCURTIS || M == M_JACCARD) {                                            \
+                asm volatile("" : "+v"(b[q]));                                                    \
+                if (SPLIT) asm volatile("" : "+v"(b[HQ + q]));                                    \
+            }                                                                                     \
             if (idx % WSTEP == WSTEP - 1) __builtin_amdgcn_sched_barrier(0);                      \
-            if (q == NC - 1) xq = xn;                                                             \
+            if (q == HQ - 1) {                                                                    \
+                xq = xn;                                                                          \
+                xq2 = xn2;                                                                        \
+            }                                                                                     \
         }                                                                                         \
         if (u + 1 < total) WIDE_STORE(SNEXT, (BUF) ^ 1)                                           \
         __syncthreads();                                                                          \
         if (++c == nch) {                                                                         \
             c = 0;                                                                                \
-            wide_group_end<T, M, MODE, NC>(A, a, b, t * DT + tid, g * NC, n, m, K, min_d, lab);   \
+            if (SPLIT) {                                                                          \
+                wide_group_end_split<T, M, MODE, NC>(A, a, b, t * DT + rl, g * NC, hh, n, m, K, min_d, lab, min_d2, lab2, rv, ri); \
+            } else {                                                                              \
+                wide_group_end<T, M, MODE, NC>(A, a, b, t * DT + tid, g * NC, n, m, K, min_d, lab); \
+            }                                                                                     \
             if (++g == ngrp) {                                                                    \
                 g = 0;                                                                            \
+                if (SPLIT) {                                                                      \
+                    if (hh == 0) {                                                                \
+                        wide_tile_end<T, M, MODE>(A, t * DT + rl, n, min_d, lab, inertia, bv, bi); \
+                        wide_tile_end<T, M, MODE>(A, t * DT + rl + DT / 2, n, min_d2, lab2, inertia, bv, bi); \
+                    }                                                                             \
+                } else                                                                            \
                 wide_tile_end<T, M, MODE>(A, t * DT + tid, n, min_d, lab, inertia, bv, bi);       \
                 t += gridDim.x;                                                                   \
             }                                                                                     \
@@ -832,6 +871,78 @@ __device__ __forceinline__ void wide_group_end(const WideArgs& A, double (&a)[NC
         }
         a[q] = 0.0;
         b[q] = 0.0;
+    }
+}
+
+// SPLIT layout (MODE 0/1): this lane holds centres j0 + hh HQ + [0, HQ) for rows i and i + DT/2.  cdist writes them out;
+// assign_nearest keeps the running (distance, label) of both rows in the hh == 0 lane: that lane's own centres come first
+// in index order, the other half's best (its FIRST minimum, through LDS) is taken only when strictly smaller -- the same
+// result as the reference's sequential strict `<` scan (assign.hpp:20-31).  All threads of the workgroup call this.
+template <typename T, int M, int MODE, int NC>
+__device__ __forceinline__ void wide_group_end_split(const WideArgs& A, double (&a)[NC], double (&b)[NC], long long i,
+                                                     long long j0, int hh, long long n, long long m, long long K,
+                                                     double& min_d, long long& lab, double& min_d2, long long& lab2,
+                                                     double* rv, long long* ri)
+{
+    constexpr int HQ = NC / 2;
+    const long long jb = j0 + hh * HQ;
+    double d1 = 1.7976931348623157e308, d2 = 1.7976931348623157e308;  // the other half's local scan starts like a fresh one
+    long long l1 = -1, l2 = -1;
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const double da = m_final<M>(a[q], b[q], m), db = m_final<M>(a[HQ + q], b[HQ + q], m);
+        if (MODE == 0) {
+            if (jb + q < K) {
+                if (hh == 0) {
+                    if (da < min_d) {
+                        min_d = da;
+                        lab = jb + q;
+                    }
+                    if (db < min_d2) {
+                        min_d2 = db;
+                        lab2 = jb + q;
+                    }
+                } else {
+                    if (da < d1) {
+                        d1 = da;
+                        l1 = jb + q;
+                    }
+                    if (db < d2) {
+                        d2 = db;
+                        l2 = jb + q;
+                    }
+                }
+            }
+        } else {
+            if (jb + q < K) {
+                if (i < n) A.pa.out[i * K + jb + q] = da;
+                if (i + DT / 2 < n) A.pa.out[(i + DT / 2) * K + jb + q] = db;
+            }
+        }
+        a[q] = b[q] = 0.0;
+        a[HQ + q] = b[HQ + q] = 0.0;
+    }
+    if (MODE == 0) {
+        const int rl = threadIdx.x & (DT / 2 - 1);
+        if (hh == 1) {
+            rv[rl] = d1;
+            ri[rl] = l1;
+            rv[DT / 2 + rl] = d2;
+            ri[DT / 2 + rl] = l2;
+        }
+        __syncthreads();
+        if (hh == 0) {
+            const double e1 = rv[rl], e2 = rv[DT / 2 + rl];
+            const long long k1 = ri[rl], k2 = ri[DT / 2 + rl];
+            if (k1 >= 0 && e1 < min_d) {
+                min_d = e1;
+                lab = k1;
+            }
+            if (k2 >= 0 && e2 < min_d2) {
+                min_d2 = e2;
+                lab2 = k2;
+            }
+        }
     }
 }
 
