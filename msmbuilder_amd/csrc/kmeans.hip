@@ -704,6 +704,227 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------
+// Small-batch step (MiniBatchKMeans' inner loop: B ~ 1000 rows, m <= 32 features, K ~ 1000 centres).  A step is
+// ~10^7 multiply-adds: the three general kernels above spent 26 + 7 + 38 us on it, all of it latency (MFMA tiles that
+// are 70% padding, a 160-shuffle argmin, a 1000-label scan with 8 barriers in each of K workgroups) plus ~20 us of
+// dependent-launch gaps.  Two launches instead:
+//  * mbk_small_label_kernel: lane = row (64 rows per workgroup), the centres split over blockIdx.y and then over the 4
+//    waves, the split's centres in LDS read as broadcast 16-byte fragments, v = ||c||^2 - 2 x.c in fp32 (the same
+//    quantity the MFMA kernel minimises; sequential fma over the features).  The LAST workgroup of a row block to arrive
+//    (an agent-scope counter) reduces the splits' candidates (lowest value, then lowest index), writes the labels and
+//    the block's fp64 inertia partial (one wave per row, lanes over features, butterfly -- as kmeans_inertia_kernel).
+//  * mbk_small_update_kernel: one WAVE per centre; the batch's labels (and row indices) are fetched with 16 + 16
+//    independent loads per lane, members found by ballot, their rows read through v_readlane'd indices up to 8 loads in
+//    flight, added in batch order (sklearn's order, _k_means_minibatch.pyx) by lane f < m.
+// ---------------------------------------------------------------------------
+constexpr int SBC = 128;  // centres per split (LDS slice)
+
+struct SmallArgs {
+    unsigned* arrive;          // [row blocks], zero between launches
+    unsigned long long* cand;  // [rows] (value, index) candidates, all-ones between launches
+    double* partial;           // [row blocks] inertia partials
+    int ns, cper;              // centre splits, centres per split
+};
+
+// (value, index) -> one unsigned word whose order is (value ascending, index ascending); -0 counts as +0
+__device__ __forceinline__ unsigned long long mbk_key(float v, int idx)
+{
+    unsigned u = __float_as_uint(v + 0.f);
+    u ^= (u & 0x80000000u) ? 0xffffffffu : 0x80000000u;
+    return ((unsigned long long)u << 32) | (unsigned)idx;
+}
+
+template <int G>  // feature groups of 4: m <= 4 G
+__global__ __launch_bounds__(KNT) void mbk_small_label_kernel(KmArgs P, SmallArgs S)
+{
+    if (P.stop && *P.stop) return;  // uniform
+    constexpr int MP = 4 * G;
+    __shared__ __attribute__((aligned(16))) float Cs[SBC * MP];
+    __shared__ float cn[SBC];
+    __shared__ float wv[4][64];
+    __shared__ int wi[4][64];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long rb = blockIdx.x;
+    const int sp = blockIdx.y;
+    const int m = (int)P.m;
+    const long long i = rb * 64 + lane;
+    const long long ic = i < P.n ? i : P.n - 1;
+    const long long r = P.rows ? P.rows[ic] : ic;
+    float x[MP];
+#pragma unroll
+    for (int f = 0; f < MP; ++f) x[f] = f < m ? P.X[r * P.m + f] : 0.f;
+    const long long j0 = (long long)sp * S.cper;
+    const int nc = (int)(P.K - j0 < S.cper ? P.K - j0 : S.cper);
+    for (int e = tid; e < nc * MP; e += KNT) {
+        const int c = e / MP, f = e - c * MP;
+        Cs[e] = f < m ? P.C[(j0 + c) * P.m + f] : 0.f;
+    }
+    for (int c = tid; c < nc; c += KNT) cn[c] = P.cnorm[j0 + c];
+    __syncthreads();
+    const int per = (nc + 3) / 4;
+    const int c0 = wave * per, c1 = (c0 + per < nc) ? c0 + per : nc;
+    float best = INFINITY;
+    int bidx = 0x7fffffff;
+    for (int c = c0; c < c1; ++c) {
+        const float4* cp = reinterpret_cast<const float4*>(Cs + c * MP);
+        float dot = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 q = cp[g];
+            dot = fmaf(x[4 * g + 0], q.x, dot);
+            dot = fmaf(x[4 * g + 1], q.y, dot);
+            dot = fmaf(x[4 * g + 2], q.z, dot);
+            dot = fmaf(x[4 * g + 3], q.w, dot);
+        }
+        const float v = cn[c] - 2.f * dot;
+        if (v < best) {  // ascending index, strict
+            best = v;
+            bidx = (int)(j0 + c);
+        }
+    }
+    wv[wave][lane] = best;
+    wi[wave][lane] = bidx;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = wv[w][lane];
+            const int oi = wi[w][lane];
+            if (ov < best || (ov == best && oi < bidx)) {
+                best = ov;
+                bidx = oi;
+            }
+        }
+        // The splits' candidates meet in ONE 64-bit word per row: (order-preserving image of the value, index), reduced
+        // by an agent-scope atomic min -- lowest value, then lowest index.  Candidates cross workgroups and XCDs (whose
+        // L2s are not coherent) inside one launch; agent-scope atomics are performed at the memory side.  (Device-wide
+        // fences instead -- an L2 write-back + invalidate per workgroup -- made this kernel 50 us; per-split candidate
+        // arrays read back by the last workgroup with 2 x 32 dependent coherent loads per row, 30 us.)
+        if (i < P.n) __hip_atomic_fetch_min(S.cand + i, mbk_key(best, bidx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this wave's atomics have been performed
+    __syncthreads();
+    if (tid == 0)
+        is_last = (__hip_atomic_fetch_add(&S.arrive[rb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S.ns - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!is_last || wave != 0) return;
+    // last workgroup of the row block, one wave: labels, and the block's inertia (lane = row, x still in registers;
+    // fp32 difference, exact fp64 squares added in feature order, then a butterfly over the 64 rows)
+    int lab = 0;
+    double sq = 0.0;
+    if (i < P.n) {
+        const unsigned long long key = __hip_atomic_load(S.cand + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(S.cand + i, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next step
+        lab = (int)(unsigned)(key & 0xffffffffull);
+        if (lab == 0x7fffffff) lab = 0;  // all-NaN row: sklearn's argmin returns 0
+        P.labels[i] = lab;
+        const float* c = P.C + (long long)lab * P.m;
+#pragma unroll
+        for (int f = 0; f < MP; ++f)
+            if (f < m) {
+                const float d = x[f] - c[f];
+                sq += (double)d * (double)d;
+            }
+    }
+#pragma unroll
+    for (int msk = 32; msk > 0; msk >>= 1) sq += __shfl_xor(sq, msk, 64);
+    if (lane == 0) {
+        S.partial[rb] = sq;
+        __hip_atomic_store(&S.arrive[rb], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* __restrict__ centers,
+                                                               float* __restrict__ counts, float* __restrict__ cnorm,
+                                                               double* __restrict__ sums, double* __restrict__ cnts,
+                                                               int apply, MbkConv cv)
+{
+    if (P.stop && *P.stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long j = (long long)blockIdx.x * 4 + wave;
+    if (j < P.K) {  // uniform over the wave
+        const float w_old = counts[j];
+        const bool fl = lane < P.m;
+        const float c_old = fl ? centers[j * P.m + lane] : 0.f;
+        float acc32 = c_old * w_old;
+        double acc64 = 0.0;
+        long long cnt = 0;
+        for (long long b0 = 0; b0 < P.n; b0 += 1024) {
+            int lab[16];
+            long long rowv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long pos = b0 + r * 64 + lane;
+                const bool in = pos < P.n;
+                lab[r] = in ? P.labels[pos] : -1;
+                rowv[r] = P.rows ? (in ? P.rows[pos] : 0) : pos;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned long long bal = __ballot(lab[r] == (int)j);
+                const int rlo = (int)(rowv[r] & 0xffffffffLL), rhi = (int)(rowv[r] >> 32);
+                while (bal) {  // uniform
+                    float xv[8];
+                    int g = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        xv[t] = 0.f;
+                        if (bal) {
+                            const int k = __builtin_ctzll(bal);
+                            bal &= bal - 1ull;
+                            const long long row = ((long long)__builtin_amdgcn_readlane(rhi, k) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane(rlo, k);
+                            if (fl) xv[t] = P.X[row * P.m + lane];
+                            g = t + 1;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t < g) {
+                            acc32 += xv[t];
+                            acc64 += (double)xv[t];
+                        }
+                    cnt += g;
+                }
+            }
+        }
+        float c_new = c_old;
+        if (apply && cnt > 0) {
+            const float w_new = w_old + (float)cnt;
+            const float alpha = 1.0f / w_new;
+            c_new = acc32 * alpha;
+        }
+        if (fl) {
+            if (sums) sums[j * P.m + lane] = acc64;
+            if (apply && cnt > 0) centers[j * P.m + lane] = c_new;
+        }
+        if (lane == 0) {
+            if (cnts) cnts[j] = (double)cnt;
+            if (apply && cnt > 0) counts[j] = w_old + (float)cnt;
+        }
+        if (apply && cnorm && cnt > 0) {  // same lane partition and butterfly as kmeans_cnorm_kernel
+            float sq = fl ? c_new * c_new : 0.f;
+#pragma unroll
+            for (int msk = 32; msk > 0; msk >>= 1) sq += __shfl_xor(sq, msk, 64);
+            if (lane == 0) cnorm[j] = sq;
+        }
+    }
+    if (cv.st) {  // uniform: the last workgroup to arrive closes the step
+        __shared__ int is_last;
+        __shared__ double cred[KNT];
+        __syncthreads();
+        if (tid == 0) is_last = (atomicAdd(cv.done, 1u) == gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        if (is_last) {
+            mbk_converge(cv, cred);
+            if (tid == 0) *cv.done = 0u;
+        }
+    }
+}
+
 // finish a centre-split labelling: lowest (value, index) over the splits
 __global__ void kmeans_label_reduce_kernel(const float* __restrict__ pv, const int* __restrict__ pi, long long n,
                                            int nsplit, int32_t* __restrict__ labels, const int* __restrict__ stop)
@@ -860,6 +1081,8 @@ struct msm_mbk {
     double* packed = nullptr;  // [K*m | K | 1] batch sums, counts, inertia (fp64)
     char* outbuf = nullptr;    // [8 + 4K]
     DevBuf labels, idx, xb, pv, pi, part, rows, which;
+    DevBuf arrive;             // small-batch step: per-row-block arrival counters (zero between launches)
+    size_t arrive_zeroed = 0;
     // msm_mbk_run: [6 doubles of convergence state | S inertias] and the stop flag on the device; pinned host mirror
     DevBuf runbuf;
     int* stop = nullptr;
@@ -868,6 +1091,24 @@ struct msm_mbk {
 };
 
 namespace {
+
+// small-batch step kernels: rows of at most 32 features, at most 1024 row blocks of 64 (MSM_MBK_SMALL=0: general kernels)
+bool mbk_small_ok(const msm_mbk* h, long long n)
+{
+    static const bool off = getenv("MSM_MBK_SMALL") && atoi(getenv("MSM_MBK_SMALL")) == 0;
+    return !off && h->m <= 32 && n <= 65536;
+}
+
+// centre update of a step: one wave per centre for small batches, else one workgroup per centre
+void mbk_launch_update(msm_mbk* h, const KmArgs& P, double* sums, double* cnts, int apply, const MbkConv& cv)
+{
+    if (mbk_small_ok(h, P.n))
+        hipLaunchKernelGGL(mbk_small_update_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), P, h->centers,
+                           h->counts, h->cnorm, sums, cnts, apply, cv);
+    else
+        hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
+                           h->counts, h->cnorm, sums, cnts, apply, cv);
+}
 
 int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n, int32_t* labels_d, double* inertia_dev_partial,
               int* nb_out, const int* stop = nullptr)
@@ -883,6 +1124,35 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
     P.cnorm = h->cnorm;
     P.labels = labels_d;
     P.stop = stop;
+    if (inertia_dev_partial && mbk_small_ok(h, n)) {  // MiniBatchKMeans' inner loop: the two-launch small-batch step
+        const int RB = (int)ceil_div(n, 64);
+        int ns = (int)std::max<long long>(1, std::min<long long>(ceil_div(512, RB), ceil_div(h->K, 16)));
+        int cper = (int)ceil_div(h->K, ns);
+        if (cper > SBC) cper = SBC;
+        ns = (int)ceil_div(h->K, cper);
+        int rc;
+        if (h->arrive_zeroed == 0) {  // [1024 arrival counters = 0 | 65536 candidate words = all ones], once
+            if ((rc = h->arrive.reserve((size_t)1024 * sizeof(unsigned) + (size_t)65536 * sizeof(unsigned long long)))) return rc;
+            MSM_HIP_CHECK(hipMemsetAsync(h->arrive.p, 0, 1024 * sizeof(unsigned), stream()));
+            MSM_HIP_CHECK(hipMemsetAsync(static_cast<char*>(h->arrive.p) + 1024 * sizeof(unsigned), 0xff, (size_t)65536 * sizeof(unsigned long long), stream()));
+            h->arrive_zeroed = 1;
+        }
+        SmallArgs S;
+        S.arrive = h->arrive.as<unsigned>();
+        S.cand = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->arrive.p) + 1024 * sizeof(unsigned));
+        S.partial = inertia_dev_partial;
+        S.ns = ns;
+        S.cper = cper;
+        const dim3 grid((unsigned)RB, (unsigned)ns);
+        switch ((int)ceil_div(h->m, 4)) {
+#define MSM_SL(G_) case G_: hipLaunchKernelGGL(mbk_small_label_kernel<G_>, grid, dim3(KNT), 0, stream(), P, S); break;
+            MSM_SL(1) MSM_SL(2) MSM_SL(3) MSM_SL(4) MSM_SL(5) MSM_SL(6) MSM_SL(7) MSM_SL(8)
+#undef MSM_SL
+        }
+        MSM_HIP_CHECK(hipGetLastError());
+        *nb_out = RB;
+        return MSM_OK;
+    }
     const long long rowblocks = ceil_div(n, KR);
     const long long ctiles = ceil_div(h->K, KCT);
     int nsplit = 1;
@@ -1022,9 +1292,8 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
     P.m = h->m;
     P.K = h->K;
     P.labels = h->labels.as<int32_t>();
-    hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
-                       h->counts, h->cnorm, apply_update ? (double*)nullptr : h->packed,
-                       apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update, MbkConv{});
+    mbk_launch_update(h, P, apply_update ? (double*)nullptr : h->packed,
+                      apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update, MbkConv{});
     MSM_HIP_CHECK(hipGetLastError());
     double* d_inertia = apply_update ? reinterpret_cast<double*>(h->outbuf) : h->packed + (size_t)h->K * h->m + h->K;
     hipLaunchKernelGGL(mbk_finish_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->counts, h->K,
@@ -1102,8 +1371,7 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
         cv.batch_size = (double)B;
         cv.alpha = alpha;
         cv.max_no_improvement = (long long)max_no_improvement;
-        hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
-                           h->counts, h->cnorm, (double*)nullptr, (double*)nullptr, 1, cv);
+        mbk_launch_update(h, P, nullptr, nullptr, 1, cv);
         MSM_HIP_CHECK(hipGetLastError());
     }
     // out: [state | inertias | stop | counts] through the pinned mirror, one synchronisation for the whole run
