@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "distance_dev.h"
@@ -1427,6 +1428,456 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
     return MSM_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Label-sorted k-centers (single GPU, rows in registers, norm metrics).
+//
+// The per-row triangle-inequality test above saves arithmetic, not bytes: rows that cannot change are scattered through
+// the array, every 128-byte line still holds one that can, and a pass stays at ~130 us of HBM time (10M x 10 float64).
+// Here the fit works on a PERMUTED copy of the rows (with their distance, label and original index), re-sorted by label
+// (a counting sort) after a few chosen passes, and keeps a summary per tile of KS_TILE rows: the label its rows had at
+// the last sort if they all shared one (else "mixed"), the largest current distance among those rows and among the
+// rows that joined a newer centre since, and the tile's argmax candidate.  A pass reads the summary first:
+//     d(new centre, centre L) >= 2(1+eps) max_old   and   min_{j newer} d(new centre, centre j) >= 2(1+eps) max_new
+// is the per-row test for every row of the tile at once (cur_i <= the tile's maximum), so none can change and the whole
+// tile -- rows, distances, labels -- is not read.  Once the data is clustered most tiles go that way.  Results are exact:
+// a tile is skipped only when the per-row test would skip each of its rows, the argmax tie rule uses the ORIGINAL row
+// index, and the order of rows inside a label is irrelevant.  labels / distances are scattered back at the end.
+// ---------------------------------------------------------------------------
+constexpr int KS_TILE = 1024;  // rows per tile (4 per thread)
+
+struct KsSummary {
+    int lab;            // >= 0: label shared by the tile's pre-sort rows; -1: mixed (always processed); -2: no such rows
+    int pad;
+    double max_old;     // largest current distance among the pre-sort rows (-1: none)
+    double max_new;     // ... among rows that joined a centre chosen after the last sort (-1: none)
+    double best_v;      // argmax candidate of the tile
+    long long best_i;   // its ORIGINAL row index
+};
+
+struct KsArgs {
+    const void* X0;          // rows in the caller's order (centre coordinates are read from here)
+    const void* Xc;          // rows in the current order (X0 before the first sort)
+    const long long* orig;   // current position -> original row (nullptr: identity)
+    long long n, m;
+    int it, epoch, nblk, vecw;
+    long long seed;
+    double* dist;            // current order
+    int* lab;
+    KsSummary* sum;          // [tiles]
+    void* centers;           // T [K][m]
+    msm_idx_t* ids;          // [K]
+    const KcPartial* prev;   // [nblk] candidates of pass it-1
+    KcPartial* next;         // [nblk]
+};
+
+template <typename T, int M>
+__global__ __launch_bounds__(DT) void kcenters_sorted_pass_kernel(KsArgs P)
+{
+    constexpr int FC = FeatChunk<T>::FC;
+    __shared__ T ys[FC];
+    __shared__ double Dc[KC_PRUNE_MAX];
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    __shared__ double wmo[4], wmn[4], wbv[4];
+    __shared__ long long wbi[4];
+    __shared__ int wl0[4], wl1[4];
+    const T* X0 = static_cast<const T*>(P.X0);
+    const T* Xc = static_cast<const T*>(P.Xc);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double F = PruneMargin<T>::F;
+
+    // ---- prologue: this pass's centre, its distances to the earlier centres ----
+    long long cidx = P.seed;
+    if (P.it > 0) {  // numpy argmax over the previous pass's per-workgroup candidates: largest, then lowest original row
+        double fv = -1.0;
+        long long fi = -1;
+        for (int k = tid; k < P.nblk; k += DT) {
+            const KcPartial q = P.prev[k];
+            if (q.i >= 0 && (fi < 0 || kc_better(q.v, q.i, fv, fi))) {
+                fv = q.v;
+                fi = q.i;
+            }
+        }
+        rv[tid] = fv;
+        ri[tid] = fi;
+        __syncthreads();
+        for (int k = DT / 2; k > 0; k >>= 1) {
+            if (tid < k && ri[tid + k] >= 0 && (ri[tid] < 0 || kc_better(rv[tid + k], ri[tid + k], rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + k];
+                ri[tid] = ri[tid + k];
+            }
+            __syncthreads();
+        }
+        cidx = ri[0] < 0 ? 0 : ri[0];
+        __syncthreads();
+    }
+    if (tid < FC) ys[tid] = tid < P.m ? X0[cidx * P.m + tid] : (T)0;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (tid == 0) P.ids[P.it] = cidx;
+        if (tid < P.m) static_cast<T*>(P.centers)[(long long)P.it * P.m + tid] = ys[tid];
+    }
+    double mdn = INFINITY;  // min over the centres chosen since the last sort
+    for (int j = tid; j < P.it; j += DT) {
+        const T* cj = static_cast<const T*>(P.centers) + (long long)j * P.m;
+        double a = 0.0, b = 0.0;
+        for (int f = 0; f < (int)P.m; ++f) m_update<T, M>(a, b, cj[f], ys[f]);
+        const double d = m_final<M>(a, b, P.m);
+        Dc[j] = d;
+        if (j >= P.epoch) mdn = d < mdn ? d : mdn;  // (a NaN distance never prunes: comparisons with it are false)
+        if (j >= P.epoch && !(d == d)) mdn = -INFINITY;
+    }
+    rv[tid] = mdn;
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (tid < k) rv[tid] = rv[tid + k] < rv[tid] ? rv[tid + k] : rv[tid];
+        __syncthreads();
+    }
+    mdn = rv[0];
+    __syncthreads();
+
+    double bv = -1.0;  // this workgroup's argmax candidate (thread 0 keeps it)
+    long long bi = -1;
+    const long long ntile = (P.n + KS_TILE - 1) / KS_TILE;
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        if (P.it > 0) {  // uniform: the whole tile at once
+            const KsSummary S = P.sum[t];
+            bool skip = S.lab != -1;
+            if (skip && S.lab >= 0) skip = Dc[S.lab] >= F * S.max_old;
+            if (skip && S.max_new >= 0.0) skip = mdn >= F * S.max_new;
+            if (skip) {
+                if (tid == 0 && S.best_i >= 0 && (bi < 0 || kc_better(S.best_v, S.best_i, bv, bi))) {
+                    bv = S.best_v;
+                    bi = S.best_i;
+                }
+                continue;
+            }
+        }
+        double tbv = -1.0, tmo = -1.0, tmn = -1.0;
+        long long tbi = -1;
+        int l0 = 0x7fffffff, l1 = -1;
+#pragma unroll
+        for (int k = 0; k < KS_TILE / DT; ++k) {
+            const long long p = t * KS_TILE + k * DT + tid;
+            if (p < P.n) {
+                double cur = (P.it == 0) ? INFINITY : P.dist[p];  // distances_.fill(inf), kcenters.py:87-88
+                int lab = (P.it == 0) ? 0 : P.lab[p];
+                const bool rowskip = P.it > 0 && Dc[lab] >= F * cur;
+                if (!rowskip) {
+                    T x[FC];
+                    load_row_regs<T>(x, Xc + p * P.m, (int)P.m, P.vecw);
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int g = 0; g < FC / 4; ++g)
+                        if (g * 4 < P.m) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) m_update<T, M>(a, b, x[g * 4 + q], ys[g * 4 + q]);
+                        }
+                    const double d = m_final<M>(a, b, P.m);
+                    const bool upd = d < cur;  // strict, kcenters.py:93
+                    if (upd) {
+                        cur = d;
+                        lab = P.it;
+                    }
+                    if (upd || P.it == 0) {
+                        P.dist[p] = cur;
+                        P.lab[p] = lab;
+                    }
+                }
+                const long long o = P.orig ? P.orig[p] : p;
+                if (tbi < 0 || kc_better(cur, o, tbv, tbi)) {
+                    tbv = cur;
+                    tbi = o;
+                }
+                if (lab < P.epoch) {
+                    l0 = lab < l0 ? lab : l0;
+                    l1 = lab > l1 ? lab : l1;
+                    tmo = cur > tmo ? cur : tmo;
+                    if (!(cur == cur)) tmo = INFINITY;
+                } else {
+                    tmn = cur > tmn ? cur : tmn;
+                    if (!(cur == cur)) tmn = INFINITY;
+                }
+            }
+        }
+        // tile summary: butterflies inside the wave, then the 4 waves through LDS
+#pragma unroll
+        for (int msk = 32; msk > 0; msk >>= 1) {
+            const double ov = __shfl_xor(tbv, msk, 64);
+            const long long oi = __shfl_xor(tbi, msk, 64);
+            if (oi >= 0 && (tbi < 0 || kc_better(ov, oi, tbv, tbi))) {
+                tbv = ov;
+                tbi = oi;
+            }
+            const double omo = __shfl_xor(tmo, msk, 64), omn = __shfl_xor(tmn, msk, 64);
+            tmo = omo > tmo ? omo : tmo;
+            tmn = omn > tmn ? omn : tmn;
+            const int ol0 = __shfl_xor(l0, msk, 64), ol1 = __shfl_xor(l1, msk, 64);
+            l0 = ol0 < l0 ? ol0 : l0;
+            l1 = ol1 > l1 ? ol1 : l1;
+        }
+        if (lane == 0) {
+            wbv[wave] = tbv;
+            wbi[wave] = tbi;
+            wmo[wave] = tmo;
+            wmn[wave] = tmn;
+            wl0[wave] = l0;
+            wl1[wave] = l1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                if (wbi[w] >= 0 && (tbi < 0 || kc_better(wbv[w], wbi[w], tbv, tbi))) {
+                    tbv = wbv[w];
+                    tbi = wbi[w];
+                }
+                tmo = wmo[w] > tmo ? wmo[w] : tmo;
+                tmn = wmn[w] > tmn ? wmn[w] : tmn;
+                l0 = wl0[w] < l0 ? wl0[w] : l0;
+                l1 = wl1[w] > l1 ? wl1[w] : l1;
+            }
+            KsSummary S;
+            S.lab = (l1 < 0) ? -2 : (l0 == l1 ? l0 : -1);
+            S.pad = 0;
+            S.max_old = tmo;
+            S.max_new = tmn;
+            S.best_v = tbv;
+            S.best_i = tbi;
+            P.sum[t] = S;
+            if (tbi >= 0 && (bi < 0 || kc_better(tbv, tbi, bv, bi))) {
+                bv = tbv;
+                bi = tbi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {  // this workgroup's candidate for the next centre; the next pass's prologue reduces them
+        KcPartial q;
+        q.v = bv;
+        q.i = bi;
+        P.next[blockIdx.x] = q;
+    }
+}
+
+// counting sort by label, 1/3: label histogram (per-workgroup in LDS, then one atomic per label)
+__global__ __launch_bounds__(DT) void ks_hist_kernel(const int* __restrict__ lab, long long n, int K,
+                                                     unsigned long long* __restrict__ counts)
+{
+    __shared__ unsigned h[KC_PRUNE_MAX];
+    for (int j = threadIdx.x; j < K; j += DT) h[j] = 0u;
+    __syncthreads();
+    for (long long p = (long long)blockIdx.x * DT + threadIdx.x; p < n; p += (long long)gridDim.x * DT) atomicAdd(&h[lab[p]], 1u);
+    __syncthreads();
+    for (int j = threadIdx.x; j < K; j += DT)
+        if (h[j]) atomicAdd(&counts[j], (unsigned long long)h[j]);
+}
+
+// 2/3: exclusive scan of the K counts -> write cursors; clears the counts for the next sort
+__global__ __launch_bounds__(DT) void ks_scan_kernel(unsigned long long* __restrict__ counts, int K,
+                                                     unsigned long long* __restrict__ cursor)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int j = 0; j < K; ++j) {
+            cursor[j] = run;
+            run += counts[j];
+            counts[j] = 0;
+        }
+    }
+}
+
+// 3/3: every workgroup takes chunks of KS_CH rows, reserves a run per label in the output (one global atomic per label
+// present) and moves its rows there -- coordinates, distance, label, original index.  The order inside a label is arbitrary.
+constexpr int KS_CH = 2048;
+template <typename T>
+__global__ __launch_bounds__(DT) void ks_scatter_kernel(const T* __restrict__ Xc, const long long* __restrict__ orig,
+                                                        const double* __restrict__ dist, const int* __restrict__ lab,
+                                                        long long n, long long m, int K, int vecw,
+                                                        unsigned long long* __restrict__ cursor, T* __restrict__ Xn,
+                                                        long long* __restrict__ orign, double* __restrict__ distn,
+                                                        int* __restrict__ labn)
+{
+    __shared__ unsigned h[KC_PRUNE_MAX];
+    __shared__ unsigned long long base[KC_PRUNE_MAX];
+    const long long nch = (n + KS_CH - 1) / KS_CH;
+    for (long long ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+        for (int j = threadIdx.x; j < K; j += DT) h[j] = 0u;
+        __syncthreads();
+        int l[KS_CH / DT];
+        unsigned r[KS_CH / DT];
+#pragma unroll
+        for (int k = 0; k < KS_CH / DT; ++k) {
+            const long long p = ch * KS_CH + k * DT + threadIdx.x;
+            l[k] = p < n ? lab[p] : -1;
+            r[k] = l[k] >= 0 ? atomicAdd(&h[l[k]], 1u) : 0u;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < K; j += DT)
+            if (h[j]) base[j] = atomicAdd(&cursor[j], (unsigned long long)h[j]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KS_CH / DT; ++k) {
+            const long long p = ch * KS_CH + k * DT + threadIdx.x;
+            if (l[k] >= 0) {
+                const long long q = (long long)(base[l[k]] + r[k]);
+                const T* src = Xc + p * m;
+                T* dst = Xn + q * m;
+                if (vecw == 16) {
+                    for (long long f = 0; f < m; f += 16 / (long long)sizeof(T))
+                        *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(src + f);
+                } else if (vecw == 8) {
+                    for (long long f = 0; f < m; f += 8 / (long long)sizeof(T))
+                        *reinterpret_cast<float2*>(dst + f) = *reinterpret_cast<const float2*>(src + f);
+                } else {
+                    for (long long f = 0; f < m; ++f) dst[f] = src[f];
+                }
+                orign[q] = orig ? orig[p] : p;
+                distn[q] = dist[p];
+                labn[q] = l[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// back to the caller's order
+__global__ __launch_bounds__(DT) void ks_unpermute_kernel(const long long* __restrict__ orig, const double* __restrict__ dist,
+                                                          const int* __restrict__ lab, long long n,
+                                                          double* __restrict__ dist_out, msm_idx_t* __restrict__ lab_out)
+{
+    for (long long p = (long long)blockIdx.x * DT + threadIdx.x; p < n; p += (long long)gridDim.x * DT) {
+        const long long o = orig ? orig[p] : p;
+        dist_out[o] = dist[p];
+        lab_out[o] = lab[p];
+    }
+}
+
+template <typename T>
+static void launch_ks_pass(int mid, int grid, const KsArgs& P)
+{
+    switch (mid) {
+        case M_EUCLIDEAN: hipLaunchKernelGGL((kcenters_sorted_pass_kernel<T, M_EUCLIDEAN>), dim3(grid), dim3(DT), 0, stream(), P); break;
+        case M_CITYBLOCK: hipLaunchKernelGGL((kcenters_sorted_pass_kernel<T, M_CITYBLOCK>), dim3(grid), dim3(DT), 0, stream(), P); break;
+        case M_CHEBYSHEV: hipLaunchKernelGGL((kcenters_sorted_pass_kernel<T, M_CHEBYSHEV>), dim3(grid), dim3(DT), 0, stream(), P); break;
+    }
+}
+
+// passes after which the rows are re-sorted by label (MSM_KC_SORT="15,31,..." overrides; MSM_KC_SORTED=0: plain passes)
+static const std::vector<int>& ks_schedule()
+{
+    static std::vector<int> sch;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char* e = getenv("MSM_KC_SORT");
+        std::string str = e ? e : "11,23,47,95,143";
+        size_t pos = 0;
+        while (pos < str.size()) {
+            sch.push_back(atoi(str.c_str() + pos));
+            pos = str.find(',', pos);
+            if (pos == std::string::npos) break;
+            ++pos;
+        }
+    }
+    return sch;
+}
+
+// Opt-in (MSM_KC_SORTED=1, read per call).  Measured on 10M x 10 float64, K = 200 (scripts/kcblobs.py, kcperf.py): 40
+// well-separated blobs 18.4 ms against 17.8 ms for plain per-row pruning, the bench's unclustered tICA projection 36.9
+// against 25.3 ms -- the counting sorts and the heavier pass cost more than the skipped tiles return, because a tile that
+// holds ANY row of a newer centre is tested against the minimum over ALL newer centres.  Kept for the exactness test and
+// as the base for per-tile newer-label lists.
+static bool ks_enabled()
+{
+    const char* e = getenv("MSM_KC_SORTED");
+    return e && atoi(e) != 0;
+}
+
+struct KsBufs {
+    DevBuf x[2], dist[2], orig[2], lab[2], sum, centers, misc;
+};
+static KsBufs& ks_bufs()
+{
+    static KsBufs b;
+    return b;
+}
+
+// device pointers throughout: Xd [n][m], labels_d / dist_d outputs in the caller's order, ids_d [K]
+template <typename T>
+int kcenters_sorted_run(int mid, const T* Xd, msm_idx_t n, msm_idx_t m, msm_idx_t K, msm_idx_t seed, int vecw,
+                        msm_idx_t* ids_d, msm_idx_t* labels_d, double* dist_d)
+{
+    KsBufs& B = ks_bufs();
+    int rc;
+    const long long ntile = ceil_div(n, KS_TILE);
+    const int nblk = (int)std::min<long long>(ntile, 4LL * num_cus());
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = B.dist[k].reserve((size_t)n * sizeof(double)))) return rc;
+        if ((rc = B.lab[k].reserve((size_t)n * sizeof(int)))) return rc;
+    }
+    if ((rc = B.sum.reserve((size_t)ntile * sizeof(KsSummary)))) return rc;
+    if ((rc = B.centers.reserve((size_t)K * m * sizeof(T)))) return rc;
+    // misc: [2 x nblk candidates | K counts | K cursors]
+    const size_t off_counts = (size_t)2 * nblk * sizeof(KcPartial), off_cursor = off_counts + (size_t)K * 8,
+                 misc_bytes = off_cursor + (size_t)K * 8;
+    if ((rc = B.misc.reserve(misc_bytes))) return rc;
+    char* misc = static_cast<char*>(B.misc.p);
+    MSM_HIP_CHECK(hipMemsetAsync(misc + off_counts, 0, misc_bytes - off_counts, stream()));
+    KsArgs P;
+    memset(&P, 0, sizeof(P));
+    P.X0 = Xd;
+    P.Xc = Xd;
+    P.orig = nullptr;
+    P.n = n;
+    P.m = m;
+    P.seed = seed;
+    P.nblk = nblk;
+    P.vecw = vecw;
+    P.epoch = (int)K + 1;  // before the first sort every label counts as "pre-sort"
+    P.dist = B.dist[0].as<double>();
+    P.lab = B.lab[0].as<int>();
+    P.sum = B.sum.as<KsSummary>();
+    P.centers = B.centers.p;
+    P.ids = ids_d;
+    KcPartial* part = reinterpret_cast<KcPartial*>(misc);
+    unsigned long long* counts = reinterpret_cast<unsigned long long*>(misc + off_counts);
+    unsigned long long* cursor = reinterpret_cast<unsigned long long*>(misc + off_cursor);
+    const std::vector<int>& sch = ks_schedule();
+    int cur = 0;
+    for (msm_idx_t it = 0; it < K; ++it) {
+        P.it = (int)it;
+        P.prev = part + (size_t)((it + 1) & 1) * nblk;
+        P.next = part + (size_t)(it & 1) * nblk;
+        launch_ks_pass<T>(mid, nblk, P);
+        if (it + 1 < K && std::find(sch.begin(), sch.end(), (int)it) != sch.end()) {
+            const int nxt = cur ^ 1;
+            if ((rc = B.x[nxt].reserve((size_t)n * m * sizeof(T)))) return rc;
+            if ((rc = B.orig[nxt].reserve((size_t)n * sizeof(long long)))) return rc;
+            const int nlab = (int)it + 1;
+            const int g = (int)std::min<long long>(ceil_div(n, KS_CH), 8LL * num_cus());
+            hipLaunchKernelGGL(ks_hist_kernel, dim3(g), dim3(DT), 0, stream(), P.lab, (long long)n, nlab, counts);
+            hipLaunchKernelGGL(ks_scan_kernel, dim3(1), dim3(DT), 0, stream(), counts, nlab, cursor);
+            hipLaunchKernelGGL((ks_scatter_kernel<T>), dim3(g), dim3(DT), 0, stream(), static_cast<const T*>(P.Xc), P.orig,
+                               P.dist, P.lab, (long long)n, (long long)m, nlab, vecw, cursor, B.x[nxt].as<T>(),
+                               B.orig[nxt].as<long long>(), B.dist[nxt].as<double>(), B.lab[nxt].as<int>());
+            cur = nxt;
+            P.Xc = B.x[cur].p;
+            P.orig = B.orig[cur].as<long long>();
+            P.dist = B.dist[cur].as<double>();
+            P.lab = B.lab[cur].as<int>();
+            P.epoch = nlab;
+            // the summaries describe the old order: mark every tile "mixed" so the next pass rebuilds them
+            MSM_HIP_CHECK(hipMemsetAsync(P.sum, 0xff, (size_t)ntile * sizeof(KsSummary), stream()));
+        }
+    }
+    MSM_HIP_CHECK(hipGetLastError());
+    const int g = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
+    hipLaunchKernelGGL(ks_unpermute_kernel, dim3(g), dim3(DT), 0, stream(), P.orig, P.dist, P.lab, (long long)n, dist_d, labels_d);
+    MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
 template <typename T>
 int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char* metric,
                   msm_idx_t seed, msm_idx_t* ids, msm_idx_t* labels, double* distances,
@@ -1469,6 +1920,11 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     P.vecw = row_vecw<T>(P.X, m, false);
     if (P.vecw == 0 && wide_ok<T>(P.X, P.X, m, false)) P.nblk = nblk = std::min(nblk, wide_grid(n));
     KcPartial* part = dPart.as<KcPartial>();
+    const bool sorted = ks_enabled() && P.prune && P.vecw > 0 && K <= KC_PRUNE_MAX && K >= 16 && n >= (1 << 18) &&
+                        (mid == M_EUCLIDEAN || mid == M_CITYBLOCK || mid == M_CHEBYSHEV);
+    if (sorted) {
+        if ((rc = kcenters_sorted_run<T>(mid, static_cast<const T*>(P.X), n, m, K, seed, P.vecw, P.ids, P.labels, P.dist))) return rc;
+    } else
     for (msm_idx_t it = 0; it < K; ++it) {
         P.it = (int)it;
         P.prev = part + (size_t)((it + 1) & 1) * nblk;

@@ -153,6 +153,30 @@ def test_config3_kcenters_280k_bit_exact(gpu):
         assert np.array_equal(pred, labels)
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cityblock", "chebyshev"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_kcenters_label_sorted_path_clustered(gpu, metric, dtype, monkeypatch):
+    """>= 2^18 rows of CLUSTERED data through the opt-in label-sorted fit (MSM_KC_SORTED=1: tiles skipped by their
+    summaries, rows re-sorted by label after chosen passes) against the C oracle, bit for bit -- with duplicate rows (zero
+    distances, argmax ties decided by the original row index) and a row count that is not a multiple of the tile."""
+    from msmbuilder_amd import KCenters
+    monkeypatch.setenv("MSM_KC_SORTED", "1")
+    from oracle.libdistance_oracle import Oracle
+    o = Oracle()
+    rs = np.random.RandomState(11)
+    n, f, k = 300_123, 10, 72
+    blobs = rs.randn(40, f) * 6.0
+    Y = (blobs[rs.randint(0, 40, n)] + rs.randn(n, f) * 0.4).astype(dtype)
+    Y[1000:1040] = Y[7]
+    Y[250_000:250_005] = Y[123_456]
+    m = KCenters(n_clusters=k, metric=metric, random_state=5).fit([Y[:100_000], Y[100_000:]])
+    ids, labels, dist = o.kcenters_fit(Y, k, metric, m.cluster_ids_[0])
+    assert m.cluster_ids_ == list(ids)
+    assert np.array_equal(np.concatenate(m.labels_), labels)
+    assert np.array_equal(np.concatenate(m.distances_), dist)
+    assert m.inertia_ == np.sum(dist)
+
+
 def test_assign_nearest_1M_device_resident_properties(gpu):
     from msmbuilder_amd import libdistance as ld
     g = torch.Generator(device="cuda").manual_seed(1)
