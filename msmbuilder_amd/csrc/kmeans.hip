@@ -211,6 +211,202 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_kernel(KmArgs P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Small batches of wide rows (MiniBatchKMeans' step at F = 512: B = 1024 rows, K = 1000 centres): 128 x 128 tiles make 8 x 8
+// = 64 workgroups -- a quarter of the chip, each MFMA-bound for 27 us.  Same arithmetic on 64 x 64 tiles (one 32 x 32
+// MFMA block per wave): 16 x 16 = 256 workgroups.  Simple double-buffered K-loop (the panels are L2-resident).
+// ---------------------------------------------------------------------------
+constexpr int KS64 = 64;
+constexpr int KB64 = 128;  // features per K-step: few, long steps (a step costs ~1.5 us of latency whatever its length)
+constexpr int KP64 = KB64 + 4;  // 16-byte aligned rows; 16 lanes x 16 bytes at this pitch cover the 64 banks once
+constexpr size_t KM64_LDS = (size_t)2 * 2 * KS64 * KP64 * sizeof(float);
+
+struct Km64Stage {
+    float4 x[KB64 / 16], c[KB64 / 16];
+};
+
+// Loads are UNCONDITIONAL on the 16-byte path (rows clamped into the batch, centres into [0, K), columns into the row;
+// what lies outside is zeroed when the stage goes to LDS, or never read back): a load under a branch or a select is
+// followed at once by s_waitcnt vmcnt(0), and sixteen serialised L2 round trips made a K-step 6 us instead of 1.7.
+__device__ __forceinline__ void km64_load(Km64Stage& st, const KmArgs& P, const long long (&xrow)[KB64 / 16], long long j0,
+                                          int k0, int tid)
+{
+    constexpr int CPR = KB64 / 4;       // threads per row
+    constexpr int RPP = KNT / CPR;      // rows per pass
+    const int c4 = (tid % CPR) * 4;
+    const int r0 = tid / CPR;
+    const bool vec = (P.m & 3) == 0 && ((((uintptr_t)P.X) | ((uintptr_t)P.C)) & 15) == 0;
+    if (vec) {  // uniform
+        const long long col = (k0 + c4 + 3 < P.m) ? (long long)(k0 + c4) : P.m - 4;
+#pragma unroll
+        for (int j = 0; j < KS64 / RPP; ++j) {
+            const long long jc = j0 + r0 + RPP * j;
+            st.x[j] = *reinterpret_cast<const float4*>(P.X + xrow[j] * P.m + col);
+            st.c[j] = *reinterpret_cast<const float4*>(P.C + (jc < P.K ? jc : P.K - 1) * P.m + col);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < KS64 / RPP; ++j) {
+        const int rr = r0 + RPP * j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+        {
+            const float* p = P.X + xrow[j] * P.m + k0 + c4;
+            if (k0 + c4 + 0 < P.m) v.x = p[0];
+            if (k0 + c4 + 1 < P.m) v.y = p[1];
+            if (k0 + c4 + 2 < P.m) v.z = p[2];
+            if (k0 + c4 + 3 < P.m) v.w = p[3];
+        }
+        const long long jc = j0 + rr;
+        if (jc < P.K) {
+            const float* p = P.C + jc * P.m + k0 + c4;
+            if (k0 + c4 + 0 < P.m) w.x = p[0];
+            if (k0 + c4 + 1 < P.m) w.y = p[1];
+            if (k0 + c4 + 2 < P.m) w.z = p[2];
+            if (k0 + c4 + 3 < P.m) w.w = p[3];
+        }
+        st.x[j] = v;
+        st.c[j] = w;
+    }
+}
+
+// `inb`: this thread's four columns of the step lie inside the row (else the stage holds clamped-address data: zeros go to LDS)
+__device__ __forceinline__ void km64_store(const Km64Stage& st, float* Xs, float* Cs, int tid, bool inb)
+{
+    constexpr int CPR = KB64 / 4, RPP = KNT / CPR;
+    const int c4 = (tid % CPR) * 4, r0 = tid / CPR;
+#pragma unroll
+    for (int j = 0; j < KS64 / RPP; ++j) {
+        float* px = Xs + (r0 + RPP * j) * KP64 + c4;
+        float* pc = Cs + (r0 + RPP * j) * KP64 + c4;
+        *reinterpret_cast<float4*>(px) = inb ? st.x[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(pc) = inb ? st.c[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(KNT) void kmeans_label64_kernel(KmArgs P)
+{
+    if (P.stop && *P.stop) return;  // uniform
+    extern __shared__ __attribute__((aligned(16))) char km64_smem[];
+    float* Xs = reinterpret_cast<float*>(km64_smem);  // [2][KS64 * KP64]
+    float* Cs = Xs + 2 * KS64 * KP64;                 // [2][KS64 * KP64]
+    __shared__ float redv[2][KS64];
+    __shared__ int redi[2][KS64];
+    constexpr int CPR = KB64 / 4, RPP = KNT / CPR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, kl = lane >> 5, cl = lane & 31;
+    const long long row0 = (long long)blockIdx.x * KS64;
+    const int nk = (int)((P.m + KB64 - 1) / KB64);
+    const int r0 = tid / CPR;
+    long long xrow[KS64 / RPP];  // this thread's staging rows (fixed for the workgroup's life)
+#pragma unroll
+    for (int j = 0; j < KS64 / RPP; ++j) {
+        long long i = row0 + r0 + RPP * j;
+        if (i > P.n - 1) i = P.n - 1;  // rows past the batch: clamped (their results are never written)
+        xrow[j] = P.rows ? P.rows[i] : i;
+    }
+    const int c4s = (tid % CPR) * 4;  // this thread's first column inside a K-step
+    float best[16];
+    int bidx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        best[r] = INFINITY;
+        bidx[r] = 0x7fffffff;
+    }
+    const long long jbeg = P.jspan ? (long long)blockIdx.y * P.jspan : 0;
+    const long long jend = P.jspan ? (jbeg + P.jspan < P.K ? jbeg + P.jspan : P.K) : P.K;
+    for (long long j0 = jbeg; j0 < jend; j0 += KS64) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // The panels come from the fabric side (the centres were rewritten by the previous step, the batch rows are fresh):
+        // ~4 us a round trip, against 1.7 us of MFMA per K-step.  Four K-steps of loads are in flight (128 VGPRs; the
+        // workgroup has a CU to itself), refilled as each stage goes to LDS.
+        Km64Stage st[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nk) km64_load(st[q], P, xrow, j0, q * KB64, tid);
+        __syncthreads();  // the previous centre tile's last fragment reads are done
+        km64_store(st[0], Xs, Cs, tid, c4s + 3 < P.m);
+        __syncthreads();
+        for (int s0 = 0; s0 < nk; s0 += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = s0 + q;
+                if (s < nk) {  // uniform
+                    const int buf = q & 1;
+                    if (s + 4 < nk) km64_load(st[q], P, xrow, j0, (s + 4) * KB64, tid);  // st[q] went to LDS a step ago
+                    // feature order of kmeans_label_v4_kernel (MFMA q of every group of 8 features contracts {q, 4 + q}):
+                    // the two kernels then form bit-identical dot products, and a row gets the same label from either
+                    const float* Ab = Xs + buf * (KS64 * KP64) + (wr * 32 + cl) * KP64 + 4 * kl;
+                    const float* Bb = Cs + buf * (KS64 * KP64) + (wc * 32 + cl) * KP64 + 4 * kl;
+#pragma unroll
+                    for (int g = 0; g < KB64 / 8; ++g) {  // a lane's 16-byte fragment: its 4 features of the group
+                        const float4 a = *reinterpret_cast<const float4*>(Ab + 8 * g), b = *reinterpret_cast<const float4*>(Bb + 8 * g);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                    }
+                    if (s + 1 < nk)
+                        km64_store(st[(q + 1) & 3], Xs + (buf ^ 1) * (KS64 * KP64), Cs + (buf ^ 1) * (KS64 * KP64), tid,
+                                   (s + 1) * KB64 + c4s + 3 < P.m);
+                    __syncthreads();
+                }
+            }
+        }
+        const long long j = j0 + wc * 32 + cl;  // running argmin over this centre tile (ascending j per lane, strict <)
+        if (j < jend) {
+            const float cn = P.cnorm[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = cn - 2.f * acc[r];
+                if (v < best[r]) {
+                    best[r] = v;
+                    bidx[r] = (int)j;
+                }
+            }
+        }
+    }
+    // min over the 32 lanes that share a row (value, lowest index), then over the two centre halves
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = best[r];
+        int ix = bidx[r];
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) {
+            const float ov = __shfl_xor(v, msk, 64);
+            const int oi = __shfl_xor(ix, msk, 64);
+            if (ov < v || (ov == v && oi < ix)) {
+                v = ov;
+                ix = oi;
+            }
+        }
+        if (cl == 0) {
+            const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            redv[wc][row] = v;
+            redi[wc][row] = ix;
+        }
+    }
+    __syncthreads();
+    if (tid < KS64) {
+        const long long i = row0 + tid;
+        if (i < P.n) {
+            const float v0 = redv[0][tid], v1 = redv[1][tid];
+            const int i0 = redi[0][tid], i1 = redi[1][tid];
+            const bool second = (v1 < v0 || (v1 == v0 && i1 < i0));
+            int lab = second ? i1 : i0;
+            if (P.jspan) {
+                P.pv[(long long)blockIdx.y * P.n + i] = second ? v1 : v0;
+                P.pi[(long long)blockIdx.y * P.n + i] = lab;
+            } else {
+                if (lab == 0x7fffffff) lab = 0;  // all-NaN row: sklearn's argmin returns 0
+                P.labels[i] = lab;
+            }
+        }
+    }
+}
+
 // running argmin over one finished centre tile (ascending j per lane, strict <); clears acc
 __device__ __forceinline__ void km4_argmin(f32x16 (&acc)[2][2], float (&best)[2][16], int (&bidx)[2][16],
                                            const KmArgs& P, long long j0, int wc, int cl)
@@ -837,79 +1033,121 @@ __global__ __launch_bounds__(KNT) void mbk_small_label_kernel(KmArgs P, SmallArg
     }
 }
 
+constexpr int MSU_CAP = 1024;  // batch rows at most (a wave's member list in LDS)
+
 __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* __restrict__ centers,
                                                                float* __restrict__ counts, float* __restrict__ cnorm,
                                                                double* __restrict__ sums, double* __restrict__ cnts,
                                                                int apply, MbkConv cv)
 {
     if (P.stop && *P.stop) return;
+    __shared__ long long mrow[4][MSU_CAP];  // per wave: the centre's member rows in batch order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long j = (long long)blockIdx.x * 4 + wave;
     if (j < P.K) {  // uniform over the wave
+        constexpr int NCH = 8;  // 64-feature blocks per round (lane = feature of each block)
         const float w_old = counts[j];
-        const bool fl = lane < P.m;
-        const float c_old = fl ? centers[j * P.m + lane] : 0.f;
-        float acc32 = c_old * w_old;
-        double acc64 = 0.0;
-        long long cnt = 0;
-        for (long long b0 = 0; b0 < P.n; b0 += 1024) {
+        float c_first[NCH];  // the first round's centre values: requested before the label scan, not after it
+        // (all loads of this kernel are unconditional at clamped addresses and masked afterwards: a load under a select
+        //  is waited for on the spot, which turns every batch of independent loads into a chain of round trips)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const long long f = (long long)c * 64 + lane;
+            c_first[c] = centers[j * P.m + (f < P.m ? f : P.m - 1)];
+        }
+        // members: 16 + 16 independent loads per lane, then ballots; rows through v_readlane
+        int cnt = 0;
+        {
             int lab[16];
             long long rowv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long pos = b0 + r * 64 + lane;
-                const bool in = pos < P.n;
-                lab[r] = in ? P.labels[pos] : -1;
-                rowv[r] = P.rows ? (in ? P.rows[pos] : 0) : pos;
+                const long long pos = (long long)r * 64 + lane;
+                const long long pc = pos < P.n ? pos : P.n - 1;
+                lab[r] = P.labels[pc];
+                rowv[r] = P.rows ? P.rows[pc] : pc;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                unsigned long long bal = __ballot(lab[r] == (int)j);
+                const bool in = (long long)r * 64 + lane < P.n;
+                unsigned long long bal = __ballot(in && lab[r] == (int)j);
                 const int rlo = (int)(rowv[r] & 0xffffffffLL), rhi = (int)(rowv[r] >> 32);
                 while (bal) {  // uniform
-                    float xv[8];
-                    int g = 0;
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        xv[t] = 0.f;
-                        if (bal) {
-                            const int k = __builtin_ctzll(bal);
-                            bal &= bal - 1ull;
-                            const long long row = ((long long)__builtin_amdgcn_readlane(rhi, k) << 32) |
-                                                  (unsigned)__builtin_amdgcn_readlane(rlo, k);
-                            if (fl) xv[t] = P.X[row * P.m + lane];
-                            g = t + 1;
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        if (t < g) {
-                            acc32 += xv[t];
-                            acc64 += (double)xv[t];
-                        }
-                    cnt += g;
+                    const int k = __builtin_ctzll(bal);
+                    bal &= bal - 1ull;
+                    const long long row = ((long long)__builtin_amdgcn_readlane(rhi, k) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane(rlo, k);
+                    if (lane == 0) mrow[wave][cnt] = row;
+                    ++cnt;
                 }
             }
         }
-        float c_new = c_old;
-        if (apply && cnt > 0) {
-            const float w_new = w_old + (float)cnt;
-            const float alpha = 1.0f / w_new;
-            c_new = acc32 * alpha;
-        }
-        if (fl) {
-            if (sums) sums[j * P.m + lane] = acc64;
-            if (apply && cnt > 0) centers[j * P.m + lane] = c_new;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float sqn = 0.f;  // ||c_new||^2, lane partition of kmeans_cnorm_kernel
+        for (long long f0 = 0; f0 < P.m; f0 += NCH * 64) {
+            bool fl[NCH];
+            float c_old[NCH], acc32[NCH];
+            double acc64[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const long long f = f0 + c * 64 + lane;
+                fl[c] = f < P.m;
+                c_old[c] = f0 == 0 ? c_first[c] : centers[j * P.m + (fl[c] ? f : P.m - 1)];
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (!fl[c]) c_old[c] = 0.f;
+                acc32[c] = c_old[c] * w_old;
+                acc64[c] = 0.0;
+            }
+            for (int q0 = 0; q0 < cnt; q0 += 4) {  // up to 4 x NCH row loads in flight
+                float xv[4][NCH];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long long row = mrow[wave][q0 + t < cnt ? q0 + t : cnt - 1];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const long long f = f0 + c * 64 + lane;
+                        xv[t][c] = P.X[row * P.m + (f < P.m ? f : P.m - 1)];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (q0 + t < cnt) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const float xq = fl[c] ? xv[t][c] : 0.f;
+                            acc32[c] += xq;
+                            acc64[c] += (double)xq;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const long long f = f0 + c * 64 + lane;
+                float c_new = c_old[c];
+                if (apply && cnt > 0) {
+                    const float w_new = w_old + (float)cnt;
+                    const float alpha = 1.0f / w_new;
+                    c_new = acc32[c] * alpha;
+                }
+                if (fl[c]) {
+                    if (sums) sums[j * P.m + f] = acc64[c];
+                    if (apply && cnt > 0) centers[j * P.m + f] = c_new;
+                    sqn += c_new * c_new;
+                }
+            }
         }
         if (lane == 0) {
             if (cnts) cnts[j] = (double)cnt;
             if (apply && cnt > 0) counts[j] = w_old + (float)cnt;
         }
         if (apply && cnorm && cnt > 0) {  // same lane partition and butterfly as kmeans_cnorm_kernel
-            float sq = fl ? c_new * c_new : 0.f;
 #pragma unroll
-            for (int msk = 32; msk > 0; msk >>= 1) sq += __shfl_xor(sq, msk, 64);
-            if (lane == 0) cnorm[j] = sq;
+            for (int msk = 32; msk > 0; msk >>= 1) sqn += __shfl_xor(sqn, msk, 64);
+            if (lane == 0) cnorm[j] = sqn;
         }
     }
     if (cv.st) {  // uniform: the last workgroup to arrive closes the step
@@ -922,6 +1160,24 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
             mbk_converge(cv, cred);
             if (tid == 0) *cv.done = 0u;
         }
+    }
+}
+
+// Mini-batch rows copied once into a compact [rows][m] buffer: the batch's rows are scattered over the whole data set (one
+// page each for wide rows), and the label, inertia and update kernels of a step each paid those address translations again
+// -- ~35 us per kernel at 1.25M x 512 whatever the arithmetic.  One wave per row, 16-byte lanes when the row allows.
+__global__ __launch_bounds__(KNT) void mbk_gather_kernel(const float* __restrict__ X, const msm_idx_t* __restrict__ rows,
+                                                         long long nrows, long long m, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nrows) return;
+    const float* src = X + rows[i] * m;
+    float* dst = out + i * m;
+    if ((m & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)out)) & 15) == 0) {
+        for (long long f = lane * 4LL; f < m; f += 256) *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(src + f);
+    } else {
+        for (long long f = lane; f < m; f += 64) dst[f] = src[f];
     }
 }
 
@@ -1093,16 +1349,27 @@ struct msm_mbk {
 namespace {
 
 // small-batch step kernels: rows of at most 32 features, at most 1024 row blocks of 64 (MSM_MBK_SMALL=0: general kernels)
-bool mbk_small_ok(const msm_mbk* h, long long n)
+bool mbk_small_off()
 {
     static const bool off = getenv("MSM_MBK_SMALL") && atoi(getenv("MSM_MBK_SMALL")) == 0;
-    return !off && h->m <= 32 && n <= 65536;
+    return off;
+}
+bool mbk_small_ok(const msm_mbk* h, long long n) { return !mbk_small_off() && h->m <= 32 && n <= 65536; }  // label kernel
+bool mbk_small_update_ok(long long n)                                                                      // update kernel
+{
+    static const bool off = getenv("MSM_MBK_UPDATE_WAVE") && atoi(getenv("MSM_MBK_UPDATE_WAVE")) == 0;  // A/B switch
+    return !off && !mbk_small_off() && n <= MSU_CAP;
+}
+bool mbk_label64_ok(const msm_mbk* h, long long n)                                                         // 64 x 64 label tiles
+{
+    static const bool off = getenv("MSM_MBK_LABEL64") && atoi(getenv("MSM_MBK_LABEL64")) == 0;  // A/B switch
+    return !off && !mbk_small_off() && n <= 4096 && h->m > 32;
 }
 
 // centre update of a step: one wave per centre for small batches, else one workgroup per centre
 void mbk_launch_update(msm_mbk* h, const KmArgs& P, double* sums, double* cnts, int apply, const MbkConv& cv)
 {
-    if (mbk_small_ok(h, P.n))
+    if (mbk_small_update_ok(P.n))
         hipLaunchKernelGGL(mbk_small_update_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), P, h->centers,
                            h->counts, h->cnorm, sums, cnts, apply, cv);
     else
@@ -1153,6 +1420,37 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
         *nb_out = RB;
         return MSM_OK;
     }
+    if (mbk_label64_ok(h, n)) {  // small batch of wide rows: 64 x 64 tiles fill the chip
+        const long long rb = ceil_div(n, KS64), ct = ceil_div(h->K, KS64);
+        int ns = (int)std::min<long long>(ct, std::max<long long>(1, ceil_div(512, rb)));
+        const long long tiles_per = ceil_div(ct, ns);
+        ns = (int)ceil_div(ct, tiles_per);
+        int rc;
+        if ((rc = h->pv.reserve((size_t)ns * n * sizeof(float)))) return rc;
+        if ((rc = h->pi.reserve((size_t)ns * n * sizeof(int)))) return rc;
+        P.jspan = tiles_per * KS64;
+        P.pv = h->pv.as<float>();
+        P.pi = h->pi.as<int>();
+        static bool attr64 = false;
+        if (!attr64) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_label64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)KM64_LDS);
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(kmeans_label64_kernel, dim3((unsigned)rb, (unsigned)ns), dim3(KNT), KM64_LDS, stream(), P);
+        MSM_HIP_CHECK(hipGetLastError());
+        if (!inertia_dev_partial) {
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(), P.pv, P.pi,
+                               n, ns, labels_d, P.stop);
+        } else {
+            const int nb = (int)std::min<long long>(ceil_div(n, 4), 1024);
+            P.jspan = 0;
+            hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial, ns);
+            *nb_out = nb;
+        }
+        MSM_HIP_CHECK(hipGetLastError());
+        return MSM_OK;
+    }
     const long long rowblocks = ceil_div(n, KR);
     const long long ctiles = ceil_div(h->K, KCT);
     int nsplit = 1;
@@ -1197,8 +1495,12 @@ int mbk_stage_batch(msm_mbk* h, const float* X, msm_idx_t n, const msm_idx_t* ba
         if ((rc = h->idx.reserve((size_t)B * sizeof(msm_idx_t)))) return rc;
         MSM_HIP_CHECK(hipMemcpyAsync(h->idx.p, batch_idx, (size_t)B * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // batch_idx is caller-owned pageable memory
-        *Xd = X;
-        *rows_d = h->idx.as<msm_idx_t>();
+        if ((rc = h->xb.reserve((size_t)B * h->m * sizeof(float)))) return rc;
+        hipLaunchKernelGGL(mbk_gather_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
+                           (long long)B, (long long)h->m, h->xb.as<float>());
+        MSM_HIP_CHECK(hipGetLastError());
+        *Xd = h->xb.as<float>();
+        *rows_d = nullptr;
     } else {
         std::vector<float> xb((size_t)B * h->m);
         for (msm_idx_t b = 0; b < B; ++b)
@@ -1347,13 +1649,19 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
     st0[5] = 0.0;
     MSM_HIP_CHECK(hipMemcpyAsync(st, st0, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, 2 * sizeof(int), stream()));
+    // all S batches into one compact buffer (one launch), so that a step's kernels read contiguous rows
+    if ((rc = h->xb.reserve((size_t)S * B * h->m * sizeof(float)))) return rc;
+    hipLaunchKernelGGL(mbk_gather_kernel, dim3((unsigned)ceil_div(S * B, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
+                       (long long)(S * B), (long long)h->m, h->xb.as<float>());
+    MSM_HIP_CHECK(hipGetLastError());
     for (msm_idx_t s = 0; s < S; ++s) {
-        const msm_idx_t* rows_d = h->idx.as<msm_idx_t>() + (size_t)s * B;
+        const float* Xs_ = h->xb.as<float>() + (size_t)s * B * h->m;
+        const msm_idx_t* rows_d = nullptr;
         int nb = 0;
-        if ((rc = mbk_label(h, X, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
+        if ((rc = mbk_label(h, Xs_, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
         KmArgs P;
         memset(&P, 0, sizeof(P));
-        P.X = X;
+        P.X = Xs_;
         P.rows = rows_d;
         P.n = B;
         P.m = h->m;
