@@ -728,16 +728,29 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
         const float* x = P.X + r * P.m;
         int lab;
         if (nsplit > 1) {  // uniform over the wave
-            float bv = P.pv[i];
-            int bi = P.pi[i];
-            for (int q = 1; q < nsplit; ++q) {
-                const float v = P.pv[(long long)q * P.n + i];
-                const int ix = P.pi[(long long)q * P.n + i];
-                if (v < bv || (v == bv && ix < bi)) {
+            // lane q fetches split q's candidate (one round trip, not nsplit of them), then a butterfly: lowest (value, index)
+            float bv = INFINITY;
+            int bi = 0x7fffffff;
+            for (int q0 = 0; q0 < nsplit; q0 += 64) {
+                const int q = q0 + lane;
+                const int qc = q < nsplit ? q : nsplit - 1;
+                const float v = P.pv[(long long)qc * P.n + i];
+                const int ix = P.pi[(long long)qc * P.n + i];
+                if (q < nsplit && (v < bv || (v == bv && ix < bi))) {
                     bv = v;
                     bi = ix;
                 }
             }
+#pragma unroll
+            for (int msk = 32; msk > 0; msk >>= 1) {
+                const float ov = __shfl_xor(bv, msk, 64);
+                const int oi = __shfl_xor(bi, msk, 64);
+                if (ov < bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (bi == 0x7fffffff) bi = 0;  // all-NaN row: sklearn's argmin returns 0
             lab = bi;
             if (lane == 0) P.labels[i] = bi;
         } else {
@@ -948,9 +961,12 @@ __global__ __launch_bounds__(KNT) void mbk_small_label_kernel(KmArgs P, SmallArg
     const long long i = rb * 64 + lane;
     const long long ic = i < P.n ? i : P.n - 1;
     const long long r = P.rows ? P.rows[ic] : ic;
-    float x[MP];
+    float x[MP];  // unconditional loads at clamped columns, masked afterwards (a load under a select is waited for at once)
 #pragma unroll
-    for (int f = 0; f < MP; ++f) x[f] = f < m ? P.X[r * P.m + f] : 0.f;
+    for (int f = 0; f < MP; ++f) x[f] = P.X[r * P.m + (f < m ? f : m - 1)];
+#pragma unroll
+    for (int f = 0; f < MP; ++f)
+        if (f >= m) x[f] = 0.f;
     const long long j0 = (long long)sp * S.cper;
     const int nc = (int)(P.K - j0 < S.cper ? P.K - j0 : S.cper);
     for (int e = tid; e < nc * MP; e += KNT) {
