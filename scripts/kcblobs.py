@@ -14,4 +14,4 @@ for _ in range(4):
     kc = KCenters(n_clusters=200, random_state=0).fit([Z])
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
 print("40 blobs: KCenters(200).fit 10M x 10 f64: %.2f ms (MSM_KC_SORTED=%s MSM_KC_SORT=%s) inertia %.9e ids[:4] %s" % (
-    1e3 * min(ts[1:]), os.environ.get("MSM_KC_SORTED", "1"), os.environ.get("MSM_KC_SORT", "default"), kc.inertia_, kc.cluster_ids_[:4]))
+    1e3 * min(ts[1:]), os.environ.get("MSM_KC_SORTED", "0"), os.environ.get("MSM_KC_SORT", "default"), kc.inertia_, kc.cluster_ids_[:4]))

@@ -46,3 +46,11 @@ pmc pmc_kernels_fetch "FETCH_SIZE" $K
 pmc pmc_kernels_write "WRITE_SIZE" $K
 pmc pmc_kernels_busy "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" $K
 grep -h "ms" $OUT/kernels_log.txt | grep -v rocprof | head -20
+# second pass of the round: the exact wide assign kernel's issue mix, the MiniBatchKMeans step kernels, per-pass k-centers times
+W="python $ROOT/scripts/assignwide.py"
+pmc pmc_wide_assign_a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" $W
+pmc pmc_wide_assign_b "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" $W
+stats mbk_step_F10 python $ROOT/scripts/mbkprof_small.py
+stats mbk_step_F512 python $ROOT/scripts/mbkprof512.py
+python $ROOT/scripts/assignperf.py 2>&1 | grep assign_nearest > $OUT/assignperf.txt; cat $OUT/assignperf.txt
+
