@@ -328,6 +328,7 @@ struct KcArgs {
     double* cand_out;         // [2 + m]
     long long row_offset;
     unsigned* counter;        // zero before the first pass; the last block resets it
+    unsigned long long* stat; // optional: += rows settled by the pruning test in this pass (register path)
 };
 
 // Exact pruning of a k-centers pass.  A row i at distance dist_i from its centre c_l cannot move to the new centre c when
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
 
     double bv = -1.0;
     long long bi = -1;
+    unsigned nskip = 0;  // rows this thread settled by the pruning test
     const long long ntile = (P.n + DT - 1) / DT;
     __shared__ double Dc[(IsNormMetric<M>::V && REG) ? KC_PRUNE_MAX : 1];  // d(new centre, centre j) for the pruning test
     const bool prune = REG && IsNormMetric<M>::V && P.prune && P.it > 0;
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
                 double cur = P.dist[i];
                 const long long lab = P.labels[i];
                 const bool skip = lab < nprev && Dc[(IsNormMetric<M>::V && REG && lab < nprev) ? lab : 0] >= PruneMargin<T>::F * cur;
+                nskip += skip ? 1 : 0;
                 if (!skip) {
                     T x[FC];
                     load_row_regs<T>(x, X + i * P.m, (int)P.m, P.vecw);
@@ -505,6 +508,16 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
                 bi = i;
             }
         }
+    }
+    if (P.stat) {  // uniform: how many rows the pruning test settled (the host picks the kernel of the later passes by it)
+        rv[tid] = (double)nskip;
+        __syncthreads();
+        for (int s = DT / 2; s > 0; s >>= 1) {
+            if (tid < s) rv[tid] += rv[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0 && rv[0] > 0.0) atomicAdd(P.stat, (unsigned long long)rv[0]);
+        __syncthreads();
     }
     rv[tid] = bv;
     ri[tid] = bi;
@@ -1429,6 +1442,294 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
 }
 
 // ---------------------------------------------------------------------------
+// k-centers pass with a float32 SCREEN (single GPU, float64 rows in registers, euclidean).
+//
+// A pass is HBM-bound: per row the float64 coordinates (80 B at m = 10), distances_ (8 B) and, for the pruning test,
+// labels_ (8 B).  But from the second pass on almost no row changes -- the new centre takes the rows near it -- and to
+// know that a row does NOT change an approximate distance is enough.  Pass 0 writes, beside distances_/labels_, a float32
+// copy of the rows and `curf` = distances_ rounded UP to float32, and records G = max ||x||.  A later pass reads only the
+// float32 row and curf (44 B) and evaluates d~ = ||x~ - y|| in float64 (y exact):
+//     | d~ - d | <= ||x~ - x|| <= 2^-24 ||x|| <= 2^-24 G =: eps      (round-to-nearest float32, triangle inequality)
+// so  d~ - eps >= curf >= distances_  proves  d >= distances_: the reference's strict `d < distances_` (kcenters.py:93) is
+// false and the row is left alone.  Every other row -- the candidates -- is re-evaluated from its float64 coordinates with
+// the exact arithmetic of kcenters_pass_kernel and updated by the exact comparison: bit-identical labels_/distances_.
+// (eps carries 1.001 x and an absolute 1e-37 for float32 underflow; the float64 rounding of d~ is 1e-9 of that margin.
+//  Non-finite data make G, hence eps, non-finite: no row passes the screen and the pass is the exact one.)
+// Argmax for the next centre: curf_i > curf_j implies distances_i > distances_j (curf is a monotone rounding and a strictly
+// larger float32 value lies above the other's whole rounding interval), so a thread tracks its best row by curf and looks
+// at the float64 values only on an exact float32 tie; the block reduction then uses the float64 value of each thread's
+// winner -- numpy's argmax (largest, lowest row on ties), as in the plain kernel.
+// ---------------------------------------------------------------------------
+struct KscArgs {
+    const double* X;
+    float* xf;                    // [n][m] float32 copy of the rows (written by pass 0)
+    float* curf;                  // [n] distances_ rounded up to float32
+    unsigned long long* gmax2;    // bits of max ||x||^2 (non-negative doubles order like their bits)
+    long long n, m;
+    int it, nblk, vecw;
+    long long seed;
+    const KcPartial* prev;
+    KcPartial* next;
+    double* dist;
+    msm_idx_t* labels;
+    msm_idx_t* ids;
+};
+
+__device__ __forceinline__ float ksc_round_up(double c)
+{
+    float f = (float)c;
+    if ((double)f < c) f = __uint_as_float(__float_as_uint(f) + 1u);  // c > 0 finite here: next float32 up
+    return f;
+}
+
+template <int NP>  // float32 row = NP pairs (m rounded up to even, zero padded)
+__global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
+{
+    constexpr int FC = FeatChunk<double>::FC;  // 16
+    constexpr int R = 2;                       // rows per thread and tile
+    __shared__ double ys[FC];
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    const int tid = threadIdx.x;
+    const int m = (int)P.m;
+
+    // ---- prologue: centre of this pass = argmax of the previous pass's per-block candidates ----
+    long long cidx = P.seed;
+    if (P.it > 0) {
+        double fv = -1.0;
+        long long fi = 0x7fffffffffffffffLL;
+        for (int k = tid; k < P.nblk; k += DT) {
+            const KcPartial q = P.prev[k];
+            if (q.i >= 0 && kc_better(q.v, q.i, fv, fi)) {
+                fv = q.v;
+                fi = q.i;
+            }
+        }
+        rv[tid] = fv;
+        ri[tid] = fi;
+        __syncthreads();
+        for (int k = DT / 2; k > 0; k >>= 1) {
+            if (tid < k && kc_better(rv[tid + k], ri[tid + k], rv[tid], ri[tid])) {
+                rv[tid] = rv[tid + k];
+                ri[tid] = ri[tid + k];
+            }
+            __syncthreads();
+        }
+        cidx = ri[0];
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
+    if (tid < FC) ys[tid] = tid < m ? P.X[cidx * P.m + tid] : 0.0;
+    __syncthreads();
+    double eps = 0.0;
+    if (P.it > 0) {
+        const double g2 = __longlong_as_double((long long)*P.gmax2);
+        eps = sqrt(g2) * (0x1p-24 * 1.001) + 1e-37;
+        if (!(g2 < 1e76)) eps = NAN;  // rows beyond the float32 range (or non-finite): nothing passes the screen
+    }
+    double yr[2 * NP];  // the centre in registers
+#pragma unroll
+    for (int f = 0; f < 2 * NP; ++f) yr[f] = ys[f];
+
+    // this thread's argmax candidate: by curf; the float64 value is fetched on exact float32 ties and at the end
+    float bf = -1.f;
+    long long bi = -1;
+    double bx = 0.0;
+    bool bknown = false;
+    double gloc = 0.0;  // pass 0: largest ||x||^2 seen by this thread
+    const long long ntile = (P.n + (long long)R * DT - 1) / ((long long)R * DT);
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        float cf[R];
+        bool cand[R];
+        long long pr[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) pr[k] = t * (R * DT) + k * DT + tid;
+        if (P.it > 0) {
+            // screen: all loads of the tile first (unconditional, clamped rows), then the arithmetic
+            float2 q[R][NP];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const long long pc = pr[k] < P.n ? pr[k] : P.n - 1;
+                const float2* xr = reinterpret_cast<const float2*>(P.xf + pc * (2 * NP));
+#pragma unroll
+                for (int j = 0; j < NP; ++j) q[k][j] = xr[j];
+                cf[k] = P.curf[pc];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double d0 = (double)q[k][j].x - yr[2 * j], d1 = (double)q[k][j].y - yr[2 * j + 1];
+                    a = fma(d0, d0, a);
+                    a = fma(d1, d1, a);
+                }
+                cand[k] = pr[k] < P.n && !(sqrt(a) - eps >= (double)cf[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                cand[k] = pr[k] < P.n;
+                cf[k] = 0.f;
+            }
+        }
+        bool anyc = false;
+#pragma unroll
+        for (int k = 0; k < R; ++k) anyc = anyc || cand[k];
+        if (anyc) {
+            // exact evaluation from the float64 rows (the arithmetic of kcenters_pass_kernel).  A lane with a candidate
+            // loads all of its R rows at once (clamped): one round trip, not one per candidate
+            double x[R][FC], cur[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const long long pc = pr[k] < P.n ? pr[k] : P.n - 1;
+                load_row_regs<double>(x[k], P.X + pc * P.m, m, P.vecw);
+                cur[k] = P.dist[pc];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (cand[k]) {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int g = 0; g < FC / 4; ++g)
+                        if (g * 4 < m) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m_update<double, M_EUCLIDEAN>(a, b, x[k][g * 4 + e], ys[g * 4 + e]);
+                        }
+                    const double d = m_final<M_EUCLIDEAN>(a, b, P.m);
+                    double c = (P.it == 0) ? INFINITY : cur[k];  // distances_.fill(inf), kcenters.py:87-88
+                    const bool upd = d < c;                      // strict, kcenters.py:93
+                    if (upd) c = d;
+                    if (P.it == 0 || upd) {
+                        P.dist[pr[k]] = c;
+                        P.labels[pr[k]] = upd ? P.it : 0;
+                        cf[k] = ksc_round_up(c);
+                        P.curf[pr[k]] = cf[k];
+                    }
+                    if (P.it == 0) {
+                        double n2 = 0.0;
+                        float* xo = P.xf + pr[k] * (2 * NP);
+#pragma unroll
+                        for (int f = 0; f < 2 * NP; ++f) {
+                            xo[f] = f < m ? (float)x[k][f] : 0.f;
+                            if (f < m) n2 = fma(x[k][f], x[k][f], n2);
+                        }
+                        if (gloc == gloc && (n2 > gloc || n2 != n2)) gloc = n2;  // a NaN sticks
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const long long p = pr[k];
+            if (p < P.n) {
+                if (cf[k] > bf || bi < 0) {
+                    bf = cf[k];
+                    bi = p;
+                    bknown = false;
+                } else if (cf[k] == bf) {  // same float32 image: the float64 values decide (rows come in ascending order)
+                    if (!bknown) {
+                        bx = P.dist[bi];
+                        bknown = true;
+                    }
+                    const double v = P.dist[p];
+                    if (v > bx) {
+                        bx = v;
+                        bi = p;
+                    }
+                }
+            }
+        }
+    }
+    if (P.it == 0) {
+        unsigned long long gb = (gloc == gloc) ? (unsigned long long)__double_as_longlong(gloc) : 0x7ff8000000000000ull;
+        rv[tid] = __longlong_as_double((long long)gb);
+        __syncthreads();
+        for (int k = DT / 2; k > 0; k >>= 1) {
+            if (tid < k) {
+                const unsigned long long o = (unsigned long long)__double_as_longlong(rv[tid + k]);
+                const unsigned long long c = (unsigned long long)__double_as_longlong(rv[tid]);
+                if (o > c) rv[tid] = rv[tid + k];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) atomicMax(P.gmax2, (unsigned long long)__double_as_longlong(rv[0]));
+        __syncthreads();
+    }
+    // block argmax on the float64 values of the threads' winners
+    double bvx = -1.0;
+    if (bi >= 0) bvx = bknown ? bx : P.dist[bi];
+    rv[tid] = bvx;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (tid < k) {
+            const long long oi = ri[tid + k];
+            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + k], oi, rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + k];
+                ri[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        KcPartial q;
+        q.v = rv[0];
+        q.i = ri[0];
+        P.next[blockIdx.x] = q;
+    }
+}
+
+// switch-over from the plain kernel: float32 row copy, rounded-up distances and max ||x||^2 from the current state
+template <int NP>
+__global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
+{
+    __shared__ double rv[DT];
+    const int tid = threadIdx.x, m = (int)P.m;
+    double gloc = 0.0;
+    for (long long p = (long long)blockIdx.x * DT + tid; p < P.n; p += (long long)gridDim.x * DT) {
+        const double* x = P.X + p * P.m;
+        float* xo = P.xf + p * (2 * NP);
+        double n2 = 0.0;
+#pragma unroll
+        for (int f = 0; f < 2 * NP; ++f) {
+            const double v = x[f < m ? f : m - 1];
+            xo[f] = f < m ? (float)v : 0.f;
+            if (f < m) n2 = fma(v, v, n2);
+        }
+        if (gloc == gloc && (n2 > gloc || n2 != n2)) gloc = n2;  // a NaN sticks
+        P.curf[p] = ksc_round_up(P.dist[p]);
+    }
+    const unsigned long long gb = (gloc == gloc) ? (unsigned long long)__double_as_longlong(gloc) : 0x7ff8000000000000ull;
+    rv[tid] = __longlong_as_double((long long)gb);
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (tid < k) {
+            const unsigned long long o = (unsigned long long)__double_as_longlong(rv[tid + k]);
+            const unsigned long long c = (unsigned long long)__double_as_longlong(rv[tid]);
+            if (o > c) rv[tid] = rv[tid + k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) atomicMax(P.gmax2, (unsigned long long)__double_as_longlong(rv[0]));
+}
+
+static bool ksc_enabled()
+{
+    static const bool on = !(getenv("MSM_KC_SCREEN") && atoi(getenv("MSM_KC_SCREEN")) == 0);  // A/B switch
+    return on;
+}
+
+struct KscBufs {
+    DevBuf xf, curf, misc;
+};
+static KscBufs& ksc_bufs()
+{
+    static KscBufs b;
+    return b;
+}
+
+// ---------------------------------------------------------------------------
 // Label-sorted k-centers (single GPU, rows in registers, norm metrics).
 //
 // The per-row triangle-inequality test above saves arithmetic, not bytes: rows that cannot change are scattered through
@@ -1922,8 +2223,76 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     KcPartial* part = dPart.as<KcPartial>();
     const bool sorted = ks_enabled() && P.prune && P.vecw > 0 && K <= KC_PRUNE_MAX && K >= 16 && n >= (1 << 18) &&
                         (mid == M_EUCLIDEAN || mid == M_CITYBLOCK || mid == M_CHEBYSHEV);
+    const bool screen = !sorted && ksc_enabled() && sizeof(T) == 8 && mid == M_EUCLIDEAN && P.vecw > 0 && n >= 65536 && K > 24;
     if (sorted) {
         if ((rc = kcenters_sorted_run<T>(mid, static_cast<const T*>(P.X), n, m, K, seed, P.vecw, P.ids, P.labels, P.dist))) return rc;
+    } else if (screen) {
+        // Plain passes (exact per-row pruning) first; after KSC_PROBE of them the share of rows the pruning test settles says
+        // what kind of data this is: clustered (most rows pruned: the plain kernel skips their coordinates) or not (the
+        // float32 screen halves the bytes of every later pass).  One 8-byte read-back per fit.
+        static const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 16;
+        KscBufs& B = ksc_bufs();
+        const int np = (int)((m + 1) / 2);
+        if ((rc = B.misc.reserve(64))) return rc;
+        MSM_HIP_CHECK(hipMemsetAsync(B.misc.p, 0, 64, stream()));
+        unsigned long long* stat = B.misc.as<unsigned long long>() + 1;
+        msm_idx_t it = 0;
+        for (; it < K && it < KSC_PROBE; ++it) {
+            P.it = (int)it;
+            P.prev = part + (size_t)((it + 1) & 1) * nblk;
+            P.next = part + (size_t)(it & 1) * nblk;
+            P.stat = (it == KSC_PROBE - 1) ? stat : nullptr;
+            launch_kc<T>(mid, nblk, P);
+        }
+        P.stat = nullptr;
+        bool use_screen = false;
+        if (it < K) {
+            unsigned long long pruned = 0;
+            MSM_HIP_CHECK(hipMemcpyAsync(&pruned, stat, sizeof(pruned), hipMemcpyDeviceToHost, stream()));
+            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+            use_screen = !P.prune || 2 * pruned < (unsigned long long)n;
+        }
+        if (use_screen) {
+            if ((rc = B.xf.reserve((size_t)n * 2 * np * sizeof(float)))) return rc;
+            if ((rc = B.curf.reserve((size_t)n * sizeof(float)))) return rc;
+            KscArgs S;
+            memset(&S, 0, sizeof(S));
+            S.X = reinterpret_cast<const double*>(P.X);
+            S.xf = B.xf.as<float>();
+            S.curf = B.curf.as<float>();
+            S.gmax2 = B.misc.as<unsigned long long>();
+            S.n = n;
+            S.m = m;
+            S.nblk = nblk;
+            S.vecw = P.vecw;
+            S.seed = seed;
+            S.dist = P.dist;
+            S.labels = P.labels;
+            S.ids = P.ids;
+            const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
+            switch (np) {
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL(ksc_convert_kernel<NP_>, dim3(gconv), dim3(DT), 0, stream(), S); break;
+                MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
+#undef MSM_KSC
+            }
+            for (; it < K; ++it) {
+                S.it = (int)it;
+                S.prev = part + (size_t)((it + 1) & 1) * nblk;
+                S.next = part + (size_t)(it & 1) * nblk;
+                switch (np) {
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL(kcenters_screen_pass_kernel<NP_>, dim3(nblk), dim3(DT), 0, stream(), S); break;
+                    MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
+#undef MSM_KSC
+                }
+            }
+        } else {
+            for (; it < K; ++it) {
+                P.it = (int)it;
+                P.prev = part + (size_t)((it + 1) & 1) * nblk;
+                P.next = part + (size_t)(it & 1) * nblk;
+                launch_kc<T>(mid, nblk, P);
+            }
+        }
     } else
     for (msm_idx_t it = 0; it < K; ++it) {
         P.it = (int)it;

@@ -9,7 +9,7 @@ grep -v rocprofv3 $OUT/log.txt | tail -3
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "kcenters_pass_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if ("kcenters_pass_kernel" in r["Kernel_Name"] or "kcenters_screen_pass_kernel" in r["Kernel_Name"])]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 print("pass kernels:", len(d))
 fit = d[:200]
