@@ -177,6 +177,35 @@ def test_kcenters_label_sorted_path_clustered(gpu, metric, dtype, monkeypatch):
     assert m.inertia_ == np.sum(dist)
 
 
+@pytest.mark.parametrize("case", ["plain", "offset", "beyond_float32", "nan_row"])
+@pytest.mark.parametrize("m", [3, 10, 16])
+def test_kcenters_float32_screened_passes(gpu, case, m):
+    """float64 rows, euclidean, unclustered data: after 16 plain passes the fit continues with float32-SCREENED passes (a
+    float32 row copy + distances rounded up decide which rows cannot change; the others are re-evaluated exactly).  Bit for
+    bit against the C oracle, with duplicate rows (float32-image ties in the argmax), a large common offset (a screen
+    margin comparable to the distances: most rows become candidates), rows outside the float32 range (the screen must
+    switch itself off) and a NaN row (never assigned, distance stays inf)."""
+    from msmbuilder_amd import KCenters
+    from oracle.libdistance_oracle import Oracle
+    o = Oracle()
+    rs = np.random.RandomState(m)
+    n, k = 100_003, 64
+    Y = rs.randn(n, m)
+    Y[2000:2030] = Y[11]
+    Y[90_000:90_004] = Y[54_321]
+    if case == "offset":
+        Y += 3.0e6
+    elif case == "beyond_float32":
+        Y[777] = 1.0e39
+    elif case == "nan_row":
+        Y[4242, 0] = np.nan
+    m_ = KCenters(n_clusters=k, random_state=2).fit([Y[:40_000], Y[40_000:]])
+    ids, labels, dist = o.kcenters_fit(Y, k, "euclidean", m_.cluster_ids_[0])
+    assert m_.cluster_ids_ == list(ids)
+    assert np.array_equal(np.concatenate(m_.labels_), labels)
+    assert np.array_equal(np.concatenate(m_.distances_), dist)
+
+
 def test_assign_nearest_1M_device_resident_properties(gpu):
     from msmbuilder_amd import libdistance as ld
     g = torch.Generator(device="cuda").manual_seed(1)
