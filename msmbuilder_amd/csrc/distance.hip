@@ -1579,23 +1579,34 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         if (anyc) {
             // exact evaluation from the float64 rows (the arithmetic of kcenters_pass_kernel).  A lane with a candidate
             // loads all of its R rows at once (clamped): one round trip, not one per candidate
-            double x[R][FC], cur[R];
+            double x[R][2 * NP], cur[R];  // (2 NP values, not FC: registers decide the occupancy of this kernel)
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const long long pc = pr[k] < P.n ? pr[k] : P.n - 1;
-                load_row_regs<double>(x[k], P.X + pc * P.m, m, P.vecw);
+                const double* xp = P.X + pc * P.m;
+                if (P.vecw == 16 && (m & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        const raw_f32x4 v = *reinterpret_cast<const raw_f32x4*>(xp + 2 * j);
+                        x[k][2 * j] = reinterpret_cast<const double*>(&v)[0];
+                        x[k][2 * j + 1] = reinterpret_cast<const double*>(&v)[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 2 * NP; ++f) x[k][f] = xp[f < m ? f : m - 1];
+#pragma unroll
+                    for (int f = 0; f < 2 * NP; ++f)
+                        if (f >= m) x[k][f] = 0.0;
+                }
                 cur[k] = P.dist[pc];
             }
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 if (cand[k]) {
+                    // zero padding is exact (a 0 - 0 pair adds nothing); features in order, one accumulator: kcenters_pass_kernel's sum
                     double a = 0.0, b = 0.0;
 #pragma unroll
-                    for (int g = 0; g < FC / 4; ++g)
-                        if (g * 4 < m) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) m_update<double, M_EUCLIDEAN>(a, b, x[k][g * 4 + e], ys[g * 4 + e]);
-                        }
+                    for (int f = 0; f < 2 * NP; ++f) m_update<double, M_EUCLIDEAN>(a, b, x[k][f], yr[f]);
                     const double d = m_final<M_EUCLIDEAN>(a, b, P.m);
                     double c = (P.it == 0) ? INFINITY : cur[k];  // distances_.fill(inf), kcenters.py:87-88
                     const bool upd = d < c;                      // strict, kcenters.py:93
