@@ -312,11 +312,12 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
             if hit:
                 break
         S = len(plan)
-        idx = np.empty((S, B), dtype=np.int64)
-        states = []
-        for k in range(S):
-            idx[k] = random_state.randint(0, n_samples, B)
-            states.append(random_state.get_state() if k + 1 < S else None)
+        # the S batches in ONE call: legacy RandomState.randint draws element by element from the bit stream, so this is
+        # the same stream (and leaves the same state) as scikit-learn's S calls of size B -- checked by the n_steps_ /
+        # generator-state comparisons against scikit-learn in the tests; S calls + S state snapshots cost 0.47 ms per run
+        # on the host, more than the run's 0.23 ms on the GPU
+        state0 = random_state.get_state()
+        idx = np.ascontiguousarray(random_state.randint(0, n_samples, (S, B)), dtype=np.int64)
         alpha = min(B * 2.0 / (n_samples + 1), 1)
         st = np.array([self._ewa_inertia or 0.0, self._ewa_inertia_min or 0.0, float(self._no_improvement),
                        0.0 if self._ewa_inertia is None else 1.0, 0.0 if self._ewa_inertia_min is None else 1.0, 0.0])
@@ -333,8 +334,9 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         if done == S and plan[-1]:
             self._n_since_last_reassign = 0
             self._reassign(ax, shard, idx[-1], random_state)
-        elif done < S:
-            random_state.set_state(states[done - 1])
+        elif done < S:  # the criterion fired early: leave the generator where scikit-learn would (rare: once per fit)
+            random_state.set_state(state0)
+            random_state.randint(0, n_samples, (done, B))
         return done, bool(conv.value)
 
     def _mbk_open(self, centers, counts):
