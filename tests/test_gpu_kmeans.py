@@ -128,3 +128,45 @@ def test_minibatch_queued_runs_equal_step_by_step(gpu, monkeypatch, K, B, mni):
     assert ref.n_steps_ == a[1]
     np.testing.assert_array_equal(gen.randint(0, 1 << 30, 4), a[3])
     np.testing.assert_allclose(a[2], ref.inertia_, rtol=1e-4)
+
+
+_STEP_AB = r"""
+import sys, hashlib, warnings
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from msmbuilder_amd import MiniBatchKMeans
+warnings.simplefilter("ignore")
+rs = np.random.RandomState(%(seed)d)
+K, F, N, B = %(K)d, %(F)d, 40000, %(B)d
+cent = rs.randn(K, F).astype(np.float32) * 2.0
+X = (cent[rs.randint(0, K, N)] + rs.randn(N, F).astype(np.float32)).astype(np.float32)
+m = MiniBatchKMeans(n_clusters=K, batch_size=B, max_iter=3, random_state=1, n_init=1, reassignment_ratio=0.01).fit([torch.from_numpy(X).cuda()])
+print("RESULT", m.n_steps_, hashlib.sha256(np.ascontiguousarray(m.cluster_centers_).tobytes()).hexdigest(),
+      hashlib.sha256(m.labels_[0].cpu().numpy().tobytes()).hexdigest(), repr(float(m.inertia_)))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,F,B", [(100, 64, 300), (257, 512, 1024), (40, 10, 1000)])
+def test_small_batch_step_kernels_equal_general_kernels(gpu, K, F, B):
+    """The small-batch step kernels are drop-ins for the general ones: the 64 x 64 label tiles use kmeans_label_v4_kernel's
+    feature order (bit-identical dot products, hence labels) and the wave-per-centre update adds a centre's members in
+    batch order like the workgroup-per-centre one -- so a whole fit (centres, labels, step count, inertia) must be
+    bit-identical with either switched off.  The switches are read once per process: each variant runs in its own."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _STEP_AB % dict(root=root, seed=K + F, K=K, F=F, B=B)
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert out.returncode == 0 and lines, out.stderr[-2000:]
+        return lines[-1]
+
+    base = run({})
+    assert run({"MSM_MBK_UPDATE_WAVE": "0"}) == base
+    if F > 32:  # (rows of <= 32 features take mbk_small_label_kernel, whose fp32 summation order is its own)
+        assert run({"MSM_MBK_LABEL64": "0"}) == base
+        assert run({"MSM_MBK_SMALL": "0"}) == base
