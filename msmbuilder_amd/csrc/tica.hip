@@ -666,6 +666,21 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(flo
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
+// Wave priority around the half-step boundary: from the barrier until k-pair MSM_SYM_PRIO_OFF the wave runs at priority
+// MSM_SYM_PRIO, so its first fragment reads, its 8 global loads and its first MFMAs are issued ahead of the co-resident
+// workgroup's stream (which otherwise lets them through about once per MFMA).  Measured on one box, 10M x 512
+// (build variants side by side): off 51.1-51.7 ms; level 1 or 3, dropped at k-pair 2-4: 50.0-50.3 ms; held until k-pair 6
+// or raised again for the staging instructions at k-pairs 5-7: no gain (51.2 ms); raised for the exposed staging at a chunk's
+// start and for the slab merge: no gain either.
+#ifndef MSM_SYM_PRIO
+#define MSM_SYM_PRIO 1
+#endif
+#ifndef MSM_SYM_PRIO_OFF
+#define MSM_SYM_PRIO_OFF 4
+#endif
+#ifndef MSM_SYM_PRIO_ON2
+#define MSM_SYM_PRIO_ON2 99
+#endif
 template <bool PARTIAL>
 __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 {
@@ -872,11 +887,14 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     } else if (kk == 7) {
                         MSM_STORE_Y(b ^ 1)
                     }
+                    if (MSM_SYM_PRIO && kk == MSM_SYM_PRIO_OFF) __builtin_amdgcn_s_setprio(0);
+                    if (MSM_SYM_PRIO && kk == MSM_SYM_PRIO_ON2) __builtin_amdgcn_s_setprio(MSM_SYM_PRIO);
                     MSM_SYM_MFMAS
                 }
                 if (more && !fast) MSM_STAGE_EDGE(k1, b ^ 1)
                 PROF_MARK(2)
                 __syncthreads();  // buffer b ^ 1 is complete, buffer b is free
+                if (MSM_SYM_PRIO) __builtin_amdgcn_s_setprio(MSM_SYM_PRIO);  // first fragment reads + MFMAs of the new half-step first
                 PROF_MARK(3)
             }
         }
