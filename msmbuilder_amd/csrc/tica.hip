@@ -671,7 +671,8 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(flo
 // workgroup's stream (which otherwise lets them through about once per MFMA).  Measured on one box, 10M x 512
 // (build variants side by side): off 51.1-51.7 ms; level 1 or 3, dropped at k-pair 2-4: 50.0-50.3 ms; held until k-pair 6
 // or raised again for the staging instructions at k-pairs 5-7: no gain (51.2 ms); raised for the exposed staging at a chunk's
-// start and for the slab merge: no gain either.
+// start and for the slab merge: no gain either.  (Starting every other workgroup half a half-step late, so that the two
+// workgroups of a CU do not meet their barriers together, COSTS 1 ms: they are better off in lockstep.)
 #ifndef MSM_SYM_PRIO
 #define MSM_SYM_PRIO 1
 #endif
