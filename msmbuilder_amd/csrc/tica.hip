@@ -672,7 +672,8 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(flo
 // (build variants side by side): off 51.1-51.7 ms; level 1 or 3, dropped at k-pair 2-4: 50.0-50.3 ms; held until k-pair 6
 // or raised again for the staging instructions at k-pairs 5-7: no gain (51.2 ms); raised for the exposed staging at a chunk's
 // start and for the slab merge: no gain either.  (Starting every other workgroup half a half-step late, so that the two
-// workgroups of a CU do not meet their barriers together, COSTS 1 ms: they are better off in lockstep.)
+// workgroups of a CU do not meet their barriers together, COSTS 1 ms: they are better off in lockstep.  Moving the barrier
+// in front of the half-step's last quad of MFMAs, with the next half-step's first fragments read behind it: +1.5 ms.)
 #ifndef MSM_SYM_PRIO
 #define MSM_SYM_PRIO 1
 #endif
