@@ -434,6 +434,12 @@ __device__ __forceinline__ void stage_store32x(const Stage32<VEC4>& st, int unif
     stage_store32<VEC4, PARTIAL>(t, As, Bs, tid, ma, mb);
 }
 
+#ifndef MSM_CG_PRIO
+#define MSM_CG_PRIO 1
+#endif
+#ifndef MSM_CG_PRIO_OFF
+#define MSM_CG_PRIO_OFF 8
+#endif
 template <bool VEC4, bool PARTIAL>
 __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
 {
@@ -538,7 +544,11 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f32_kernel(TicaArgs P)
                 /* the step boundary too: before its last four MFMAs a step passes the barrier     */ \
                 /* (every wave has written step s+1's panel by then) and fetches the first          */ \
                 /* fragments of step s+1, so the next step starts without an LDS round trip        */ \
-                if (kk == BK32 / 2 - 1) __syncthreads();                                          \
+                if (kk == BK32 / 2 - 1) {                                                         \
+                    __syncthreads();                                                              \
+                    if (MSM_CG_PRIO) __builtin_amdgcn_s_setprio(MSM_CG_PRIO); /* as in the sum/difference kernel */ \
+                }                                                                                 \
+                if (MSM_CG_PRIO && kk == MSM_CG_PRIO_OFF) __builtin_amdgcn_s_setprio(0);          \
                 const float* An = (kk == BK32 / 2 - 1) ? Ab + (((BUF) ^ 1) - (BUF)) * (BK32 * TM) : Ab + (kk + 1) * 2 * TM; \
                 const float* Bn = (kk == BK32 / 2 - 1) ? Bb + (((BUF) ^ 1) - (BUF)) * (BK32 * TM) : Bb + (kk + 1) * 2 * TM; \
                 const float na0 = An[0], na1 = An[32];                                            \
