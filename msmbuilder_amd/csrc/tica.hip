@@ -1072,6 +1072,12 @@ __device__ __forceinline__ void stage_store64(const Stage64<TIn>& st, double* As
     }
 }
 
+#ifndef MSM_F64_PRIO
+#define MSM_F64_PRIO 1
+#endif
+#ifndef MSM_F64_PRIO_OFF
+#define MSM_F64_PRIO_OFF 1
+#endif
 template <typename TIn>
 __global__ __launch_bounds__(NT, 2) void tica_mfma_f64_kernel(TicaArgs P)
 {
@@ -1123,6 +1129,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f64_kernel(TicaArgs P)
             const double* Bb = Bs + (BUF) * (BK64 * P64) + kl * P64 + wc * 64 + cl;               \
             _Pragma("unroll") for (int kk = 0; kk < BK64 / 4; ++kk) {                             \
                 double a[4], b[4];                                                                \
+                if (MSM_F64_PRIO && kk == MSM_F64_PRIO_OFF) __builtin_amdgcn_s_setprio(0);        \
                 _Pragma("unroll") for (int bi = 0; bi < 4; ++bi) a[bi] = Ab[kk * 4 * P64 + bi * 16]; \
                 _Pragma("unroll") for (int bj = 0; bj < 4; ++bj) b[bj] = Bb[kk * 4 * P64 + bj * 16]; \
                 _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                  \
@@ -1132,6 +1139,7 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f64_kernel(TicaArgs P)
             if (s + 1 < nsteps)                                                                   \
                 stage_store64<TIn>(SNEXT, As + ((BUF) ^ 1) * (BK64 * P64), Bs + ((BUF) ^ 1) * (BK64 * P64), P.F, I0, J0, tid); \
             __syncthreads();                                                                      \
+            if (MSM_F64_PRIO) __builtin_amdgcn_s_setprio(MSM_F64_PRIO); /* as in the sum/difference kernel */ \
         }
         for (int s = 0; s < nsteps; s += 2) {
             MSM_TICA_STEP64(st0, st1, 0)
