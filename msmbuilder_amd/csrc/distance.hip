@@ -328,7 +328,6 @@ struct KcArgs {
     double* cand_out;         // [2 + m]
     long long row_offset;
     unsigned* counter;        // zero before the first pass; the last block resets it
-    unsigned long long* stat; // optional: += rows settled by the pruning test in this pass (register path)
 };
 
 // Exact pruning of a k-centers pass.  A row i at distance dist_i from its centre c_l cannot move to the new centre c when
@@ -420,7 +419,6 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
 
     double bv = -1.0;
     long long bi = -1;
-    unsigned nskip = 0;  // rows this thread settled by the pruning test
     const long long ntile = (P.n + DT - 1) / DT;
     __shared__ double Dc[(IsNormMetric<M>::V && REG) ? KC_PRUNE_MAX : 1];  // d(new centre, centre j) for the pruning test
     const bool prune = REG && IsNormMetric<M>::V && P.prune && P.it > 0;
@@ -451,7 +449,6 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
                 double cur = P.dist[i];
                 const long long lab = P.labels[i];
                 const bool skip = lab < nprev && Dc[(IsNormMetric<M>::V && REG && lab < nprev) ? lab : 0] >= PruneMargin<T>::F * cur;
-                nskip += skip ? 1 : 0;
                 if (!skip) {
                     T x[FC];
                     load_row_regs<T>(x, X + i * P.m, (int)P.m, P.vecw);
@@ -508,16 +505,6 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
                 bi = i;
             }
         }
-    }
-    if (P.stat) {  // uniform: how many rows the pruning test settled (the host picks the kernel of the later passes by it)
-        rv[tid] = (double)nskip;
-        __syncthreads();
-        for (int s = DT / 2; s > 0; s >>= 1) {
-            if (tid < s) rv[tid] += rv[tid + s];
-            __syncthreads();
-        }
-        if (tid == 0 && rv[0] > 0.0) atomicAdd(P.stat, (unsigned long long)rv[0]);
-        __syncthreads();
     }
     rv[tid] = bv;
     ri[tid] = bi;
@@ -1442,19 +1429,22 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
 }
 
 // ---------------------------------------------------------------------------
-// k-centers pass with a float32 SCREEN (single GPU, float64 rows in registers, euclidean).
+// k-centers pass with a low-precision SCREEN (single GPU, float64 rows in registers, euclidean).
 //
 // A pass is HBM-bound: per row the float64 coordinates (80 B at m = 10), distances_ (8 B) and, for the pruning test,
 // labels_ (8 B).  But from the second pass on almost no row changes -- the new centre takes the rows near it -- and to
-// know that a row does NOT change an approximate distance is enough.  Pass 0 writes, beside distances_/labels_, a float32
-// copy of the rows and `curf` = distances_ rounded UP to float32, and records G = max ||x||.  A later pass reads only the
-// float32 row and curf (44 B) and evaluates d~ = ||x~ - y|| in float64 (y exact):
-//     | d~ - d | <= ||x~ - x|| <= 2^-24 ||x|| <= 2^-24 G =: eps      (round-to-nearest float32, triangle inequality)
+// know that a row does NOT change an approximate distance is enough.  At the switch-over (ksc_convert_kernel) the rows
+// are copied once, CENTRED on the first centre c0 (distances are translation invariant; the copy's rounding error then
+// scales with the data's spread, not with its offset) and rounded to bfloat16 (u = 2^-9; float32, u = 2^-24, is the
+// MSM_KC_SCREEN=1 variant), together with `curf` = distances_ rounded UP to float32, G = max ||x - c0|| and R = max ||x||.
+// A later pass reads only that copy and curf (24 B per row at m = 10) and evaluates d~ = || x~ - (y - c0) || in float64:
+//     | d~ - d | <= || x~ - (x - c0) || + float64 rounding of the two centrings <= u G + 2^-48 (R + ||c0||) =: eps
 // so  d~ - eps >= curf >= distances_  proves  d >= distances_: the reference's strict `d < distances_` (kcenters.py:93) is
 // false and the row is left alone.  Every other row -- the candidates -- is re-evaluated from its float64 coordinates with
 // the exact arithmetic of kcenters_pass_kernel and updated by the exact comparison: bit-identical labels_/distances_.
-// (eps carries 1.001 x and an absolute 1e-37 for float32 underflow; the float64 rounding of d~ is 1e-9 of that margin.
-//  Non-finite data make G, hence eps, non-finite: no row passes the screen and the pass is the exact one.)
+// (eps carries 1.01 x on the first term and an absolute 1e-37 for underflow; the float64 rounding of d~ is 1e-6 of that
+//  margin.  Non-finite data, or data beyond the float32 range, make eps NaN: no row passes the screen and the pass is the
+//  exact one.)
 // Argmax for the next centre: curf_i > curf_j implies distances_i > distances_j (curf is a monotone rounding and a strictly
 // larger float32 value lies above the other's whole rounding interval), so a thread tracks its best row by curf and looks
 // at the float64 values only on an exact float32 tie; the block reduction then uses the float64 value of each thread's
@@ -1462,9 +1452,10 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
 // ---------------------------------------------------------------------------
 struct KscArgs {
     const double* X;
-    float* xf;                    // [n][m] float32 copy of the rows (written by pass 0)
+    void* xs;                     // screen copy of the rows: [n][2 NP] float32, or [n][NP] packed bfloat16 pairs
     float* curf;                  // [n] distances_ rounded up to float32
-    unsigned long long* gmax2;    // bits of max ||x||^2 (non-negative doubles order like their bits)
+    unsigned long long* gmax2;    // [0] bits of max ||x - c0||^2, [1] bits of max ||x||^2 (non-negative doubles order like their bits)
+    double* c0;                   // [16] the first centre (the copy's origin)
     long long n, m;
     int it, nblk, vecw;
     long long seed;
@@ -1482,7 +1473,14 @@ __device__ __forceinline__ float ksc_round_up(double c)
     return f;
 }
 
-template <int NP>  // float32 row = NP pairs (m rounded up to even, zero padded)
+__device__ __forceinline__ unsigned ksc_bf16_rne(float f)  // round-to-nearest-even bfloat16 image (upper 16 bits)
+{
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7f800000u) == 0x7f800000u) return u >> 16;  // inf / nan as they are
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int NP, bool BF16>  // screen row = NP pairs (m rounded up to even, zero padded)
 __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
 {
     constexpr int FC = FeatChunk<double>::FC;  // 16
@@ -1493,50 +1491,52 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     const int tid = threadIdx.x;
     const int m = (int)P.m;
 
-    // ---- prologue: centre of this pass = argmax of the previous pass's per-block candidates ----
-    long long cidx = P.seed;
-    if (P.it > 0) {
-        double fv = -1.0;
-        long long fi = 0x7fffffffffffffffLL;
-        for (int k = tid; k < P.nblk; k += DT) {
-            const KcPartial q = P.prev[k];
-            if (q.i >= 0 && kc_better(q.v, q.i, fv, fi)) {
-                fv = q.v;
-                fi = q.i;
-            }
+    // ---- prologue: centre of this pass = argmax of the previous pass's per-block candidates (P.it >= 1 here) ----
+    double fv = -1.0;
+    long long fi = 0x7fffffffffffffffLL;
+    for (int k = tid; k < P.nblk; k += DT) {
+        const KcPartial q = P.prev[k];
+        if (q.i >= 0 && kc_better(q.v, q.i, fv, fi)) {
+            fv = q.v;
+            fi = q.i;
         }
-        rv[tid] = fv;
-        ri[tid] = fi;
-        __syncthreads();
-        for (int k = DT / 2; k > 0; k >>= 1) {
-            if (tid < k && kc_better(rv[tid + k], ri[tid + k], rv[tid], ri[tid])) {
-                rv[tid] = rv[tid + k];
-                ri[tid] = ri[tid + k];
-            }
-            __syncthreads();
+    }
+    rv[tid] = fv;
+    ri[tid] = fi;
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (tid < k && kc_better(rv[tid + k], ri[tid + k], rv[tid], ri[tid])) {
+            rv[tid] = rv[tid + k];
+            ri[tid] = ri[tid + k];
         }
-        cidx = ri[0];
         __syncthreads();
     }
+    const long long cidx = ri[0];
+    __syncthreads();
     if (blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
     if (tid < FC) ys[tid] = tid < m ? P.X[cidx * P.m + tid] : 0.0;
     __syncthreads();
-    double eps = 0.0;
-    if (P.it > 0) {
-        const double g2 = __longlong_as_double((long long)*P.gmax2);
-        eps = sqrt(g2) * (0x1p-24 * 1.001) + 1e-37;
-        if (!(g2 < 1e76)) eps = NAN;  // rows beyond the float32 range (or non-finite): nothing passes the screen
-    }
-    double yr[2 * NP];  // the centre in registers
+    double yr[2 * NP], yc[2 * NP];  // the centre, and the centre relative to the copy's origin
+    double c0n2 = 0.0;
 #pragma unroll
-    for (int f = 0; f < 2 * NP; ++f) yr[f] = ys[f];
+    for (int f = 0; f < 2 * NP; ++f) {
+        yr[f] = ys[f];
+        const double c0f = f < m ? P.c0[f] : 0.0;
+        yc[f] = ys[f] - c0f;
+        c0n2 = fma(c0f, c0f, c0n2);
+    }
+    double eps;
+    {
+        const double g2 = __longlong_as_double((long long)P.gmax2[0]), r2 = __longlong_as_double((long long)P.gmax2[1]);
+        eps = sqrt(g2) * ((BF16 ? 0x1p-9 : 0x1p-24) * 1.01) + (sqrt(r2) + sqrt(c0n2)) * 0x1p-48 + 1e-37;
+        if (!(g2 < 1e76) || !(r2 < 1e76)) eps = NAN;  // rows beyond the float32 range (or non-finite): nothing passes the screen
+    }
 
     // this thread's argmax candidate: by curf; the float64 value is fetched on exact float32 ties and at the end
     float bf = -1.f;
     long long bi = -1;
     double bx = 0.0;
     bool bknown = false;
-    double gloc = 0.0;  // pass 0: largest ||x||^2 seen by this thread
     const long long ntile = (P.n + (long long)R * DT - 1) / ((long long)R * DT);
     for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
         float cf[R];
@@ -1544,15 +1544,25 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         long long pr[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) pr[k] = t * (R * DT) + k * DT + tid;
-        if (P.it > 0) {
+        {
             // screen: all loads of the tile first (unconditional, clamped rows), then the arithmetic
-            float2 q[R][NP];
+            constexpr int NW = BF16 ? NP : 2 * NP;  // 32-bit words per row of the copy
+            unsigned q[R][NW];
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const long long pc = pr[k] < P.n ? pr[k] : P.n - 1;
-                const float2* xr = reinterpret_cast<const float2*>(P.xf + pc * (2 * NP));
+                const unsigned* xr = static_cast<const unsigned*>(P.xs) + pc * NW;
+                if ((NW & 1) == 0) {
 #pragma unroll
-                for (int j = 0; j < NP; ++j) q[k][j] = xr[j];
+                    for (int j = 0; j < NW / 2; ++j) {
+                        const uint2 v = reinterpret_cast<const uint2*>(xr)[j];
+                        q[k][2 * j] = v.x;
+                        q[k][2 * j + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) q[k][j] = xr[j];
+                }
                 cf[k] = P.curf[pc];
             }
 #pragma unroll
@@ -1560,17 +1570,19 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
                 double a = 0.0;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
-                    const double d0 = (double)q[k][j].x - yr[2 * j], d1 = (double)q[k][j].y - yr[2 * j + 1];
+                    float x0, x1;
+                    if (BF16) {
+                        x0 = __uint_as_float(q[k][j] << 16);
+                        x1 = __uint_as_float(q[k][j] & 0xffff0000u);
+                    } else {
+                        x0 = __uint_as_float(q[k][2 * j]);
+                        x1 = __uint_as_float(q[k][2 * j + 1]);
+                    }
+                    const double d0 = (double)x0 - yc[2 * j], d1 = (double)x1 - yc[2 * j + 1];
                     a = fma(d0, d0, a);
                     a = fma(d1, d1, a);
                 }
                 cand[k] = pr[k] < P.n && !(sqrt(a) - eps >= (double)cf[k]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                cand[k] = pr[k] < P.n;
-                cf[k] = 0.f;
             }
         }
         bool anyc = false;
@@ -1608,24 +1620,11 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
 #pragma unroll
                     for (int f = 0; f < 2 * NP; ++f) m_update<double, M_EUCLIDEAN>(a, b, x[k][f], yr[f]);
                     const double d = m_final<M_EUCLIDEAN>(a, b, P.m);
-                    double c = (P.it == 0) ? INFINITY : cur[k];  // distances_.fill(inf), kcenters.py:87-88
-                    const bool upd = d < c;                      // strict, kcenters.py:93
-                    if (upd) c = d;
-                    if (P.it == 0 || upd) {
-                        P.dist[pr[k]] = c;
-                        P.labels[pr[k]] = upd ? P.it : 0;
-                        cf[k] = ksc_round_up(c);
+                    if (d < cur[k]) {  // strict, kcenters.py:93
+                        P.dist[pr[k]] = d;
+                        P.labels[pr[k]] = P.it;
+                        cf[k] = ksc_round_up(d);
                         P.curf[pr[k]] = cf[k];
-                    }
-                    if (P.it == 0) {
-                        double n2 = 0.0;
-                        float* xo = P.xf + pr[k] * (2 * NP);
-#pragma unroll
-                        for (int f = 0; f < 2 * NP; ++f) {
-                            xo[f] = f < m ? (float)x[k][f] : 0.f;
-                            if (f < m) n2 = fma(x[k][f], x[k][f], n2);
-                        }
-                        if (gloc == gloc && (n2 > gloc || n2 != n2)) gloc = n2;  // a NaN sticks
                     }
                 }
             }
@@ -1652,21 +1651,6 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
             }
         }
     }
-    if (P.it == 0) {
-        unsigned long long gb = (gloc == gloc) ? (unsigned long long)__double_as_longlong(gloc) : 0x7ff8000000000000ull;
-        rv[tid] = __longlong_as_double((long long)gb);
-        __syncthreads();
-        for (int k = DT / 2; k > 0; k >>= 1) {
-            if (tid < k) {
-                const unsigned long long o = (unsigned long long)__double_as_longlong(rv[tid + k]);
-                const unsigned long long c = (unsigned long long)__double_as_longlong(rv[tid]);
-                if (o > c) rv[tid] = rv[tid + k];
-            }
-            __syncthreads();
-        }
-        if (tid == 0) atomicMax(P.gmax2, (unsigned long long)__double_as_longlong(rv[0]));
-        __syncthreads();
-    }
     // block argmax on the float64 values of the threads' winners
     double bvx = -1.0;
     if (bi >= 0) bvx = bknown ? bx : P.dist[bi];
@@ -1691,45 +1675,76 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     }
 }
 
-// switch-over from the plain kernel: float32 row copy, rounded-up distances and max ||x||^2 from the current state
-template <int NP>
+// switch-over from the plain kernel: the centred screen copy, rounded-up distances, max ||x - c0||^2 and max ||x||^2
+template <int NP, bool BF16>
 __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
 {
     __shared__ double rv[DT];
+    __shared__ double rw[DT];
     const int tid = threadIdx.x, m = (int)P.m;
-    double gloc = 0.0;
+    constexpr int NW = BF16 ? NP : 2 * NP;
+    double c0[2 * NP];
+#pragma unroll
+    for (int f = 0; f < 2 * NP; ++f) c0[f] = f < m ? P.c0[f] : 0.0;
+    double gloc = 0.0, rloc = 0.0;
     for (long long p = (long long)blockIdx.x * DT + tid; p < P.n; p += (long long)gridDim.x * DT) {
         const double* x = P.X + p * P.m;
-        float* xo = P.xf + p * (2 * NP);
-        double n2 = 0.0;
+        unsigned* xo = static_cast<unsigned*>(P.xs) + p * NW;
+        double n2 = 0.0, r2 = 0.0;
+        float xc[2 * NP];
 #pragma unroll
         for (int f = 0; f < 2 * NP; ++f) {
             const double v = x[f < m ? f : m - 1];
-            xo[f] = f < m ? (float)v : 0.f;
-            if (f < m) n2 = fma(v, v, n2);
+            const double c = f < m ? v - c0[f] : 0.0;
+            xc[f] = (float)c;
+            if (f < m) {
+                n2 = fma(c, c, n2);
+                r2 = fma(v, v, r2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (BF16) {
+                xo[j] = ksc_bf16_rne(xc[2 * j]) | (ksc_bf16_rne(xc[2 * j + 1]) << 16);
+            } else {
+                xo[2 * j] = __float_as_uint(xc[2 * j]);
+                xo[2 * j + 1] = __float_as_uint(xc[2 * j + 1]);
+            }
         }
         if (gloc == gloc && (n2 > gloc || n2 != n2)) gloc = n2;  // a NaN sticks
+        if (rloc == rloc && (r2 > rloc || r2 != r2)) rloc = r2;
         P.curf[p] = ksc_round_up(P.dist[p]);
     }
     const unsigned long long gb = (gloc == gloc) ? (unsigned long long)__double_as_longlong(gloc) : 0x7ff8000000000000ull;
+    const unsigned long long rb = (rloc == rloc) ? (unsigned long long)__double_as_longlong(rloc) : 0x7ff8000000000000ull;
     rv[tid] = __longlong_as_double((long long)gb);
+    rw[tid] = __longlong_as_double((long long)rb);
     __syncthreads();
     for (int k = DT / 2; k > 0; k >>= 1) {
         if (tid < k) {
-            const unsigned long long o = (unsigned long long)__double_as_longlong(rv[tid + k]);
-            const unsigned long long c = (unsigned long long)__double_as_longlong(rv[tid]);
-            if (o > c) rv[tid] = rv[tid + k];
+            if ((unsigned long long)__double_as_longlong(rv[tid + k]) > (unsigned long long)__double_as_longlong(rv[tid])) rv[tid] = rv[tid + k];
+            if ((unsigned long long)__double_as_longlong(rw[tid + k]) > (unsigned long long)__double_as_longlong(rw[tid])) rw[tid] = rw[tid + k];
         }
         __syncthreads();
     }
-    if (tid == 0) atomicMax(P.gmax2, (unsigned long long)__double_as_longlong(rv[0]));
+    if (tid == 0) {
+        atomicMax(P.gmax2, (unsigned long long)__double_as_longlong(rv[0]));
+        atomicMax(P.gmax2 + 1, (unsigned long long)__double_as_longlong(rw[0]));
+    }
 }
 
-static bool ksc_enabled()
+// c0 = coordinates of the first centre (ids[0]), for the copy's origin
+__global__ void ksc_origin_kernel(const double* __restrict__ X, const msm_idx_t* __restrict__ ids, long long m, double* __restrict__ c0)
 {
-    static const bool on = !(getenv("MSM_KC_SCREEN") && atoi(getenv("MSM_KC_SCREEN")) == 0);  // A/B switch
-    return on;
+    if (threadIdx.x < 16) c0[threadIdx.x] = threadIdx.x < m ? X[ids[0] * m + threadIdx.x] : 0.0;
 }
+
+static int ksc_mode()  // MSM_KC_SCREEN: 0 = plain passes only, 1 = float32 screen copy, 2 (default) = bfloat16 screen copy
+{
+    static const int mode = getenv("MSM_KC_SCREEN") ? atoi(getenv("MSM_KC_SCREEN")) : 2;
+    return mode;
+}
+static bool ksc_enabled() { return ksc_mode() != 0; }
 
 struct KscBufs {
     DevBuf xf, curf, misc;
@@ -2234,44 +2249,40 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     KcPartial* part = dPart.as<KcPartial>();
     const bool sorted = ks_enabled() && P.prune && P.vecw > 0 && K <= KC_PRUNE_MAX && K >= 16 && n >= (1 << 18) &&
                         (mid == M_EUCLIDEAN || mid == M_CITYBLOCK || mid == M_CHEBYSHEV);
-    const bool screen = !sorted && ksc_enabled() && sizeof(T) == 8 && mid == M_EUCLIDEAN && P.vecw > 0 && n >= 65536 && K > 24;
+    const bool screen = !sorted && ksc_enabled() && sizeof(T) == 8 && mid == M_EUCLIDEAN && P.vecw > 0 && n >= 65536 && K > 8;
     if (sorted) {
         if ((rc = kcenters_sorted_run<T>(mid, static_cast<const T*>(P.X), n, m, K, seed, P.vecw, P.ids, P.labels, P.dist))) return rc;
     } else if (screen) {
-        // Plain passes (exact per-row pruning) first; after KSC_PROBE of them the share of rows the pruning test settles says
-        // what kind of data this is: clustered (most rows pruned: the plain kernel skips their coordinates) or not (the
-        // float32 screen halves the bytes of every later pass).  One 8-byte read-back per fit.
-        static const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 16;
+        // A few plain passes first (in the first passes most rows change, and a candidate costs the screen's bytes on top of
+        // the plain pass's), then the screened ones.  Measured on 10M x 10 float64, K = 200 (scripts/kcperf.py, kcblobs.py),
+        // plain / screened from pass 16 / from pass 4 / from pass 1: tICA projection 26.6 / 13.1 / 11.8 / 11.8 ms, white
+        // noise 33.7 / 15.1 / 13.3 / 17.6 ms, 40 separated blobs (where per-row pruning is at its best) 17.9 / 17.1 / 17.1 /
+        // 17.5 ms -- so no decision is needed.
+        static const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 4;
         KscBufs& B = ksc_bufs();
         const int np = (int)((m + 1) / 2);
-        if ((rc = B.misc.reserve(64))) return rc;
+        if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;  // [gmax2[2] | ... | c0[16]]
         MSM_HIP_CHECK(hipMemsetAsync(B.misc.p, 0, 64, stream()));
-        unsigned long long* stat = B.misc.as<unsigned long long>() + 1;
         msm_idx_t it = 0;
         for (; it < K && it < KSC_PROBE; ++it) {
             P.it = (int)it;
             P.prev = part + (size_t)((it + 1) & 1) * nblk;
             P.next = part + (size_t)(it & 1) * nblk;
-            P.stat = (it == KSC_PROBE - 1) ? stat : nullptr;
             launch_kc<T>(mid, nblk, P);
         }
-        P.stat = nullptr;
-        bool use_screen = false;
-        if (it < K) {
-            unsigned long long pruned = 0;
-            MSM_HIP_CHECK(hipMemcpyAsync(&pruned, stat, sizeof(pruned), hipMemcpyDeviceToHost, stream()));
-            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-            use_screen = !P.prune || 2 * pruned < (unsigned long long)n;
-        }
+        const bool use_screen = it < K;
         if (use_screen) {
-            if ((rc = B.xf.reserve((size_t)n * 2 * np * sizeof(float)))) return rc;
+            const bool bf16 = ksc_mode() != 1;
+            if ((rc = B.xf.reserve((size_t)n * (bf16 ? np : 2 * np) * sizeof(float)))) return rc;
             if ((rc = B.curf.reserve((size_t)n * sizeof(float)))) return rc;
             KscArgs S;
             memset(&S, 0, sizeof(S));
             S.X = reinterpret_cast<const double*>(P.X);
-            S.xf = B.xf.as<float>();
+            S.xs = B.xf.p;
             S.curf = B.curf.as<float>();
             S.gmax2 = B.misc.as<unsigned long long>();
+            S.c0 = reinterpret_cast<double*>(static_cast<char*>(B.misc.p) + 64);
+            hipLaunchKernelGGL(ksc_origin_kernel, dim3(1), dim3(64), 0, stream(), S.X, P.ids, (long long)m, S.c0);
             S.n = n;
             S.m = m;
             S.nblk = nblk;
@@ -2282,7 +2293,8 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
             S.ids = P.ids;
             const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
             switch (np) {
-#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL(ksc_convert_kernel<NP_>, dim3(gconv), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((ksc_convert_kernel<NP_, true>), dim3(gconv), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, false>), dim3(gconv), dim3(DT), 0, stream(), S); break;
                 MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
             }
@@ -2291,17 +2303,11 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                 S.prev = part + (size_t)((it + 1) & 1) * nblk;
                 S.next = part + (size_t)(it & 1) * nblk;
                 switch (np) {
-#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL(kcenters_screen_pass_kernel<NP_>, dim3(nblk), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, true>), dim3(nblk), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, false>), dim3(nblk), dim3(DT), 0, stream(), S); break;
                     MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                 }
-            }
-        } else {
-            for (; it < K; ++it) {
-                P.it = (int)it;
-                P.prev = part + (size_t)((it + 1) & 1) * nblk;
-                P.next = part + (size_t)(it & 1) * nblk;
-                launch_kc<T>(mid, nblk, P);
             }
         }
     } else

@@ -180,11 +180,11 @@ def test_kcenters_label_sorted_path_clustered(gpu, metric, dtype, monkeypatch):
 @pytest.mark.parametrize("case", ["plain", "offset", "beyond_float32", "nan_row"])
 @pytest.mark.parametrize("m", [3, 10, 16])
 def test_kcenters_float32_screened_passes(gpu, case, m):
-    """float64 rows, euclidean, unclustered data: after 16 plain passes the fit continues with float32-SCREENED passes (a
-    float32 row copy + distances rounded up decide which rows cannot change; the others are re-evaluated exactly).  Bit for
-    bit against the C oracle, with duplicate rows (float32-image ties in the argmax), a large common offset (a screen
-    margin comparable to the distances: most rows become candidates), rows outside the float32 range (the screen must
-    switch itself off) and a NaN row (never assigned, distance stays inf)."""
+    """float64 rows, euclidean: after 4 plain passes the fit continues with SCREENED passes (a bfloat16 copy of the rows,
+    centred on the first centre, + distances rounded up to float32 decide which rows cannot change; the others are
+    re-evaluated exactly).  Bit for bit against the C oracle, with duplicate rows (float32-image ties in the argmax), a large
+    common offset (what the centring is for), a row outside the float32 range (the screen must switch itself off) and a NaN
+    row (never assigned, distance stays inf)."""
     from msmbuilder_amd import KCenters
     from oracle.libdistance_oracle import Oracle
     o = Oracle()
