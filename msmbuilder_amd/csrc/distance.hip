@@ -1435,15 +1435,15 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
 // labels_ (8 B).  But from the second pass on almost no row changes -- the new centre takes the rows near it -- and to
 // know that a row does NOT change an approximate distance is enough.  At the switch-over (ksc_convert_kernel) the rows
 // are copied once, CENTRED on the first centre c0 (distances are translation invariant; the copy's rounding error then
-// scales with the data's spread, not with its offset) and rounded to bfloat16 (u = 2^-9; float32, u = 2^-24, is the
+// scales with the data's spread, not with its offset) and rounded to bfloat16 (u = 2^-8; float32, u = 2^-24, is the
 // MSM_KC_SCREEN=1 variant), together with `curf` = distances_ rounded UP to float32, G = max ||x - c0|| and R = max ||x||.
 // A later pass reads only that copy and curf (24 B per row at m = 10) and evaluates d~ = || x~ - (y - c0) || in float64:
-//     | d~ - d | <= || x~ - (x - c0) || + float64 rounding of the two centrings <= u G + 2^-48 (R + ||c0||) =: eps
+//     | d~ - d | <= || x~ - (x - c0) || + float64 rounding of the two centrings <= u/(1-u) ||x~|| + 2^-48 (R + ||c0||) =: eps
 // so  d~ - eps >= curf >= distances_  proves  d >= distances_: the reference's strict `d < distances_` (kcenters.py:93) is
 // false and the row is left alone.  Every other row -- the candidates -- is re-evaluated from its float64 coordinates with
 // the exact arithmetic of kcenters_pass_kernel and updated by the exact comparison: bit-identical labels_/distances_.
-// (eps carries 1.01 x on the first term and an absolute 1e-37 for underflow; the float64 rounding of d~ is 1e-6 of that
-//  margin.  Non-finite data, or data beyond the float32 range, make eps NaN: no row passes the screen and the pass is the
+// (eps carries 1.02 x on the first term and an absolute 1e-37 for underflow; the float64 rounding of d~ and the float32
+//  are 1e-9 of that margin.  Non-finite data, or data beyond the float32 range, make eps NaN: no row passes the screen and the pass is the
 //  exact one.)
 // Argmax for the next centre: curf_i > curf_j implies distances_i > distances_j (curf is a monotone rounding and a strictly
 // larger float32 value lies above the other's whole rounding interval), so a thread tracks its best row by curf and looks
@@ -1525,11 +1525,14 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         yc[f] = ys[f] - c0f;
         c0n2 = fma(c0f, c0f, c0n2);
     }
-    double eps;
+    // eps of a row = u' ||x~|| + eps0: ||x~ - (x - c0)|| <= u/(1-u) ||x~|| per row (tighter than u max||x - c0||: fewer false
+    // candidates), eps0 = the float64 roundings of the two centrings + an absolute term for underflow
+    constexpr double UREL = (BF16 ? 0x1p-8 : 0x1p-24) * 1.02;  // unit roundoff 2^-p: p = 8 significand bits for bfloat16, 24 for float32
+    double eps0;
     {
         const double g2 = __longlong_as_double((long long)P.gmax2[0]), r2 = __longlong_as_double((long long)P.gmax2[1]);
-        eps = sqrt(g2) * ((BF16 ? 0x1p-9 : 0x1p-24) * 1.01) + (sqrt(r2) + sqrt(c0n2)) * 0x1p-48 + 1e-37;
-        if (!(g2 < 1e76) || !(r2 < 1e76)) eps = NAN;  // rows beyond the float32 range (or non-finite): nothing passes the screen
+        eps0 = (sqrt(r2) + sqrt(c0n2)) * 0x1p-48 + 1e-37;
+        if (!(g2 < 1e76) || !(r2 < 1e76)) eps0 = NAN;  // rows beyond the float32 range (or non-finite): nothing passes the screen
     }
 
     // this thread's argmax candidate: by curf; the float64 value is fetched on exact float32 ties and at the end
@@ -1568,6 +1571,7 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 double a = 0.0;
+                double n2 = 0.0;  // ||x~||^2
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     float x0, x1;
@@ -1581,7 +1585,10 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
                     const double d0 = (double)x0 - yc[2 * j], d1 = (double)x1 - yc[2 * j + 1];
                     a = fma(d0, d0, a);
                     a = fma(d1, d1, a);
+                    n2 = fma((double)x0, (double)x0, n2);
+                    n2 = fma((double)x1, (double)x1, n2);
                 }
+                const double eps = sqrt(n2) * UREL + eps0;
                 cand[k] = pr[k] < P.n && !(sqrt(a) - eps >= (double)cf[k]);
             }
         }

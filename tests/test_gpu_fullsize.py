@@ -177,7 +177,7 @@ def test_kcenters_label_sorted_path_clustered(gpu, metric, dtype, monkeypatch):
     assert m.inertia_ == np.sum(dist)
 
 
-@pytest.mark.parametrize("case", ["plain", "offset", "beyond_float32", "nan_row"])
+@pytest.mark.parametrize("case", ["plain", "offset", "beyond_float32", "nan_row", "shell", "anisotropic"])
 @pytest.mark.parametrize("m", [3, 10, 16])
 def test_kcenters_float32_screened_passes(gpu, case, m):
     """float64 rows, euclidean: after 4 plain passes the fit continues with SCREENED passes (a bfloat16 copy of the rows,
@@ -199,6 +199,11 @@ def test_kcenters_float32_screened_passes(gpu, case, m):
         Y[777] = 1.0e39
     elif case == "nan_row":
         Y[4242, 0] = np.nan
+    elif case == "shell":  # every row at the same distance from the copy's origin: the rounding margin is tight for all of them
+        Y = Y / np.linalg.norm(Y, axis=1, keepdims=True) * 7.0 + 0.01 * rs.randn(n, m)
+        Y[2000:2030] = Y[11]
+    elif case == "anisotropic":  # configs[2]-like scales; what caught a margin of 2^-9 ||x~|| (bfloat16's unit roundoff is 2^-8)
+        Y *= np.linspace(3.0, 0.3, m)
     m_ = KCenters(n_clusters=k, random_state=2).fit([Y[:40_000], Y[40_000:]])
     ids, labels, dist = o.kcenters_fit(Y, k, "euclidean", m_.cluster_ids_[0])
     assert m_.cluster_ids_ == list(ids)
