@@ -177,7 +177,7 @@ def test_kcenters_label_sorted_path_clustered(gpu, metric, dtype, monkeypatch):
     assert m.inertia_ == np.sum(dist)
 
 
-@pytest.mark.parametrize("case", ["plain", "offset", "beyond_float32", "nan_row", "shell", "anisotropic"])
+@pytest.mark.parametrize("case", ["plain", "offset", "beyond_float32", "nan_row", "shell", "anisotropic", "lattice", "tiny", "huge"])
 @pytest.mark.parametrize("m", [3, 10, 16])
 def test_kcenters_float32_screened_passes(gpu, case, m):
     """float64 rows, euclidean: after 4 plain passes the fit continues with SCREENED passes (a bfloat16 copy of the rows,
@@ -204,6 +204,12 @@ def test_kcenters_float32_screened_passes(gpu, case, m):
         Y[2000:2030] = Y[11]
     elif case == "anisotropic":  # configs[2]-like scales; what caught a margin of 2^-9 ||x~|| (bfloat16's unit roundoff is 2^-8)
         Y *= np.linspace(3.0, 0.3, m)
+    elif case == "lattice":  # half-integer lattice: masses of exactly equal distances, duplicates and argmax ties
+        Y = np.round(Y * 2.0) / 2.0
+    elif case == "tiny":  # everything far below float32's (and bfloat16's) normal range scale of interest
+        Y *= 1e-20
+    elif case == "huge":
+        Y *= 1e18
     m_ = KCenters(n_clusters=k, random_state=2).fit([Y[:40_000], Y[40_000:]])
     ids, labels, dist = o.kcenters_fit(Y, k, "euclidean", m_.cluster_ids_[0])
     assert m_.cluster_ids_ == list(ids)
