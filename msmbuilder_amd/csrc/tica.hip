@@ -2294,10 +2294,14 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         P.kflush = kf ? atoi(kf) : (h->shift_on ? 2 * KFLUSH_SYM : KFLUSH_SYM);
     }
     {
-        // measured (10M x 512): pacing cuts the L2 fabric-side fetch from 207 GB to 79-82 GB per launch but
-        // makes the kernel 4 % slower (78.4 -> 81.7 ms), so it is opt-in
+        // Cohort pacing (the workgroups of a cohort wait for each other at chunk boundaries, bounded).  C/G kernel, measured
+        // at 10M x 512: the L2 fabric-side fetch drops from 207 GB to 79-82 GB per launch but the kernel is 4 % slower
+        // (78.4 -> 81.7 ms): opt-in there.  Sum/difference kernel WITH the wave-priority window (round 2): 110 GB -> 32 GB
+        // fetched per launch (1.8x the algorithmic bytes instead of 5.5x) AND 1 % faster (50.45 -> 49.8 ms; without the
+        // priority window pacing cost 2 %): on by default there.  MSM_TICA_COHORT_PACING=0 / 1 forces it either way.
         const char* e = getenv("MSM_TICA_COHORT_PACING");
-        P.cosync = (e && atoi(e)) ? h->cosync : nullptr;
+        const bool pace = e ? atoi(e) != 0 : (usesym && !useimg);
+        P.cosync = pace ? h->cosync : nullptr;
     }
 
     long long img_groups = 0;  // bf16 image path: 8-pair groups of the packed image (whole K-steps per chunk)
