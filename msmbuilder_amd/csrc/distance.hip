@@ -1494,11 +1494,22 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     // ---- prologue: centre of this pass = argmax of the previous pass's per-block candidates (P.it >= 1 here) ----
     double fv = -1.0;
     long long fi = 0x7fffffffffffffffLL;
-    for (int k = tid; k < P.nblk; k += DT) {
-        const KcPartial q = P.prev[k];
-        if (q.i >= 0 && kc_better(q.v, q.i, fv, fi)) {
-            fv = q.v;
-            fi = q.i;
+    {
+        // nblk <= KC_MAXBLK = 4 DT: the thread's (up to) four candidates in ONE round trip (unconditional loads at clamped
+        // indices, compared afterwards), not four dependent ones -- this sits at the head of every pass
+        KcPartial q[KC_MAXBLK / DT];
+#pragma unroll
+        for (int j = 0; j < KC_MAXBLK / DT; ++j) {
+            const int k = tid + j * DT;
+            q[j] = P.prev[k < P.nblk ? k : P.nblk - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < KC_MAXBLK / DT; ++j) {
+            const int k = tid + j * DT;
+            if (k < P.nblk && q[j].i >= 0 && kc_better(q[j].v, q[j].i, fv, fi)) {
+                fv = q[j].v;
+                fi = q[j].i;
+            }
         }
     }
     rv[tid] = fv;
