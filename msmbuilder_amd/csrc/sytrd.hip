@@ -185,11 +185,27 @@ __global__ __launch_bounds__(TRD_NT, 1) void sytrd_coop_kernel(TrdArgs P)
         // ---- everyone: w = p + alpha2 v, rank-2 update of the owned columns, next pivot column
         const double* cbr = P.cbuf + (size_t)(i & 1) * n;
         double pv = 0.0;
-        for (int r = tid; r < n; r += TRD_NT) {
-            const double pr = trd_load(pb + r);
-            w[r] = pr;
-            pv += pr * v[r];
-            col[r] = r > i ? trd_load(cbr + r) : 0.0;
+        {
+            // all of the thread's exchange loads first (clamped indices), then the arithmetic: a load that is consumed in
+            // the same loop iteration is a round trip per iteration, and this sits on the critical path of every column
+            constexpr int NL = TRD_MAXN / TRD_NT;
+            double pr[NL], cr[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int r = tid + k * TRD_NT;
+                const int rc = r < n ? r : n - 1;
+                pr[k] = trd_load(pb + rc);
+                cr[k] = trd_load(cbr + rc);
+            }
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int r = tid + k * TRD_NT;
+                if (r < n) {
+                    w[r] = pr[k];
+                    pv += pr[k] * v[r];
+                    col[r] = r > i ? cr[k] : 0.0;
+                }
+            }
         }
         const double ptv = trd_block_sum(pv, red, tid);
         const double alpha2 = -0.5 * tau * ptv;
