@@ -338,3 +338,26 @@ def test_dir_npy_dataset_host_protocol(tmp_path):
     assert est.n_ == 341 and list(out.keys()) == [0, 1, 2]
     np.testing.assert_array_equal(out[2], arrays[2][:, :2] * 0.5)
     assert "Derived from" in out.provenance and path in out.provenance
+
+
+@pytest.mark.parametrize("n", [1000, 70_000, 10_000_000, 2**31 + 5, 2**33])
+def test_randomstate_randint_batched_equals_sequential(n):
+    """MiniBatchKMeans._run draws the S batches of a queued run with ONE ``RandomState.randint(0, n, (S, B))`` call and,
+    when the convergence criterion fires after `done` steps, rewinds by restoring the state and re-drawing (done, B).  Both
+    rely on legacy ``randint`` consuming the bit stream element by element: the batched call must give the same numbers
+    AND leave the same generator state as scikit-learn's S calls of size B."""
+    S, B = 7, 1024
+    a, b = np.random.RandomState(5), np.random.RandomState(5)
+    seq = np.stack([a.randint(0, n, B) for _ in range(S)])
+    bat = b.randint(0, n, (S, B))
+    assert np.array_equal(seq, bat)
+    assert a.randint(0, 2**31 - 1, 16).tolist() == b.randint(0, 2**31 - 1, 16).tolist()   # same state afterwards
+    # rewind: restore + re-draw `done` batches == the state after `done` sequential calls
+    c, d = np.random.RandomState(9), np.random.RandomState(9)
+    st = c.get_state()
+    c.randint(0, n, (S, B))
+    c.set_state(st)
+    c.randint(0, n, (3, B))
+    for _ in range(3):
+        d.randint(0, n, B)
+    assert c.uniform(size=4).tolist() == d.uniform(size=4).tolist()
