@@ -361,3 +361,50 @@ def test_randomstate_randint_batched_equals_sequential(n):
     for _ in range(3):
         d.randint(0, n, B)
     assert c.uniform(size=4).tolist() == d.uniform(size=4).tolist()
+
+
+def _bf16_rne(x32):
+    """round-to-nearest-even bfloat16 image of float32 values, returned as float32 (ksc_bf16_rne in distance.hip)"""
+    u = np.ascontiguousarray(x32, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1.0, 3.0e6), (1e-20, 0.0), (1e18, 0.0), (1.0, -2.5e3)])
+@pytest.mark.parametrize("m", [3, 10, 16])
+def test_kcenters_screen_margin_is_safe(scale, offset, m):
+    """The screened k-centers passes (distance.hip, kcenters_screen_pass_kernel) leave a row alone when
+    ``d~ - eps >= curf`` with d~ evaluated on a bfloat16 copy of the row centred on c0 and
+    ``eps = 1.02 * 2^-8 * ||x~|| + 2^-48 (R + ||c0||) + 1e-37``.  Numpy emulation of exactly that arithmetic on adversarial
+    `distances_` values (the largest float32 the screen still accepts): the float64 distance the reference would compute
+    must then never be below it.  (With a margin of 2^-9 -- bfloat16 has 8 significand bits, not 9 -- this test fails.)"""
+    rs = np.random.RandomState(m + int(abs(offset)) % 97)
+    n = 200_000
+    X = rs.randn(n, m) * scale + offset
+    X[::7] = (rs.randn(len(X[::7]), m) * 4.0) * scale + offset            # a wider shell as well
+    c0 = X[0].copy()
+    Y = X[rs.randint(0, n, 64)]                                           # centres are data rows
+    R = np.sqrt((X * X).sum(1).max())
+    xc = (X - c0).astype(np.float32)
+    xt = _bf16_rne(xc).astype(np.float64)
+    nrm = np.sqrt((xt * xt).sum(1))
+    eps0 = (R + np.sqrt((c0 * c0).sum())) * 2.0 ** -48 + 1e-37
+    worst = np.inf
+    for y in Y:
+        yc = y - c0
+        dt = np.sqrt(((xt - yc) ** 2).sum(1))
+        eps = nrm * (2.0 ** -8 * 1.02) + eps0
+        # the reference's distance: float64, features in order, separately rounded multiply and add, sqrt
+        a = np.zeros(n)
+        for f in range(m):
+            d = X[:, f] - y[f]
+            a = a + d * d
+        dref = np.sqrt(a)
+        # adversarial distances_: the largest float32 <= d~ - eps (curf = distances_ rounded up to float32 would equal it)
+        lim = dt - eps
+        cur = lim.astype(np.float32)
+        cur = np.where(cur.astype(np.float64) > lim, np.nextafter(cur, np.float32(-np.inf)), cur).astype(np.float64)
+        ok = cur > 0
+        assert np.all(dref[ok] >= cur[ok]), (scale, offset, m)
+        worst = min(worst, float(np.min((dref[ok] - cur[ok]) / np.maximum(eps[ok], 1e-300))))
+    assert worst >= 0.0
