@@ -1710,9 +1710,21 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
         unsigned* xo = static_cast<unsigned*>(P.xs) + p * NW;
         double n2 = 0.0, r2 = 0.0;
         float xc[2 * NP];
+        double xv[2 * NP];
+        if (P.vecw == 16 && (m & 1) == 0) {  // 16-byte loads (the per-feature loads fetched 3x the row's bytes)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const raw_f32x4 q = *reinterpret_cast<const raw_f32x4*>(x + 2 * j);
+                xv[2 * j] = reinterpret_cast<const double*>(&q)[0];
+                xv[2 * j + 1] = reinterpret_cast<const double*>(&q)[1];
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 2 * NP; ++f) xv[f] = x[f < m ? f : m - 1];
+        }
 #pragma unroll
         for (int f = 0; f < 2 * NP; ++f) {
-            const double v = x[f < m ? f : m - 1];
+            const double v = xv[f];
             const double c = f < m ? v - c0[f] : 0.0;
             xc[f] = (float)c;
             if (f < m) {
