@@ -1,20 +1,24 @@
-"""dir-npy datasets feeding the hot path.
+"""dir-npy trajectory stores feeding the hot path.
 
-``NumpyDirDataset`` mirrors the reference container of the same name
-(/root/reference/msmbuilder/dataset.py:290-331 and the ``_BaseDataset`` protocol, :100-277): a
-directory of ``%08d.npy`` files, one 2-D array per trajectory, with ``keys() / get(i, mmap) /
-set(i, x) / __getitem__ / __setitem__ / __len__ / items() / fit_with / transform_with /
-fit_transform_with`` -- host arrays through numpy exactly as upstream.
+On-disk contract (the reference's "dir-npy" format, /root/reference/msmbuilder/dataset.py:290-331): a
+directory holding one ``%08d.npy`` file per trajectory -- the integer in the name is the key,
+keys iterate in ascending order -- plus a free-text ``PROVENANCE.txt``.  Estimator hooks
+(dataset.py:158-237): ``fit_with(est)``, ``transform_with(est, out)``, ``fit_transform_with(est, out)``.
 
-``device_sequences()`` is the MI355X side: a re-iterable view whose iteration streams every
-trajectory straight into HBM through the native loader of csrc/npyio.hip (worker-thread pread
-into pinned buffers + hipMemcpyAsync on a private stream, ``prefetch`` files in flight), so
-``tICA().fit(ds.device_sequences())`` overlaps disk, PCIe and the covariance kernel.
+This container is built around the native reader of csrc/npyio.hip rather than around ``np.load``:
+
+* every file is described once by ``msm_npy_info`` (dtype, shape, payload offset); host reads are
+  ``np.memmap`` / ``np.fromfile`` views of that payload, so ``get(i, mmap=True)`` costs no copy and
+  no header re-parse in Python;
+* ``device_sequences()`` streams the same payloads straight into HBM (reader threads pread into pinned
+  buffers, hipMemcpyAsync on private streams, ``prefetch`` files in flight), so
+  ``tICA().fit(ds.device_sequences())`` overlaps disk, PCIe and the covariance kernel;
+* writes go to a temporary name and are renamed into place, so a reader never sees half a trajectory.
 """
 import ctypes as C
 import os
 import re
-from os.path import exists, join
+import tempfile
 
 import numpy as np
 
@@ -23,96 +27,121 @@ from ._lib import check
 
 __all__ = ['NumpyDirDataset', 'dataset']
 
+_NAME = re.compile(r'\d{8}\.npy')
+_NOTES = 'PROVENANCE.txt'
+_NP_KINDS = {'f': 'f', 'i': 'i', 'u': 'u', 'b': 'b'}
+_TORCH_NAMES = {'f4': 'float32', 'f8': 'float64', 'i4': 'int32', 'i8': 'int64', 'u1': 'uint8', 'b1': 'bool',
+                'i2': 'int16', 'i1': 'int8', 'f2': 'float16'}
 
-def _keynat(string):
-    """natural sort key (dataset.py:451-463)"""
-    r = []
-    for c in string:
-        if c.isdigit():
-            if r and isinstance(r[-1], int):
-                r[-1] = r[-1] * 10 + int(c)
-            else:
-                r.append(int(c))
-        else:
-            r.append(9 + ord(c))
-    return r
+
+class _Payload(object):
+    """What msm_npy_info says about one file."""
+    __slots__ = ('path', 'code', 'shape', 'offset', 'fortran')
+
+    def __init__(self, path):
+        nb, kind, fo, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        shape, off = (C.c_int64 * 4)(), C.c_int64()
+        check(_lib.lib().msm_npy_info(os.fsencode(path), C.byref(nb), C.byref(kind), C.byref(fo), C.byref(nd),
+                                      shape, C.byref(off)))
+        self.path = path
+        self.code = '%s%d' % (_NP_KINDS[chr(kind.value)], nb.value)
+        self.shape = tuple(int(shape[d]) for d in range(nd.value))
+        self.offset = int(off.value)
+        self.fortran = bool(fo.value)
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64)) * int(self.code[1:])
+
+    def host_array(self, mapped):
+        dt = np.dtype('<' + self.code if self.code[1:] != '1' else '|' + self.code)
+        order = 'F' if self.fortran else 'C'
+        if mapped:
+            if 0 in self.shape:
+                return np.empty(self.shape, dtype=dt, order=order)
+            return np.memmap(self.path, dtype=dt, mode='r', offset=self.offset, shape=self.shape, order=order)
+        flat = np.fromfile(self.path, dtype=dt, count=int(np.prod(self.shape, dtype=np.int64)), offset=self.offset)
+        return flat.reshape(self.shape, order=order)
 
 
 def dataset(path, mode='r', fmt=None, verbose=False, **kwargs):
-    """Open a dir-npy dataset (the only on-disk format in scope here; dataset.py:30-97)."""
+    """Open a trajectory store.  Only ``fmt='dir-npy'`` (or None) exists here: the reference's HDF5 and
+    mdtraj containers (dataset.py:30-97) are file formats outside the hot path."""
     if fmt not in (None, 'dir-npy'):
         raise NotImplementedError("msmbuilder_amd.dataset only implements fmt='dir-npy', got %r" % (fmt,))
     return NumpyDirDataset(path, mode=mode, verbose=verbose)
 
 
 class NumpyDirDataset(object):
-    _ITEM_FORMAT = '%08d.npy'
-    _ITEM_RE = re.compile(r'(\d{8}).npy')
-    _PROVENANCE_FILE = 'PROVENANCE.txt'
-
     def __init__(self, path, mode='r', verbose=False):
-        self.path = path
-        self.mode = mode
-        self.verbose = verbose
         if mode not in ('r', 'w', 'a'):
             raise ValueError('mode must be one of "r", "w", "a"')
-        if mode in 'wa':
-            if mode == 'w' and exists(path):
+        self.path, self.mode, self.verbose = path, mode, verbose
+        if self.writable:
+            if mode == 'w' and os.path.exists(path):
                 raise ValueError('File exists: %s' % path)
-            try:
-                os.makedirs(path)
-            except OSError:
-                pass
-            self._write_provenance()
+            os.makedirs(path, exist_ok=True)
+            self._note()
 
-    # ------------------------------------------------------------------ container protocol
-    def get(self, i, mmap=False):
-        filename = join(self.path, self._ITEM_FORMAT % i)
+    writable = property(lambda self: self.mode != 'r')
+
+    def _file(self, key):
+        return os.path.join(self.path, '%08d.npy' % key)
+
+    def _say(self, what, name):
         if self.verbose:
-            print('[NumpydirDataset] loading %s' % filename)
+            print('[dir-npy] %s %s' % (what, name))
+
+    # ------------------------------------------------------------------ keyed access
+    def keys(self):
+        with os.scandir(os.path.expanduser(self.path)) as entries:
+            found = sorted(int(e.name[:8]) for e in entries if _NAME.fullmatch(e.name))
+        return iter(found)
+
+    def get(self, i, mmap=False):
+        name = self._file(i)
+        if not os.path.isfile(name):
+            raise IndexError('%s: no trajectory %r in this dataset' % (name, i))
+        self._say('reading', name)
         try:
-            return np.load(filename, 'r' if mmap else None)
-        except IOError as e:
-            raise IndexError(e)
+            return _Payload(name).host_array(mmap)
+        except ValueError:
+            # structured / object / big-endian payloads are not device material; numpy still reads them
+            return np.load(name, mmap_mode='r' if mmap else None, allow_pickle=False)
 
     def set(self, i, x):
-        if self.mode not in 'wa':
+        if not self.writable:
             raise IOError('Dataset not opened for writing')
-        filename = join(self.path, self._ITEM_FORMAT % i)
-        if self.verbose:
-            print('[NumpydirDataset] saving %s' % filename)
-        if hasattr(x, "is_cuda"):
-            x = x.cpu().numpy()
-        return np.save(filename, x)
+        if hasattr(x, 'detach'):                       # torch tensor, possibly resident in HBM
+            x = x.detach().cpu().numpy()
+        name = self._file(i)
+        self._say('writing', name)
+        fd, tmp = tempfile.mkstemp(suffix='.part', dir=self.path)
+        try:
+            with os.fdopen(fd, 'wb') as f:
+                np.lib.format.write_array(f, np.asanyarray(x), allow_pickle=False)
+            os.replace(tmp, name)
+        except BaseException:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+            raise
 
-    def keys(self):
-        for fn in sorted(os.listdir(os.path.expanduser(self.path)), key=_keynat):
-            match = self._ITEM_RE.match(fn)
-            if match:
-                yield int(match.group(1))
+    __getitem__ = get
+    __setitem__ = set
 
     def items(self):
-        for key in self.keys():
-            yield (key, self.get(key))
+        return ((k, self.get(k)) for k in self.keys())
 
     def __iter__(self):
-        for key in self.keys():
-            yield self.get(key)
+        return (self.get(k) for k in self.keys())
 
     def __len__(self):
-        return sum(1 for _ in self.keys())
-
-    def __getitem__(self, i):
-        return self.get(i)
-
-    def __setitem__(self, i, x):
-        return self.set(i, x)
+        return len(list(self.keys()))
 
     def close(self):
         pass
 
-    def flush(self):
-        pass
+    flush = close
 
     def __enter__(self):
         return self
@@ -120,58 +149,56 @@ class NumpyDirDataset(object):
     def __exit__(self, *exc_info):
         self.close()
 
+    # ------------------------------------------------------------------ provenance chain
     @property
     def provenance(self):
         try:
-            with open(join(self.path, self._PROVENANCE_FILE), 'r') as f:
+            with open(os.path.join(self.path, _NOTES)) as f:
                 return f.read()
         except IOError:
             return 'No available provenance'
 
-    def _write_provenance(self, previous=None, comments=''):
+    def _note(self, parent=None, comments=''):
         from . import __version__
-        with open(join(self.path, self._PROVENANCE_FILE), 'w') as f:
-            f.write('MSMBuilder Dataset:\n  msmbuilder_amd:\t%s\n  Path:\t\t%s\n  Comments:\t\t%s\n'
-                    % (__version__, self.path, comments))
-            if previous:
-                f.write('\n== Derived from ==\n%s\n' % previous)
+        lines = ['MSMBuilder Dataset:', '  msmbuilder_amd:\t%s' % __version__, '  Path:\t\t%s' % self.path,
+                 '  Comments:\t\t%s' % comments]
+        if parent:
+            lines += ['', '== Derived from ==', parent]
+        with open(os.path.join(self.path, _NOTES), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
 
     def create_derived(self, out_path, comments='', fmt=None):
-        out = dataset(out_path, mode='w', verbose=self.verbose, fmt=fmt)
-        out._write_provenance(previous=self.provenance, comments=comments)
-        return out
+        child = dataset(out_path, mode='w', verbose=self.verbose, fmt=fmt)
+        child._note(parent=self.provenance, comments=comments)
+        return child
 
-    # -------------------------------------------------------------- estimator hooks (dataset.py:158-233)
+    # ------------------------------------------------------------------ estimator hooks
     def fit_with(self, estimator):
         estimator.fit(self)
         return estimator
 
     def transform_with(self, estimator, out_ds, fmt=None):
-        if isinstance(out_ds, str):
-            out_ds = self.create_derived(out_ds, fmt=fmt)
-        elif getattr(out_ds, "mode", "w") not in 'wa':
+        sink = self.create_derived(out_ds, fmt=fmt) if isinstance(out_ds, str) else out_ds
+        if getattr(sink, 'mode', 'w') == 'r':
             raise ValueError('out_ds must be opened for writing')
-        for key in self.keys():
-            out_ds[key] = estimator.partial_transform(self.get(key))
-        return out_ds
+        for k in self.keys():
+            sink[k] = estimator.partial_transform(self.get(k))
+        return sink
 
     def fit_transform_with(self, estimator, out_ds, fmt=None):
-        self.fit_with(estimator)
-        return self.transform_with(estimator, out_ds, fmt=fmt)
+        return self.transform_with(self.fit_with(estimator), out_ds, fmt=fmt)
 
-    # ------------------------------------------------------------------------- device streaming
+    # ------------------------------------------------------------------ device streaming
     def device_sequences(self, prefetch=4, buffer_bytes=8 << 20, readers=4, device=None):
         """Re-iterable view yielding each trajectory as a ``torch`` CUDA tensor loaded by the
         native pipelined reader (float32 / float64 / int32 / int64 C-ordered files): ``readers``
         threads with one pinned ``buffer_bytes`` buffer each, ``prefetch`` files in flight."""
-        return _DeviceView(self, prefetch, buffer_bytes, device, readers)
+        return DeviceSequences(self, prefetch, buffer_bytes, device, readers)
 
 
-_TORCH_DTYPES = {('f', 4): 'float32', ('f', 8): 'float64', ('i', 4): 'int32', ('i', 8): 'int64',
-                 ('u', 1): 'uint8', ('b', 1): 'bool', ('i', 2): 'int16', ('i', 1): 'int8'}
+class DeviceSequences(object):
+    """The trajectories of a dir-npy store as device tensors, loaded on demand (see module docstring)."""
 
-
-class _DeviceView(object):
     def __init__(self, ds, prefetch, buffer_bytes, device, readers=4):
         self.ds = ds
         self.readers = max(1, int(readers))
@@ -183,17 +210,13 @@ class _DeviceView(object):
     def __len__(self):
         return len(self._keys)
 
-    def _info(self, key):
-        path = join(self.ds.path, self.ds._ITEM_FORMAT % key).encode()
-        nb, kind, fo, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        shape, off = (C.c_int64 * 4)(), C.c_int64()
-        check(_lib.lib().msm_npy_info(path, C.byref(nb), C.byref(kind), C.byref(fo), C.byref(nd), shape, C.byref(off)))
-        if fo.value and nd.value > 1:
-            raise ValueError("%s is Fortran-ordered; the device loader needs C-ordered arrays" % path.decode())
-        dt = _TORCH_DTYPES.get((chr(kind.value), nb.value))
-        if dt is None:
-            raise TypeError("%s: dtype %s%d has no device loader" % (path.decode(), chr(kind.value), nb.value))
-        return path, dt, tuple(shape[i] for i in range(nd.value))
+    def _describe(self, key):
+        p = _Payload(self.ds._file(key))
+        if p.fortran and len(p.shape) > 1:
+            raise ValueError("%s is Fortran-ordered; the device loader needs C-ordered arrays" % p.path)
+        if p.code not in _TORCH_NAMES:
+            raise TypeError("%s: dtype %s has no device loader" % (p.path, p.code))
+        return p
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -218,13 +241,13 @@ class _DeviceView(object):
                 key = next(it, None)
                 if key is None:
                     return False
-                path, dt, shape = self._info(key)
-                t = torch.empty(shape, dtype=getattr(torch, dt), device=dev)
+                p = self._describe(key)
+                t = torch.empty(p.shape, dtype=getattr(torch, _TORCH_NAMES[p.code]), device=dev)
                 # `t` may re-use a block that kernels queued on torch's stream are still reading (a trajectory the consumer
                 # has already dropped): submit() records a fence on the library stream, which must be that stream
                 _lib.set_stream(torch.cuda.current_stream(dev).cuda_stream)
                 job = C.c_int64(0)
-                check(L.msm_npy_loader_submit(h, path, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), C.byref(job)))
+                check(L.msm_npy_loader_submit(h, os.fsencode(p.path), C.c_void_p(t.data_ptr()), p.nbytes, C.byref(job)))
                 pending.append((job.value, t))
                 return True
 
