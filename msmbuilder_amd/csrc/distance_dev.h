@@ -39,7 +39,13 @@ __device__ __forceinline__ void m_update(double& a, double& b, const T u, const 
     } else if (M == M_CANBERRA) {
         const T df = u - v;
         const double snum = fabs((double)df);
-        const double sdenom = fabs((double)u) + fabs((double)v);
+        // the reference's translation unit (Cython C++: Python.h first) resolves fabs(float) to the FLOAT overload, so
+        // for float rows the denominator is a float add, widened afterwards (the compiled reference agrees bit for bit)
+        double sdenom;
+        if constexpr (sizeof(T) == 4)
+            sdenom = (double)(__builtin_fabsf((float)u) + __builtin_fabsf((float)v));
+        else
+            sdenom = fabs((double)u) + fabs((double)v);
         if (sdenom > 0.0) a = a + snum / sdenom;
     } else if (M == M_BRAYCURTIS) {
         const T df = u - v;

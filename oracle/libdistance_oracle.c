@@ -22,10 +22,15 @@
  *
  * Arithmetic contract being pinned (this is what "bit-exact labels" means):
  *   - float inputs: `u[i] - v[i]` and `u[i] + v[i]` are evaluated in FLOAT
- *     (both operands float), then widened to double; the global-namespace
- *     `fabs` the reference calls is the DOUBLE one, so canberra's
- *     `fabs(u[i]) + fabs(v[i])` is a DOUBLE add (pinned empirically against
- *     oracle/_ref: a float add mismatches, a double add is bit-identical).
+ *     (both operands float), then widened to double.  The reference's
+ *     translation unit is Cython C++ (setup.py:146-147): Python.h and numpy's
+ *     headers come first, so <math.h> is libstdc++'s C++ wrapper and the
+ *     global-namespace `fabs(float)` the kernels call is the FLOAT overload:
+ *     canberra's `fabs(u[i]) + fabs(v[i])` is a FLOAT add, widened afterwards
+ *     (pinned against oracle/_ref built in that context -- ref_shim.cpp
+ *     includes Python.h + numpy/npy_common.h: a double add mismatches, a float
+ *     add is bit-identical.  A translation unit that only sees C's <math.h>,
+ *     as round 2's hand-typedef'd shim did, gets the double add).
  *     Everything accumulates in ONE double accumulator, features visited in
  *     order i = 0..n-1, multiply and add rounded separately.
  *   - euclidean = sqrt(sqeuclidean), compared AFTER the sqrt.
@@ -173,7 +178,7 @@ static double metric_f32(int m, const float *u, const float *v, idx_t n)
         for (i = 0; i < n; i++) {
             float fn = fabsf(u[i] - v[i]);
             snum = fn;
-            sdenom = (double)fabsf(u[i]) + (double)fabsf(v[i]); /* DOUBLE add: pinned vs oracle/_ref */
+            sdenom = (double)(float)(fabsf(u[i]) + fabsf(v[i])); /* FLOAT add: pinned vs oracle/_ref */
             if (sdenom > 0.0) tot += snum / sdenom;
         }
         return tot;

@@ -4,10 +4,11 @@
 // reference's own libdistance headers WHERE THEY LIE under /root/reference
 // (the Makefile passes -I$(REF)/msmbuilder/libdistance/src; no reference
 // source is copied into this repository) and exposes them with C linkage so
-// ctypes can call the real reference arithmetic.  The prelude below is what
-// the Cython-generated translation unit provides in the reference build
-// (numpy's npy_intp / NPY_INLINE, libdistance.pyx:13) -- two typedef-level
-// lines, not a stand-in for any header's contents.
+// ctypes can call the real reference arithmetic.  npy_intp and NPY_INLINE come
+// from numpy's OWN header (numpy/npy_common.h, found by the Makefile through
+// numpy.get_include() and Python's include directory), exactly what the
+// Cython-generated translation unit pulls in in the reference build
+// (libdistance.pyx:13 `cimport numpy`); nothing is typedef'ed by hand.
 //
 // Used only by tests/ (to pin oracle/libdistance_oracle.c) and optionally by
 // bench.py's cpu_baseline leg (kind="reference").
@@ -16,8 +17,8 @@
 #include <cstdio>
 #include <cstring>
 
-typedef intptr_t npy_intp;
-#define NPY_INLINE inline
+#include <Python.h>
+#include <numpy/npy_common.h>
 
 #include "assign.hpp"
 #include "cdist.hpp"
