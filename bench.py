@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- frames/sec of the MSMBuilder hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W          (any N: with N > 1 and no WORLD_SIZE in the environment the
+                                                            script re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over the HBM-resident synthetic data set of BASELINE.json configs[3]
@@ -114,54 +115,93 @@ def executed_flop_per_frame_bf16(F, x2):
     return 2.0 * 256 * 256 * nt2 * (nt2 + 1) * (4 if x2 else 1)
 
 
-def cpu_baseline(X_host_list, lag, k_comp, k_clusters, budget_s=10.0):
-    """The CPU checker timed on the host cores on a bounded sample of the same workload (SURVEY 8(d) i-iii):
-    (i) oracle tICA = the reference's op sequence (f64 up-cast + 3 dgemm, tica.py:402-422) on all BLAS threads and on
-    one; (ii) the C restatement of KCenters.fit + assign_nearest single-threaded (the reference has no threads there)
-    and assign_nearest row-parallel over all cores; (iii) scikit-learn's MiniBatchKMeans(k=1000) itself."""
+def cpu_baseline(X_host_list, lag, k_comp, k_clusters, budget_s=8.0):
+    """The CPU checkers timed on the host cores on a bounded sample of the same workload (SURVEY 8(d) i-iii):
+    (i) oracle tICA = the reference's op sequence (f64 up-cast + 3 dgemm, tica.py:402-422) through numpy's BLAS, with the
+    thread pool as numpy found it ("all") and limited to one thread (threadpoolctl; both pools are reported as
+    threadpoolctl.threadpool_info() saw them INSIDE the timed region); (ii) KCenters.fit + assign_nearest through the
+    reference's own libdistance (oracle/_ref, `kinds.clustering` = "reference": the loop of kcenters.py:79-102 around
+    libdistance.dist, single-threaded like the reference) when that prebuilt file travelled with the snapshot, else
+    through the C restatement ("port"); assign_nearest also row-parallel over the cores; (iii) scikit-learn's
+    MiniBatchKMeans(k=1000) itself."""
     from oracle.tica_oracle import TicaOracle
-    from oracle.libdistance_oracle import Oracle
+    from oracle.libdistance_oracle import Oracle, Ref
     from concurrent.futures import ThreadPoolExecutor
-    ncpu = os.cpu_count() or 1
-    o = TicaOracle(n_components=k_comp, lag_time=lag)
-    t0 = time.perf_counter()
-    used = []
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        for X in X_host_list:
-            o.partial_fit(X)
-            used.append(X)
-            if time.perf_counter() - t0 > budget_s:
-                break
-    t_fit = time.perf_counter() - t0
-    # (i) one BLAS thread, on as many of the same trajectories as ~3 s allow
-    t_fit1, n1 = None, 0
     try:
-        from threadpoolctl import threadpool_limits
-        o1 = TicaOracle(n_components=k_comp, lag_time=lag)
-        with threadpool_limits(1, "blas"), warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            t1 = time.perf_counter()
-            for X in used:
-                o1.partial_fit(X)
-                n1 += len(X)
-                if time.perf_counter() - t1 > 3.0:
-                    break
-            t_fit1 = time.perf_counter() - t1
-    except Exception:
-        pass
+        from threadpoolctl import threadpool_limits, threadpool_info
+    except Exception:  # reported, not required
+        threadpool_limits = threadpool_info = None
+    ncpu = os.cpu_count() or 1
+
+    def pools():
+        if threadpool_info is None:
+            return None
+        return [{k: p.get(k) for k in ("user_api", "internal_api", "num_threads", "threading_layer", "version")}
+                for p in threadpool_info()]
+
+    def fit_for(budget, limit):
+        """partial_fit trajectories until `budget` seconds have passed; (oracle, used trajectories, seconds, pools)."""
+        o = TicaOracle(n_components=k_comp, lag_time=lag)
+        used, seen = [], None
+        ctx = threadpool_limits(limit, "blas") if (limit and threadpool_limits) else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                wo = TicaOracle(n_components=k_comp, lag_time=lag)       # BLAS warm-up (thread start-up: ~1 s on first use)
+                for X in X_host_list[:3]:
+                    wo.partial_fit(X)
+                seen = pools()
+                t0 = time.perf_counter()
+                for X in X_host_list:
+                    o.partial_fit(X)
+                    used.append(X)
+                    if time.perf_counter() - t0 > budget:
+                        break
+                el = time.perf_counter() - t0
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        return o, used, el, seen
+
+    o, used, t_fit, pools_all = fit_for(budget_s, None)
+    _o1, used1, t_fit1, pools_one = fit_for(3.0, 1)
+    _o8, used8, t_fit8, _p8 = fit_for(3.0, 8)
+    n = sum(len(x) for x in used)
+    n1 = sum(len(x) for x in used1)
+    n8 = sum(len(x) for x in used8)
+    # `value` uses the FASTEST of the three thread settings for the tICA part (many-thread BLAS on 10,000-row dgemms is
+    # not always the fastest on a 256-core host; the baseline should not be handicapped by a bad default)
+    rate_best = max(n / t_fit, n1 / t_fit1, n8 / t_fit8)
+    t_fit_best = n / rate_best
     t1 = time.perf_counter()
     Y = np.concatenate(o.transform(used))
     t_proj = time.perf_counter() - t1
-    lo = Oracle()
+
+    have_ref = Ref.available()
+    lo = Ref() if have_ref else Oracle()
     t2 = time.perf_counter()
-    ids, labels, dist = lo.kcenters_fit(Y, k_clusters, "euclidean", 0)
+    if have_ref:
+        # kcenters.py:79-102 around the reference's libdistance.dist
+        dist_ = np.full(len(Y), np.inf)
+        labels = np.zeros(len(Y), dtype=int)
+        ids, c = [], 0
+        for i in range(k_clusters):
+            d = lo.dist(Y, Y[c], "euclidean")
+            mask = d < dist_
+            dist_[mask] = d[mask]
+            labels[mask] = i
+            ids.append(c)
+            c = int(np.argmax(dist_))
+    else:
+        ids, labels, dist_ = lo.kcenters_fit(Y, k_clusters, "euclidean", 0)
     centers = np.ascontiguousarray(Y[ids])
     t2b = time.perf_counter()
-    lab, _ = lo.assign_nearest(Y, centers, "euclidean")
+    lab = lo.assign_nearest(Y, centers, "euclidean")[0]
     t_clu = time.perf_counter() - t2
     t_assign1 = time.perf_counter() - t2b
-    # (ii) row-parallel variant of the same scalar routine (ctypes releases the GIL)
+    # row-parallel variant of the same scalar routine (ctypes releases the GIL)
     nth = min(ncpu, 64)
     bounds = np.linspace(0, len(Y), nth + 1).astype(np.int64)
     t3 = time.perf_counter()
@@ -170,16 +210,24 @@ def cpu_baseline(X_host_list, lag, k_comp, k_clusters, budget_s=10.0):
                             range(nth)))
     t_assign_par = time.perf_counter() - t3
     assert np.array_equal(np.concatenate(parts), lab)
-    n = sum(len(x) for x in used)
-    total = t_fit + t_proj + t_clu
+    total = t_fit_best + t_proj + t_clu
+    blas_threads = None
+    if pools_all:
+        blas_threads = max([p["num_threads"] or 1 for p in pools_all if p["user_api"] == "blas"] or [1])
     out = dict(value=n / total, unit="frames/s", cores=ncpu, kind="port",
-               sample="%d trajectories x %d frames x %d f32 of the same synthetic data: oracle tICA (numpy BLAS, all host "
-                      "threads) %.2fs + projection %.2fs + single-thread C KCenters K=%d fit+assign %.2fs"
-                      % (len(used), len(used[0]), used[0].shape[1], t_fit, t_proj, k_clusters, t_clu),
-               tica_fit_frames_per_s=n / t_fit,
-               tica_fit_1thread_frames_per_s=(n1 / t_fit1) if t_fit1 else None,
-               assign_1thread_frames_per_s=n / t_assign1,
-               assign_row_parallel_frames_per_s=n / t_assign_par, assign_row_parallel_threads=nth)
+               kinds={"tica": "port (oracle/tica_oracle.py: the Python reference cannot travel to the GPU box)",
+                      "clustering": "reference (oracle/_ref: the reference's libdistance headers compiled)" if have_ref
+                      else "port (oracle/libdistance_oracle.c)"},
+               blas_threads=blas_threads, threadpool_info=pools_all, threadpool_info_limited=pools_one,
+               sample="%d trajectories x %d frames x %d f32 of the same synthetic data: oracle tICA (numpy BLAS, default pool of %s threads: "
+                      "%.2fs; `value` uses the fastest of default / 8 / 1 threads) + projection %.2fs + single-thread KCenters K=%d fit+assign %.2fs"
+                      % (len(used), len(used[0]), used[0].shape[1], blas_threads, t_fit, t_proj, k_clusters, t_clu),
+               tica_fit_frames_per_s=n / t_fit, tica_fit_frames=n,
+               tica_fit_1thread_frames_per_s=(n1 / t_fit1) if t_fit1 else None, tica_fit_1thread_frames=n1,
+               tica_fit_8thread_frames_per_s=(n8 / t_fit8) if t_fit8 else None,
+               tica_fit_best_frames_per_s=rate_best,
+               assign_1thread_frames_per_s=len(Y) / t_assign1,
+               assign_row_parallel_frames_per_s=len(Y) / t_assign_par, assign_row_parallel_threads=nth)
     # (iii) scikit-learn's MiniBatchKMeans on the projected sample
     try:
         from sklearn.cluster import MiniBatchKMeans as SkMBK
@@ -194,6 +242,31 @@ def cpu_baseline(X_host_list, lag, k_comp, k_clusters, budget_s=10.0):
     except Exception as e:  # baseline only
         out["sklearn_minibatchkmeans"] = dict(error=str(e)[:100])
     return out, o, used
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on a free
+    local port and hand its exit code back.  When the node shows fewer devices than ranks (a 1-GPU test box) the ranks
+    share devices and torch.distributed falls back to gloo (RCCL cannot put two ranks on one device); the JSON line says
+    so (`rccl_ranks`, `comm`)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        from msmbuilder_amd import _lib
+        ndev = _lib.device_count()
+    except Exception:
+        ndev = 0
+    if 0 < ndev < n:
+        env.setdefault("MSMBUILDER_AMD_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -214,6 +287,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed f64 / config2 / config5 / model legs")
     args = ap.parse_args()
     os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -291,6 +366,17 @@ def main():
 
     times = {}
     elapsed, (ev, labels, kc, Y, tica) = timed(times, seqs, X, args.warmup, args.steps)
+    # which transport the library's own collectives ran on: msm_comm_info -> (rank, world, kind 0 none / 1 RCCL / 2 host)
+    ci = [C.c_int(0), C.c_int(1), C.c_int(0)]
+    _lib.lib().msm_comm_info(C.byref(ci[0]), C.byref(ci[1]), C.byref(ci[2]))
+    comm_kind = {0: "none", 1: "rccl", 2: "host"}[ci[2].value]
+    rccl_ranks = ci[1].value if ci[2].value == 1 else (1 if world == 1 else 0)
+    if world > 1:
+        assert ci[1].value == world, "library communicator has %d ranks, launched %d" % (ci[1].value, world)
+        if torch.cuda.device_count() >= world:
+            assert comm_kind == "rccl" and rccl_ranks == world, (comm_kind, rccl_ranks, world)
+    kst = (C.c_int64 * 5)()
+    _lib.check(_lib.lib().msm_kcenters_last_stats(kst))
 
     weak = None
     if world > 1 and args.scaling == "strong" and not args.no_extras:
@@ -321,12 +407,19 @@ def main():
         peak = PEAK_TFLOPS.get(args.mode, 157.3)
         executed = exe_flop * frames / (mfma_ms * 1e-3) / 1e12
         algorithmic = alg_flop * frames / (mfma_ms * 1e-3) / 1e12
-        traffic, traffic_source = None, None   # PMC counters need their own rocprofv3 passes (scripts/pmc.sh)
+        # PMC counters need their own rocprofv3 passes (scripts/pmc.sh), so `traffic` cannot be measured inside this run.
+        # It is reported only when the committed profile was taken on THIS kernel source (sha256 of csrc/tica.hip
+        # recorded next to the counters) and this workload; otherwise null, with the stale profile named beside it.
+        traffic, traffic_source = None, None
         try:
+            import hashlib
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
-            if tj["workload"].startswith("%dx%d " % (frames, F)):
+            sha = hashlib.sha256(open(os.path.join(ROOT, "msmbuilder_amd", "csrc", "tica.hip"), "rb").read()).hexdigest()[:16]
+            if tj["workload"].startswith("%dx%d " % (frames, F)) and tj.get("tica_hip_sha16") == sha:
                 traffic = tj["bytes_per_launch"]
-                traffic_source = "committed profile, not this run: " + tj["source"]
+                traffic_source = "rocprofv3 PMC passes of this kernel source (tica.hip sha16 %s), separate run: %s" % (sha, tj["source"])
+            else:
+                traffic_source = "null: profiles/traffic.json (%s) was taken on another kernel source or workload" % tj.get("source", "?")
         except Exception:
             pass
         out = {
@@ -334,6 +427,7 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "comm": comm_kind,
             "config": {"workload": "BASELINE configs[3]: %d x %d fp32 as %d trajectories x %d (%d frames on each of %d GPU%s), "
                                    "tICA(n_components=%d, lag_time=%d) fit+solve+transform -> KCenters(k=%d) fit+predict"
                                    % (total_frames, F, total_frames // T, T, frames, world, "s" if world > 1 else "",
@@ -359,9 +453,17 @@ def main():
         if weak is not None:
             out["weak_scaling"] = weak
         fit_s, pred_s = float(np.mean(times["kcenters_fit"])), float(np.mean(times["kcenters_predict"]))
-        pass_bytes = frames * (args.components * 8 + 16)          # read X row + distances_, update distances_/labels_
+        # bytes the K passes of one fit READ on this rank (msm_kcenters_last_stats): plain passes stream the float64 row +
+        # distances_ + labels_, screened passes the bfloat16 copy + the rounded-up distance; the one-off conversion reads
+        # the rows once more and writes the copy.  Exact re-evaluations of screen candidates and the label / distance
+        # updates are not counted, so this is a lower bound on the traffic and stays under the HBM peak by construction.
+        kc_rows, kc_plain, kc_scr, kc_pb, kc_sb = [int(v) for v in kst]
+        kc_bytes = kc_rows * (kc_plain * kc_pb + kc_scr * kc_sb + ((kc_pb - 8 + kc_sb) if kc_scr else 0))
         out["clustering"] = {"kcenters_fit_frames_per_s": total_frames / fit_s, "assign_frames_per_s": total_frames / pred_s,
-                             "kcenters_pass_TBps_per_gpu": args.clusters * pass_bytes / fit_s / 1e12, "hbm_peak_TBps": 8.0}
+                             "kcenters_plain_passes": kc_plain, "kcenters_screened_passes": kc_scr,
+                             "kcenters_plain_pass_bytes_per_row": kc_pb, "kcenters_screened_pass_bytes_per_row": kc_sb,
+                             "kcenters_streamed_bytes_per_fit": kc_bytes,
+                             "kcenters_pass_TBps_per_gpu": kc_bytes / fit_s / 1e12, "hbm_peak_TBps": 8.0}
 
         extras = world == 1 and not args.no_extras
         if world == 1 and not args.no_mbk:
@@ -380,8 +482,39 @@ def main():
                                       "fit_frames_per_s": frames / tm, "inertia_per_frame": float(mb.inertia_) / frames,
                                       "note": "MiniBatchKMeans(n_clusters=1000).fit on the [frames, %d] projection (fp32), "
                                               "k-means++ seeding + mini-batch steps + labels_ of every frame" % args.components}
-            del Y32, mb
+            # SURVEY 8(d)'s "large-batch" variant: 65,536 rows per step (64 steps' worth of rows per launch group)
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                mbl = MiniBatchKMeans(n_clusters=1000, random_state=0, batch_size=65536).fit([Y32])
+            torch.cuda.synchronize()
+            tm = time.perf_counter() - tm
+            out["minibatchkmeans_batch65536"] = {"n_clusters": 1000, "batch_size": 65536, "fit_ms": 1e3 * tm,
+                                                 "n_steps": int(mbl.n_steps_), "fit_frames_per_s": frames / tm,
+                                                 "rows_through_steps_per_s": int(mbl.n_steps_) * 65536 / tm,
+                                                 "inertia_per_frame": float(mbl.inertia_) / frames}
+            del Y32, mb, mbl
         del labels, kc, Y
+
+        if extras:
+            # PCIe-inclusive rate (never `value`): tICA.fit on HOST numpy trajectories of the same data, staged through the
+            # library's pinned ring (runtime.hip h2d_bulk) while the kernels run
+            nh = min(n_seq, 200)
+            host_seqs = [t.cpu().numpy() for t in seqs[:nh]]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tICA(n_components=args.components, lag_time=args.lag).fit(host_seqs[:20])      # warm the staging buffers
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                mh = tICA(n_components=args.components, lag_time=args.lag).fit(host_seqs)
+                torch.cuda.synchronize()
+                th = time.perf_counter() - th
+            out["h2d_inclusive"] = {"what": "tICA.fit on %d host (numpy, pageable) trajectories x %d x %d f32: PCIe staging + column "
+                                            "sums + MFMA accumulation" % (nh, T, F),
+                                    "h2d_inclusive_frames_per_s": nh * T / th, "GBps": nh * T * F * 4 / th / 1e9,
+                                    "pcie_gen5_x16_GBps": 63.0}
+            del host_seqs, mh
 
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             sample = [s.cpu().numpy() for s in seqs[:64]]

@@ -96,6 +96,9 @@ int msm_event_destroy(void* ev);
  * all-gather of nbytes from every rank into recv[world][nbytes]; non-zero return = failure).  It exists for runs
  * where RCCL cannot form a communicator -- several ranks on ONE GPU, gloo-only test runs. */
 typedef int (*msm_host_collective_fn)(int op, void* send, void* recv, int64_t nbytes);
+int msm_comm_rccl_available(void); /* 1: librccl loadable and a device visible.  Ranks must agree on this (an all-reduce
+                                      MIN over the bootstrap channel) before ANY of them calls msm_comm_init_rccl, because
+                                      ncclCommInitRank blocks until every rank has joined */
 int msm_comm_unique_id(char* id128);
 int msm_comm_init_rccl(const char* id128, int rank, int world);
 int msm_comm_init_host(msm_host_collective_fn fn, int rank, int world);
@@ -308,6 +311,12 @@ int msm_kcenters_fit_sharded_f32(const float* X, msm_idx_t n_local, msm_idx_t m,
 int msm_kcenters_fit_sharded_f64(const double* X, msm_idx_t n_local, msm_idx_t m, msm_idx_t n_clusters, const char* metric,
                                  msm_idx_t seed_index, msm_idx_t row_offset, msm_idx_t* labels, double* distances,
                                  msm_idx_t* ids, double* centers, double* inertia);
+
+/* What the last k-centers fit of this process streamed: out5 = {rows, plain passes, screened passes, bytes a plain pass
+ * reads per row (the row + distances_ + labels_), bytes a screened pass reads per row (the low-precision copy + the
+ * rounded-up distance)}.  bench.py derives its bytes-per-pass figure from it (exact re-evaluations of screen candidates
+ * and the updates are not counted: a lower bound on the traffic). */
+int msm_kcenters_last_stats(msm_idx_t* out5);
 
 /* ---- k-means labelling / mini-batch step (fp32, GEMM form on MFMA) ---- */
 /* labels[i] = argmin_j ||X[i]-C[j]||^2 computed as ||c||^2 - 2 x.c (+||x||^2 for the

@@ -90,6 +90,7 @@ def _declare(lib):
     f("msm_tica_last_prepass_ms", C.c_int, _p, C.POINTER(C.c_float))
     f("msm_tica_allreduce", C.c_int, _p)
     f("msm_tica_counts", C.c_int, _p, _i64p, _i64p)
+    f("msm_comm_rccl_available", C.c_int)
     f("msm_comm_unique_id", C.c_int, _p)
     f("msm_comm_init_rccl", C.c_int, _p, C.c_int, C.c_int)
     f("msm_comm_init_host", C.c_int, _p, C.c_int, C.c_int)
@@ -101,6 +102,7 @@ def _declare(lib):
     f("msm_mbk_allreduce", C.c_int, _p, _f64p, _p)
     for sfx in ("f32", "f64"):
         f("msm_kcenters_fit_sharded_" + sfx, C.c_int, _p, _i64, _i64, _i64, C.c_char_p, _i64, _i64, _p, _p, _p, _p, _f64p)
+    f("msm_kcenters_last_stats", C.c_int, _i64p)
     f("msm_tica_export_sums", C.c_int, _p, _p, _p)
     f("msm_tica_reduce", C.c_int, _p, C.c_double, _i64, _p, _p, _p, _p)
     f("msm_tica_backsolve", C.c_int, _p, _p, _i64, _p)

@@ -53,7 +53,9 @@ Rccl& rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-        r.lib = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);  // PyTorch's copy, if it is in the process
+        // a copy already in the process (PyTorch's, under whichever name it was loaded) before a fresh one: two RCCL
+        // instances in one process would each bring their own bootstrap threads and IPC state
+        for (int i = 0; !r.lib && i < 3; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
         for (int i = 0; !r.lib && i < 3; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         if (!r.lib) {
             r.error = "librccl.so not found";
@@ -165,6 +167,14 @@ int msm_comm_unique_id(char* id128)
     if (st != 0) return fail(MSM_ERR_HIP, "ncclGetUniqueId failed: %s", nccl_err(st));
     memcpy(id128, id.internal, 128);
     return MSM_OK;
+}
+
+/* 1 when this process could join an RCCL communicator (librccl loadable with every entry point, a device visible).
+ * Ranks agree on this BEFORE any of them enters ncclCommInitRank, which blocks until all ranks have joined. */
+int msm_comm_rccl_available(void)
+{
+    if (msm_device_count() <= 0) return 0;
+    return rccl().error.empty() ? 1 : 0;
 }
 
 int msm_comm_init_rccl(const char* id128, int rank, int world)

@@ -1464,6 +1464,15 @@ struct KscArgs {
     double* dist;
     msm_idx_t* labels;
     msm_idx_t* ids;
+    // Row-sharded fit (same protocol as KcArgs): the centre of this pass is reduced from the all-gathered candidate
+    // records in the prologue, the shard's record for the next pass is written by the last block to finish
+    const double* sel_cands;  // [sel_world][2 + m]; nullptr: single-process fit (centre = argmax of `prev`)
+    int sel_world;
+    double* sel_centers;      // [K][m]
+    msm_idx_t* sel_ids;       // [K]
+    double* cand_out;         // [2 + m]
+    long long row_offset;
+    unsigned* counter;
 };
 
 __device__ __forceinline__ float ksc_round_up(double c)
@@ -1491,7 +1500,29 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     const int tid = threadIdx.x;
     const int m = (int)P.m;
 
-    // ---- prologue: centre of this pass = argmax of the previous pass's per-block candidates (P.it >= 1 here) ----
+    // ---- prologue: centre of this pass = argmax of the previous pass's per-block candidates (P.it >= 1 here), or -- sharded
+    // fit -- of the candidate records all-gathered from the ranks ----
+    if (P.sel_cands) {
+        __shared__ int sel_win;
+        const long long rec = 2 + P.m;
+        if (tid == 0) {   // largest distance, ties to the lowest GLOBAL row (numpy's argmax over the concatenated array)
+            int w = -1;
+            for (int r = 0; r < P.sel_world; ++r) {
+                const double v = P.sel_cands[r * rec], g = P.sel_cands[r * rec + 1];
+                if (g < 0.0) continue;
+                if (w < 0 || v > P.sel_cands[w * rec] || (v == P.sel_cands[w * rec] && g < P.sel_cands[w * rec + 1])) w = r;
+            }
+            sel_win = w;
+            if (blockIdx.x == 0) P.sel_ids[P.it] = w >= 0 ? (msm_idx_t)P.sel_cands[w * rec + 1] : -1;
+        }
+        __syncthreads();
+        if (tid < FC) {
+            const double v = (tid < m && sel_win >= 0) ? P.sel_cands[sel_win * rec + 2 + tid] : 0.0;
+            ys[tid] = v;
+            if (blockIdx.x == 0 && tid < m) P.sel_centers[(long long)P.it * P.m + tid] = v;
+        }
+        __syncthreads();
+    } else {
     double fv = -1.0;
     long long fi = 0x7fffffffffffffffLL;
     {
@@ -1527,14 +1558,16 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     if (blockIdx.x == 0 && tid == 0) P.ids[P.it] = cidx;
     if (tid < FC) ys[tid] = tid < m ? P.X[cidx * P.m + tid] : 0.0;
     __syncthreads();
+    }
     double yr[2 * NP], yc[2 * NP];  // the centre, and the centre relative to the copy's origin
-    double c0n2 = 0.0;
+    double c0n2 = 0.0, yn2 = 0.0;
 #pragma unroll
     for (int f = 0; f < 2 * NP; ++f) {
         yr[f] = ys[f];
         const double c0f = f < m ? P.c0[f] : 0.0;
         yc[f] = ys[f] - c0f;
         c0n2 = fma(c0f, c0f, c0n2);
+        yn2 = fma(ys[f], ys[f], yn2);
     }
     // eps of a row = u' ||x~|| + eps0: ||x~ - (x - c0)|| <= u/(1-u) ||x~|| per row (tighter than u max||x - c0||: fewer false
     // candidates), eps0 = the float64 roundings of the two centrings + an absolute term for underflow
@@ -1542,7 +1575,8 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     double eps0;
     {
         const double g2 = __longlong_as_double((long long)P.gmax2[0]), r2 = __longlong_as_double((long long)P.gmax2[1]);
-        eps0 = (sqrt(r2) + sqrt(c0n2)) * 0x1p-48 + 1e-37;
+        // (the centre's own centring y - c0 rounds too; in a sharded fit y may be another rank's row, outside this shard's R)
+        eps0 = (sqrt(r2) + sqrt(yn2) + 2.0 * sqrt(c0n2)) * 0x1p-48 + 1e-37;
         if (!(g2 < 1e76) || !(r2 < 1e76)) eps0 = NAN;  // rows beyond the float32 range (or non-finite): nothing passes the screen
     }
 
@@ -1691,6 +1725,46 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         q.i = ri[0];
         P.next[blockIdx.x] = q;
     }
+    if (P.cand_out) {
+        // sharded fit: the last block to arrive reduces all partials to the shard's candidate record (as in kcenters_pass_kernel)
+        __shared__ int am_last;
+        if (tid == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            am_last = prev == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (am_last) {
+            double cv = -1.0;
+            long long ci = -1;
+            for (int k = tid; k < (int)gridDim.x; k += DT) {
+                const KcPartial q = P.next[k];
+                if (q.i >= 0 && (ci < 0 || kc_better(q.v, q.i, cv, ci))) {
+                    cv = q.v;
+                    ci = q.i;
+                }
+            }
+            rv[tid] = cv;
+            ri[tid] = ci;
+            __syncthreads();
+            for (int s = DT / 2; s > 0; s >>= 1) {
+                if (tid < s) {
+                    const long long oi = ri[tid + s];
+                    if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + s], oi, rv[tid], ri[tid]))) {
+                        rv[tid] = rv[tid + s];
+                        ri[tid] = oi;
+                    }
+                }
+                __syncthreads();
+            }
+            const long long w = ri[0];
+            if (tid == 0) {
+                P.cand_out[0] = w >= 0 ? rv[0] : -1.0;
+                P.cand_out[1] = w >= 0 ? (double)(P.row_offset + w) : -1.0;
+                __hip_atomic_store(P.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (long long f = tid; f < P.m; f += DT) P.cand_out[2 + f] = w >= 0 ? P.X[w * P.m + f] : 0.0;
+        }
+    }
 }
 
 // switch-over from the plain kernel: the centred screen copy, rounded-up distances, max ||x - c0||^2 and max ||x||^2
@@ -1764,10 +1838,18 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
 }
 
 // c0 = coordinates of the first centre (ids[0]), for the copy's origin
-__global__ void ksc_origin_kernel(const double* __restrict__ X, const msm_idx_t* __restrict__ ids, long long m, double* __restrict__ c0)
+// (sharded fit: `centre0` = the first centre's coordinates as selected from the exchanged records -- it may be another rank's row)
+__global__ void ksc_origin_kernel(const double* __restrict__ X, const msm_idx_t* __restrict__ ids, long long m, double* __restrict__ c0,
+                                  const double* __restrict__ centre0)
 {
-    if (threadIdx.x < 16) c0[threadIdx.x] = threadIdx.x < m ? X[ids[0] * m + threadIdx.x] : 0.0;
+    if (threadIdx.x < 16) c0[threadIdx.x] = threadIdx.x < m ? (centre0 ? centre0[threadIdx.x] : X[ids[0] * m + threadIdx.x]) : 0.0;
 }
+
+// what the last k-centers fit streamed (for bench.py's bytes-per-pass figure): pass counts and the bytes a pass reads per row
+struct KcStats {
+    long long rows = 0, plain_passes = 0, screened_passes = 0, plain_row_bytes = 0, screen_row_bytes = 0;
+};
+static KcStats g_kc_stats;
 
 static int ksc_mode()  // MSM_KC_SCREEN: 0 = plain passes only, 1 = float32 screen copy, 2 (default) = bfloat16 screen copy
 {
@@ -2280,6 +2362,10 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     const bool sorted = ks_enabled() && P.prune && P.vecw > 0 && K <= KC_PRUNE_MAX && K >= 16 && n >= (1 << 18) &&
                         (mid == M_EUCLIDEAN || mid == M_CITYBLOCK || mid == M_CHEBYSHEV);
     const bool screen = !sorted && ksc_enabled() && sizeof(T) == 8 && mid == M_EUCLIDEAN && P.vecw > 0 && n >= 65536 && K > 8;
+    g_kc_stats = KcStats();
+    g_kc_stats.rows = n;
+    g_kc_stats.plain_row_bytes = (long long)(m * sizeof(T) + 16);   // the row, distances_, labels_ (pruning test)
+    g_kc_stats.plain_passes = K;
     if (sorted) {
         if ((rc = kcenters_sorted_run<T>(mid, static_cast<const T*>(P.X), n, m, K, seed, P.vecw, P.ids, P.labels, P.dist))) return rc;
     } else if (screen) {
@@ -2303,6 +2389,9 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         const bool use_screen = it < K;
         if (use_screen) {
             const bool bf16 = ksc_mode() != 1;
+            g_kc_stats.plain_passes = it;
+            g_kc_stats.screened_passes = K - it;
+            g_kc_stats.screen_row_bytes = (long long)((bf16 ? np : 2 * np) * 4 + 4);   // the screen copy's row + curf
             if ((rc = B.xf.reserve((size_t)n * (bf16 ? np : 2 * np) * sizeof(float)))) return rc;
             if ((rc = B.curf.reserve((size_t)n * sizeof(float)))) return rc;
             KscArgs S;
@@ -2312,7 +2401,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
             S.curf = B.curf.as<float>();
             S.gmax2 = B.misc.as<unsigned long long>();
             S.c0 = reinterpret_cast<double*>(static_cast<char*>(B.misc.p) + 64);
-            hipLaunchKernelGGL(ksc_origin_kernel, dim3(1), dim3(64), 0, stream(), S.X, P.ids, (long long)m, S.c0);
+            hipLaunchKernelGGL(ksc_origin_kernel, dim3(1), dim3(64), 0, stream(), S.X, P.ids, (long long)m, S.c0, (const double*)nullptr);
             S.n = n;
             S.m = m;
             S.nblk = nblk;
@@ -2620,9 +2709,75 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
         P.cand_out = cand;
         P.row_offset = row_offset;
         P.counter = counter;
+        // Screened passes (float64 rows, euclidean; see kcenters_screen_pass_kernel) after a few plain ones, as in the
+        // single-process fit.  The decision is LOCAL to a rank: the exchange pattern (one all-gather per centre) is the same
+        // for both kernels, so a rank with a small shard may keep the plain kernel while its peers screen.
+        static const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 4;
+        static const long long KSC_MIN_ROWS = getenv("MSM_KC_SCREEN_MIN_ROWS") ? atoll(getenv("MSM_KC_SCREEN_MIN_ROWS")) : 65536;
+        const bool screen = ksc_enabled() && sizeof(T) == 8 && mid == M_EUCLIDEAN && n >= KSC_MIN_ROWS && K > 8 && K > KSC_PROBE;
+        KscArgs S;
+        memset(&S, 0, sizeof(S));
+        const int np = (int)((m + 1) / 2);
+        const bool bf16 = ksc_mode() != 1;
+        if (screen) {
+            KscBufs& B = ksc_bufs();
+            if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;
+            if ((rc = B.xf.reserve((size_t)n * (bf16 ? np : 2 * np) * sizeof(float)))) return rc;
+            if ((rc = B.curf.reserve((size_t)n * sizeof(float)))) return rc;
+            MSM_HIP_CHECK(hipMemsetAsync(B.misc.p, 0, 64, stream()));
+            S.X = reinterpret_cast<const double*>(X);
+            S.xs = B.xf.p;
+            S.curf = B.curf.as<float>();
+            S.gmax2 = B.misc.as<unsigned long long>();
+            S.c0 = reinterpret_cast<double*>(static_cast<char*>(B.misc.p) + 64);
+            S.n = n;
+            S.m = m;
+            S.nblk = nblk;
+            S.vecw = P.vecw;
+            S.seed = seed;
+            S.dist = distances;
+            S.labels = labels;
+            S.ids = dids;
+            S.next = dPart.as<KcPartial>();
+            S.sel_cands = cands;
+            S.sel_world = world;
+            S.sel_centers = reinterpret_cast<double*>(cen);
+            S.sel_ids = dids;
+            S.cand_out = cand;
+            S.row_offset = row_offset;
+            S.counter = counter;
+        }
+        g_kc_stats = KcStats();
+        g_kc_stats.rows = n;
+        g_kc_stats.plain_row_bytes = (long long)(m * sizeof(T) + 16);
+        g_kc_stats.screen_row_bytes = (long long)((bf16 ? np : 2 * np) * 4 + 4);
         for (msm_idx_t it = 0; it < K; ++it) {
-            P.it = (int)it;
-            launch_kc<T>(mid, nblk, P);
+            if (screen && it >= KSC_PROBE) {
+                if (it == KSC_PROBE) {
+                    // the copy's origin is centre 0 as every rank selected it (possibly another rank's row)
+                    hipLaunchKernelGGL(ksc_origin_kernel, dim3(1), dim3(64), 0, stream(), S.X, dids, (long long)m, S.c0,
+                                       reinterpret_cast<const double*>(cen));
+                    const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
+                    switch (np) {
+#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((ksc_convert_kernel<NP_, true>), dim3(gconv), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, false>), dim3(gconv), dim3(DT), 0, stream(), S); break;
+                        MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
+#undef MSM_KSC
+                    }
+                }
+                S.it = (int)it;
+                switch (np) {
+#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, true>), dim3(nblk), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, false>), dim3(nblk), dim3(DT), 0, stream(), S); break;
+                    MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
+#undef MSM_KSC
+                }
+                ++g_kc_stats.screened_passes;
+            } else {
+                P.it = (int)it;
+                launch_kc<T>(mid, nblk, P);
+                ++g_kc_stats.plain_passes;
+            }
             if (it + 1 < K && (rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
         }
         MSM_HIP_CHECK(hipGetLastError());
@@ -2761,6 +2916,17 @@ int msm_assign_nearest_f64(const double* X, const double* Y, const char* metric,
 {
     return assign_nearest_impl<double>(X, Y, metric, X_indices, n_X, n_Y, n_features, n_X_indices,
                                        assignments, min_dist, inertia, on_device);
+}
+
+int msm_kcenters_last_stats(msm_idx_t* out5)
+{
+    if (!out5) return fail(MSM_ERR_INVALID, "msm_kcenters_last_stats: null pointer");
+    out5[0] = g_kc_stats.rows;
+    out5[1] = g_kc_stats.plain_passes;
+    out5[2] = g_kc_stats.screened_passes;
+    out5[3] = g_kc_stats.plain_row_bytes;
+    out5[4] = g_kc_stats.screen_row_bytes;
+    return MSM_OK;
 }
 
 int msm_kcenters_fit_sharded_f32(const float* X, msm_idx_t n_local, msm_idx_t m, msm_idx_t n_clusters, const char* metric,

@@ -177,6 +177,7 @@ class tICA(BaseEstimator, TransformerMixin):
         self._sum_tau_to_T = np.zeros(n_features)
         self._outer_gram_sum = np.zeros((n_features, n_features))
         self._host_stale = False
+        self._mu_raw = None
         self._initialized = True
 
     def _release(self):
@@ -243,13 +244,47 @@ class tICA(BaseEstimator, TransformerMixin):
         self.__dict__.update(d)
         self._handle = None
 
+    @classmethod
+    def from_reference_state(cls, state, **subclass_kwargs):
+        """A model carrying on from a fitted REFERENCE tICA: ``state`` is that object's ``__dict__`` (or any mapping
+        with the same keys) -- hyper-parameters ``n_components, lag_time, shrinkage, kinetic_mapping,
+        commute_mapping``, counters ``n_features, n_observations_, n_sequences_`` and the accumulators the reference
+        declares (tica.py:128-148): ``_outer_0_to_T_lagged, _sum_0_to_TminusTau, _sum_tau_to_T,
+        _outer_0_to_TminusTau, _outer_offset_to_T``.  The moments go to the device through ``msm_tica_import`` (the two
+        Gram halves as their sum, the only form the reference ever reads: tica.py:245); ``partial_fit``, ``transform``
+        and every fitted attribute then behave as if this class had seen the reference's data."""
+        get = state.get if hasattr(state, "get") else (lambda k, d=None: getattr(state, k, d))
+        m = cls(n_components=get("n_components"), lag_time=get("lag_time", 1), shrinkage=get("shrinkage"),
+                kinetic_mapping=bool(get("kinetic_mapping", False)), commute_mapping=bool(get("commute_mapping", False)),
+                **subclass_kwargs)
+        F = get("n_features")
+        if F is None or get("_outer_0_to_T_lagged") is None:
+            return m                                  # an unfitted reference model: nothing to import
+        F = int(F)
+        c = np.ascontiguousarray(get("_outer_0_to_T_lagged"), dtype=np.float64)
+        g = np.ascontiguousarray(np.asarray(get("_outer_0_to_TminusTau"), dtype=np.float64)
+                                 + np.asarray(get("_outer_offset_to_T"), dtype=np.float64))
+        s0 = np.ascontiguousarray(get("_sum_0_to_TminusTau"), dtype=np.float64)
+        st = np.ascontiguousarray(get("_sum_tau_to_T"), dtype=np.float64)
+        if c.shape != (F, F) or g.shape != (F, F) or s0.shape != (F,) or st.shape != (F,):
+            raise ValueError("reference state does not describe a %d-feature model" % F)
+        m._initialize(F)                              # creates the handle (zeroed)
+        m.n_observations_ = int(get("n_observations_") or 0)
+        m.n_sequences_ = int(get("n_sequences_") or 0)
+        check(_lib.lib().msm_tica_import(m._handle, c.ctypes.data, g.ctypes.data, s0.ctypes.data, st.ctypes.data,
+                                         m.n_observations_, m.n_sequences_))
+        m._host_stale = True                          # the host mirrors are refreshed from the device on demand
+        m._is_dirty = True
+        m._mu_raw = None
+        return m
+
     # --------------------------------------------------------------------- solve
     def _solve(self):
         """Top ``n_components`` generalized eigenpairs of (offset_correlation_, covariance_), cached until the
         accumulators change (tica.py:167-199).  The finalisation of the moments, the shrinkage estimate, the Cholesky
         reduction and the back-substitution run on the device (``msm_tica_reduce`` / ``msm_tica_backsolve``); only the
         reduced F x F standard problem visits the host for LAPACK's dsyevr (its tridiagonalisation is latency-bound on
-        a GPU at F = 512), and from F = 1024 the device does that too (``msm_tica_solve_device``).
+        a GPU at F = 512), and from ``_moments.DEVICE_SOLVE_MIN_FEATURES`` the device does that too (``msm_tica_solve_device``).
         ``MSMBUILDER_AMD_DEVICE_SOLVE=0`` restores the all-host numpy / dsygvx path of round 1."""
         if not self._is_dirty:
             # n_components may have been raised since the last solve
@@ -268,6 +303,7 @@ class tICA(BaseEstimator, TransformerMixin):
             if not _moments.is_symmetric(rhs):
                 raise RuntimeError('correlation matrix is not symmetric')
             vals, vecs = _moments.top_generalized_eigenpairs(lhs, rhs, self.n_components)
+            self._mu_raw = None      # only the device solve leaves a mean behind; never keep one from an older state
         else:
             vals, vecs = self._solve_on_device(mode)
 
@@ -377,8 +413,9 @@ class tICA(BaseEstimator, TransformerMixin):
         return self
 
     def _raw_means(self):
-        if not self._is_dirty and getattr(self, "_mu_raw", None) is not None:
-            return self._mu_raw                 # left behind by the device-side solve of the current state
+        if getattr(self, "_mu_raw", None) is not None:
+            return self._mu_raw                 # left behind by the device-side solve of the CURRENT accumulators
+                                                # (every accumulate / import / all-reduce clears it)
         if self._host_stale and self._handle is not None:
             # the two column sums alone: no need to download the F x F moments for a mean
             s0, st = np.empty(self.n_features), np.empty(self.n_features)
@@ -460,7 +497,10 @@ class tICA(BaseEstimator, TransformerMixin):
             if X.dtype == torch.bfloat16:
                 # bf16-STORED trajectories (BASELINE configs[4]: half the bytes) feed the bf16 modes as they are;
                 # the other modes take them as float32 (an exact widening)
-                if not (keep_bf16 and _mode_from_env() in (_lib.TICA_BF16, _lib.TICA_BF16X2)):
+                # (the mode is the HANDLE's, fixed when it was created; the environment may have changed since)
+                hk = getattr(self, "_handle_key", None)
+                mode = hk[2] if (hk is not None and self._initialized) else _mode_from_env()
+                if not (keep_bf16 and mode in (_lib.TICA_BF16, _lib.TICA_BF16X2)):
                     X = X.to(torch.float32)
             elif X.dtype not in (torch.float32, torch.float64):
                 X = X.to(torch.float64)
@@ -543,6 +583,7 @@ class tICA(BaseEstimator, TransformerMixin):
             self.n_sequences_ += n
         self._host_stale = True
         self._is_dirty = True
+        self._mu_raw = None
 
     # ------------------------------------------------------------------ multi-GPU
     def partial_fit_segments(self, pieces):
@@ -581,6 +622,7 @@ class tICA(BaseEstimator, TransformerMixin):
                 self.n_sequences_ += 1 if (it[3] == 0 and it[4] > it[3]) else 0
         self._host_stale = True
         self._is_dirty = True
+        self._mu_raw = None
         return self
 
     def fit_sharded(self, sequences, group=None):

@@ -78,6 +78,8 @@ def init_from_env(backend=None):
 # ---------------------------------------------------------------------------------------------------
 _lib_comm_kind = None      # None | "rccl" | "host"
 _host_cb_keepalive = None
+_lib_comm_key = None       # (backend, world, rank, default group identity) the communicator belongs to
+_atexit_registered = False
 
 
 def _host_collective(op, send, recv, nbytes):
@@ -116,14 +118,27 @@ def _host_collective(op, send, recv, nbytes):
         return 1
 
 
+def _world_key():
+    """Identity of the torch.distributed world a library communicator was built for."""
+    dist = _dist()
+    return (dist.get_backend(), dist.get_world_size(), dist.get_rank(), id(dist.distributed_c10d._get_default_group()))
+
+
 def library_comm():
     """Make sure libmsmhip has a communicator for the current torch.distributed world (collective call: every
-    rank reaches it from the same SPMD entry point).  Returns "rccl", "host" or None (single process)."""
-    global _lib_comm_kind, _host_cb_keepalive
+    rank reaches it from the same SPMD entry point).  Returns "rccl", "host" or None (single process).
+    A communicator built for an earlier process group (destroyed and re-created with another size / rank / backend)
+    is torn down first."""
+    global _lib_comm_kind, _lib_comm_key, _host_cb_keepalive
     if not active():
+        if _lib_comm_kind is not None:
+            library_comm_shutdown()
         return None
+    key = _world_key()
     if _lib_comm_kind is not None:
-        return _lib_comm_kind
+        if key == _lib_comm_key:
+            return _lib_comm_kind
+        library_comm_shutdown()
     import ctypes as C
     import torch
     from . import _lib
@@ -134,21 +149,26 @@ def library_comm():
     kind = None
     if want != "host" and _backend_is_nccl():
         _lib.ensure_device()
-        uid = (C.c_char * 128)()
-        ok = 1
-        if r == 0:
-            ok = 1 if L.msm_comm_unique_id(uid) == 0 else 0
-        t = torch.tensor(list(bytes(uid)) + [ok], dtype=torch.uint8, device="cuda")
-        dist.broadcast(t, src=0)
-        raw = bytes(t.cpu().numpy().tolist())
-        if raw[128]:
-            rc = L.msm_comm_init_rccl(raw[:128], r, w)
-            flag = torch.tensor([1.0 if rc == 0 else 0.0], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if flag.item() > 0:
-                kind = "rccl"
-            else:
-                L.msm_comm_destroy()
+        # 1) every rank says whether it could join (librccl loadable, device visible) BEFORE anyone enters
+        #    ncclCommInitRank, which blocks until all ranks have joined: one rank bailing out early would hang the rest
+        usable = torch.tensor([float(L.msm_comm_rccl_available())], device="cuda")
+        dist.all_reduce(usable, op=dist.ReduceOp.MIN)
+        if usable.item() > 0:
+            uid = (C.c_char * 128)()
+            ok = 1
+            if r == 0:
+                ok = 1 if L.msm_comm_unique_id(uid) == 0 else 0
+            t = torch.tensor(list(bytes(uid)) + [ok], dtype=torch.uint8, device="cuda")
+            dist.broadcast(t, src=0)
+            raw = bytes(t.cpu().numpy().tolist())
+            if raw[128]:
+                rc = L.msm_comm_init_rccl(raw[:128], r, w)
+                flag = torch.tensor([1.0 if rc == 0 else 0.0], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() > 0:
+                    kind = "rccl"
+                else:
+                    L.msm_comm_destroy()
         if kind is None and want == "rccl":
             raise RuntimeError("libmsmhip could not create its RCCL communicator: " + _lib.last_error())
     if kind is None:
@@ -156,16 +176,22 @@ def library_comm():
         _host_cb_keepalive = cbt(_host_collective)
         _lib.check(L.msm_comm_init_host(C.cast(_host_cb_keepalive, C.c_void_p), r, w))
         kind = "host"
-    _lib_comm_kind = kind
+    _lib_comm_kind, _lib_comm_key = kind, key
+    global _atexit_registered
+    if not _atexit_registered:
+        import atexit
+        atexit.register(library_comm_shutdown)      # before interpreter teardown destroys the process group
+        _atexit_registered = True
     return kind
 
 
 def library_comm_shutdown():
-    global _lib_comm_kind, _host_cb_keepalive
+    global _lib_comm_kind, _lib_comm_key, _host_cb_keepalive
     if _lib_comm_kind is not None:
         from . import _lib
         _lib.lib().msm_comm_destroy()
     _lib_comm_kind = None
+    _lib_comm_key = None
     _host_cb_keepalive = None
 
 

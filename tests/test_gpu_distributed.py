@@ -77,6 +77,28 @@ assert abs(kc.inertia_ - kref.inertia_) <= 1e-12 * kref.inertia_
 assert np.array_equal(kc.cluster_centers_, kref.cluster_centers_)
 assert np.array_equal(kc.predict([block])[0], kref.predict([X])[0][lo:hi])
 
+# SCREENED passes in the sharded loop (float64 rows, >= 65536 rows per shard): both ranks screen / only rank 0 does (the
+# decision is local, the exchange pattern identical); centres far from the origin, duplicates across the boundary
+import ctypes as C
+zs = np.cumsum(rs.randn(200_000, 10) * 0.05, axis=0) + rs.randn(200_000, 10) * 0.3 + 7.0
+zs[150_000:150_004] = zs[17]
+for cutz in (120_000, 160_000):
+    blk = zs[:cutz] if rank == 0 else zs[cutz:]
+    kz = KCenters(n_clusters=40, random_state=2).fit([blk])
+    st = (C.c_int64 * 5)()
+    _lib.check(_lib.lib().msm_kcenters_last_stats(st))
+    assert st[0] == len(blk) and st[1] + st[2] == 40
+    assert (st[2] == 36) == (len(blk) >= 65536), list(st)
+    os.environ["MSMBUILDER_AMD_PARALLEL"] = "0"
+    kzr = KCenters(n_clusters=40, random_state=2).fit([zs])
+    os.environ["MSMBUILDER_AMD_PARALLEL"] = "1"
+    assert kz.cluster_ids_ == kzr.cluster_ids_, (kz.cluster_ids_, kzr.cluster_ids_)
+    lz, hz = (0, cutz) if rank == 0 else (cutz, len(zs))
+    assert np.array_equal(kz.labels_[0].cpu().numpy(), kzr.labels_[0][lz:hz])
+    assert np.array_equal(kz.distances_[0].cpu().numpy(), kzr.distances_[0][lz:hz])
+    assert np.array_equal(kz.cluster_centers_, kzr.cluster_centers_)
+    assert abs(kz.inertia_ - kzr.inertia_) <= 1e-12 * kzr.inertia_
+
 # an EMPTY shard on one rank, float32 rows longer than one chunk (wide-row kernel)
 Xw = rs.randn(3000, 40).astype(np.float32)
 blockw = Xw if rank == 0 else Xw[:0]
@@ -156,6 +178,18 @@ assert list(ids) == ref.cluster_ids_
 assert torch.equal(lab, ref.labels_[0]) and torch.equal(dist_, ref.distances_[0])
 assert np.array_equal(cen, ref.cluster_centers_.cpu().numpy() if hasattr(ref.cluster_centers_, "cpu") else ref.cluster_centers_)
 assert abs(inertia.value - ref.inertia_) <= 1e-12 * ref.inertia_
+# ... and with enough rows for the screened passes
+X2 = torch.from_numpy(np.cumsum(rs.randn(100_000, 10) * 0.05, axis=0) + 3.0).cuda()
+ref2 = KCenters(n_clusters=30, random_state=3).fit([X2])
+ax2 = Arr(X2)
+lab2 = torch.empty(100_000, dtype=torch.int64, device="cuda"); dist2 = torch.empty(100_000, dtype=torch.float64, device="cuda")
+_lib.check(L.msm_kcenters_fit_sharded_f64(ax2.vp, 100_000, 10, 30, b"euclidean", ref2.cluster_ids_[0], 0, C.c_void_p(lab2.data_ptr()),
+                                          C.c_void_p(dist2.data_ptr()), ids.ctypes.data, cen.ctypes.data, C.byref(inertia)))
+st = (C.c_int64 * 5)()
+_lib.check(L.msm_kcenters_last_stats(st))
+assert list(st)[:3] == [100_000, 4, 26], list(st)
+assert list(ids) == ref2.cluster_ids_
+assert torch.equal(lab2, ref2.labels_[0]) and torch.equal(dist2, ref2.distances_[0])
 L.msm_comm_destroy()
 print("rccl world-of-one ok")
 '''
