@@ -266,7 +266,20 @@ def self_launch(n):
         env.setdefault("MSMBUILDER_AMD_DIST_BACKEND", "gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd, env=env))
+    # stdout of the job carries ONE JSON line (rank 0's); anything else a backend prints there (gloo's connection banner)
+    # is passed on through stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(rc if rc else (0 if line is not None else 1))
 
 
 def main():
