@@ -205,6 +205,21 @@ int msm_tica_reduce_tridiag(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, c
 /* The tridiagonalisation on its own: symmetric A (n x n, host or device per on_device), n <= 1024. */
 int msm_sytrd(const double* A, msm_idx_t n, double* d, double* e, double* tau, double* V, int* status, int on_device);
 int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V);
+/* The whole top-k solve without LAPACK and with ONE synchronisation (n_features <= 1024, k <= 64): msm_tica_reduce's
+ * finalisation and reduction (Cholesky by the library's own blocked kernel), the cooperative tridiagonalisation, the k
+ * largest eigenpairs of the tridiagonal matrix by multisection + inverse iteration (msm_tridiag_topk), the Householder
+ * back-transform, v = L^-T y.  vals[k] descending, vecs[k][F] rows B-orthonormal like dsygvx's, mu[F], info[8] as
+ * msm_tica_reduce plus info[6] = max_j ||Cs y_j - lambda_j y_j||_inf and info[7] = max_j | ||y_j||^2 - 1 |.
+ * *status = 0: pairs returned and verified on the reduced matrix; 1: the cooperative kernel gave up; 2: the residual
+ * check failed -- in both cases Cs (host, F x F) holds the reduced matrix for the caller's LAPACK route
+ * (msm_tica_backsolve afterwards), as with msm_tica_reduce_tridiag. */
+int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k, double* vals,
+                        double* vecs, double* Cs, double* mu, double* info, int* status);
+/* Building blocks, exported for the tests: k largest eigenpairs of the symmetric tridiagonal (d[n], e[n-1]), n <= 1024,
+ * k <= 64 (vals descending, vecs[k][n] orthonormal rows); Cholesky B = U^T U on the row-major upper triangle (LAPACK
+ * dpotrf 'L' on the column-major view), *info = first non-positive pivot (1-based) or 0. */
+int msm_tridiag_topk(const double* d, const double* e, msm_idx_t n, msm_idx_t k, double* vals, double* vecs, int on_device);
+int msm_potrf(double* B, msm_idx_t n, int* info, int on_device);
 int msm_tica_solve_device(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k,
                           double* vals, double* vecs, double* mu, double* info);
 

@@ -82,6 +82,12 @@ int syevd_device(double* A, int n, double* D, double* E, int* dinfo);
 // exchange records; *status (device int) = 1 if the kernel gave up
 int sytrd_device(const double* A, int n, double* d, double* e, double* tau, double* V, double* work8n, int* status);
 
+// toppairs.hip: the LAPACK-free tail of the solve, queued on stream(), nothing synchronised
+int potrf_upper_device(double* B, int n, int* dinfo);   // B = U^T U on the row-major upper triangle (== dpotrf 'L', col-major)
+int tri_topk_device(const double* d, const double* e, int n, int k, double* vals, double* S);   // n <= 1024, k <= 64; e has n entries
+int apply_q_device(const double* V, const double* tau, int n, int k, const double* S, double* Y);
+int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res2k);
+
 // A data pointer that was itself LOADED from memory (e.g. out of a descriptor table) is a
 // generic pointer to the compiler, which then emits flat_load: slower, and because FLAT counts on
 // both vmcnt and lgkmcnt every counted wait degenerates to vmcnt(0).  Re-type it as global.

@@ -80,8 +80,18 @@ int sygv_reduce_device(double* A, double* B, int n, int* dinfo)
     if (!s.error.empty()) return fail(MSM_ERR_STATE, "device eigensolver unavailable: %s", s.error.c_str());
     if (s.set_stream(s.handle, stream()) != 0) return fail(MSM_ERR_HIP, "rocblas_set_stream failed");
     const double one = 1.0;
-    int st = s.dpotrf(s.handle, 122, n, B, n, dinfo);
-    if (st != 0) return fail(MSM_ERR_HIP, "rocsolver_dpotrf failed with rocblas_status %d", st);
+    int st;
+    // B = L L^T: the library's own blocked kernel up to n = 1024 (one launch per 32 rows; rocSOLVER's dpotrf is launch-
+    // latency bound there: 1.3 ms at n = 512), rocSOLVER beyond.  MSM_POTRF=rocsolver|own forces one of them.
+    static const char* pf = getenv("MSM_POTRF");
+    const bool own = pf ? (pf[0] == 'o') : n <= 1024;
+    if (own) {
+        int rc = potrf_upper_device(B, n, dinfo);
+        if (rc) return rc;
+    } else {
+        st = s.dpotrf(s.handle, 122, n, B, n, dinfo);
+        if (st != 0) return fail(MSM_ERR_HIP, "rocsolver_dpotrf failed with rocblas_status %d", st);
+    }
     st = s.dtrsm(s.handle, 141, 122, 111, 131, n, n, &one, B, n, A, n);               // X = L^-1 A
     if (st == 0) st = s.dtrsm(s.handle, 142, 122, 112, 131, n, n, &one, B, n, A, n);  // C = X L^-T
     if (st != 0) return fail(MSM_ERR_HIP, "rocblas_dtrsm failed with rocblas_status %d", st);

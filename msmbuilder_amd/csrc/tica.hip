@@ -2954,6 +2954,7 @@ namespace {
 
 struct SolveBufs {
     double *A, *B, *mu, *D, *E, *scal, *part, *scale, *Y, *vals, *trdw;
+    double *lam, *S, *Yk, *res;   // top-k tail (toppairs.hip): eigenvalues [64], tridiagonal vectors / back-transformed vectors [64][F], residuals [128]
     int* ints;  // [0..1] non-finite flags (OC, S), [2] potrf info, [3] syevd info; [8 ..] sytrd barrier flags + status
     int nblk;
 };
@@ -2962,7 +2963,7 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
 {
     const size_t F = (size_t)h->F, FF = F * F;
     const int nblk = (int)ceil_div((int64_t)FF, 256);
-    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk;
+    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk + 192 + 128 * F;
     int rc = h->solve.reserve(nd * sizeof(double) + (8 + F / 16 + 4) * sizeof(int));
     if (rc) return rc;
     double* p = h->solve.as<double>();
@@ -2977,7 +2978,11 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
     b->scal = b->vals + F;
     b->part = b->scal + 4;
     b->trdw = b->part + 2 * (size_t)nblk;   // 8F doubles of sytrd exchange records
-    b->ints = reinterpret_cast<int*>(b->trdw + 8 * F);
+    b->lam = b->trdw + 8 * F;
+    b->res = b->lam + 64;
+    b->S = b->res + 128;
+    b->Yk = b->S + 64 * F;
+    b->ints = reinterpret_cast<int*>(b->Yk + 64 * F);
     b->nblk = nblk;
     return MSM_OK;
 }
@@ -3085,6 +3090,58 @@ int msm_tica_reduce_tridiag(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, c
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     }
     return tica_reduce_status(scal, ints, info);
+}
+
+int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k, double* vals,
+                        double* vecs, double* Cs, double* mu, double* info, int* status)
+{
+    if (!h || !vals || !vecs || !Cs || !mu || !status) return fail(MSM_ERR_STATE, "msm_tica_solve_topk: null argument");
+    if (h->F > 1024 || h->F < 3) return fail(MSM_ERR_INVALID, "msm_tica_solve_topk: need 3 <= n_features <= 1024");
+    if (k < 1 || k > h->F || k > 64) return fail(MSM_ERR_INVALID, "msm_tica_solve_topk: need 1 <= k <= min(n_features, 64)");
+    SolveBufs b;
+    int rc = tica_reduce_device(h, shrinkage, n_rblw, scale, &b);
+    if (rc) return rc;
+    const int n = h->F;
+    const size_t FF = (size_t)n * n;
+    // A = Cs = L^-1 OC L^-T stays intact (sytrd copies it into registers); reflectors -> Y slot, tau -> vals slot
+    if ((rc = sytrd_device(b.A, n, b.D, b.E, b.vals, b.Y, b.trdw, b.ints + 8))) return rc;
+    if ((rc = tri_topk_device(b.D, b.E, n, (int)k, b.lam, b.S))) return rc;
+    if ((rc = apply_q_device(b.Y, b.vals, n, (int)k, b.S, b.Yk))) return rc;
+    if ((rc = pair_residual_device(b.A, n, b.Yk, b.lam, (int)k, b.res))) return rc;
+    // the residual kernel has read Yk; L^-T in place for the k vectors
+    MSM_HIP_CHECK(hipMemcpyAsync(b.S, b.Yk, (size_t)k * n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+    if ((rc = sygv_back_device(b.B, b.S, n, (int)k))) return rc;
+    double scal[4], res[128];
+    int ints[8], st = 0;
+    MSM_HIP_CHECK(hipMemcpyAsync(vecs, b.S, (size_t)k * n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(vals, b.lam, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(res, b.res, 2 * (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(&st, b.ints + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    rc = tica_reduce_status(scal, ints, info);
+    if (rc) return rc;
+    // self-check on the reduced matrix: every returned pair must satisfy C y = lambda y to rounding and be normalised.
+    // A failure (the cooperative tridiagonalisation gave up or exchanged a stale value, the inverse iteration stalled)
+    // hands the reduced matrix to the caller's LAPACK route instead of returning a wrong pair.
+    double lmax = 1.0, rmax = 0.0, nmax = 0.0;
+    for (int j = 0; j < (int)k; ++j) {
+        lmax = std::max(lmax, std::fabs(vals[j]));
+        rmax = std::max(rmax, res[j]);
+        nmax = std::max(nmax, res[k + j]);
+    }
+    if (info) {
+        info[6] = rmax;
+        info[7] = nmax;
+    }
+    *status = st ? 1 : ((!(rmax <= 1e-11 * lmax) || !(nmax <= 1e-10)) ? 2 : 0);
+    if (*status) {
+        MSM_HIP_CHECK(hipMemcpyAsync(Cs, b.A, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+    return MSM_OK;
 }
 
 int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V)

@@ -126,6 +126,15 @@ def use_device_tridiagonalisation(F):
     return F <= 1024 and os.environ.get("MSMBUILDER_AMD_DEVICE_TRD", "1") != "0"
 
 
+def use_device_topk(F, k):
+    """Hybrid solve, all of it on the device (csrc/toppairs.hip: own Cholesky, cooperative tridiagonalisation, multisection +
+    inverse iteration on the tridiagonal matrix, Householder back-transform; one synchronisation, no LAPACK), for
+    3 <= F <= 1024 and k <= 64.  MSMBUILDER_AMD_DEVICE_TOPK=0 keeps dstemr / dormqr on the host."""
+    import os
+    return (3 <= F <= 1024 and 1 <= k <= min(F, 64) and use_device_tridiagonalisation(F)
+            and os.environ.get("MSMBUILDER_AMD_DEVICE_TOPK", "1") != "0")
+
+
 def eigenpairs_from_tridiagonal(d, e, tau, V, k):
     """k largest eigenpairs of the symmetric matrix whose LAPACK dsytrd(lower) factors are (d, e, tau, V = the reflector
     block A(2:n, 1:n-1), flat column-major): dstemr on the tridiagonal for the selected pairs (O(k n)), then Q = H(0) ... H(n-2) applied to the k vectors with

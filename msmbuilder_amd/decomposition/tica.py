@@ -342,7 +342,22 @@ class tICA(BaseEstimator, TransformerMixin):
         else:
             Cs = np.empty((F, F))
             done = False
-            if _moments.use_device_tridiagonalisation(F):
+            V = None
+            if _moments.use_device_topk(F, k):
+                # everything on the device, one synchronisation: reduction, cooperative tridiagonalisation, the k largest
+                # pairs of the tridiagonal matrix, Householder back-transform, L^-T (csrc/toppairs.hip); the pairs are
+                # verified against the reduced matrix there -- status != 0 hands Cs to the LAPACK route below
+                vals = np.empty(k)
+                V = np.empty((k, F))
+                status = C.c_int(0)
+                run(L.msm_tica_solve_topk(self._handle, shrink, int(self.n_observations_),
+                                          None if scale_p is None else scale_p.ctypes.data, k, vals.ctypes.data, V.ctypes.data,
+                                          Cs.ctypes.data, mu.ctypes.data, info.ctypes.data, C.byref(status)))
+                if status.value == 0:
+                    done = True
+                else:
+                    V = None
+            elif _moments.use_device_tridiagonalisation(F):
                 # the reduced matrix is tridiagonalised on the device too (cooperative Householder kernel, sytrd.hip);
                 # the host only runs dstemr on the tridiagonal and applies the reflectors to the k vectors
                 d, e, tau, Vr = np.empty(F), np.empty(max(F - 1, 1)), np.empty(max(F - 1, 1)), np.empty(max(F - 1, 1) ** 2)
@@ -360,8 +375,9 @@ class tICA(BaseEstimator, TransformerMixin):
                                       info.ctypes.data))
             if not done:   # host dsyevr on the reduced matrix (also the fallback when the cooperative kernel gave up)
                 vals, Y = _moments.top_standard_eigenpairs(Cs, k)   # Y: k x F, rows = eigenvectors of the reduced problem
-            V = np.empty((k, F))
-            check(L.msm_tica_backsolve(self._handle, Y.ctypes.data, k, V.ctypes.data))
+            if V is None:
+                V = np.empty((k, F))
+                check(L.msm_tica_backsolve(self._handle, Y.ctypes.data, k, V.ctypes.data))
         self.shrinkage_ = float(info[0]) if self.shrinkage is None else self.shrinkage
         self._mu_raw = mu
         return vals, np.ascontiguousarray(V.T)

@@ -467,20 +467,24 @@ def test_device_tridiagonalisation_vs_lapack(gpu, n):
 
 
 def test_solve_paths_agree(gpu, monkeypatch):
-    """host (numpy + dsygvx), hybrid with host dsyevr, hybrid with the device tridiagonalisation, all-device: one model."""
+    """host (numpy + dsygvx), hybrid with host dsyevr, hybrid with the device tridiagonalisation (host dstemr / dormqr),
+    the LAPACK-free device tail (csrc/toppairs.hip), all-device rocSOLVER: one model."""
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
     seqs = _ar1(5, 6, 3000, 200)
     out = {}
     for name, env in (("host", {"MSMBUILDER_AMD_DEVICE_SOLVE": "0"}),
                       ("evr", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "0"}),
-                      ("trd", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1"}),
+                      ("trd", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1",
+                               "MSMBUILDER_AMD_DEVICE_TOPK": "0"}),
+                      ("topk", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1",
+                                "MSMBUILDER_AMD_DEVICE_TOPK": "1"}),
                       ("dev", {"MSMBUILDER_AMD_DEVICE_SOLVE": "1"})):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         m = tICA(n_components=6, lag_time=9).fit(seqs)
         out[name] = (m.eigenvalues_.copy(), m.eigenvectors_.copy(), m.shrinkage_, m.means_.copy())
-    for name in ("evr", "trd", "dev"):
+    for name in ("evr", "trd", "topk", "dev"):
         np.testing.assert_allclose(out[name][0], out["host"][0], rtol=1e-11)
         sg = np.sign((out[name][1] * out["host"][1]).sum(0))
         np.testing.assert_allclose(out[name][1] * sg, out["host"][1], rtol=0, atol=1e-8 * np.abs(out["host"][1]).max())
