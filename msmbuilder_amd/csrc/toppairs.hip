@@ -5,7 +5,7 @@
 //   potrf_upper_device      B = U^T U, blocked, one launch per 32-row block (rocSOLVER's dpotrf is ~40 launches per block
 //                           at this size: 1.3 ms at n = 512, all of it launch latency)
 //   tri_topk_device         the k largest eigenpairs of the symmetric tridiagonal (d, e) that sytrd.hip produces:
-//                           multisection on Sturm counts (one workgroup per eigenvalue, 1024 shifts per sweep), then
+//                           multisection on Sturm counts (one workgroup per eigenvalue, 256 shifts per sweep), then
 //                           inverse iteration on the pivoted LU of T - lambda I with modified Gram-Schmidt inside clusters
 //                           (LAPACK's dstebz / dstein recipe, restated for one lane per vector)
 //   apply_q_device          y_j = Q s_j for the Householder product Q = H_0 H_1 ... H_{n-3} of sytrd.hip, formed ROW BY ROW:
@@ -32,21 +32,61 @@ namespace msm {
 // =====================================================================================================================
 constexpr int CH_NB = 32;
 
-__global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict__ B, int n, int j0, int* __restrict__ info)
+// The diagonal block of a block row is factored by EVERY workgroup of the launch while workgroup 0 writes the factor back
+// in place, so the others must not read the block where it is being overwritten: they take it from the row-major LOWER
+// triangle (the mirror image, never written) and the diagonal itself from a copy saved before the first launch.
+__global__ void potrf_save_diag_kernel(const double* __restrict__ B, int n, double* __restrict__ dsave, int* __restrict__ minidx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dsave[i] = B[(size_t)i * n + i];
+    if (i == 0) *minidx = 0x7fffffff;
+}
+
+__device__ __forceinline__ double fast_recip(double q)
+{
+    double r = __builtin_amdgcn_rcp(q);
+    r = fma(fma(-q, r, 1.0), r, r);
+    r = fma(fma(-q, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double fast_rsqrt(double x)   // x > 0
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict__ B, int n, int j0, int* __restrict__ minidx,
+                                                             const double* __restrict__ dsave)
 {
     __shared__ double sA[CH_NB][CH_NB + 1], sB[CH_NB][CH_NB + 1], sD[CH_NB][CH_NB + 1], sT[CH_NB][CH_NB + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int c0 = j0 + CH_NB * blockIdx.x;
     const bool diag = blockIdx.x == 0;
     double accD[2][2] = {{0, 0}, {0, 0}}, accT[2][2] = {{0, 0}, {0, 0}};
+    // staging slots of this thread: elements q = tid + 256 s of a 32 x 32 chunk (row q >> 5, column q & 31)
+    double pa[4], pb[4];
+    auto fetch = [&](int kk) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int q = tid + 256 * s4, r = q >> 5, c = q & 31;   // rows kk + r < j0 <= n
+            pa[s4] = (j0 + c < n) ? B[(size_t)(kk + r) * n + j0 + c] : 0.0;
+            pb[s4] = (!diag && c0 + c < n) ? B[(size_t)(kk + r) * n + c0 + c] : 0.0;
+        }
+    };
+    if (j0 > 0) fetch(0);
     for (int kk = 0; kk < j0; kk += CH_NB) {
         __syncthreads();
-        for (int q = tid; q < CH_NB * CH_NB; q += 256) {
-            const int r = q >> 5, c = q & 31;   // rows kk + r < j0 <= n
-            sA[r][c] = (j0 + c < n) ? B[(size_t)(kk + r) * n + j0 + c] : 0.0;
-            sB[r][c] = (!diag && c0 + c < n) ? B[(size_t)(kk + r) * n + c0 + c] : 0.0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int q = tid + 256 * s4, r = q >> 5, c = q & 31;
+            sA[r][c] = pa[s4];
+            sB[r][c] = pb[s4];
         }
         __syncthreads();
+        if (kk + CH_NB < j0) fetch(kk + CH_NB);   // the next chunk's loads fly while this one is multiplied
 #pragma unroll 8
         for (int q = 0; q < CH_NB; ++q) {
             const double a0 = sA[q][2 * ty], a1 = sA[q][2 * ty + 1];
@@ -71,74 +111,87 @@ __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict_
             const int r = 2 * ty + a, c = 2 * tx + b;
             const bool in = j0 + r < n && j0 + c < n;
             // rows / columns beyond n: identity, so the factorisation below needs no special cases
-            sD[r][c] = in ? B[(size_t)(j0 + r) * n + j0 + c] - accD[a][b] : (r == c ? 1.0 : 0.0);
+            const double orig = !in ? 0.0 : (r == c ? dsave[j0 + r] : B[(size_t)(j0 + (r > c ? r : c)) * n + j0 + (r > c ? c : r)]);
+            sD[r][c] = in ? orig - accD[a][b] : (r == c ? 1.0 : 0.0);
             sT[r][c] = (!diag && j0 + r < n && c0 + c < n) ? B[(size_t)(j0 + r) * n + c0 + c] - accT[a][b] : 0.0;
         }
     __syncthreads();
-    // ---- U_JJ = chol(sD), upper, in place; W <- U_JJ^-T W alongside (right-looking elimination of both tiles)
-    for (int p = 0; p < CH_NB; ++p) {
+    // ---- right-looking elimination of the diagonal block and of this workgroup's tile with UNSCALED pivot rows: step p
+    // subtracts sD[p][r] sD[p][c] / piv_p (and sD[p][r] sT[p][c] / piv_p) from the rows r > p -- one barrier and one
+    // reciprocal per step; the rows are scaled by piv_p^-1/2 afterwards, all at once: U[p][c] = sD[p][c] / sqrt(piv_p).
+    for (int p = 0; p < CH_NB - 1; ++p) {
         const double piv = sD[p][p];
-        if (!(piv > 0.0) && tid == 0 && j0 + p < n) atomicCAS(info, 0, j0 + p + 1);
-        const double u = sqrt(piv), ui = 1.0 / u;
-        __syncthreads();
-        if (tid < CH_NB) {
-            if (tid >= p) sD[p][tid] = tid == p ? u : sD[p][tid] * ui;
-        } else if (tid < 2 * CH_NB) {
-            sT[p][tid - CH_NB] *= ui;
-        }
-        __syncthreads();
+        const double inv = fast_recip(piv);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            const int r = 2 * ty + a;
+            if (r > p) {
+                const double f = sD[p][r] * inv;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int r = 2 * ty + a, c = 2 * tx + b;
-                if (r > p) {
-                    const double upr = sD[p][r];
-                    if (c >= r) sD[r][c] -= upr * sD[p][c];
-                    sT[r][c] -= upr * sT[p][c];
+                for (int b = 0; b < 2; ++b) {
+                    const int c = 2 * tx + b;
+                    if (c >= r) sD[r][c] -= f * sD[p][c];
+                    sT[r][c] -= f * sT[p][c];
                 }
             }
+        }
         __syncthreads();
     }
+    if (diag && tid < CH_NB && j0 + tid < n && !(sD[tid][tid] > 0.0)) atomicMin(minidx, j0 + tid + 1);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
+        const int r = 2 * ty + a;
+        if (j0 + r >= n) continue;
+        const double ui = fast_rsqrt(sD[r][r]);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int r = 2 * ty + a, c = 2 * tx + b;
-            if (j0 + r >= n) continue;
+            const int c = 2 * tx + b;
             if (diag) {
-                if (c >= r && j0 + c < n) B[(size_t)(j0 + r) * n + j0 + c] = sD[r][c];
+                if (c >= r && j0 + c < n) B[(size_t)(j0 + r) * n + j0 + c] = sD[r][c] * ui;
             } else if (c0 + c < n) {
-                B[(size_t)(j0 + r) * n + c0 + c] = sT[r][c];
+                B[(size_t)(j0 + r) * n + c0 + c] = sT[r][c] * ui;
             }
         }
+    }
+}
+
+// *info = LAPACK's info: 0, or the 1-based index of the first non-positive pivot (the running minimum over the launches)
+__global__ void potrf_info_kernel(const int* __restrict__ minidx, int* __restrict__ info)
+{
+    if (threadIdx.x == 0) *info = *minidx == 0x7fffffff ? 0 : *minidx;
 }
 
 int potrf_upper_device(double* B, int n, int* dinfo)
 {
     const int nb = (int)ceil_div(n, CH_NB);
+    DevBuf& sv = pool(PS_PAR);   // n doubles + 1 int of scratch; every entry point that reaches here synchronises before it returns
+    int rc = sv.reserve((size_t)n * sizeof(double) + 16);
+    if (rc) return rc;
+    double* dsave = sv.as<double>();
+    int* minidx = reinterpret_cast<int*>(dsave + n);
+    hipLaunchKernelGGL(potrf_save_diag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(), B, n, dsave, minidx);
     for (int J = 0; J < nb; ++J)
-        hipLaunchKernelGGL(potrf_blockrow_kernel, dim3(nb - J), dim3(256), 0, stream(), B, n, J * CH_NB, dinfo);
+        hipLaunchKernelGGL(potrf_blockrow_kernel, dim3(nb - J), dim3(256), 0, stream(), B, n, J * CH_NB, minidx, dsave);
+    hipLaunchKernelGGL(potrf_info_kernel, dim3(1), dim3(64), 0, stream(), minidx, dinfo);
     MSM_HIP_CHECK(hipGetLastError());
     return MSM_OK;
 }
 
 // =====================================================================================================================
 // k largest eigenvalues of the symmetric tridiagonal T = tridiag(e, d, e), n <= 1024.
-// Workgroup j brackets the j-th largest eigenvalue by multisection: every sweep its 1024 threads evaluate the Sturm count
+// Workgroup j brackets the j-th largest eigenvalue by multisection: every sweep its 256 threads evaluate the Sturm count
 // (number of eigenvalues below the shift: the sign count of q_i = d_i - x - e_{i-1}^2 / q_{i-1}, LAPACK dlaebz's form
-// with its pivmin guard) at 1024 interior points of the bracket and keep the sub-interval where the count passes n - 1 - j;
-// six sweeps take the Gershgorin interval down to rounding.  The division is a reciprocal with one Newton step: relative
+// with its pivmin guard) at 256 interior points of the bracket and keep the sub-interval where the count passes n - 1 - j;
+// seven sweeps take the Gershgorin interval down to rounding.  The division is a reciprocal with one Newton step: relative
 // error 2^-48 per step acts like a 2^-48 relative perturbation of e^2 -- far inside the tolerance of the count.
 // =====================================================================================================================
 constexpr int TRI_MAXN = 1024;
-constexpr int TRI_P = 1024;
+constexpr int TRI_P = 256;   // shifts per sweep: one wavefront per SIMD keeps the dependent chain latency-bound, not issue-bound
 
-__device__ __forceinline__ double fast_recip(double q)
+__device__ __forceinline__ double fast_recip1(double q)   // 2^-48: enough for a Sturm count
 {
-    double r = __builtin_amdgcn_rcp(q);
-    r = fma(fma(-q, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(q);
+    return fma(fma(-q, r, 1.0), r, r);
 }
 
 __global__ __launch_bounds__(TRI_P) void tri_topk_values_kernel(const double* __restrict__ d, const double* __restrict__ e,
@@ -183,7 +236,7 @@ __global__ __launch_bounds__(TRI_P) void tri_topk_values_kernel(const double* __
     const double pivmin = 1e-300 * fmax(1.0, e2m);
     const double pad = 2.0 * tn * DBL_EPSILON * n + 2.0 * pivmin;
     double lo = lo_g - pad, hi = hi_g + pad;   // count(lo) = 0 <= idx < n = count(hi)
-    for (int sweep = 0; sweep < 16; ++sweep) {
+    for (int sweep = 0; sweep < 24; ++sweep) {
         if (tid == 0) first = TRI_P;
         __syncthreads();
         const double w = hi - lo;
@@ -193,7 +246,7 @@ __global__ __launch_bounds__(TRI_P) void tri_topk_values_kernel(const double* __
         if (fabs(q) < pivmin) q = -pivmin;
         cnt += q < 0.0;
         for (int i = 1; i < n; ++i) {
-            q = (sd[i] - x) - se2[i - 1] * fast_recip(q);
+            q = (sd[i] - x) - se2[i - 1] * fast_recip1(q);
             if (fabs(q) < pivmin) q = -pivmin;
             cnt += q < 0.0;
         }
@@ -216,7 +269,7 @@ __global__ __launch_bounds__(TRI_P) void tri_topk_values_kernel(const double* __
 // Gram-Schmidt against the earlier vectors of a cluster |lambda_i - lambda_j| < 1e-3 ||T||_1 after every solve).
 // The factors of a vector (a^-1, b, c, dd: 4 n doubles, the pivot flags, and the iterate) live in LDS; a chunk of G
 // vectors is iterated in lockstep by G lanes, the Gram-Schmidt and normalisation steps use the whole workgroup.
-// Chunks are independent unless a cluster straddles a chunk boundary; then workgroup 0 takes all of them in order.
+// Without clusters the vectors are independent and every workgroup takes one; with a cluster workgroup 0 takes them all.
 // =====================================================================================================================
 constexpr int TV_NT = 256;
 constexpr int TV_ITERS = 3;
@@ -273,14 +326,17 @@ __global__ __launch_bounds__(TV_NT) void tri_topk_vectors_kernel(const double* _
             if (j > 0 && slam[j - 1] - l < 10.0 * DBL_EPSILON * fabs(l)) l = slam[j - 1] - 10.0 * DBL_EPSILON * fabs(l);
             slam[j] = l;
             scs[j] = (j > 0 && fabs(l - slam[j - 1]) < ortol) ? scs[j - 1] : j;
-            if (j % G == 0 && scs[j] < j) cr = 1;
+            if (scs[j] < j) cr = 1;
         }
         cross = cr;
     }
     __syncthreads();
-    const int nchunk = (k + G - 1) / G;
+    // no cluster anywhere (the usual case): the vectors are independent, one workgroup each.  Otherwise workgroup 0 takes
+    // them all, in index order, G at a time (Gram-Schmidt needs the earlier members of a cluster).
     const bool serial = cross != 0;
     if (serial && blockIdx.x != 0) return;
+    if (!serial) G = 1;
+    const int nchunk = (k + G - 1) / G;
     for (int ch = serial ? 0 : (int)blockIdx.x; ch < nchunk; ch += serial ? 1 : (int)gridDim.x) {
         const int j0 = ch * G, g = min(G, k - j0);
         __syncthreads();
@@ -306,12 +362,12 @@ __global__ __launch_bounds__(TV_NT) void tri_topk_vectors_kernel(const double* _
                     cmul = 0.0;
                     scale1 = scale2;
                 } else if (ak != 0.0 && fabs(ck) * scale1 <= fabs(ak) * scale2) {   // piv2 <= piv1: no interchange
-                    cmul = ck / ak;
+                    cmul = ck * fast_recip(ak);
                     an -= cmul * bk;
                     scale1 = scale2;
                 } else {                                   // interchange rows k and k + 1
                     piv = 1;
-                    const double mult = ak / ck;
+                    const double mult = ak * fast_recip(ck);
                     ak = ck;
                     const double temp = an;
                     an = bk - mult * temp;
@@ -342,7 +398,7 @@ __global__ __launch_bounds__(TV_NT) void tri_topk_vectors_kernel(const double* _
             double* ainv = lds + (size_t)t * vstride;
             double a = ainv[i];
             if (fabs(a) < ptol) a = a < 0.0 ? -ptol : ptol;   // dlagts job = -1: perturb a tiny pivot
-            ainv[i] = 1.0 / a;
+            ainv[i] = fast_recip(a);
             ainv[4 * (size_t)n + i] = tv_uniform((unsigned)(j0 + t), (unsigned)i);   // x
         }
         __syncthreads();
@@ -354,11 +410,35 @@ __global__ __launch_bounds__(TV_NT) void tri_topk_vectors_kernel(const double* _
                 const double* dd = c + n;
                 double* x = ainv + 4 * (size_t)n;
                 const unsigned char* in = reinterpret_cast<const unsigned char*>(dd + 2 * (size_t)n);
-                // forward: y <- L^-1 P y
+                // forward: y <- L^-1 P y.  Four steps per trip: the coefficients of the next four rows are loaded before the
+                // dependent chain runs (one LDS round trip per four steps instead of one per step)
                 double yp = x[0];
-                for (int kx = 1; kx < n; ++kx) {
-                    const double ck = c[kx - 1];
-                    const double yk = x[kx];
+                int kx = 1;
+                for (; kx + 3 < n; kx += 4) {
+                    double cq[4], yq[4];
+                    unsigned char iq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cq[u] = c[kx - 1 + u];
+                        yq[u] = x[kx + u];
+                        iq[u] = in[kx - 1 + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        double ynew, out;
+                        if (iq[u] == 0) {
+                            ynew = yq[u] - cq[u] * yp;
+                            out = yp;
+                        } else {
+                            out = yq[u];
+                            ynew = yp - cq[u] * yq[u];
+                        }
+                        x[kx - 1 + u] = out;
+                        yp = ynew;
+                    }
+                }
+                for (; kx < n; ++kx) {
+                    const double ck = c[kx - 1], yk = x[kx];
                     double ynew;
                     if (in[kx - 1] == 0) {
                         ynew = yk - ck * yp;
@@ -372,9 +452,26 @@ __global__ __launch_bounds__(TV_NT) void tri_topk_vectors_kernel(const double* _
                 x[n - 1] = yp;
                 // backward: x <- U^-1 y
                 double x1 = 0.0, x2 = 0.0;
-                for (int kx = n - 1; kx >= 0; --kx) {
-                    const double t = x[kx] - b[kx] * x1 - dd[kx] * x2;
-                    const double xk = t * ainv[kx];
+                kx = n - 1;
+                for (; kx >= 3; kx -= 4) {
+                    double bq[4], dq[4], aq[4], yq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bq[u] = b[kx - u];
+                        dq[u] = dd[kx - u];
+                        aq[u] = ainv[kx - u];
+                        yq[u] = x[kx - u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double xk = (yq[u] - bq[u] * x1 - dq[u] * x2) * aq[u];
+                        x[kx - u] = xk;
+                        x2 = x1;
+                        x1 = xk;
+                    }
+                }
+                for (; kx >= 0; --kx) {
+                    const double xk = (x[kx] - b[kx] * x1 - dd[kx] * x2) * ainv[kx];
                     x[kx] = xk;
                     x2 = x1;
                     x1 = xk;
@@ -436,8 +533,7 @@ int tri_topk_device(const double* d, const double* e, int n, int k, double* vals
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
         attr_set = true;
     }
-    const int nchunk = (k + G - 1) / G;
-    hipLaunchKernelGGL(tri_topk_vectors_kernel, dim3(nchunk), dim3(TV_NT), (size_t)G * per, stream(), d, e, n, k, G, vals, S);
+    hipLaunchKernelGGL(tri_topk_vectors_kernel, dim3(k), dim3(TV_NT), (size_t)G * per, stream(), d, e, n, k, G, vals, S);
     MSM_HIP_CHECK(hipGetLastError());
     return MSM_OK;
 }

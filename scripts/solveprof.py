@@ -1,23 +1,15 @@
-"""Profiling helper: where the time between tICA.fit and transform goes (export + finalise + eigensolve)."""
-import cProfile, pstats, os, sys, time, warnings
+"""The device-tail solve alone, for rocprofv3 --kernel-trace --stats (per-kernel durations of one tICA._solve at F = 512)."""
+import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from msmbuilder_amd import tICA
-torch.manual_seed(0)
-n_seq, T, F = 200, 10000, 512
-Z = torch.randn(n_seq * T, 16, device="cuda").cumsum(0) * 0.01
-X = Z @ torch.randn(16, F, device="cuda") + torch.randn(n_seq * T, F, device="cuda")
-seqs = list(X.view(n_seq, T, F).unbind(0))
 warnings.simplefilter("ignore")
-for _ in range(2):
-    m = tICA(n_components=10, lag_time=100).fit(seqs); m.eigenvalues_
-ts = []
-pr = cProfile.Profile()
-for _ in range(5):
-    m = tICA(n_components=10, lag_time=100).fit(seqs)
-    torch.cuda.synchronize()
-    t = time.perf_counter(); pr.enable()
-    ev = m.eigenvalues_
-    pr.disable(); ts.append((time.perf_counter() - t) * 1e3)
-print("solve (export + finalise + eigh): %s ms" % np.round(ts, 2))
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+z = torch.cumsum(torch.randn(200000, 16, generator=g, device="cuda"), 0) * 0.01
+X = (torch.tanh(z - z.mean(0)) @ torch.randn(16, F, generator=g, device="cuda") + 0.5 * torch.randn(200000, F, generator=g, device="cuda")).float()
+m = tICA(n_components=10, lag_time=100).fit(list(X.view(20, 10000, F).unbind(0)))
+for _ in range(20):
+    m._is_dirty = True
+    m.eigenvalues_
+print(m.eigenvalues_[:3])
