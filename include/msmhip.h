@@ -208,8 +208,11 @@ int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V);
 /* The whole top-k solve without LAPACK and with ONE synchronisation (n_features <= 1024, k <= 64): msm_tica_reduce's
  * finalisation and reduction (Cholesky by the library's own blocked kernel), the cooperative tridiagonalisation, the k
  * largest eigenpairs of the tridiagonal matrix by multisection + inverse iteration (msm_tridiag_topk), the Householder
- * back-transform, v = L^-T y.  vals[k] descending, vecs[k][F] rows B-orthonormal like dsygvx's, mu[F], info[8] as
- * msm_tica_reduce plus info[6] = max_j ||Cs y_j - lambda_j y_j||_inf and info[7] = max_j | ||y_j||^2 - 1 |.
+ * back-transform, v = L^-T y.  For n_features >= 128 and k <= 16 a Chebyshev-filtered subspace iteration on the reduced
+ * matrix (csrc/subspace.hip; its 32 x 32 Rayleigh-Ritz problems are solved on the host, so it synchronises a few times)
+ * is tried first and the tridiagonalisation runs only when it stalls.  vals[k] descending, vecs[k][F] rows B-orthonormal
+ * like dsygvx's, mu[F], info[12]: [0..5] as msm_tica_reduce, info[6] = max_j ||Cs y_j - lambda_j y_j||_inf, info[7] =
+ * max_j | ||y_j||^2 - 1 |, info[8] = 1 if the pairs came from the subspace iteration, info[9] = its filtered iterations.
  * *status = 0: pairs returned and verified on the reduced matrix; 1: the cooperative kernel gave up; 2: the residual
  * check failed -- in both cases Cs (host, F x F) holds the reduced matrix for the caller's LAPACK route
  * (msm_tica_backsolve afterwards), as with msm_tica_reduce_tridiag. */

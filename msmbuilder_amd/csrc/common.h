@@ -88,6 +88,12 @@ int tri_topk_device(const double* d, const double* e, int n, int k, double* vals
 int apply_q_device(const double* V, const double* tau, int n, int k, const double* S, double* Y);
 int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res2k);
 
+// subspace.hip: k largest eigenpairs of a symmetric matrix with spectrum in [lower, inf) by Chebyshev-filtered subspace
+// iteration (block of 32, Rayleigh-Ritz on the host); synchronises; *converged = 0 -> outputs meaningless, use the direct route
+int subspace_topk_device(const double* Cm, int n, int k, double lower, double tol, int degree, int max_outer, double* lam,
+                         double* Yk, double* work, int* converged, int* outer_used);
+size_t subspace_work_doubles(int n);
+
 // A data pointer that was itself LOADED from memory (e.g. out of a descriptor table) is a
 // generic pointer to the compiler, which then emits flat_load: slower, and because FLAT counts on
 // both vmcnt and lgkmcnt every counted wait degenerates to vmcnt(0).  Re-type it as global.

@@ -965,31 +965,50 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 #undef MSM_SYM_UD
 
 // packed C and G contributions of the symmetric kernel's slabs: G += (H + D) / 2 and "C" += (H - D) / 4
-// (a symmetric matrix whose symmetrisation (C + C^T) / 2 is the lagged moment's)
+// (a symmetric matrix whose symmetrisation (C + C^T) / 2 is the lagged moment's).  One thread per element of an UPPER tile
+// (diagonal tiles: r <= c): every slab word is read once -- coalesced along the tile row -- and the four outputs it feeds
+// (C and G, (i, j) and its mirror image) are written from the same thread.
 __global__ void tica_export_sym_kernel(const double* __restrict__ slabs, double* __restrict__ out, int F, int T,
                                        int ntiles, int S)
 {
     const size_t FF = (size_t)F * F;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * FF) return;
-    const int type = idx >= FF;
-    const size_t e = idx - (type ? FF : 0);
-    int i = (int)(e / F), j = (int)(e % F);
-    if (i > j) {
-        const int t = i;
-        i = j;
-        j = t;
+    if (idx >= (size_t)ntiles * TM * TM) return;
+    const int tile = (int)(idx / (TM * TM));
+    const int off = (int)(idx - (size_t)tile * (TM * TM));
+    const int r = off / TM, c = off - r * TM;
+    // tile -> (ti, tj), ti <= tj, in the row-major order of the upper triangle
+    int ti = 0, first = 0;
+    while (tile >= first + (T - ti)) {
+        first += T - ti;
+        ++ti;
     }
-    const int ti = i / TM, tj = j / TM;
-    const int tile = ti * T - ti * (ti - 1) / 2 + (tj - ti);
-    const size_t off = (size_t)(i % TM) * TM + (j % TM);
-    double h = 0.0, d = 0.0;
-    for (int s = 0; s < S; ++s) {
-        const double* sl = slabs + ((size_t)s * ntiles + tile) * (2 * TM * TM);
-        h += sl[off];
-        d += sl[TM * TM + off];
+    const int tj = ti + (tile - first);
+    const int i = ti * TM + r, j = tj * TM + c;
+    if (i >= F || j >= F || (ti == tj && r > c)) return;
+    double h0 = 0.0, d0 = 0.0, h1 = 0.0, d1 = 0.0;
+    const double* sl = slabs + (size_t)tile * (2 * TM * TM) + off;
+    const size_t step = (size_t)ntiles * (2 * TM * TM);
+    int s = 0;
+    for (; s + 1 < S; s += 2) {   // two independent chains: the loads of consecutive slabs overlap
+        h0 += sl[0];
+        d0 += sl[TM * TM];
+        h1 += sl[step];
+        d1 += sl[step + TM * TM];
+        sl += 2 * step;
     }
-    out[idx] += type ? 0.5 * (h + d) : 0.25 * (h - d);
+    if (s < S) {
+        h0 += sl[0];
+        d0 += sl[TM * TM];
+    }
+    const double h = h0 + h1, d = d0 + d1;
+    const double cv = 0.25 * (h - d), gv = 0.5 * (h + d);
+    out[(size_t)i * F + j] += cv;
+    out[FF + (size_t)i * F + j] += gv;
+    if (i != j) {
+        out[(size_t)j * F + i] += cv;
+        out[FF + (size_t)j * F + i] += gv;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2550,8 +2569,8 @@ int tica_export_device(msm_tica* h)
     MSM_HIP_CHECK(hipGetLastError());
     if (h->sym) {
         const size_t ff2 = 2 * (size_t)h->F * h->F;
-        hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->slabs_sym,
-                           h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
+        hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div((size_t)h->ntiles_sym * TM * TM, 256)), dim3(256), 0, stream(),
+                           h->slabs_sym, h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
         MSM_HIP_CHECK(hipGetLastError());
     }
     if (h->have_shift) {  // restore the raw moments from the shifted ones (fp64)
@@ -2954,6 +2973,7 @@ namespace {
 
 struct SolveBufs {
     double *A, *B, *mu, *D, *E, *scal, *part, *scale, *Y, *vals, *trdw;
+    double* sswork;               // subspace iteration workspace (subspace.hip)
     double *lam, *S, *Yk, *res;   // top-k tail (toppairs.hip): eigenvalues [64], tridiagonal vectors / back-transformed vectors [64][F], residuals [128]
     int* ints;  // [0..1] non-finite flags (OC, S), [2] potrf info, [3] syevd info; [8 ..] sytrd barrier flags + status
     int nblk;
@@ -2963,7 +2983,7 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
 {
     const size_t F = (size_t)h->F, FF = F * F;
     const int nblk = (int)ceil_div((int64_t)FF, 256);
-    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk + 192 + 128 * F;
+    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk + 192 + 128 * F + subspace_work_doubles((int)F);
     int rc = h->solve.reserve(nd * sizeof(double) + (8 + F / 16 + 4) * sizeof(int));
     if (rc) return rc;
     double* p = h->solve.as<double>();
@@ -2982,7 +3002,8 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
     b->res = b->lam + 64;
     b->S = b->res + 128;
     b->Yk = b->S + 64 * F;
-    b->ints = reinterpret_cast<int*>(b->Yk + 64 * F);
+    b->sswork = b->Yk + 64 * F;
+    b->ints = reinterpret_cast<int*>(b->sswork + subspace_work_doubles((int)F));
     b->nblk = nblk;
     return MSM_OK;
 }
@@ -3000,8 +3021,8 @@ int tica_reduce_device(msm_tica* h, double shrinkage, long long n_rblw, const do
                        h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
     if (h->sym) {
         const size_t ff2 = 2 * (size_t)h->F * h->F;
-        hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->slabs_sym,
-                           h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
+        hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div((size_t)h->ntiles_sym * TM * TM, 256)), dim3(256), 0, stream(),
+                           h->slabs_sym, h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
     }
     if (h->have_shift) {
         const size_t ff2 = 2 * (size_t)h->F * h->F;
@@ -3103,10 +3124,20 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
     if (rc) return rc;
     const int n = h->F;
     const size_t FF = (size_t)n * n;
-    // A = Cs = L^-1 OC L^-T stays intact (sytrd copies it into registers); reflectors -> Y slot, tau -> vals slot
-    if ((rc = sytrd_device(b.A, n, b.D, b.E, b.vals, b.Y, b.trdw, b.ints + 8))) return rc;
-    if ((rc = tri_topk_device(b.D, b.E, n, (int)k, b.lam, b.S))) return rc;
-    if ((rc = apply_q_device(b.Y, b.vals, n, (int)k, b.S, b.Yk))) return rc;
+    // 1) Chebyshev-filtered subspace iteration (subspace.hip): a few short launch chains when the spectrum has the gap
+    //    tICA is run for; the reduced tICA matrix has its spectrum in [-1, 1].  MSM_SOLVE_SUBSPACE=0 skips it.
+    const char* ssenv = getenv("MSM_SOLVE_SUBSPACE");
+    const int ssdeg = getenv("MSM_SOLVE_SUBSPACE_DEGREE") ? std::max(2, atoi(getenv("MSM_SOLVE_SUBSPACE_DEGREE"))) : 10;
+    int conv = 0, outer = 0;
+    if (!(ssenv && ssenv[0] == '0') && n >= 128 && k <= 16) {
+        if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, ssdeg, 6, b.lam, b.Yk, b.sswork, &conv, &outer))) return rc;
+    }
+    // 2) the direct route: A = Cs = L^-1 OC L^-T stays intact (sytrd copies it into registers); reflectors -> Y slot, tau -> vals slot
+    if (!conv) {
+        if ((rc = sytrd_device(b.A, n, b.D, b.E, b.vals, b.Y, b.trdw, b.ints + 8))) return rc;
+        if ((rc = tri_topk_device(b.D, b.E, n, (int)k, b.lam, b.S))) return rc;
+        if ((rc = apply_q_device(b.Y, b.vals, n, (int)k, b.S, b.Yk))) return rc;
+    }
     if ((rc = pair_residual_device(b.A, n, b.Yk, b.lam, (int)k, b.res))) return rc;
     // the residual kernel has read Yk; L^-T in place for the k vectors
     MSM_HIP_CHECK(hipMemcpyAsync(b.S, b.Yk, (size_t)k * n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
@@ -3119,10 +3150,14 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
     MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(&st, b.ints + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    if (!conv) MSM_HIP_CHECK(hipMemcpyAsync(&st, b.ints + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     rc = tica_reduce_status(scal, ints, info);
     if (rc) return rc;
+    if (info) {
+        info[8] = conv ? 1.0 : 0.0;   // 1: the pairs came from the subspace iteration, 0: from the tridiagonalisation
+        info[9] = (double)outer;      // filtered iterations spent (also when they did not converge)
+    }
     // self-check on the reduced matrix: every returned pair must satisfy C y = lambda y to rounding and be normalised.
     // A failure (the cooperative tridiagonalisation gave up or exchanged a stale value, the inverse iteration stalled)
     // hands the reduced matrix to the caller's LAPACK route instead of returning a wrong pair.

@@ -58,98 +58,164 @@ __device__ __forceinline__ double fast_rsqrt(double x)   // x > 0
     return r;
 }
 
+// Sum over the 64 lanes of a wavefront, result in every lane, on the DPP network (quad swaps, half-row and row mirrors,
+// then the four row totals through v_readlane): ~25 instructions with short latencies, where six __shfl_xor levels are
+// twelve ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror: every lane holds the sum of its row of 16
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict__ B, int n, int j0, int* __restrict__ minidx,
                                                              const double* __restrict__ dsave)
 {
-    __shared__ double sA[CH_NB][CH_NB + 1], sB[CH_NB][CH_NB + 1], sD[CH_NB][CH_NB + 1], sT[CH_NB][CH_NB + 1];
+    // pW: wave-private staging of a 32-row chunk of the panel above
+    // ([wave][A | B][32][33]) and, afterwards, the four waves' partial products
+    __shared__ double pW[4][2][CH_NB][CH_NB + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lx = lane & 7, ly = lane >> 3;   // the lane's 4 x 4 patch of the 32 x 32 product: rows 4 ly.., columns 4 lx..
     const int c0 = j0 + CH_NB * blockIdx.x;
     const bool diag = blockIdx.x == 0;
-    double accD[2][2] = {{0, 0}, {0, 0}}, accT[2][2] = {{0, 0}, {0, 0}};
-    // staging slots of this thread: elements q = tid + 256 s of a 32 x 32 chunk (row q >> 5, column q & 31)
-    double pa[4], pb[4];
-    auto fetch = [&](int kk) {
+    // ---- W = sum_K U[K, J]^T U[K, tile]: the K chunks are dealt out over the four waves (no barrier inside the loop: a
+    // wave stages and multiplies its own chunk), each lane accumulating a 4 x 4 patch of both products
+    double accD[4][4], accT[4][4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int q = tid + 256 * s4, r = q >> 5, c = q & 31;   // rows kk + r < j0 <= n
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) accD[a][b] = accT[a][b] = 0.0;
+    const int nchunk = j0 / CH_NB;
+    double pa[16], pb[16];   // a 32 x 32 chunk = 1024 values = 16 per lane
+    auto fetch = [&](int ch) {
+        const int kk = ch * CH_NB;
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const int q = lane + 64 * s4, r = q >> 5, c = q & 31;
             pa[s4] = (j0 + c < n) ? B[(size_t)(kk + r) * n + j0 + c] : 0.0;
             pb[s4] = (!diag && c0 + c < n) ? B[(size_t)(kk + r) * n + c0 + c] : 0.0;
         }
     };
-    if (j0 > 0) fetch(0);
-    for (int kk = 0; kk < j0; kk += CH_NB) {
-        __syncthreads();
+    if (wave < nchunk) fetch(wave);
+    for (int ch = wave; ch < nchunk; ch += 4) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int q = tid + 256 * s4, r = q >> 5, c = q & 31;
-            sA[r][c] = pa[s4];
-            sB[r][c] = pb[s4];
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const int q = lane + 64 * s4, r = q >> 5, c = q & 31;
+            pW[wave][0][r][c] = pa[s4];
+            pW[wave][1][r][c] = pb[s4];
         }
-        __syncthreads();
-        if (kk + CH_NB < j0) fetch(kk + CH_NB);   // the next chunk's loads fly while this one is multiplied
-#pragma unroll 8
+        if (ch + 4 < nchunk) fetch(ch + 4);   // the next chunk's loads fly while this one is multiplied
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
         for (int q = 0; q < CH_NB; ++q) {
-            const double a0 = sA[q][2 * ty], a1 = sA[q][2 * ty + 1];
-            const double d0 = sA[q][2 * tx], d1 = sA[q][2 * tx + 1];
-            accD[0][0] += a0 * d0;
-            accD[0][1] += a0 * d1;
-            accD[1][0] += a1 * d0;
-            accD[1][1] += a1 * d1;
-            if (!diag) {
-                const double b0 = sB[q][2 * tx], b1 = sB[q][2 * tx + 1];
-                accT[0][0] += a0 * b0;
-                accT[0][1] += a0 * b1;
-                accT[1][0] += a1 * b0;
-                accT[1][1] += a1 * b1;
+            double av[4], dv[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                av[a] = pW[wave][0][q][4 * ly + a];
+                dv[a] = pW[wave][0][q][4 * lx + a];
+                bv[a] = pW[wave][1][q][4 * lx + a];
             }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    accD[a][b] += av[a] * dv[b];
+                    if (!diag) accT[a][b] += av[a] * bv[b];
+                }
         }
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
+    // partial products of the four waves -> pW[wave][0 / 1], then summed while the blocks are formed
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            pW[wave][0][4 * ly + a][4 * lx + b] = accD[a][b];
+            pW[wave][1][4 * ly + a][4 * lx + b] = accT[a][b];
+        }
+    __syncthreads();
+    // ---- right-looking elimination of the diagonal block and of this workgroup's tile with UNSCALED pivot rows: step p
+    // subtracts sD[p][r] sD[p][c] / piv_p (and sD[p][r] sT[p][c] / piv_p) from the rows r > p; the rows are scaled by
+    // piv_p^-1/2 afterwards, all at once: U[p][c] = sD[p][c] / sqrt(piv_p).  Every thread keeps its 2 x 2 patch of both
+    // blocks in registers; per step only the owners of row p publish it (with 1 / piv_p), one barrier per step.
+    __shared__ double rowD[2][CH_NB], rowT[2][CH_NB], rinv[2];
+    double eD[2][2], eT[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int r = 2 * ty + a, c = 2 * tx + b;
             const bool in = j0 + r < n && j0 + c < n;
+            const double sumD = (pW[0][0][r][c] + pW[1][0][r][c]) + (pW[2][0][r][c] + pW[3][0][r][c]);
+            const double sumT = (pW[0][1][r][c] + pW[1][1][r][c]) + (pW[2][1][r][c] + pW[3][1][r][c]);
             // rows / columns beyond n: identity, so the factorisation below needs no special cases
             const double orig = !in ? 0.0 : (r == c ? dsave[j0 + r] : B[(size_t)(j0 + (r > c ? r : c)) * n + j0 + (r > c ? c : r)]);
-            sD[r][c] = in ? orig - accD[a][b] : (r == c ? 1.0 : 0.0);
-            sT[r][c] = (!diag && j0 + r < n && c0 + c < n) ? B[(size_t)(j0 + r) * n + c0 + c] - accT[a][b] : 0.0;
+            eD[a][b] = in ? orig - sumD : (r == c ? 1.0 : 0.0);
+            eT[a][b] = (!diag && j0 + r < n && c0 + c < n) ? B[(size_t)(j0 + r) * n + c0 + c] - sumT : 0.0;
         }
-    __syncthreads();
-    // ---- right-looking elimination of the diagonal block and of this workgroup's tile with UNSCALED pivot rows: step p
-    // subtracts sD[p][r] sD[p][c] / piv_p (and sD[p][r] sT[p][c] / piv_p) from the rows r > p -- one barrier and one
-    // reciprocal per step; the rows are scaled by piv_p^-1/2 afterwards, all at once: U[p][c] = sD[p][c] / sqrt(piv_p).
-    for (int p = 0; p < CH_NB - 1; ++p) {
-        const double piv = sD[p][p];
-        const double inv = fast_recip(piv);
+    double pivsave[2] = {1.0, 1.0};   // the pivots of this thread's two rows (valid in every thread of the row)
+    for (int p = 0; p < CH_NB; ++p) {
+        const int buf = p & 1;
+        if (ty == (p >> 1)) {   // owners of row p: publish it as it stands (all earlier steps applied)
+            const int a = p & 1;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                rowD[buf][2 * tx + b] = eD[a][b];
+                rowT[buf][2 * tx + b] = eT[a][b];
+            }
+            if (tx == (p >> 1)) rinv[buf] = fast_recip(eD[a][p & 1]);   // the thread holding (p, p)
+        }
+        __syncthreads();
+        const double piv_inv = rinv[buf];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int r = 2 * ty + a;
+            if (r == p) pivsave[a] = rowD[buf][p];
             if (r > p) {
-                const double f = sD[p][r] * inv;
+                const double f = rowD[buf][r] * piv_inv;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int c = 2 * tx + b;
-                    if (c >= r) sD[r][c] -= f * sD[p][c];
-                    sT[r][c] -= f * sT[p][c];
+                    if (c >= r) eD[a][b] -= f * rowD[buf][c];
+                    eT[a][b] -= f * rowT[buf][c];
                 }
             }
         }
-        __syncthreads();
+        // (double-buffered rows: the owners of row p + 1 may publish while others still read row p)
     }
-    if (diag && tid < CH_NB && j0 + tid < n && !(sD[tid][tid] > 0.0)) atomicMin(minidx, j0 + tid + 1);
+    if (diag && tx == ty) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            if (j0 + 2 * ty + a < n && !(eD[a][a] > 0.0)) atomicMin(minidx, j0 + 2 * ty + a + 1);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int r = 2 * ty + a;
         if (j0 + r >= n) continue;
-        const double ui = fast_rsqrt(sD[r][r]);
+        const double ui = fast_rsqrt(pivsave[a]);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int c = 2 * tx + b;
             if (diag) {
-                if (c >= r && j0 + c < n) B[(size_t)(j0 + r) * n + j0 + c] = sD[r][c] * ui;
+                if (c >= r && j0 + c < n) B[(size_t)(j0 + r) * n + j0 + c] = eD[a][b] * ui;
             } else if (c0 + c < n) {
-                B[(size_t)(j0 + r) * n + c0 + c] = sT[r][c] * ui;
+                B[(size_t)(j0 + r) * n + c0 + c] = eT[a][b] * ui;
             }
         }
     }
@@ -272,7 +338,7 @@ __global__ __launch_bounds__(TRI_P) void tri_topk_values_kernel(const double* __
 // Without clusters the vectors are independent and every workgroup takes one; with a cluster workgroup 0 takes them all.
 // =====================================================================================================================
 constexpr int TV_NT = 256;
-constexpr int TV_ITERS = 3;
+constexpr int TV_ITERS = 2;   // the first solve already amplifies the eigenvector by ~1 / eps; the pairs are verified afterwards
 
 __device__ __forceinline__ double tv_block_sum(double x, double* red, int tid)
 {
@@ -305,8 +371,14 @@ __global__ __launch_bounds__(TV_NT) void tri_topk_vectors_kernel(const double* _
     __shared__ int scs[64];
     __shared__ int cross;
     const int tid = threadIdx.x;
-    // per-vector LDS block: ainv[n] b[n] c[n] dd[n] x[n] + n pivot bytes (rounded to 8)
+    // per-vector LDS block: ainv[n] b[n] c[n] dd[n] x[n] + n pivot bytes (rounded to 8); T itself (d, e) behind the last one
     const size_t vstride = 5 * (size_t)n + (size_t)((n + 7) / 8);
+    double* sd = lds + (size_t)G * vstride;
+    double* se = sd + n;
+    for (int i = tid; i < n; i += TV_NT) {
+        sd[i] = d[i];
+        se[i] = i + 1 < n ? e[i] : 0.0;
+    }
     // ---- ||T||_1, cluster starts, separated eigenvalues (dstein: equal eigenvalues are pushed 10 eps apart)
     double cs = 0.0;
     for (int i = tid; i < n; i += TV_NT)
@@ -348,13 +420,13 @@ __global__ __launch_bounds__(TV_NT) void tri_topk_vectors_kernel(const double* _
             double* dd = c + n;
             unsigned char* in = reinterpret_cast<unsigned char*>(dd + 2 * (size_t)n);
             const double lam = slam[j0 + tid];
-            double ak = d[0] - lam;                      // a[k], updated as the elimination proceeds
-            double bk = n > 1 ? e[0] : 0.0;              // b[k]
+            double ak = sd[0] - lam;                     // a[k], updated as the elimination proceeds
+            double bk = se[0];                           // b[k]
             double scale1 = fabs(ak) + fabs(bk);
             for (int kx = 0; kx + 1 < n; ++kx) {
-                const double ck = e[kx];
-                double an = d[kx + 1] - lam;             // a[k+1]
-                double bn = kx + 2 < n ? e[kx + 1] : 0.0;   // b[k+1]
+                const double ck = se[kx];
+                double an = sd[kx + 1] - lam;            // a[k+1]
+                double bn = se[kx + 1];                  // b[k+1] (0 behind the last coupling)
                 const double scale2 = fabs(ck) + fabs(an) + fabs(bn);
                 double ddk = 0.0, cmul;
                 int piv = 0;
@@ -525,15 +597,16 @@ int tri_topk_device(const double* d, const double* e, int n, int k, double* vals
     if (n < 1 || n > TRI_MAXN || k < 1 || k > 64 || k > n) return fail(MSM_ERR_INVALID, "tri_topk_device: need n <= %d, k <= 64", TRI_MAXN);
     hipLaunchKernelGGL(tri_topk_values_kernel, dim3(k), dim3(TRI_P), 0, stream(), d, e, n, vals);
     const size_t per = (5 * (size_t)n + (size_t)((n + 7) / 8)) * sizeof(double);
+    const size_t extra = 2 * (size_t)n * sizeof(double);   // d, e
     const size_t budget = 150 * 1024;
-    int G = (int)std::min<size_t>(std::max<size_t>(budget / per, 1), (size_t)k);
+    int G = (int)std::min<size_t>(std::max<size_t>((budget - extra) / per, 1), (size_t)k);
     static bool attr_set = false;
     if (!attr_set) {
         MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tri_topk_vectors_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
         attr_set = true;
     }
-    hipLaunchKernelGGL(tri_topk_vectors_kernel, dim3(k), dim3(TV_NT), (size_t)G * per, stream(), d, e, n, k, G, vals, S);
+    hipLaunchKernelGGL(tri_topk_vectors_kernel, dim3(k), dim3(TV_NT), (size_t)G * per + extra, stream(), d, e, n, k, G, vals, S);
     MSM_HIP_CHECK(hipGetLastError());
     return MSM_OK;
 }
@@ -548,25 +621,26 @@ constexpr int AQ_NT = 256;
 constexpr int AQ_RW = 2;                      // rows per wavefront
 constexpr int AQ_ROWS = AQ_RW * (AQ_NT / 64);   // rows per workgroup
 constexpr int AQ_RB = 8;                      // reflectors per staged block
-constexpr int AQ_NQ = TRI_MAXN / 64;          // register slots per row
 
+template <int NQ>   // register slots per row: n <= 64 NQ
 __global__ __launch_bounds__(AQ_NT) void apply_q_rows_kernel(const double* __restrict__ V, const double* __restrict__ tau, int n,
                                                              int k, const double* __restrict__ S, double* __restrict__ Y)
 {
-    __shared__ double sv[2][AQ_RB][TRI_MAXN];
+    constexpr int NMAX = 64 * NQ;
+    __shared__ double sv[2][AQ_RB][NMAX];
     __shared__ double stau[2][AQ_RB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nq = (n + 63) / 64;
     const int row0 = blockIdx.x * AQ_ROWS + wave * AQ_RW;
-    double z[AQ_RW][AQ_NQ];
+    double z[AQ_RW][NQ];
 #pragma unroll
     for (int a = 0; a < AQ_RW; ++a)
 #pragma unroll
-        for (int q = 0; q < AQ_NQ; ++q) z[a][q] = (lane + 64 * q == row0 + a) ? 1.0 : 0.0;
+        for (int q = 0; q < NQ; ++q) z[a][q] = (lane + 64 * q == row0 + a) ? 1.0 : 0.0;
     const int nref = n - 2;
     const int nblk = nref > 0 ? (nref + AQ_RB - 1) / AQ_RB : 0;
-    // staging: block `blk` of AQ_RB reflectors -> registers (loads in flight while the previous block is applied) -> LDS
-    constexpr int PFW = TRI_MAXN / AQ_NT;   // column slots per thread and reflector
+    // staging: block `blk` of AQ_RB reflectors -> registers (loads in flight while the previous block is applied) -> LDS;
+    // columns >= n are staged as zeros, so the arithmetic below needs no bounds
+    constexpr int PFW = NMAX / AQ_NT;   // column slots per thread and reflector
     double pf[AQ_RB][PFW];
     auto fetch = [&](int blk) {
 #pragma unroll
@@ -583,10 +657,7 @@ __global__ __launch_bounds__(AQ_NT) void apply_q_rows_kernel(const double* __res
 #pragma unroll
         for (int rr = 0; rr < AQ_RB; ++rr)
 #pragma unroll
-            for (int w = 0; w < PFW; ++w) {
-                const int c = tid + AQ_NT * w;
-                if (c < n) sv[buf][rr][c] = pf[rr][w];
-            }
+            for (int w = 0; w < PFW; ++w) sv[buf][rr][tid + AQ_NT * w] = pf[rr][w];
         if (tid < AQ_RB) {
             const int i = blk * AQ_RB + tid;
             stau[buf][tid] = i < nref ? tau[i] : 0.0;
@@ -600,28 +671,30 @@ __global__ __launch_bounds__(AQ_NT) void apply_q_rows_kernel(const double* __res
     for (int blk = 0; blk < nblk; ++blk) {
         const int buf = blk & 1;
         if (blk + 1 < nblk) fetch(blk + 1);
+#pragma unroll 2
         for (int rr = 0; rr < AQ_RB; ++rr) {
             const double t = stau[buf][rr];
-            double vq[AQ_NQ];
+            double vq[NQ];
 #pragma unroll
-            for (int q = 0; q < AQ_NQ; ++q) vq[q] = (q < nq && (lane + 64 * q) < n) ? sv[buf][rr][lane + 64 * q] : 0.0;
+            for (int q = 0; q < NQ; ++q) vq[q] = sv[buf][rr][lane + 64 * q];
             double dot[AQ_RW];
 #pragma unroll
             for (int a = 0; a < AQ_RW; ++a) {
-                double s = 0.0;
+                double s0 = 0.0, s1 = 0.0;   // two chains per row: half the dependent depth
 #pragma unroll
-                for (int q = 0; q < AQ_NQ; ++q) s += z[a][q] * vq[q];
-                dot[a] = s;
+                for (int q = 0; q < NQ; q += 2) {
+                    s0 += z[a][q] * vq[q];
+                    s1 += z[a][q + 1] * vq[q + 1];
+                }
+                dot[a] = s0 + s1;
             }
 #pragma unroll
-            for (int m = 32; m > 0; m >>= 1)
-#pragma unroll
-                for (int a = 0; a < AQ_RW; ++a) dot[a] += __shfl_xor(dot[a], m, 64);
+            for (int a = 0; a < AQ_RW; ++a) dot[a] = wave_sum_f64(dot[a]);
 #pragma unroll
             for (int a = 0; a < AQ_RW; ++a) {
                 const double f = t * dot[a];
 #pragma unroll
-                for (int q = 0; q < AQ_NQ; ++q) z[a][q] -= f * vq[q];
+                for (int q = 0; q < NQ; ++q) z[a][q] -= f * vq[q];
             }
         }
         if (blk + 1 < nblk) commit(blk + 1, buf ^ 1);
@@ -630,17 +703,16 @@ __global__ __launch_bounds__(AQ_NT) void apply_q_rows_kernel(const double* __res
     // Y[j][r] = z_r . S[j]
     for (int j = 0; j < k; ++j) {
         const double* sj = S + (size_t)j * n;
-        double sq[AQ_NQ];
+        double sq[NQ];
 #pragma unroll
-        for (int q = 0; q < AQ_NQ; ++q) sq[q] = (q < nq && (lane + 64 * q) < n) ? sj[lane + 64 * q] : 0.0;
+        for (int q = 0; q < NQ; ++q) sq[q] = (lane + 64 * q) < n ? sj[lane + 64 * q] : 0.0;
 #pragma unroll
         for (int a = 0; a < AQ_RW; ++a) {
-            double s = 0.0;
+            double s2 = 0.0;
 #pragma unroll
-            for (int q = 0; q < AQ_NQ; ++q) s += z[a][q] * sq[q];
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
-            if (lane == 0 && row0 + a < n) Y[(size_t)j * n + row0 + a] = s;
+            for (int q = 0; q < NQ; ++q) s2 += z[a][q] * sq[q];
+            s2 = wave_sum_f64(s2);
+            if (lane == 0 && row0 + a < n) Y[(size_t)j * n + row0 + a] = s2;
         }
     }
 }
@@ -648,7 +720,13 @@ __global__ __launch_bounds__(AQ_NT) void apply_q_rows_kernel(const double* __res
 int apply_q_device(const double* V, const double* tau, int n, int k, const double* S, double* Y)
 {
     if (n < 1 || n > TRI_MAXN) return fail(MSM_ERR_INVALID, "apply_q_device: n out of range");
-    hipLaunchKernelGGL(apply_q_rows_kernel, dim3((unsigned)ceil_div(n, AQ_ROWS)), dim3(AQ_NT), 0, stream(), V, tau, n, k, S, Y);
+    const dim3 grid((unsigned)ceil_div(n, AQ_ROWS));
+    if (n <= 256)
+        hipLaunchKernelGGL(apply_q_rows_kernel<4>, grid, dim3(AQ_NT), 0, stream(), V, tau, n, k, S, Y);
+    else if (n <= 512)
+        hipLaunchKernelGGL(apply_q_rows_kernel<8>, grid, dim3(AQ_NT), 0, stream(), V, tau, n, k, S, Y);
+    else
+        hipLaunchKernelGGL(apply_q_rows_kernel<16>, grid, dim3(AQ_NT), 0, stream(), V, tau, n, k, S, Y);
     MSM_HIP_CHECK(hipGetLastError());
     return MSM_OK;
 }

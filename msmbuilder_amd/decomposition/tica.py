@@ -323,7 +323,7 @@ class tICA(BaseEstimator, TransformerMixin):
         scale = getattr(self, "_input_scale", None)
         scale_p = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
         mu = np.empty(F)
-        info = np.zeros(8)
+        info = np.zeros(12)
 
         def run(rc):
             if rc == _lib.MSM_ERR_NONFINITE:
@@ -353,6 +353,7 @@ class tICA(BaseEstimator, TransformerMixin):
                 run(L.msm_tica_solve_topk(self._handle, shrink, int(self.n_observations_),
                                           None if scale_p is None else scale_p.ctypes.data, k, vals.ctypes.data, V.ctypes.data,
                                           Cs.ctypes.data, mu.ctypes.data, info.ctypes.data, C.byref(status)))
+                self._solve_route = ("subspace" if info[8] else "tridiagonal", int(info[9]), status.value)
                 if status.value == 0:
                     done = True
                 else:

@@ -24,8 +24,10 @@ base = None
 for name, env in (("host dsygvx", {"MSMBUILDER_AMD_DEVICE_SOLVE": "0"}),
                   ("hybrid, host dsyevr", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "0"}),
                   ("hybrid, device sytrd + host dstemr/dormqr", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1", "MSMBUILDER_AMD_DEVICE_TOPK": "0"}),
-                  ("device tail (toppairs.hip)", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1", "MSMBUILDER_AMD_DEVICE_TOPK": "1"})):
+                  ("device tail, tridiagonal route", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1", "MSMBUILDER_AMD_DEVICE_TOPK": "1", "MSM_SOLVE_SUBSPACE": "0"}),
+                  ("device tail, subspace iteration first", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1", "MSMBUILDER_AMD_DEVICE_TOPK": "1", "MSM_SOLVE_SUBSPACE": "1"})):
     ms, ev = solve_ms(env)
+    print("      route:", getattr(m, "_solve_route", None))
     base = ev if base is None else base
     print("%-45s %.2f ms   max rel diff vs host %.1e   (MSM_POTRF=%s)" % (name, ms, np.abs(ev / base - 1).max(), os.environ.get("MSM_POTRF", "default")))
 L = _lib.lib()

@@ -83,33 +83,49 @@ def test_tridiag_topk_matches_lapack(gpu, case):
     np.testing.assert_allclose(vecs.dot(vecs.T), np.eye(k), rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("F,k", [(200, 10), (512, 10), (512, 64), (700, 3)])
-def test_topk_solve_matches_host_route(gpu, monkeypatch, F, k):
-    """msm_tica_solve_topk on wide models against the all-host numpy / dsygvx route of the same accumulators."""
+@pytest.mark.parametrize("F,k,flat", [(200, 10, False), (512, 10, False), (512, 64, False), (700, 3, False), (512, 10, True),
+                                      (130, 16, False)])
+def test_topk_solve_matches_host_route(gpu, monkeypatch, F, k, flat):
+    """msm_tica_solve_topk on wide models against the all-host numpy / dsygvx route of the same accumulators: through the
+    subspace iteration where the spectrum has a gap (k <= 16), through the tridiagonalisation where it has none (`flat`:
+    white-noise features -- the iteration must notice that it stalls and hand over) or k is large, and with the subspace
+    iteration switched off."""
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
     rs = np.random.RandomState(F + k)
-    z = np.cumsum(rs.randn(6000, 12), axis=0) * 0.02
-    z -= z.mean(0)
-    X = (np.tanh(z).dot(rs.randn(12, F)) + 0.4 * rs.randn(6000, F) + rs.randn(F)).astype(np.float64)
+    if flat:
+        X = rs.randn(6000, F) + rs.randn(F)
+    else:
+        z = np.cumsum(rs.randn(6000, 12), axis=0) * 0.02
+        z -= z.mean(0)
+        X = (np.tanh(z).dot(rs.randn(12, F)) + 0.4 * rs.randn(6000, F) + rs.randn(F)).astype(np.float64)
     seqs = [X[:3500], X[3500:]]
     out = {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for name, env in (("host", {"MSMBUILDER_AMD_DEVICE_SOLVE": "0"}),
-                          ("topk", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TOPK": "1"})):
+                          ("topk", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TOPK": "1", "MSM_SOLVE_SUBSPACE": "1"}),
+                          ("direct", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TOPK": "1", "MSM_SOLVE_SUBSPACE": "0"})):
             for k_, v_ in env.items():
                 monkeypatch.setenv(k_, v_)
             m = tICA(n_components=k, lag_time=5).fit(seqs)
-            out[name] = (m.eigenvalues_.copy(), m.eigenvectors_.copy(), m.covariance_.copy())
-    np.testing.assert_allclose(out["topk"][0], out["host"][0], rtol=1e-10)
-    V, Vh, S = out["topk"][1], out["host"][1], out["host"][2]
-    np.testing.assert_allclose(V.T.dot(S).dot(V), np.eye(k), rtol=0, atol=1e-9)      # B-orthonormal like dsygvx
-    # eigenvectors of well separated eigenvalues agree up to sign; inside near-degenerate groups compare the subspace
-    gaps = np.abs(np.diff(out["host"][0]))
-    for j in range(k):
-        lo = gaps[j - 1] if j > 0 else np.inf
-        hi = gaps[j] if j < k - 1 else np.inf
-        if min(lo, hi) > 1e-4:
-            sg = np.sign(V[:, j].dot(S).dot(Vh[:, j]))
-            np.testing.assert_allclose(V[:, j] * sg, Vh[:, j], rtol=0, atol=1e-8 * np.abs(Vh[:, j]).max() / min(lo, hi, 1.0))
+            out[name] = (m.eigenvalues_.copy(), m.eigenvectors_.copy(), m.covariance_.copy(), getattr(m, "_solve_route", None))
+    assert out["direct"][3][0] == "tridiagonal" and out["direct"][3][2] == 0
+    route = out["topk"][3]
+    assert route[2] == 0
+    if k <= 16 and F >= 128:
+        assert route[0] == ("tridiagonal" if flat else "subspace"), route
+    else:
+        assert route[0] == "tridiagonal"
+    for name in ("topk", "direct"):
+        np.testing.assert_allclose(out[name][0], out["host"][0], rtol=1e-10)
+        V, Vh, S = out[name][1], out["host"][1], out["host"][2]
+        np.testing.assert_allclose(V.T.dot(S).dot(V), np.eye(k), rtol=0, atol=1e-9)      # B-orthonormal like dsygvx
+        # eigenvectors of well separated eigenvalues agree up to sign; inside near-degenerate groups compare the subspace
+        gaps = np.abs(np.diff(out["host"][0]))
+        for j in range(k):
+            lo = gaps[j - 1] if j > 0 else np.inf
+            hi = gaps[j] if j < k - 1 else np.inf
+            if min(lo, hi) > 1e-4:
+                sg = np.sign(V[:, j].dot(S).dot(Vh[:, j]))
+                np.testing.assert_allclose(V[:, j] * sg, Vh[:, j], rtol=0, atol=1e-8 * np.abs(Vh[:, j]).max() / min(lo, hi, 1.0))
