@@ -27,43 +27,87 @@ namespace {
 
 constexpr int SB = 32;        // block size
 constexpr int SS_NT = 256;
-constexpr int SS_RT = 8;      // rows of the product per workgroup
-constexpr int SS_CK = 64;     // columns staged per chunk
+constexpr int SS_RT = 4;      // rows of the product per workgroup
 
 // out = alpha * (C X) + beta * X + gamma * P   (C: n x n row-major; X, P, out: n x SB row-major; out may alias P)
+// A workgroup owns SS_RT = 4 rows of the product.  Columns are processed in panels of SS_PANEL = 512: the panel of X
+// (512 x 32 doubles = 128 KB) and the workgroup's 4 x 512 slice of C are loaded into LDS with every load in flight at
+// once, then each wave multiplies a quarter of the panel's columns (lane = a 1 x 2 patch of the 4 x 32 block: one
+// broadcast read of C and one 16-byte read of X per two multiply-adds) and the four partial blocks are summed.
+constexpr int SS_PANEL = 512;
 __global__ __launch_bounds__(SS_NT) void ss_product_kernel(const double* __restrict__ Cm, int n, const double* __restrict__ X,
                                                            const double* P, double* out, double alpha, double beta, double gamma)
 {
-    __shared__ double sc[SS_RT][SS_CK + 1];
-    __shared__ double sx[SS_CK][SB];
-    const int tid = threadIdx.x, j = tid & (SB - 1), rl = tid >> 5;
-    const int r0 = blockIdx.x * SS_RT, r = r0 + rl;
-    double acc0 = 0.0, acc1 = 0.0;
-    for (int c0 = 0; c0 < n; c0 += SS_CK) {
+    extern __shared__ double ssm[];
+    double* sx = ssm;                              // [SS_PANEL][SB]
+    double* sc = sx + SS_PANEL * SB;               // [SS_RT][SS_PANEL + 2]
+    double* sp = sc + SS_RT * (SS_PANEL + 2);      // [4][SS_RT][SB] partial blocks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * SS_RT;
+    const int pr = lane >> 4, pc = (lane & 15) * 2;   // the lane's patch: row pr; columns pc, pc + 1
+    double a00 = 0.0, a01 = 0.0;
+    for (int c0 = 0; c0 < n; c0 += SS_PANEL) {
+        const int pw = min(SS_PANEL, n - c0);
         __syncthreads();
-        for (int q = tid; q < SS_RT * SS_CK; q += SS_NT) {
-            const int rr = q / SS_CK, cc = q - rr * SS_CK;
-            sc[rr][cc] = (r0 + rr < n && c0 + cc < n) ? Cm[(size_t)(r0 + rr) * n + c0 + cc] : 0.0;
-        }
-        for (int q = tid; q < SS_CK * SB; q += SS_NT) {
-            const int cc = q >> 5, jj = q & (SB - 1);
-            sx[cc][jj] = (c0 + cc < n) ? X[(size_t)(c0 + cc) * SB + jj] : 0.0;
+        {
+            // the whole panel in flight before the first LDS write: 32 x 16 bytes per thread, in batches of 16 loads
+            // (a plain copy loop waits for every load before it issues the next: one L2 round trip per element)
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2* xg = reinterpret_cast<const d2*>(X + (size_t)c0 * SB);
+            d2* xs2 = reinterpret_cast<d2*>(sx);
+            const int nv = pw * SB / 2;
+#pragma unroll
+            for (int b0 = 0; b0 < SS_PANEL * SB / 2 / SS_NT; b0 += 16) {
+                d2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int q = tid + SS_NT * (b0 + u);
+                    v[u] = q < nv ? xg[q] : d2{0.0, 0.0};
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int q = tid + SS_NT * (b0 + u);
+                    if (q < nv) xs2[q] = v[u];
+                }
+            }
+            double cv[SS_RT * SS_PANEL / SS_NT];
+#pragma unroll
+            for (int u = 0; u < SS_RT * SS_PANEL / SS_NT; ++u) {
+                const int q = tid + SS_NT * u, rr = q / SS_PANEL, cc = q - rr * SS_PANEL;
+                cv[u] = (r0 + rr < n && cc < pw) ? Cm[(size_t)(r0 + rr) * n + c0 + cc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < SS_RT * SS_PANEL / SS_NT; ++u) {
+                const int q = tid + SS_NT * u, rr = q / SS_PANEL, cc = q - rr * SS_PANEL;
+                sc[rr * (SS_PANEL + 2) + cc] = cv[u];
+            }
         }
         __syncthreads();
+        const int q4 = (pw + 3) / 4, cb = wave * q4, ce = min(pw, cb + q4);
+        const double* c_r0 = sc + pr * (SS_PANEL + 2);
 #pragma unroll 8
-        for (int cc = 0; cc < SS_CK; cc += 2) {
-            acc0 += sc[rl][cc] * sx[cc][j];
-            acc1 += sc[rl][cc + 1] * sx[cc + 1][j];
+        for (int cc = cb; cc < ce; ++cc) {
+            const double c0v = c_r0[cc];
+            a00 += c0v * sx[cc * SB + pc];
+            a01 += c0v * sx[cc * SB + pc + 1];
         }
     }
-    if (r < n) {
+    double* mine = sp + wave * (SS_RT * SB);
+    mine[pr * SB + pc] = a00;
+    mine[pr * SB + pc + 1] = a01;
+    __syncthreads();
+    const int rl = tid >> 5, j = tid & (SB - 1), r = r0 + rl;
+    if (rl < SS_RT && r < n) {
+        const int e = rl * SB + j;
+        const double acc = (sp[e] + sp[SS_RT * SB + e]) + (sp[2 * SS_RT * SB + e] + sp[3 * SS_RT * SB + e]);
         const size_t o = (size_t)r * SB + j;
-        double v = alpha * (acc0 + acc1);
+        double v = alpha * acc;
         if (beta != 0.0) v += beta * X[o];
         if (gamma != 0.0) v += gamma * P[o];
         out[o] = v;
     }
 }
+constexpr size_t SS_PRODUCT_LDS = ((size_t)SS_PANEL * SB + (size_t)SS_RT * (SS_PANEL + 2) + 4 * SS_RT * SB) * sizeof(double);
 
 // part[blockIdx][i][j] = sum over this block's rows of A[r][i] B[r][j]   (A, B: n x SB)
 constexpr int SG_ROWS = 64;
@@ -96,11 +140,23 @@ __global__ __launch_bounds__(SS_NT) void ss_gram_kernel(const double* __restrict
 // G = sum of the partial Gram matrices (deterministic order); out[0 .. SB*SB) = G (used for H = X^T W)
 __global__ __launch_bounds__(SS_NT) void ss_gram_sum_kernel(const double* __restrict__ part, int nparts, double* __restrict__ G)
 {
-    for (int q = threadIdx.x; q < SB * SB; q += SS_NT) {
-        double s = 0.0;
-        for (int p = 0; p < nparts; ++p) s += part[(size_t)p * SB * SB + q];
-        G[q] = s;
+    const double* mine = part + (size_t)blockIdx.x * nparts * SB * SB;   // block 0: part -> G, block 1: part2 -> H (adjacent)
+    const int tid = threadIdx.x;
+    double acc[SB * SB / SS_NT] = {0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < nparts; p0 += 4) {   // 16 loads in flight per trip
+        double v[4][SB * SB / SS_NT];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int u = 0; u < SB * SB / SS_NT; ++u)
+                v[pp][u] = p0 + pp < nparts ? mine[(size_t)(p0 + pp) * SB * SB + tid + SS_NT * u] : 0.0;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int u = 0; u < SB * SB / SS_NT; ++u) acc[u] += v[pp][u];
     }
+#pragma unroll
+    for (int u = 0; u < SB * SB / SS_NT; ++u) G[(size_t)blockIdx.x * SB * SB + tid + SS_NT * u] = acc[u];
 }
 
 // One round of Cholesky QR: G = X^T X (summed from the partials), G = R^T R, X <- X R^-1.  Every workgroup factors the
@@ -112,25 +168,51 @@ __global__ __launch_bounds__(SS_NT) void ss_cholqr_kernel(const double* __restri
     __shared__ double sg[SB][SB + 1];
     __shared__ double sinv[SB];
     const int tid = threadIdx.x;
-    for (int q = tid; q < SB * SB; q += SS_NT) {
-        double s = 0.0;
-        for (int p = 0; p < nparts; ++p) s += part[(size_t)p * SB * SB + q];
-        sg[q >> 5][q & (SB - 1)] = s;
+    {
+        double acc[SB * SB / SS_NT] = {0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < nparts; p0 += 4) {   // 16 loads in flight per trip
+            double v[4][SB * SB / SS_NT];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int u = 0; u < SB * SB / SS_NT; ++u)
+                    v[pp][u] = p0 + pp < nparts ? part[(size_t)(p0 + pp) * SB * SB + tid + SS_NT * u] : 0.0;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int u = 0; u < SB * SB / SS_NT; ++u) acc[u] += v[pp][u];
+        }
+#pragma unroll
+        for (int u = 0; u < SB * SB / SS_NT; ++u) {
+            const int q = tid + SS_NT * u;
+            sg[q >> 5][q & (SB - 1)] = acc[u];
+        }
     }
     __syncthreads();
-    // upper Cholesky in place, right-looking: 1024 entries over 256 threads
-    for (int p = 0; p < SB; ++p) {
-        const double piv = sg[p][p];
-        if (!(piv > 0.0) && tid == 0 && blockIdx.x == 0) *flag = 1;
-        const double u = sqrt(piv), ui = 1.0 / u;
-        __syncthreads();
-        if (tid < SB && tid >= p) sg[p][tid] = tid == p ? u : sg[p][tid] * ui;
-        if (tid == 0) sinv[p] = ui;
-        __syncthreads();
-        for (int q = tid; q < SB * SB; q += SS_NT) {
-            const int rr = q >> 5, cc = q & (SB - 1);
-            if (rr > p && cc >= rr) sg[rr][cc] -= sg[p][rr] * sg[p][cc];
+    // upper Cholesky with unscaled pivot rows (see potrf_blockrow_kernel): step p subtracts g[p][r] g[p][c] / piv_p from the
+    // rows r > p, one barrier per step; R[p][c] = g[p][c] / sqrt(piv_p) afterwards.  Thread -> entries (i, 4 j0 .. 4 j0 + 3).
+    {
+        const int i = tid >> 3, j0 = (tid & 7) * 4;
+        for (int p = 0; p < SB - 1; ++p) {
+            const double piv = sg[p][p];
+            if (i > p) {
+                const double f = sg[p][i] / piv;
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4)
+                    if (j0 + b4 >= i) sg[i][j0 + b4] -= f * sg[p][j0 + b4];
+            }
+            __syncthreads();
         }
+        if (tid < SB) {
+            const double piv = sg[tid][tid];
+            if (!(piv > 0.0) && blockIdx.x == 0) *flag = 1;
+            sinv[tid] = 1.0 / sqrt(piv);
+        }
+        __syncthreads();
+        // R[p][c] = g[p][c] * sinv[p]; 1 / R[p][p] = sinv[p]
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4)
+            if (j0 + b4 > i) sg[i][j0 + b4] *= sinv[i];
         __syncthreads();
     }
     const int r = blockIdx.x * SS_NT + tid;
@@ -189,9 +271,19 @@ __global__ __launch_bounds__(SS_NT) void ss_residual_kernel(const double* __rest
     const int tid = threadIdx.x, j = tid & (SB - 1), part = tid >> 5;
     const double th = theta[j];
     double s = 0.0;
-    for (int r = part; r < n; r += SS_NT / SB) {
-        const double dlt = W[(size_t)r * SB + j] - th * X[(size_t)r * SB + j];
-        s += dlt * dlt;
+    for (int r = part; r < n; r += 8 * (SS_NT / SB)) {   // 16 loads in flight per trip
+        double wv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rr = r + u * (SS_NT / SB);
+            wv[u] = rr < n ? W[(size_t)rr * SB + j] : 0.0;
+            xv[u] = rr < n ? X[(size_t)rr * SB + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double dlt = wv[u] - th * xv[u];
+            s += dlt * dlt;
+        }
     }
     red[part][j] = s;
     __syncthreads();
@@ -224,54 +316,168 @@ __global__ void ss_emit_kernel(const double* __restrict__ X, int n, int k, doubl
     Yk[q] = X[(size_t)r * SB + j];
 }
 
-// cyclic Jacobi for a small symmetric matrix (host): A (m x m, row-major, destroyed) -> eigenvalues w, eigenvectors as
-// columns of V, sorted by descending eigenvalue
-void jacobi_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vector<double>& V)
+// Small dense symmetric eigenproblem on the host: Householder tridiagonalisation with accumulated transformations, then
+// QL with implicit shifts (the classical tred2 / tql2 pair).  A (m x m, row-major, destroyed) -> eigenvalues w and
+// eigenvectors as COLUMNS of V, sorted by descending eigenvalue.  ~m^3 flops: microseconds at m = 32.
+void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vector<double>& V)
 {
-    V.assign((size_t)m * m, 0.0);
-    for (int i = 0; i < m; ++i) V[(size_t)i * m + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, dia = 0.0;
-        for (int i = 0; i < m; ++i) {
-            dia += A[(size_t)i * m + i] * A[(size_t)i * m + i];
-            for (int j = i + 1; j < m; ++j) off += A[(size_t)i * m + j] * A[(size_t)i * m + j];
-        }
-        if (off <= 1e-60 || off <= 1e-34 * dia) break;
-        for (int p = 0; p < m - 1; ++p)
-            for (int q = p + 1; q < m; ++q) {
-                const double apq = A[(size_t)p * m + q];
-                if (apq == 0.0) continue;
-                const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q];
-                const double tau = (aqq - app) / (2.0 * apq);
-                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
-                for (int i = 0; i < m; ++i) {   // columns p, q
-                    const double aip = A[(size_t)i * m + p], aiq = A[(size_t)i * m + q];
-                    A[(size_t)i * m + p] = c * aip - s * aiq;
-                    A[(size_t)i * m + q] = s * aip + c * aiq;
+    std::vector<double> d(m), e(m);
+    auto a = [&](int i, int j) -> double& { return A[(size_t)i * m + j]; };
+    for (int i = m - 1; i > 0; --i) {
+        const int l = i - 1;
+        double h = 0.0, scale = 0.0;
+        if (l > 0) {
+            for (int k2 = 0; k2 <= l; ++k2) scale += std::fabs(a(i, k2));
+            if (scale == 0.0) {
+                e[i] = a(i, l);
+            } else {
+                for (int k2 = 0; k2 <= l; ++k2) {
+                    a(i, k2) /= scale;
+                    h += a(i, k2) * a(i, k2);
                 }
-                for (int i = 0; i < m; ++i) {   // rows p, q
-                    const double api = A[(size_t)p * m + i], aqi = A[(size_t)q * m + i];
-                    A[(size_t)p * m + i] = c * api - s * aqi;
-                    A[(size_t)q * m + i] = s * api + c * aqi;
+                double f = a(i, l);
+                double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+                e[i] = scale * g;
+                h -= f * g;
+                a(i, l) = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    a(j, i) = a(i, j) / h;
+                    g = 0.0;
+                    for (int k2 = 0; k2 <= j; ++k2) g += a(j, k2) * a(i, k2);
+                    for (int k2 = j + 1; k2 <= l; ++k2) g += a(k2, j) * a(i, k2);
+                    e[j] = g / h;
+                    f += e[j] * a(i, j);
                 }
-                for (int i = 0; i < m; ++i) {
-                    const double vip = V[(size_t)i * m + p], viq = V[(size_t)i * m + q];
-                    V[(size_t)i * m + p] = c * vip - s * viq;
-                    V[(size_t)i * m + q] = s * vip + c * viq;
+                const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = a(i, j);
+                    e[j] = g = e[j] - hh * f;
+                    for (int k2 = 0; k2 <= j; ++k2) a(j, k2) -= f * e[k2] + g * a(i, k2);
                 }
             }
+        } else {
+            e[i] = a(i, l);
+        }
+        d[i] = h;
+    }
+    d[0] = 0.0;
+    e[0] = 0.0;
+    for (int i = 0; i < m; ++i) {
+        const int l = i - 1;
+        if (d[i] != 0.0) {
+            for (int j = 0; j <= l; ++j) {
+                double g = 0.0;
+                for (int k2 = 0; k2 <= l; ++k2) g += a(i, k2) * a(k2, j);
+                for (int k2 = 0; k2 <= l; ++k2) a(k2, j) -= g * a(k2, i);
+            }
+        }
+        d[i] = a(i, i);
+        a(i, i) = 1.0;
+        for (int j = 0; j <= l; ++j) a(j, i) = a(i, j) = 0.0;
+    }
+    // QL with implicit shifts on (d, e), rotations accumulated into A (columns = eigenvectors)
+    for (int i = 1; i < m; ++i) e[i - 1] = e[i];
+    e[m - 1] = 0.0;
+    for (int l = 0; l < m; ++l) {
+        int iter = 0, mm;
+        do {
+            for (mm = l; mm < m - 1; ++mm) {
+                const double dd = std::fabs(d[mm]) + std::fabs(d[mm + 1]);
+                if (std::fabs(e[mm]) <= 2.3e-16 * dd) break;
+            }
+            if (mm != l) {
+                if (iter++ == 60) break;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[mm] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double s2 = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = mm - 1; i >= l; --i) {
+                    double f = s2 * e[i];
+                    const double bb = c * e[i];
+                    e[i + 1] = (r = std::hypot(f, g));
+                    if (r == 0.0) {
+                        d[i + 1] -= p;
+                        e[mm] = 0.0;
+                        break;
+                    }
+                    s2 = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s2 + 2.0 * c * bb;
+                    d[i + 1] = g + (p = s2 * r);
+                    g = c * r - bb;
+                    for (int k2 = 0; k2 < m; ++k2) {
+                        f = a(k2, i + 1);
+                        a(k2, i + 1) = s2 * a(k2, i) + c * f;
+                        a(k2, i) = c * a(k2, i) - s2 * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p;
+                e[l] = g;
+                e[mm] = 0.0;
+            }
+        } while (mm != l);
     }
     std::vector<int> order(m);
     for (int i = 0; i < m; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return A[(size_t)a * m + a] > A[(size_t)b * m + b]; });
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return d[x] > d[y]; });
     w.resize(m);
-    std::vector<double> Vs((size_t)m * m);
+    V.assign((size_t)m * m, 0.0);
     for (int j = 0; j < m; ++j) {
-        w[j] = A[(size_t)order[j] * m + order[j]];
-        for (int i = 0; i < m; ++i) Vs[(size_t)i * m + j] = V[(size_t)i * m + order[j]];
+        w[j] = d[order[j]];
+        for (int i = 0; i < m; ++i) V[(size_t)i * m + j] = a(i, order[j]);
     }
-    V.swap(Vs);
+}
+
+// Generalized small problem H s = theta G s (G symmetric positive definite, close to I): G = L L^T, eig(L^-1 H L^-T),
+// S = L^-T S'.  Columns of S are G-orthonormal, so X S is orthonormal when G = X^T X.  Returns false if G is not SPD.
+bool small_geigh(std::vector<double>& H, std::vector<double>& G, int m, std::vector<double>& w, std::vector<double>& S)
+{
+    std::vector<double> L((size_t)m * m, 0.0);
+    for (int j = 0; j < m; ++j) {
+        double s = G[(size_t)j * m + j];
+        for (int k2 = 0; k2 < j; ++k2) s -= L[(size_t)j * m + k2] * L[(size_t)j * m + k2];
+        if (!(s > 0.0)) return false;
+        const double ljj = std::sqrt(s);
+        L[(size_t)j * m + j] = ljj;
+        for (int i = j + 1; i < m; ++i) {
+            double t = G[(size_t)i * m + j];
+            for (int k2 = 0; k2 < j; ++k2) t -= L[(size_t)i * m + k2] * L[(size_t)j * m + k2];
+            L[(size_t)i * m + j] = t / ljj;
+        }
+    }
+    // M = L^-1 H L^-T: forward substitutions on the rows, then on the columns
+    std::vector<double> M(H);
+    for (int c = 0; c < m; ++c)          // M <- L^-1 M (column by column)
+        for (int i = 0; i < m; ++i) {
+            double t = M[(size_t)i * m + c];
+            for (int k2 = 0; k2 < i; ++k2) t -= L[(size_t)i * m + k2] * M[(size_t)k2 * m + c];
+            M[(size_t)i * m + c] = t / L[(size_t)i * m + i];
+        }
+    for (int r = 0; r < m; ++r)          // M <- M L^-T (row by row)
+        for (int j = 0; j < m; ++j) {
+            double t = M[(size_t)r * m + j];
+            for (int k2 = 0; k2 < j; ++k2) t -= M[(size_t)r * m + k2] * L[(size_t)j * m + k2];
+            M[(size_t)r * m + j] = t / L[(size_t)j * m + j];
+        }
+    for (int i = 0; i < m; ++i)
+        for (int j = i + 1; j < m; ++j) {
+            const double t = 0.5 * (M[(size_t)i * m + j] + M[(size_t)j * m + i]);
+            M[(size_t)i * m + j] = M[(size_t)j * m + i] = t;
+        }
+    std::vector<double> Sp;
+    small_eigh(M, m, w, Sp);
+    S.assign((size_t)m * m, 0.0);
+    for (int c = 0; c < m; ++c)          // S = L^-T S': back substitution per column
+        for (int i = m - 1; i >= 0; --i) {
+            double t = Sp[(size_t)i * m + c];
+            for (int k2 = i + 1; k2 < m; ++k2) t -= L[(size_t)k2 * m + i] * S[(size_t)k2 * m + c];
+            S[(size_t)i * m + c] = t / L[(size_t)i * m + i];
+        }
+    return true;
 }
 
 }  // namespace
@@ -291,56 +497,73 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     double* Y = X + NB;
     double* Z = Y + NB;
     double* W = Z + NB;
-    double* part = W + NB;                    // [nparts <= 8 .. n / 64][SB][SB]
     const int nparts = (int)ceil_div(n, SG_ROWS);
-    double* G = part + (size_t)nparts * SB * SB;   // [2][SB][SB]: H, then S
-    double* dS = G + SB * SB;
+    double* part = W + NB;                             // [nparts][SB][SB]
+    double* part2 = part + (size_t)nparts * SB * SB;   // [nparts][SB][SB]
+    double* GH = part2 + (size_t)nparts * SB * SB;     // [2][SB][SB]: G = X^T X, H = X^T W
+    double* dS = GH + 2 * SB * SB;
     double* dtheta = dS + SB * SB;
     double* dres = dtheta + SB;
     int* dflag = reinterpret_cast<int*>(dres + SB);
+    // pinned staging for the small host <-> device transfers of the Rayleigh-Ritz steps
+    static double* pin = nullptr;
+    if (!pin) MSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pin), (4 * SB * SB + 4 * SB) * sizeof(double), hipHostMallocDefault));
+    double* hGH = pin;                 // 2 SB^2
+    double* hS = pin + 2 * SB * SB;    // SB^2
+    double* htheta = hS + SB * SB;     // SB
+    double* hres = htheta + SB;        // SB
+    int* hflag = reinterpret_cast<int*>(hres + SB);
+    static bool attr = false;
+    if (!attr) {
+        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_product_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)SS_PRODUCT_LDS));
+        attr = true;
+    }
     const dim3 gprod((unsigned)ceil_div(n, SS_RT)), gqr((unsigned)ceil_div(n, SS_NT)), grot((unsigned)ceil_div(n, SS_NT / SB));
     auto product = [&](const double* Xin, const double* P, double* out, double a, double b, double c) {
-        hipLaunchKernelGGL(ss_product_kernel, gprod, dim3(SS_NT), 0, stream(), Cm, n, Xin, P, out, a, b, c);
+        hipLaunchKernelGGL(ss_product_kernel, gprod, dim3(SS_NT), SS_PRODUCT_LDS, stream(), Cm, n, Xin, P, out, a, b, c);
     };
-    auto cholqr2 = [&](double* Q) {
-        for (int rep = 0; rep < 2; ++rep) {
-            hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), Q, Q, n, part);
-            hipLaunchKernelGGL(ss_cholqr_kernel, gqr, dim3(SS_NT), 0, stream(), part, nparts, Q, n, dflag);
-        }
+    // one round of Cholesky QR: orthonormal to ~ cond(X)^2 eps, which the Rayleigh-Ritz step below absorbs by solving
+    // the small GENERALIZED problem H s = theta G s with G = X^T X
+    auto cholqr = [&](double* Q) {
+        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), Q, Q, n, part);
+        hipLaunchKernelGGL(ss_cholqr_kernel, gqr, dim3(SS_NT), 0, stream(), part, nparts, Q, n, dflag);
     };
     MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
     hipLaunchKernelGGL(ss_init_kernel, dim3((unsigned)ceil_div(NB, 256)), dim3(256), 0, stream(), X, n);
-    cholqr2(X);
-    std::vector<double> H(SB * SB), w, V, res(SB);
+    cholqr(X);
+    std::vector<double> H(SB * SB), G(SB * SB), w, V;
     double prev_res = INFINITY;
     for (int outer = 0; outer <= max_outer; ++outer) {
         // ---- Rayleigh-Ritz on span(X)
         product(X, nullptr, W, 1.0, 0.0, 0.0);
-        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, W, n, part);
-        hipLaunchKernelGGL(ss_gram_sum_kernel, dim3(1), dim3(SS_NT), 0, stream(), part, nparts, G);
+        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, X, n, part);
+        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, W, n, part2);
+        hipLaunchKernelGGL(ss_gram_sum_kernel, dim3(2), dim3(SS_NT), 0, stream(), part, nparts, GH);
         MSM_HIP_CHECK(hipGetLastError());
-        int flag = 0;
-        MSM_HIP_CHECK(hipMemcpyAsync(H.data(), G, SB * SB * sizeof(double), hipMemcpyDeviceToHost, stream()));
-        MSM_HIP_CHECK(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(hGH, GH, 2 * SB * SB * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-        if (flag) return MSM_OK;   // rank loss in the Cholesky QR (or non-finite data): let the direct method decide
+        if (*hflag) return MSM_OK;   // rank loss in the Cholesky QR (or non-finite data): let the direct method decide
         for (int i = 0; i < SB; ++i)
-            for (int j = i + 1; j < SB; ++j) {
-                const double s = 0.5 * (H[i * SB + j] + H[j * SB + i]);
-                H[i * SB + j] = H[j * SB + i] = s;
+            for (int j = 0; j < SB; ++j) {
+                G[i * SB + j] = 0.5 * (hGH[i * SB + j] + hGH[j * SB + i]);
+                H[i * SB + j] = 0.5 * (hGH[SB * SB + i * SB + j] + hGH[SB * SB + j * SB + i]);
             }
         for (int i = 0; i < SB * SB; ++i)
-            if (!(std::fabs(H[i]) < 1e300)) return MSM_OK;
-        jacobi_eigh(H, SB, w, V);
-        MSM_HIP_CHECK(hipMemcpyAsync(dS, V.data(), SB * SB * sizeof(double), hipMemcpyHostToDevice, stream()));
-        MSM_HIP_CHECK(hipMemcpyAsync(dtheta, w.data(), SB * sizeof(double), hipMemcpyHostToDevice, stream()));
+            if (!(std::fabs(H[i]) < 1e300) || !(std::fabs(G[i]) < 1e300)) return MSM_OK;
+        if (!small_geigh(H, G, SB, w, V)) return MSM_OK;
+        memcpy(hS, V.data(), SB * SB * sizeof(double));
+        memcpy(htheta, w.data(), SB * sizeof(double));
+        MSM_HIP_CHECK(hipMemcpyAsync(dS, hS, (SB * SB + SB) * sizeof(double), hipMemcpyHostToDevice, stream()));   // S and theta are adjacent
         hipLaunchKernelGGL(ss_rotate_kernel, grot, dim3(SS_NT), 0, stream(), X, W, n, dS);
         hipLaunchKernelGGL(ss_residual_kernel, dim3(1), dim3(SS_NT), 0, stream(), X, W, n, dtheta, dres);
         MSM_HIP_CHECK(hipGetLastError());
-        MSM_HIP_CHECK(hipMemcpyAsync(res.data(), dres, SB * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(hres, dres, SB * sizeof(double), hipMemcpyDeviceToHost, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
         double rmax = 0.0;
-        for (int j = 0; j < k; ++j) rmax = std::max(rmax, res[j]);
+        for (int j = 0; j < k; ++j) rmax = std::max(rmax, hres[j]);
+        if (!(rmax == rmax)) return MSM_OK;
         if (outer_used) *outer_used = outer;
         if (rmax <= tol * std::max(1.0, std::fabs(w[0]))) {
             MSM_HIP_CHECK(hipMemcpyAsync(lam, dtheta, k * sizeof(double), hipMemcpyDeviceToDevice, stream()));
@@ -372,14 +595,14 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
             sigma = sn;
         }
         if (xc != X) MSM_HIP_CHECK(hipMemcpyAsync(X, xc, NB * sizeof(double), hipMemcpyDeviceToDevice, stream()));
-        cholqr2(X);
+        cholqr(X);
     }
     return MSM_OK;
 }
 
 size_t subspace_work_doubles(int n)
 {
-    return 4 * (size_t)n * SB + ((size_t)ceil_div(n, SG_ROWS) + 2) * SB * SB + 4 * SB + 8;
+    return 4 * (size_t)n * SB + (2 * (size_t)ceil_div(n, SG_ROWS) + 3) * SB * SB + 4 * SB + 8;
 }
 
 }  // namespace msm

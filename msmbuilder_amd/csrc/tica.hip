@@ -1850,12 +1850,44 @@ __global__ void tica_export_kernel(const double* __restrict__ slabs, const doubl
             tile = T * T + ti * T - ti * (ti - 1) / 2 + (tj - ti);
         }
         const size_t off = (size_t)(i % TM) * TM + (j % TM);
-        for (int s = 0; s < S; ++s) v += slabs[((size_t)s * ntiles + tile) * (TM * TM) + off];
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {   // four slabs' loads in flight per trip
+            double q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = slabs[((size_t)(s + u) * ntiles + tile) * (TM * TM) + off];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += q[u];
+        }
+        for (; s < S; ++s) v += slabs[((size_t)s * ntiles + tile) * (TM * TM) + off];
     } else {
-        const size_t e = idx - 2 * FF;  // [s0 | stau]
-        for (int b = 0; b < NCB; ++b) v += colpart[(size_t)b * 2 * F + e];
+        return;   // [s0 | stau]: tica_export_cols_kernel (NCB partials per column: a reduction, not a per-thread loop)
     }
     out[idx] = v;
+}
+
+// out[2 F^2 + e] = base[2 F^2 + e] + sum over the NCB column partials, e in [s0 | stau].  64 columns per workgroup, four
+// waves take a quarter of the partials each with 16 loads in flight per trip (the per-thread loop over all 1024 partials
+// was 1024 dependent L2 round trips: 70 us of a 2 ms solve), summed in partial order (deterministic).
+__global__ __launch_bounds__(256) void tica_export_cols_kernel(const double* __restrict__ colpart, const double* __restrict__ base,
+                                                               double* __restrict__ out, int F)
+{
+    __shared__ double red[4][64];
+    const size_t FF = (size_t)F * F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool in = e < 2 * F;
+    double acc = 0.0;
+    constexpr int PER = NCB / 4;
+    for (int b0 = wave * PER; b0 < (wave + 1) * PER; b0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = in ? colpart[(size_t)(b0 + u) * 2 * F + e] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && in) out[2 * FF + e] = base[2 * FF + e] + ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 // out[n,k] = (X - mean) @ comps^T in fp64 (tica.py:329-333), evaluated as X @ comps^T - (mean @ comps^T)
@@ -2566,6 +2598,8 @@ int tica_export_device(msm_tica* h)
     const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
                        h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
+    hipLaunchKernelGGL(tica_export_cols_kernel, dim3((unsigned)ceil_div(2 * (int64_t)h->F, 64)), dim3(256), 0, stream(), h->colpart, h->base,
+                       h->packed, h->F);
     MSM_HIP_CHECK(hipGetLastError());
     if (h->sym) {
         const size_t ff2 = 2 * (size_t)h->F * h->F;
@@ -3019,6 +3053,8 @@ int tica_reduce_device(msm_tica* h, double shrinkage, long long n_rblw, const do
     const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
                        h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
+    hipLaunchKernelGGL(tica_export_cols_kernel, dim3((unsigned)ceil_div(2 * (int64_t)h->F, 64)), dim3(256), 0, stream(), h->colpart, h->base,
+                       h->packed, h->F);
     if (h->sym) {
         const size_t ff2 = 2 * (size_t)h->F * h->F;
         hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div((size_t)h->ntiles_sym * TM * TM, 256)), dim3(256), 0, stream(),

@@ -744,7 +744,15 @@ __global__ __launch_bounds__(256) void pair_residual_kernel(const double* __rest
     double mx = 0.0, ss = 0.0;
     for (int r = tid; r < n; r += 256) {
         double acc = 0.0;
-        for (int c = 0; c < n; ++c) acc += Cm[(size_t)c * n + r] * sy[c];   // symmetric: column r read as a row, coalesced
+        int c = 0;
+        for (; c + 8 <= n; c += 8) {   // symmetric: column r read as a row, coalesced; eight loads in flight per trip
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Cm[(size_t)(c + u) * n + r];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u] * sy[c + u];
+        }
+        for (; c < n; ++c) acc += Cm[(size_t)c * n + r] * sy[c];
         mx = fmax(mx, fabs(acc - lam * sy[r]));
         ss += sy[r] * sy[r];
     }

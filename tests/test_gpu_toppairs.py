@@ -84,7 +84,7 @@ def test_tridiag_topk_matches_lapack(gpu, case):
 
 
 @pytest.mark.parametrize("F,k,flat", [(200, 10, False), (512, 10, False), (512, 64, False), (700, 3, False), (512, 10, True),
-                                      (130, 16, False)])
+                                      (130, 8, False)])
 def test_topk_solve_matches_host_route(gpu, monkeypatch, F, k, flat):
     """msm_tica_solve_topk on wide models against the all-host numpy / dsygvx route of the same accumulators: through the
     subspace iteration where the spectrum has a gap (k <= 16), through the tridiagonalisation where it has none (`flat`:
