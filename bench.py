@@ -88,6 +88,16 @@ def synth(torch, n_seq, n_frames, F, seed, device, n_slow=16, mean_scale=1.0):
     return X
 
 
+def synth_bf16(torch, n_seq, n_frames, F, seed, device, block=125):
+    """The same recipe stored as bfloat16 (BASELINE configs[4]: half the bytes), generated block-wise so that the fp32
+    intermediate never exceeds `block` trajectories.  Returns [n_seq * n_frames, F] bf16."""
+    X = torch.empty((n_seq * n_frames, F), dtype=torch.bfloat16, device=device)
+    for i, s0 in enumerate(range(0, n_seq, block)):
+        s1 = min(n_seq, s0 + block)
+        X[s0 * n_frames:s1 * n_frames] = synth(torch, s1 - s0, n_frames, F, seed + 1000 * i, device).to(torch.bfloat16)
+    return X
+
+
 def executed_flop_per_frame(F, sym):
     """MFMA flop the accumulation kernel issues per frame, in 128 x 128 tile products: all T^2 lagged tiles + the
     T(T+1)/2 upper Gram tiles, or -- fp32 sum/difference kernel -- the H and the D block of the upper tiles only."""
@@ -572,9 +582,13 @@ def main():
             X8 = X[: n8 * T]
             seqs8 = seqs[:n8]
             rec8 = {}
+            # the ROW-SHARDED k-centers loop (msm_kcenters_fit_sharded_*, a world of one: its all-gathers are copies), i.e.
+            # the code an N = 8 rank runs, not the single-GPU fit
+            os.environ["MSMBUILDER_AMD_FORCE_SHARDED"] = "1"
             step(None, seqs8, X8)
             for _ in range(3):
                 step(rec8, seqs8, X8)
+            os.environ.pop("MSMBUILDER_AMD_FORCE_SHARDED", None)
             rec8.pop("sym", None)
             ph8 = {k: 1e3 * float(np.mean(v)) for k, v in rec8.items() if k != "mfma_ms"}
             step8 = sum(ph8.values())
@@ -582,8 +596,8 @@ def main():
             comm_ms = (comm_us["allreduce_4MB"] + args.clusters * comm_us["allgather_per_centre"]) / 1e3
             serial = ph8.get("solve", 0.0) + comm_ms
             out["strong_scaling_model"] = {
-                "what": "one rank's share at N=8 (%d of %d trajectories) run alone on this GPU: per-phase ms measured, collectives "
-                        "modelled" % (n8, n_seq),
+                "what": "one rank's share at N=8 (%d of %d trajectories) run alone on this GPU through the sharded code path "
+                        "(msm_kcenters_fit_sharded, screened passes): per-phase ms measured, collectives modelled" % (n8, n_seq),
                 "phases_ms": ph8, "mfma_ms": float(np.mean(rec8["mfma_ms"])), "measured_step_ms": step8,
                 "assumed_comm_us": comm_us, "modelled_step_ms": step8 + comm_ms,
                 "modelled_speedup_at_8": ms_per_step / (step8 + comm_ms),
@@ -642,6 +656,41 @@ def main():
             os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
             out["config5_width"] = c5
             del X5, seqs5
+            torch.cuda.empty_cache()
+            # --- BASELINE configs[4] at ONE GPU's share of the 8-GPU run: 6,250,000 x 2048, bfloat16-STORED (25.6 GB),
+            # through the bf16 image path (fit = column sums + image pre-pass + MFMA kernel; wall time of the whole fit)
+            n5g = 625
+            X5g = synth_bf16(torch, n5g, T, 2048, 11, dev)
+            seqs5g = list(X5g.view(n5g, T, 2048).unbind(0))
+            c5g = {"workload": "%d x 2048 bfloat16-stored (%.1f GB) as %d trajectories x %d, lag %d: one rank's share of 50M x 2048 over 8 GPUs"
+                               % (n5g * T, n5g * T * 2048 * 2 / 1e9, n5g, T, args.lag), "modes": {}}
+            ref5g = None
+            for mode in ("bf16x2", "bf16"):
+                os.environ["MSMBUILDER_AMD_TICA_MODE"] = mode
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    m5 = tICA(n_components=args.components, lag_time=args.lag).fit(seqs5g)      # warm-up (image buffers)
+                    torch.cuda.synchronize()
+                    t5 = time.perf_counter()
+                    m5 = tICA(n_components=args.components, lag_time=args.lag).fit(seqs5g)
+                    torch.cuda.synchronize()
+                    t5 = time.perf_counter() - t5
+                    ms5, pre5 = kernel_ms_of(m5, _lib), prepass_ms_of(m5, _lib)
+                    e5 = np.asarray(m5.eigenvalues_)
+                ref5g = e5 if ref5g is None else ref5g
+                ex5 = executed_flop_per_frame_bf16(2048, mode == "bf16x2")
+                c5g["modes"][mode] = {"fit_wall_ms": 1e3 * t5, "fit_frames_per_s": n5g * T / t5,
+                                      "mfma_kernel_ms": ms5, "image_prepass_ms": pre5,
+                                      "executed_TFLOPs": ex5 * n5g * T / ms5 / 1e9,
+                                      "frac_of_bf16_mfma_peak": ex5 * n5g * T / ms5 / 1e9 / PEAK_TFLOPS["bf16"],
+                                      "algorithmic_TFLOPs_whole_fit": 4.0 * 2048 * 2048 * n5g * T / t5 / 1e12,
+                                      "hbm_GBps_if_read_once": n5g * T * 2048 * 2 / t5 / 1e9,
+                                      "eigenvalues_max_rel_diff_vs_bf16x2": float(np.abs(e5 / ref5g - 1).max())}
+                del m5
+                torch.cuda.empty_cache()
+            os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
+            out["config5_per_gpu"] = c5g
+            del X5g, seqs5g
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

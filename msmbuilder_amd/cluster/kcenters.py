@@ -73,7 +73,10 @@ class _KCenters(ClusterMixin, TransformerMixin):
             raise ValueError('metric must be one of %s' %
                              ', '.join("'%s'" % s for s in libdistance.VECTOR_METRICS))
         from .. import parallel
-        if parallel.active():
+        import os
+        # MSMBUILDER_AMD_FORCE_SHARDED=1: take the row-sharded library loop in a single process too (a world of one; its
+        # all-gathers degenerate to copies) -- what bench.py's strong-scaling model times
+        if parallel.active() or (os.environ.get("MSMBUILDER_AMD_FORCE_SHARDED") == "1" and is_device_array(X)):
             return self._fit_sharded(X, metric)
         n_samples = len(X)
         seed = check_random_state(self.random_state).randint(0, n_samples)

@@ -187,3 +187,55 @@ def test_config5_bf16_image_path_vs_oracle(gpu, monkeypatch, mode, rtol, ctol, F
     np.testing.assert_allclose(mb.eigenvalues_, ob.eigenvalues_, rtol=rtol)
     np.testing.assert_allclose(mb.means_, ob.means_, rtol=1e-10)
     np.testing.assert_allclose(mb.covariance_, ob.covariance_, rtol=0, atol=ctol * np.abs(ob.covariance_).max())
+
+
+def test_config5_per_gpu_share_6250000_x_2048_bf16_stored(gpu, monkeypatch):
+    """BASELINE configs[4] at the size ONE of its 8 GPUs holds: 6,250,000 x 2048, bfloat16-STORED (25.6 GB), lag 100,
+    through the bf16 image path in both of its modes.  Reference: an independent float64 contraction of the stored values
+    (torch matmuls on the device, per block of trajectories: different kernels, different summation order), finalised
+    with the oracle's formulas and solved on the host.  Tolerances are the modes' stated ones (bf16x2: fp32 class,
+    bf16: 8-bit significands)."""
+    import torch
+    import scipy.linalg
+    import bench
+    from msmbuilder_amd import tICA
+    from oracle.tica_oracle import rao_blackwell_ledoit_wolf
+    n_seq, T, F, lag, k = 625, 10_000, 2048, 100, 10
+    X = bench.synth_bf16(torch, n_seq, T, F, 11, torch.device("cuda"))
+    assert X.dtype == torch.bfloat16 and X.shape == (n_seq * T, F) and X.element_size() * X.numel() == 25_600_000_000
+    seqs = list(X.view(n_seq, T, F).unbind(0))
+    C = torch.zeros(F, F, dtype=torch.float64, device="cuda")
+    G = torch.zeros_like(C)
+    s0 = torch.zeros(F, dtype=torch.float64, device="cuda")
+    st = torch.zeros_like(s0)
+    for s in range(0, n_seq, 25):
+        V = X.view(n_seq, T, F)[s:s + 25].double()
+        A, B = V[:, :-lag].reshape(-1, F), V[:, lag:].reshape(-1, F)
+        C += A.T @ B
+        G += A.T @ A + B.T @ B
+        s0 += A.sum(0)
+        st += B.sum(0)
+        del V, A, B
+    C, G, s0, st = C.cpu().numpy(), G.cpu().numpy(), s0.cpu().numpy(), st.cpu().numpy()
+    two_n = 2.0 * n_seq * (T - lag)
+    mu = (s0 + st) / two_n
+    S = G / two_n - np.outer(mu, mu)
+    OC = (C + C.T) / two_n - np.outer(mu, mu)
+    Sig, rho = rao_blackwell_ledoit_wolf(S, n_seq * T)
+    ref = scipy.linalg.eigh(OC, b=Sig, subset_by_index=[F - k, F - 1])[0][::-1]
+    for mode, rtol, ctol in (("bf16x2", 1e-5, 1e-5), ("bf16", 1e-3, 5e-3)):
+        monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=k, lag_time=lag).fit(seqs)
+            ev = np.asarray(m.eigenvalues_)
+        assert m._lagged_symmetrised and (m.n_observations_, m.n_sequences_) == (n_seq * T, n_seq)
+        np.testing.assert_allclose(ev, ref, rtol=rtol)
+        np.testing.assert_allclose(m.means_, mu, rtol=1e-10)
+        np.testing.assert_allclose(m.covariance_, Sig, rtol=0, atol=ctol * np.abs(Sig).max())
+        np.testing.assert_allclose(m.offset_correlation_, OC, rtol=0, atol=ctol * np.abs(OC).max())
+        m._pull()
+        np.testing.assert_allclose(m._sum_0_to_TminusTau, s0, rtol=1e-11)
+        np.testing.assert_allclose(m._sum_tau_to_T, st, rtol=1e-11)
+        del m
+        torch.cuda.empty_cache()
