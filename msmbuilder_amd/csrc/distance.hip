@@ -615,16 +615,22 @@ struct WideStage {
     int inb;
 };
 
-template <typename T, int M, int MODE>
-__global__ __launch_bounds__(DT, 2) void wide_kernel(WideArgs A)
+// NCT = centres per register tile in MODE 0 / 1.  16 is the general choice (see WNC); 8 serves K <= 8 (a 16-centre group
+// spends half its arithmetic on padding there: 0.45 of the fp64-VALU bound at K = 8); 32 serves float64 rows with many
+// centres, whose 256-byte-per-chunk row tile was re-streamed from L2 / MALL once per 16-centre group (0.50 of the bound at
+// 2M x 256, K = 100) -- at 32 the LDS of a workgroup grows by 4 KiB and one workgroup fits a CU, which the 64 independent
+// accumulator chains of a lane make up for.
+template <typename T, int M, int MODE, int NCT = WNC>
+__global__ __launch_bounds__(DT, (NCT > WNC ? 1 : 2)) void wide_kernel(WideArgs A)
 {
     constexpr int E = 16 / (int)sizeof(T);    // elements per 16-byte vector
     constexpr int FC = 128 / (int)sizeof(T);  // features per chunk
-    constexpr int NC = (MODE == 2) ? 1 : WNC;
+    constexpr int NC = (MODE == 2) ? 1 : NCT;
+    constexpr int NCL = (MODE == 2) ? WNC : NCT;   // centre rows the LDS layout provides for
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     float* Xs = reinterpret_cast<float*>(wsm);                   // [2][DT * WP]
-    float* Ys = Xs + 2 * DT * WP;                                // [2][NC * 32]
-    double* rv = reinterpret_cast<double*>(Ys + 2 * WNC * 32);   // [DT]
+    float* Ys = Xs + 2 * DT * WP;                                // [2][NCL * 32]
+    double* rv = reinterpret_cast<double*>(Ys + 2 * NCL * 32);   // [DT]
     long long* ri = reinterpret_cast<long long*>(rv + DT);       // [DT]
     const int tid = threadIdx.x;
     const long long n = (MODE == 2) ? A.kc.n : A.pa.n;
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(DT, 2) void wide_kernel(WideArgs A)
         if (r0 < NC) {                                                                            \
             raw_f32x4 v = (ST).y;                                                                 \
             v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f; \
-            *reinterpret_cast<raw_f32x4*>(Ys + (BUF) * (WNC * 32) + r0 * 32 + c8 * 4) = v;        \
+            *reinterpret_cast<raw_f32x4*>(Ys + (BUF) * (NCL * 32) + r0 * 32 + c8 * 4) = v;        \
         }                                                                                         \
     }
 
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(DT, 2) void wide_kernel(WideArgs A)
         const T* xr2 = reinterpret_cast<const T*>(Xs + (BUF) * (DT * WP) + (rl + DT / 2) * WP);   \
         /* the centre tile's address is uniform; left in SGPRs every fragment read needs its own  */ \
         /* v_mov (and the 128 addresses spill to VGPR lanes): one opaque VGPR base + immediates   */ \
-        unsigned yo = (BUF) * (WNC * 32) * 4 + hh * (HQ * 128);                                   \
+        unsigned yo = (BUF) * (NCL * 32) * 4 + hh * (HQ * 128);                                   \
         asm volatile("" : "+v"(yo));                                                              \
         const T* yr = reinterpret_cast<const T*>(reinterpret_cast<const char*>(Ys) + yo);         \
         /* flat over the 8 x HQ (row fragment, centre fragment) pairs of the chunk, fully unrolled, with the centre   */ \
@@ -1189,7 +1195,8 @@ static int row_vecw(const void* X, long long m, bool has_indices)
     return (a % sizeof(T) == 0) ? (int)sizeof(T) : 0;
 }
 
-constexpr size_t WIDE_LDS = (size_t)2 * DT * WP * 4 + (size_t)2 * WNC * 32 * 4 + (size_t)DT * 16;
+constexpr size_t wide_lds(int ncl) { return (size_t)2 * DT * WP * 4 + (size_t)2 * ncl * 32 * 4 + (size_t)DT * 16; }
+constexpr size_t WIDE_LDS = wide_lds(WNC);
 
 // wide-row streaming path applies: long rows, 16-byte aligned vectors, no row gather
 template <typename T>
@@ -1207,16 +1214,29 @@ static int wide_grid(long long n)
     return (int)std::min<long long>(ceil_div(n, DT), 2LL * num_cus());  // one resident round (2 workgroups / CU)
 }
 
+template <typename T, int MM, int MODE, int NCT>
+static void launch_wide_nc(int grid, const WideArgs& A)
+{
+    constexpr size_t lds = wide_lds(MODE == 2 ? WNC : NCT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel<T, MM, MODE, NCT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wide_kernel<T, MM, MODE, NCT>), dim3(grid), dim3(DT), lds, stream(), A);
+}
+
 template <typename T, int MM, int MODE>
 static void launch_wide(int grid, const WideArgs& A)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel<T, MM, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS);
-        attr_set = true;
+    // assign_nearest picks its centre-group size by shape (MSM_WIDE_NC=16 keeps the general one, for A/B runs)
+    static const bool fixed = getenv("MSM_WIDE_NC") && atoi(getenv("MSM_WIDE_NC")) == 16;
+    if (MODE == 0 && !fixed) {
+        if (A.pa.K <= 8) return launch_wide_nc<T, MM, 0, 8>(grid, A);
+        if (sizeof(T) == 8 && A.pa.K > 16) return launch_wide_nc<T, MM, 0, 32>(grid, A);
     }
-    hipLaunchKernelGGL((wide_kernel<T, MM, MODE>), dim3(grid), dim3(DT), WIDE_LDS, stream(), A);
+    launch_wide_nc<T, MM, MODE, WNC>(grid, A);
 }
 
 template <typename T, int MODE>
@@ -2671,7 +2691,9 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
     int rc = dS.reserve(bytes);
     if (rc) return rc;
     double* cand = dS.as<double>();
-    double* cands = cand + rec;
+    // without a communicator (a world of one: bench.py's strong-scaling model, single-process use) the "gathered" records
+    // ARE the shard's record: no copy per centre
+    double* cands = comm_active() ? cand + rec : cand;
     double* sums = cands + (size_t)world * rec;
     T* y = reinterpret_cast<T*>(sums + 1032);
     T* cen = y + m;

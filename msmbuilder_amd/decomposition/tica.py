@@ -74,6 +74,14 @@ def _park_handle(h, n_features, lag_time, mode, sym=""):
         _lib.lib().msm_tica_destroy(h)
 
 
+def release_parked_handles():
+    """Destroy the device handles parked for re-use (each keeps its accumulator slabs and, in the bf16 modes, its packed
+    image: tens of GB at configs[4]'s size).  Models in use are not affected."""
+    for free in _HANDLE_POOL.values():
+        while free:
+            _lib.lib().msm_tica_destroy(free.pop())
+
+
 def _mode_from_env():
     m = os.environ.get("MSMBUILDER_AMD_TICA_MODE", "f32").lower()
     modes = {"f32": _lib.TICA_F32, "f64": _lib.TICA_F64, "bf16": _lib.TICA_BF16, "bf16x2": _lib.TICA_BF16X2}

@@ -49,7 +49,10 @@ def test_golden_vectors(gpu, golden_dir, metric, dtype):
                                    # wide-row streaming path (16-byte aligned rows longer than one chunk)
                                    (777, 200, 44), (513, 17, 132), (2100, 8, 64), (300, 1, 36), (70000, 3, 40),
                                    # two rows per lane (more than 32 centres): several 512-row tiles, partial last chunk / group
-                                   (1500, 70, 132), (1030, 33, 48)])
+                                   (1500, 70, 132), (1030, 33, 48),
+                                   # centre groups sized to the shape: K <= 8 (8-centre groups), float64 with K > 16 (32-centre
+                                   # groups: one full group, a partial one, several)
+                                   (600, 5, 260), (520, 32, 48), (520, 31, 48), (900, 100, 256)])
 def test_bit_exact_vs_oracle(gpu, oracle, metric, dtype, n, k, f):
     from msmbuilder_amd import libdistance as ld
     rs = np.random.RandomState(n + k + f)
