@@ -380,6 +380,15 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
 int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
                 msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
                 msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
+/* The same for a ROW-SHARDED fit (one process per GPU, rows in consecutive blocks): the S batches are global and identical
+ * on every rank; a rank passes the rows of each batch that IT owns as local row numbers -- local_idx (host) back to back,
+ * offsets[S + 1] (host) delimiting the steps -- and the size B of the whole batch.  Per step: label + fp64 sums / counts /
+ * inertia of the local rows, ONE all-reduce of the packed [K m | K | 1] buffer over the library communicator (RCCL on the
+ * library stream, device to device), the identical update and convergence step on every rank (every rank stops at the same
+ * step: the criterion sees the all-reduced inertia).  One host synchronisation per run; outputs as msm_mbk_run. */
+int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const msm_idx_t* local_idx, const msm_idx_t* offsets,
+                        msm_idx_t S, msm_idx_t B, msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement,
+                        double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
 msm_idx_t msm_mbk_packed_size(msm_mbk_t* h);
 int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device);
 int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int on_device);

@@ -149,6 +149,8 @@ def _declare(lib):
     f("msm_mbk_step", C.c_int, _p, _p, _i64, _p, _i64, _f64p, _p, C.c_int, C.c_int)
     f("msm_mbk_run", C.c_int, _p, _p, _i64, _p, _i64, _i64, _i64, C.c_double, _i64, _p, C.POINTER(C.c_int64),
       C.POINTER(C.c_int), _p, _p)
+    f("msm_mbk_run_sharded", C.c_int, _p, _p, _i64, _p, _p, _i64, _i64, _i64, C.c_double, _i64, _p, C.POINTER(C.c_int64),
+      C.POINTER(C.c_int), _p, _p)
     f("msm_mbk_packed_size", _i64, _p)
     f("msm_mbk_export_packed", C.c_int, _p, _p, C.c_int)
     f("msm_mbk_apply_packed", C.c_int, _p, _p, _p, C.c_int)

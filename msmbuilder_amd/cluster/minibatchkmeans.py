@@ -324,8 +324,22 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         done, conv = C.c_int64(0), C.c_int(0)
         inertias = np.empty(S)
         mni = -1 if self.max_no_improvement is None else int(self.max_no_improvement)
-        check(L.msm_mbk_run(self._mbk, ax.vp, ax.shape[0], idx.ctypes.data, S, B, first_step, alpha, mni,
-                            st.ctypes.data, C.byref(done), C.byref(conv), inertias.ctypes.data, self._counts.ctypes.data))
+        from .. import parallel
+        if parallel.active():
+            # row-sharded: the same global batches on every rank; this rank's rows of each batch as local row numbers, one
+            # library all-reduce per step inside msm_mbk_run_sharded (no Python, no host synchronisation inside the run)
+            parallel.library_comm()
+            flat = idx.ravel()
+            mine = (flat >= shard.offset) & (flat < shard.offset + shard.n_local)
+            local = np.ascontiguousarray(flat[mine] - shard.offset, dtype=np.int64)
+            offs = np.zeros(S + 1, dtype=np.int64)
+            np.cumsum(mine.reshape(S, B).sum(axis=1), out=offs[1:])
+            check(L.msm_mbk_run_sharded(self._mbk, ax.vp, ax.shape[0], local.ctypes.data, offs.ctypes.data, S, B, first_step,
+                                        alpha, mni, st.ctypes.data, C.byref(done), C.byref(conv), inertias.ctypes.data,
+                                        self._counts.ctypes.data))
+        else:
+            check(L.msm_mbk_run(self._mbk, ax.vp, ax.shape[0], idx.ctypes.data, S, B, first_step, alpha, mni,
+                                st.ctypes.data, C.byref(done), C.byref(conv), inertias.ctypes.data, self._counts.ctypes.data))
         done = int(done.value)
         self._ewa_inertia = float(st[0]) if st[3] else None
         self._ewa_inertia_min = float(st[1]) if st[4] else None
@@ -425,14 +439,14 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         self._mbk_open(centers, self._counts)
         import os
         from .. import parallel
-        runs = (ax.on_device and not parallel.active() and not self.verbose and self._tol == 0.0
+        runs = (ax.on_device and not self.verbose and self._tol == 0.0
                 and os.environ.get("MSMBUILDER_AMD_MBK_RUNS", "1") != "0")
         try:
             while i + 1 < n_steps:
                 if runs and not (self._counts == 0).any():
                     done, converged = self._run(ax, shard, i + 1, n_steps, n_samples, random_state)
                     i += done
-                else:  # one step at a time: starved centres (the first steps), tol > 0, verbose, host data, multi-GPU
+                else:  # one step at a time: starved centres (the first steps), tol > 0, verbose, host data
                     i += 1
                     minibatch_indices = random_state.randint(0, n_samples, self._batch_size)
                     minibatch_indices = np.ascontiguousarray(minibatch_indices, dtype=np.int64)

@@ -616,10 +616,8 @@ struct WideStage {
 };
 
 // NCT = centres per register tile in MODE 0 / 1.  16 is the general choice (see WNC); 8 serves K <= 8 (a 16-centre group
-// spends half its arithmetic on padding there: 0.45 of the fp64-VALU bound at K = 8); 32 serves float64 rows with many
-// centres, whose 256-byte-per-chunk row tile was re-streamed from L2 / MALL once per 16-centre group (0.50 of the bound at
-// 2M x 256, K = 100) -- at 32 the LDS of a workgroup grows by 4 KiB and one workgroup fits a CU, which the 64 independent
-// accumulator chains of a lane make up for.
+// spends half its arithmetic on padding there: 4M x 512 float32, K = 8: 3.40 -> 2.11 ms, 0.43 -> 0.69 of the fp64-VALU
+// bound and at the HBM floor of its 8.2 GB).
 template <typename T, int M, int MODE, int NCT = WNC>
 __global__ __launch_bounds__(DT, (NCT > WNC ? 1 : 2)) void wide_kernel(WideArgs A)
 {
@@ -1234,7 +1232,8 @@ static void launch_wide(int grid, const WideArgs& A)
     static const bool fixed = getenv("MSM_WIDE_NC") && atoi(getenv("MSM_WIDE_NC")) == 16;
     if (MODE == 0 && !fixed) {
         if (A.pa.K <= 8) return launch_wide_nc<T, MM, 0, 8>(grid, A);
-        if (sizeof(T) == 8 && A.pa.K > 16) return launch_wide_nc<T, MM, 0, 32>(grid, A);
+        // (32-centre groups for float64 rows were measured too: 2M x 256 x K = 100 8.74 ms against 8.31 ms with 16 -- the
+        //  4 KiB of extra LDS cost the second workgroup of a CU and more than the halved re-streaming of the row tile gains)
     }
     launch_wide_nc<T, MM, MODE, WNC>(grid, A);
 }

@@ -1251,8 +1251,9 @@ __global__ __launch_bounds__(KNT) void mbk_finish_kernel(const double* __restric
 
 // centres (+counts) <- (centres * w + batch sums) / (w + n) from all-reduced fp64 sums (multi-GPU)
 __global__ void mbk_apply_kernel(float* __restrict__ centers, float* __restrict__ counts,
-                                 const double* __restrict__ packed, long long K, long long m)
+                                 const double* __restrict__ packed, long long K, long long m, const int* __restrict__ stop = nullptr)
 {
+    if (stop && *stop) return;   // a queued run that has converged: the remaining steps are no-ops on every rank
     const long long j = blockIdx.x;
     const double n = packed[K * m + j];
     if (n <= 0.0) return;
@@ -1262,6 +1263,14 @@ __global__ void mbk_apply_kernel(float* __restrict__ centers, float* __restrict_
         centers[j * m + f] = (float)(((double)centers[j * m + f] * (double)w_old + packed[j * m + f]) / (double)w_new);
     __syncthreads();
     if (threadIdx.x == 0) counts[j] = w_new;
+}
+
+// sharded run: the convergence bookkeeping of a step on the ALL-REDUCED batch inertia (cv.partial points at it, nb = 1)
+__global__ __launch_bounds__(KNT) void mbk_conv_kernel(MbkConv cv)
+{
+    __shared__ double red[KNT];
+    if (*cv.stop) return;
+    mbk_converge(cv, red);
 }
 
 __global__ void mbk_reassign_kernel(float* __restrict__ centers, float* __restrict__ counts,
@@ -1707,6 +1716,112 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
     const double* so = reinterpret_cast<const double*>(o);
     for (int i = 0; i < 5; ++i) state6[i] = so[i];
     state6[5] = so[5];
+    *steps_done = (msm_idx_t)so[5];
+    memcpy(inertias, so + 6, (size_t)(*steps_done) * sizeof(double));
+    *converged = *reinterpret_cast<const int*>(o + st_bytes);
+    if (counts_out) memcpy(counts_out, o + st_bytes + 8, (size_t)h->K * sizeof(float));
+    return MSM_OK;
+}
+
+/* msm_mbk_run for a ROW-SHARDED fit (one process per GPU): the S batches are GLOBAL (identical on every rank); this rank
+ * passes the rows of each batch that it owns as local row numbers -- local_idx (host) holds them back to back, offsets[S + 1]
+ * (host) delimits the steps -- and the batch size B of the whole batch.  Per step: label + fp64 sums / counts / inertia of
+ * the local rows, ONE all-reduce of the packed [K m sums | K counts | inertia] buffer over the library communicator (RCCL on
+ * the library stream), the identical update and convergence step on every rank.  Nothing returns to the host inside the
+ * run; every rank stops at the same step (the criterion sees the all-reduced inertia).  Outputs as msm_mbk_run. */
+int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const msm_idx_t* local_idx, const msm_idx_t* offsets,
+                        msm_idx_t S, msm_idx_t B, msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement,
+                        double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
+{
+    if (!h || !offsets || !state6 || !steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run_sharded: null argument");
+    if (n_local < 0 || B < 1 || S < 1 || S > 4096) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: bad shape");
+    const msm_idx_t total = offsets[S];
+    if (offsets[0] != 0 || total < 0 || (total > 0 && (!local_idx || !X))) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: bad offsets");
+    for (msm_idx_t s = 0; s < S; ++s)
+        if (offsets[s + 1] < offsets[s]) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: offsets must not decrease");
+    for (msm_idx_t b = 0; b < total; ++b)
+        if (local_idx[b] < 0 || local_idx[b] >= n_local) return fail(MSM_ERR_INVALID, "mbk: batch index out of range");
+    int rc;
+    const size_t idx_bytes = (size_t)std::max<msm_idx_t>(total, 1) * sizeof(msm_idx_t);
+    const size_t st_bytes = (6 + (size_t)S) * sizeof(double);
+    const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(float);
+    const size_t need = idx_bytes + 64 + out_bytes;
+    if (h->pinned_bytes < need) {
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        h->pinned = nullptr;
+        h->pinned_bytes = 0;
+        MSM_HIP_CHECK(hipHostMalloc((void**)&h->pinned, need, hipHostMallocDefault));
+        h->pinned_bytes = need;
+    }
+    if (!h->stop) MSM_HIP_CHECK(hipMalloc((void**)&h->stop, 2 * sizeof(int)));
+    if ((rc = h->idx.reserve(idx_bytes))) return rc;
+    if ((rc = h->runbuf.reserve(st_bytes))) return rc;
+    if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
+    if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
+    double* st = h->runbuf.as<double>();
+    if (total > 0) {
+        memcpy(h->pinned, local_idx, (size_t)total * sizeof(msm_idx_t));
+        MSM_HIP_CHECK(hipMemcpyAsync(h->idx.p, h->pinned, (size_t)total * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
+    }
+    double* st0 = reinterpret_cast<double*>(h->pinned + idx_bytes);
+    for (int i = 0; i < 5; ++i) st0[i] = state6[i];
+    st0[5] = 0.0;
+    MSM_HIP_CHECK(hipMemcpyAsync(st, st0, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, 2 * sizeof(int), stream()));
+    if (total > 0) {
+        if ((rc = h->xb.reserve((size_t)total * h->m * sizeof(float)))) return rc;
+        hipLaunchKernelGGL(mbk_gather_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
+                           (long long)total, (long long)h->m, h->xb.as<float>());
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    const size_t psz = (size_t)msm_mbk_packed_size(h);
+    double* d_inertia = h->packed + (size_t)h->K * h->m + h->K;
+    for (msm_idx_t s = 0; s < S; ++s) {
+        const msm_idx_t Bs = offsets[s + 1] - offsets[s];
+        MSM_HIP_CHECK(hipMemsetAsync(h->packed, 0, psz * sizeof(double), stream()));
+        if (Bs > 0) {
+            const float* Xs_ = h->xb.as<float>() + (size_t)offsets[s] * h->m;
+            int nb = 0;
+            if ((rc = mbk_label(h, Xs_, nullptr, Bs, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
+            KmArgs P;
+            memset(&P, 0, sizeof(P));
+            P.X = Xs_;
+            P.n = Bs;
+            P.m = h->m;
+            P.K = h->K;
+            P.labels = h->labels.as<int32_t>();
+            P.stop = h->stop;
+            mbk_launch_update(h, P, h->packed, h->packed + (size_t)h->K * h->m, 0, MbkConv{});
+            MSM_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(mbk_finish_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->counts, h->K,
+                               d_inertia, reinterpret_cast<float*>(h->outbuf + 8));
+            MSM_HIP_CHECK(hipGetLastError());
+        }
+        if ((rc = comm_allreduce_f64(h->packed, psz))) return rc;
+        hipLaunchKernelGGL(mbk_apply_kernel, dim3((unsigned)h->K), dim3(256), 0, stream(), h->centers, h->counts, h->packed, h->K,
+                           h->m, h->stop);
+        hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
+        MbkConv cv;
+        cv.partial = d_inertia;
+        cv.nb = 1;
+        cv.st = st;
+        cv.stop = h->stop;
+        cv.inertias = st + 6;
+        cv.done = reinterpret_cast<unsigned*>(h->stop + 1);
+        cv.step_index = (long long)(first_step + s);
+        cv.batch_size = (double)B;
+        cv.alpha = alpha;
+        cv.max_no_improvement = (long long)max_no_improvement;
+        hipLaunchKernelGGL(mbk_conv_kernel, dim3(1), dim3(KNT), 0, stream(), cv);
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    char* o = h->pinned + idx_bytes + 64;
+    MSM_HIP_CHECK(hipMemcpyAsync(o, st, st_bytes, hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes, h->stop, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes + 8, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    const double* so = reinterpret_cast<const double*>(o);
+    for (int i = 0; i < 6; ++i) state6[i] = so[i];
     *steps_done = (msm_idx_t)so[5];
     memcpy(inertias, so + 6, (size_t)(*steps_done) * sizeof(double));
     *converged = *reinterpret_cast<const int*>(o + st_bytes);

@@ -125,6 +125,23 @@ assert mb.n_steps_ == mref.n_steps_
 np.testing.assert_allclose(mb.cluster_centers_, mref.cluster_centers_, rtol=1e-5, atol=1e-6)
 np.testing.assert_allclose(mb.inertia_, mref.inertia_, rtol=1e-5)
 assert (mb.labels_[0] != mref.labels_[0][lo:hi]).mean() < 5e-3
+# device-resident shards: the queued runs (msm_mbk_run_sharded: one library all-reduce per step, no Python inside a run)
+# against the step-by-step sharded path and the single-process fit; enough steps for several runs and an early stop
+kw2 = dict(n_clusters=6, init=init, n_init=1, batch_size=200, max_iter=40, random_state=9, reassignment_ratio=0.01,
+           max_no_improvement=5)
+dblock = torch.from_numpy(blockf).cuda()
+mb_run = MiniBatchKMeans(**kw2).fit([dblock])
+os.environ["MSMBUILDER_AMD_MBK_RUNS"] = "0"
+mb_step = MiniBatchKMeans(**kw2).fit([dblock])
+os.environ["MSMBUILDER_AMD_MBK_RUNS"] = "1"
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "0"
+mref2 = MiniBatchKMeans(**kw2).fit([torch.from_numpy(Xf).cuda()])
+os.environ["MSMBUILDER_AMD_PARALLEL"] = "1"
+assert mb_run.n_steps_ == mb_step.n_steps_ == mref2.n_steps_, (mb_run.n_steps_, mb_step.n_steps_, mref2.n_steps_)
+assert mb_run.n_steps_ < (40 * len(Xf)) // 200                      # the criterion fired inside a queued run
+np.testing.assert_array_equal(mb_run.cluster_centers_, mb_step.cluster_centers_)     # same kernels, same reductions
+np.testing.assert_allclose(mb_run.cluster_centers_, mref2.cluster_centers_, rtol=1e-4, atol=1e-5)
+np.testing.assert_allclose(mb_run.inertia_, mref2.inertia_, rtol=1e-4)
 # random_state=None: rank 0's draw seeds every rank (ADVICE r1) -- the ranks must agree on every centre
 mn = MiniBatchKMeans(n_clusters=5, batch_size=150, max_iter=2, n_init=1, tol=1e-4).fit([blockf])
 spread = parallel.allreduce_array(mn.cluster_centers_.astype(np.float64).ravel(), op="max") + \
