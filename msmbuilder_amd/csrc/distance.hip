@@ -1471,8 +1471,9 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
 // ---------------------------------------------------------------------------
 struct KscArgs {
     const double* X;
-    void* xs;                     // screen copy of the rows: [n][2 NP] float32, or [n][NP] packed bfloat16 pairs
-    float* curf;                  // [n] distances_ rounded up to float32
+    void* xs;                     // screen copy of the rows: [n][2 NP + 1] float32, or [n][NP + 1] words: NP packed bfloat16 pairs and,
+                                  // last word, the row's distances_ rounded UP to float32 (`curf` in the text above): one stream
+    float* curf;                  // (unused: the rounded-up distance lives in the row)
     unsigned long long* gmax2;    // [0] bits of max ||x - c0||^2, [1] bits of max ||x||^2 (non-negative doubles order like their bits)
     double* c0;                   // [16] the first centre (the copy's origin)
     long long n, m;
@@ -1518,6 +1519,34 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     __shared__ long long ri[DT];
     const int tid = threadIdx.x;
     const int m = (int)P.m;
+
+    // The tile stream is software-pipelined: a tile's rows (screen copy + rounded-up distance, one stream) are loaded one
+    // tile ahead, the first one BEFORE the prologue -- its loads do not depend on the centre, and the prologue's reduction
+    // (a few microseconds at the head of every pass) then overlaps the first HBM round trip instead of preceding it.
+    constexpr int NW = BF16 ? NP : 2 * NP;  // 32-bit words of coordinates per row of the copy
+    constexpr int RW = NW + 1;              // + the row's rounded-up distance: ONE stream, 8-byte loads when RW is even
+    const long long ntile = (P.n + (long long)R * DT - 1) / ((long long)R * DT);
+    unsigned qn[R][RW];
+    auto load_tile = [&](long long t) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const long long p0 = t * (R * DT) + k * DT + tid;
+            const long long pc = p0 < P.n ? p0 : P.n - 1;
+            const unsigned* xr = static_cast<const unsigned*>(P.xs) + pc * RW;
+            if ((RW & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < RW / 2; ++j) {
+                    const uint2 v = reinterpret_cast<const uint2*>(xr)[j];
+                    qn[k][2 * j] = v.x;
+                    qn[k][2 * j + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RW; ++j) qn[k][j] = xr[j];
+            }
+        }
+    };
+    if ((long long)blockIdx.x < ntile) load_tile(blockIdx.x);
 
     // ---- prologue: centre of this pass = argmax of the previous pass's per-block candidates (P.it >= 1 here), or -- sharded
     // fit -- of the candidate records all-gathered from the ranks ----
@@ -1588,15 +1617,33 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         c0n2 = fma(c0f, c0f, c0n2);
         yn2 = fma(ys[f], ys[f], yn2);
     }
-    // eps of a row = u' ||x~|| + eps0: ||x~ - (x - c0)|| <= u/(1-u) ||x~|| per row (tighter than u max||x - c0||: fewer false
-    // candidates), eps0 = the float64 roundings of the two centrings + an absolute term for underflow
-    constexpr double UREL = (BF16 ? 0x1p-8 : 0x1p-24) * 1.02;  // unit roundoff 2^-p: p = 8 significand bits for bfloat16, 24 for float32
-    double eps0;
+    // eps of a row = u' ||x~|| + eps0 + e32 (||x~|| + ||yc||):
+    //   u' ||x~||  -- ||x~ - (x - c0)|| <= u/(1-u) ||x~|| per row (tighter than u max||x - c0||: fewer false candidates);
+    //   eps0       -- the float64 roundings of the two centrings + an absolute term for underflow;
+    //   e32 (...)  -- the screen's own arithmetic is FLOAT32 (round 3: the float64 version was 134 VALU instructions per
+    //                 row, 36 us of VALU time in a 60 us pass): with ycf = fl32(yc), t_j = fl32(x~_j - ycf_j), a = sum t_j^2
+    //                 by float32 fma and d~ = sqrtf(a),  |d~ - ||x~ - yc||| <= 2^-24 ||yc|| + 11.5 * 2^-24 ||x~ - ycf||
+    //                 < 2^-20 * 1.07 (||x~|| + ||yc||)   (2 NP <= 16 terms; subtraction, 17 accumulation steps, sqrt),
+    //                 and the float32 subtraction d~ - eps rounds by another 2^-24 d~: e32 = 2^-19 covers both twice over.
+    //                 Underflow (products, flushed denormals) only makes d~ SMALLER, i.e. more rows re-evaluated: safe.
+    //                 Overflow would make d~ = inf and pass every row: the screen is switched off (eps = NaN) unless
+    //                 max ||x - c0|| and ||yc|| are below 1e18 (squares below 1e36, sums of 16 of them below FLT_MAX).
+    constexpr float UREL = (float)((BF16 ? 0x1p-8 : 0x1p-24) * 1.02);  // unit roundoff 2^-p: p = 8 significand bits for bfloat16, 24 for float32
+    constexpr float E32 = 0x1p-19f;
+    float eps0f, ycnf, ycf[2 * NP];
     {
         const double g2 = __longlong_as_double((long long)P.gmax2[0]), r2 = __longlong_as_double((long long)P.gmax2[1]);
         // (the centre's own centring y - c0 rounds too; in a sharded fit y may be another rank's row, outside this shard's R)
-        eps0 = (sqrt(r2) + sqrt(yn2) + 2.0 * sqrt(c0n2)) * 0x1p-48 + 1e-37;
-        if (!(g2 < 1e76) || !(r2 < 1e76)) eps0 = NAN;  // rows beyond the float32 range (or non-finite): nothing passes the screen
+        double eps0 = (sqrt(r2) + sqrt(yn2) + 2.0 * sqrt(c0n2)) * 0x1p-48 + 1e-37;
+        double ycn2 = 0.0;
+#pragma unroll
+        for (int f = 0; f < 2 * NP; ++f) {
+            ycn2 = fma(yc[f], yc[f], ycn2);
+            ycf[f] = (float)yc[f];
+        }
+        if (!(g2 < 1e36) || !(r2 < 1e76) || !(ycn2 < 1e36)) eps0 = NAN;  // beyond the float32 screen's range (or non-finite): nothing passes
+        eps0f = (float)(eps0 * 1.000001);              // rounded to float32 with slack (inf if it does not fit: nothing passes)
+        ycnf = (float)(sqrt(ycn2) * 1.000001);
     }
 
     // this thread's argmax candidate: by curf; the float64 value is fetched on exact float32 ties and at the end
@@ -1604,7 +1651,6 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     long long bi = -1;
     double bx = 0.0;
     bool bknown = false;
-    const long long ntile = (P.n + (long long)R * DT - 1) / ((long long)R * DT);
     for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
         float cf[R];
         bool cand[R];
@@ -1612,30 +1658,19 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
 #pragma unroll
         for (int k = 0; k < R; ++k) pr[k] = t * (R * DT) + k * DT + tid;
         {
-            // screen: all loads of the tile first (unconditional, clamped rows), then the arithmetic
-            constexpr int NW = BF16 ? NP : 2 * NP;  // 32-bit words per row of the copy
-            unsigned q[R][NW];
+            // this tile's rows were loaded one tile ago; the next tile's loads go out before the arithmetic
+            unsigned q[R][RW];
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const long long pc = pr[k] < P.n ? pr[k] : P.n - 1;
-                const unsigned* xr = static_cast<const unsigned*>(P.xs) + pc * NW;
-                if ((NW & 1) == 0) {
 #pragma unroll
-                    for (int j = 0; j < NW / 2; ++j) {
-                        const uint2 v = reinterpret_cast<const uint2*>(xr)[j];
-                        q[k][2 * j] = v.x;
-                        q[k][2 * j + 1] = v.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) q[k][j] = xr[j];
-                }
-                cf[k] = P.curf[pc];
+                for (int j = 0; j < RW; ++j) q[k][j] = qn[k][j];
+                cf[k] = __uint_as_float(q[k][NW]);
             }
+            if (t + gridDim.x < ntile) load_tile(t + gridDim.x);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                double a = 0.0;
-                double n2 = 0.0;  // ||x~||^2
+                float a = 0.f;
+                float n2 = 0.f;  // ||x~||^2
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     float x0, x1;
@@ -1646,14 +1681,15 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
                         x0 = __uint_as_float(q[k][2 * j]);
                         x1 = __uint_as_float(q[k][2 * j + 1]);
                     }
-                    const double d0 = (double)x0 - yc[2 * j], d1 = (double)x1 - yc[2 * j + 1];
-                    a = fma(d0, d0, a);
-                    a = fma(d1, d1, a);
-                    n2 = fma((double)x0, (double)x0, n2);
-                    n2 = fma((double)x1, (double)x1, n2);
+                    const float d0 = x0 - ycf[2 * j], d1 = x1 - ycf[2 * j + 1];
+                    a = fmaf(d0, d0, a);
+                    a = fmaf(d1, d1, a);
+                    n2 = fmaf(x0, x0, n2);
+                    n2 = fmaf(x1, x1, n2);
                 }
-                const double eps = sqrt(n2) * UREL + eps0;
-                cand[k] = pr[k] < P.n && !(sqrt(a) - eps >= (double)cf[k]);
+                const float nrm = sqrtf(n2);
+                const float eps = fmaf(nrm, UREL, fmaf(E32, nrm + ycnf, eps0f));
+                cand[k] = pr[k] < P.n && !(sqrtf(a) - eps >= cf[k]);
             }
         }
         bool anyc = false;
@@ -1695,7 +1731,7 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
                         P.dist[pr[k]] = d;
                         P.labels[pr[k]] = P.it;
                         cf[k] = ksc_round_up(d);
-                        P.curf[pr[k]] = cf[k];
+                        static_cast<unsigned*>(P.xs)[pr[k] * ((BF16 ? NP : 2 * NP) + 1) + (BF16 ? NP : 2 * NP)] = __float_as_uint(cf[k]);
                     }
                 }
             }
@@ -1800,7 +1836,7 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
     double gloc = 0.0, rloc = 0.0;
     for (long long p = (long long)blockIdx.x * DT + tid; p < P.n; p += (long long)gridDim.x * DT) {
         const double* x = P.X + p * P.m;
-        unsigned* xo = static_cast<unsigned*>(P.xs) + p * NW;
+        unsigned* xo = static_cast<unsigned*>(P.xs) + p * (NW + 1);
         double n2 = 0.0, r2 = 0.0;
         float xc[2 * NP];
         double xv[2 * NP];
@@ -1836,7 +1872,7 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
         }
         if (gloc == gloc && (n2 > gloc || n2 != n2)) gloc = n2;  // a NaN sticks
         if (rloc == rloc && (r2 > rloc || r2 != r2)) rloc = r2;
-        P.curf[p] = ksc_round_up(P.dist[p]);
+        xo[NW] = __float_as_uint(ksc_round_up(P.dist[p]));   // the row's distance rounded up to float32, in the row
     }
     const unsigned long long gb = (gloc == gloc) ? (unsigned long long)__double_as_longlong(gloc) : 0x7ff8000000000000ull;
     const unsigned long long rb = (rloc == rloc) ? (unsigned long long)__double_as_longlong(rloc) : 0x7ff8000000000000ull;
@@ -2411,13 +2447,11 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
             g_kc_stats.plain_passes = it;
             g_kc_stats.screened_passes = K - it;
             g_kc_stats.screen_row_bytes = (long long)((bf16 ? np : 2 * np) * 4 + 4);   // the screen copy's row + curf
-            if ((rc = B.xf.reserve((size_t)n * (bf16 ? np : 2 * np) * sizeof(float)))) return rc;
-            if ((rc = B.curf.reserve((size_t)n * sizeof(float)))) return rc;
+            if ((rc = B.xf.reserve((size_t)n * ((bf16 ? np : 2 * np) + 1) * sizeof(float)))) return rc;
             KscArgs S;
             memset(&S, 0, sizeof(S));
             S.X = reinterpret_cast<const double*>(P.X);
             S.xs = B.xf.p;
-            S.curf = B.curf.as<float>();
             S.gmax2 = B.misc.as<unsigned long long>();
             S.c0 = reinterpret_cast<double*>(static_cast<char*>(B.misc.p) + 64);
             hipLaunchKernelGGL(ksc_origin_kernel, dim3(1), dim3(64), 0, stream(), S.X, P.ids, (long long)m, S.c0, (const double*)nullptr);
@@ -2743,12 +2777,10 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
         if (screen) {
             KscBufs& B = ksc_bufs();
             if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;
-            if ((rc = B.xf.reserve((size_t)n * (bf16 ? np : 2 * np) * sizeof(float)))) return rc;
-            if ((rc = B.curf.reserve((size_t)n * sizeof(float)))) return rc;
+            if ((rc = B.xf.reserve((size_t)n * ((bf16 ? np : 2 * np) + 1) * sizeof(float)))) return rc;
             MSM_HIP_CHECK(hipMemsetAsync(B.misc.p, 0, 64, stream()));
             S.X = reinterpret_cast<const double*>(X);
             S.xs = B.xf.p;
-            S.curf = B.curf.as<float>();
             S.gmax2 = B.misc.as<unsigned long long>();
             S.c0 = reinterpret_cast<double*>(static_cast<char*>(B.misc.p) + 64);
             S.n = n;

@@ -374,10 +374,13 @@ def _bf16_rne(x32):
 @pytest.mark.parametrize("m", [3, 10, 16])
 def test_kcenters_screen_margin_is_safe(scale, offset, m):
     """The screened k-centers passes (distance.hip, kcenters_screen_pass_kernel) leave a row alone when
-    ``d~ - eps >= curf`` with d~ evaluated on a bfloat16 copy of the row centred on c0 and
-    ``eps = 1.02 * 2^-8 * ||x~|| + 2^-48 (R + ||c0||) + 1e-37``.  Numpy emulation of exactly that arithmetic on adversarial
-    `distances_` values (the largest float32 the screen still accepts): the float64 distance the reference would compute
-    must then never be below it.  (With a margin of 2^-9 -- bfloat16 has 8 significand bits, not 9 -- this test fails.)"""
+    ``d~ - eps >= curf`` with d~ evaluated IN FLOAT32 on a bfloat16 copy of the row centred on c0 and
+    ``eps = 1.02 * 2^-8 ||x~|| + 2^-19 (||x~|| + ||yc||) + [2^-48 (R + ||y|| + 2 ||c0||) + 1e-37]``.  Numpy emulation of
+    exactly that arithmetic (float32 subtract / multiply / add / sqrt, each rounded -- two roundings per product-sum where
+    the kernel has one fma: the bound covers both) on adversarial `distances_` values (the largest float32 the screen still
+    accepts): the float64 distance the reference would compute must then never be below it.  (With a margin of 2^-9 --
+    bfloat16 has 8 significand bits, not 9 -- this test fails.)"""
+    f32 = np.float32
     rs = np.random.RandomState(m + int(abs(offset)) % 97)
     n = 200_000
     X = rs.randn(n, m) * scale + offset
@@ -385,26 +388,39 @@ def test_kcenters_screen_margin_is_safe(scale, offset, m):
     c0 = X[0].copy()
     Y = X[rs.randint(0, n, 64)]                                           # centres are data rows
     R = np.sqrt((X * X).sum(1).max())
+    G2 = ((X - c0) ** 2).sum(1).max()
     xc = (X - c0).astype(np.float32)
-    xt = _bf16_rne(xc).astype(np.float64)
-    nrm = np.sqrt((xt * xt).sum(1))
-    eps0 = (R + np.sqrt((c0 * c0).sum())) * 2.0 ** -48 + 1e-37
+    xt = _bf16_rne(xc)                                                    # float32 values with 8 significant bits
+    n2 = np.zeros(n, dtype=f32)
+    for f in range(m):
+        n2 = (n2 + xt[:, f] * xt[:, f]).astype(f32)
+    nrm = np.sqrt(n2).astype(f32)
     worst = np.inf
-    for y in Y:
-        yc = y - c0
-        dt = np.sqrt(((xt - yc) ** 2).sum(1))
-        eps = nrm * (2.0 ** -8 * 1.02) + eps0
-        # the reference's distance: float64, features in order, separately rounded multiply and add, sqrt
-        a = np.zeros(n)
-        for f in range(m):
-            d = X[:, f] - y[f]
-            a = a + d * d
-        dref = np.sqrt(a)
-        # adversarial distances_: the largest float32 <= d~ - eps (curf = distances_ rounded up to float32 would equal it)
-        lim = dt - eps
-        cur = lim.astype(np.float32)
-        cur = np.where(cur.astype(np.float64) > lim, np.nextafter(cur, np.float32(-np.inf)), cur).astype(np.float64)
-        ok = cur > 0
-        assert np.all(dref[ok] >= cur[ok]), (scale, offset, m)
-        worst = min(worst, float(np.min((dref[ok] - cur[ok]) / np.maximum(eps[ok], 1e-300))))
+    with np.errstate(over="ignore", invalid="ignore", under="ignore"):
+        for y in Y:
+            yc = y - c0
+            ycn2 = float((yc * yc).sum())
+            eps0 = (R + np.sqrt((y * y).sum()) + 2.0 * np.sqrt((c0 * c0).sum())) * 2.0 ** -48 + 1e-37
+            if not (G2 < 1e36 and ycn2 < 1e36):
+                continue                                                  # the kernel switches the screen off: nothing passes
+            eps0f = f32(eps0 * 1.000001)
+            ycnf = f32(np.sqrt(ycn2) * 1.000001)
+            ycf = yc.astype(f32)
+            a = np.zeros(n, dtype=f32)
+            for f in range(m):
+                t = (xt[:, f] - ycf[f]).astype(f32)
+                a = (a + (t * t).astype(f32)).astype(f32)
+            dt = np.sqrt(a).astype(f32)
+            eps = (nrm * f32(2.0 ** -8 * 1.02) + (f32(2.0 ** -19) * (nrm + ycnf)).astype(f32) + eps0f).astype(f32)
+            # the reference's distance: float64, features in order, separately rounded multiply and add, sqrt
+            ar = np.zeros(n)
+            for f in range(m):
+                d = X[:, f] - y[f]
+                ar = ar + d * d
+            dref = np.sqrt(ar)
+            # adversarial distances_: curf = the largest float32 the test `d~ - eps >= curf` (in float32) still accepts
+            cur = (dt - eps).astype(f32).astype(np.float64)
+            ok = cur > 0
+            assert np.all(dref[ok] >= cur[ok]), (scale, offset, m)
+            worst = min(worst, float(np.min((dref[ok] - cur[ok]) / np.maximum(eps[ok].astype(np.float64), 1e-300))))
     assert worst >= 0.0
