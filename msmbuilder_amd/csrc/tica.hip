@@ -1490,13 +1490,20 @@ struct ImgMfmaArgs {
 };
 
 constexpr int IMG_NT = 512;                       // 8 waves: 4 (rows) x 2 (columns), each 64 x 128 outputs
-constexpr size_t IMG_LDS = 2 * 2 * 4 * 256 * 16;  // 64 KiB: [2 buffers][A, B][4 packet rows][256 features] 16-byte packets
+constexpr int IMG_SLOTS = 3;                      // LDS ring: K-steps s (being multiplied), s + 1 (complete), s + 2 (being written)
+constexpr size_t IMG_LDS = (size_t)IMG_SLOTS * 2 * 4 * 256 * 16;  // 96 KiB: [3 slots][A, B][4 packet rows][256 features] 16-byte packets
 
+// Round 3: fragments PREFETCHED ACROSS THE BARRIER.  With two LDS buffers every K-step began, for all eight waves at once,
+// with its fragment reads behind the barrier (and the second k-half's reads behind the first half's MFMAs): the matrix
+// pipe idled for two LDS round trips per step (MFMA busy 0.43, 2,500 cycles per step against 1,024 of MFMA work).  With a
+// ring of three slots step s + 1 is complete in LDS while step s is multiplied, so a wave reads the FIRST fragment set of
+// step s + 1 during step s and starts its MFMAs right behind the barrier; the second set is read at the top of the step,
+// under those MFMAs.  The accumulation order per accumulator is unchanged (bit-identical sums).
 template <bool X2>
 __global__ __launch_bounds__(IMG_NT, 1) void tica_img_mfma_kernel(ImgMfmaArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16x8* L = reinterpret_cast<bf16x8*>(smem);   // [2][2][4][256]
+    bf16x8* L = reinterpret_cast<bf16x8*>(smem);   // [3][2][4][256]
     constexpr int PAN = 4 * 256;                   // packets per panel
     const int tid = threadIdx.x;
     const int p = xcd_linear_id();
@@ -1529,84 +1536,110 @@ __global__ __launch_bounds__(IMG_NT, 1) void tica_img_mfma_kernel(ImgMfmaArgs P)
     //   bf16x2: rows 0-1 = groups 2 s, 2 s + 1 of the hi image, rows 2-3 = the same groups of the mid image
     const int c0 = tid & 255, q0 = tid >> 8;  // q0 in {0, 1}: packet rows q0 and q0 + 2
     raw_f32x4 ra[2], rb[2], na[2], nb[2];
+    // (steps beyond the share are clamped to its last one: never out of the image, loaded and stored but not multiplied)
 #define MSM_IMG_LOAD(RA, RB, S_)                                                                   \
     {                                                                                              \
+        const long long sc_ = (S_) < s1 ? (S_) : s1 - 1;                                           \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                            \
             const int row = q0 + 2 * h;                                                            \
             const bf16x8* src = (X2 && row >= 2) ? mid : hi;                                       \
-            const long long g = X2 ? (S_) * 2 + (row & 1) : (S_) * 4 + row;                        \
+            const long long g = X2 ? sc_ * 2 + (row & 1) : sc_ * 4 + row;                          \
             const global_ptr<raw_f32x4> base = as_global<raw_f32x4>(src + (size_t)g * (size_t)P.Fp); \
             RA[h] = base[I * 256 + c0];                                                            \
             RB[h] = base[J * 256 + c0];                                                            \
         }                                                                                          \
     }
-#define MSM_IMG_STORE(RA, RB, BUF)                                                                 \
+#define MSM_IMG_STORE(RA, RB, SLOT)                                                                \
     {                                                                                              \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                            \
             const int row = q0 + 2 * h;                                                            \
-            *reinterpret_cast<raw_f32x4*>(L + (BUF) * 2 * PAN + row * 256 + c0) = RA[h];           \
-            *reinterpret_cast<raw_f32x4*>(L + (BUF) * 2 * PAN + PAN + row * 256 + c0) = RB[h];     \
+            *reinterpret_cast<raw_f32x4*>(L + (SLOT) * 2 * PAN + row * 256 + c0) = RA[h];          \
+            *reinterpret_cast<raw_f32x4*>(L + (SLOT) * 2 * PAN + PAN + row * 256 + c0) = RB[h];    \
         }                                                                                          \
     }
+    // fragment sets of a K-step in slot SLOT: set 0 is what the step's first MFMAs need (bf16: the k-half of pairs 0-15;
+    // bf16x2: the mid images), set 1 the rest (pairs 16-31; the hi images)
+#define MSM_IMG_FRAGS(FA, FB, SLOT, SET)                                                           \
+    {                                                                                              \
+        const bf16x8* Ah_ = L + (SLOT) * 2 * PAN;                                                  \
+        const bf16x8* Bh_ = Ah_ + PAN;                                                             \
+        const int kg_ = X2 ? ((SET) == 0 ? 2 + kl : kl) : 2 * (SET) + kl;                          \
+        _Pragma("unroll") for (int bi = 0; bi < 2; ++bi) FA[bi] = Ah_[kg_ * 256 + wr * 64 + bi * 32 + cl];   \
+        _Pragma("unroll") for (int bj = 0; bj < 4; ++bj) FB[bj] = Bh_[kg_ * 256 + wc * 128 + bj * 32 + cl];  \
+    }
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
     if (s1 > s0) {
         MSM_IMG_LOAD(ra, rb, s0)
         MSM_IMG_STORE(ra, rb, 0)
-        MSM_IMG_LOAD(ra, rb, (s0 + 1 < s1 ? s0 + 1 : s0))
+        MSM_IMG_LOAD(ra, rb, s0 + 1)
+        MSM_IMG_STORE(ra, rb, 1)
+        MSM_IMG_LOAD(ra, rb, s0 + 2)
     }
     __syncthreads();
+    if (s1 > s0) MSM_IMG_FRAGS(fa0, fb0, 0, 0)
     int steps_acc = 0;
+    int slot = 0;   // slot of step s; s + 1 -> slot + 1, s + 2 -> slot + 2 (mod 3)
     for (long long s = s0; s < s1; ++s) {
-        const int buf = (int)((s - s0) & 1);
-        {   // K-step s + 2 -> the other register set (clamped to the last step: never out of the image)
-            const long long sn = s + 2 < s1 ? s + 2 : s1 - 1;
-            MSM_IMG_LOAD(na, nb, sn)
-        }
-        const bf16x8* Ah = L + buf * 2 * PAN;
-        const bf16x8* Bh = Ah + PAN;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        MSM_IMG_LOAD(na, nb, s + 3)            // K-step s + 3 -> the other register set
+        MSM_IMG_FRAGS(fa1, fb1, slot, 1)       // this step's second fragment set: lands under the first set's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         if (!X2) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {      // two k-halves of 16 pairs
-                const int kg = 2 * q + kl;
-                bf16x8 a[2], b[4];
+            for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-                for (int bi = 0; bi < 2; ++bi) a[bi] = Ah[kg * 256 + wr * 64 + bi * 32 + cl];
+                for (int bj = 0; bj < 4; ++bj)
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 na0[2], nb0[4];
+            MSM_IMG_FRAGS(na0, nb0, slot1, 0)  // the NEXT step's first set (its slot has been complete since the last barrier)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int bj = 0; bj < 4; ++bj) b[bj] = Bh[kg * 256 + wc * 128 + bj * 32 + cl];
+            for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-                for (int bi = 0; bi < 2; ++bi)
+                for (int bj = 0; bj < 4; ++bj)
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
 #pragma unroll
-                    for (int bj = 0; bj < 4; ++bj)
-                        acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[bi], b[bj], acc[bi][bj], 0, 0, 0);
-            }
+            for (int bi = 0; bi < 2; ++bi) fa0[bi] = na0[bi];
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) fb0[bj] = nb0[bj];
         } else {
-            bf16x8 ah[2], am[2], bh[4], bm[4];
+            // set 0 = (am, bm), set 1 = (ah, bh); per accumulator the products come in the order mm, hm, mh, hh as before
 #pragma unroll
-            for (int bi = 0; bi < 2; ++bi) {
-                ah[bi] = Ah[kl * 256 + wr * 64 + bi * 32 + cl];
-                am[bi] = Ah[(2 + kl) * 256 + wr * 64 + bi * 32 + cl];
-            }
+            for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-            for (int bj = 0; bj < 4; ++bj) {
-                bh[bj] = Bh[kl * 256 + wc * 128 + bj * 32 + cl];
-                bm[bj] = Bh[(2 + kl) * 256 + wc * 128 + bj * 32 + cl];
-            }
+                for (int bj = 0; bj < 4; ++bj)
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
                 for (int bj = 0; bj < 4; ++bj) {
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[bi], bm[bj], acc[bi][bj], 0, 0, 0);
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[bi], bm[bj], acc[bi][bj], 0, 0, 0);
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[bi], bh[bj], acc[bi][bj], 0, 0, 0);
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[bi], bh[bj], acc[bi][bj], 0, 0, 0);
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 na0[2], nb0[4];
+            MSM_IMG_FRAGS(na0, nb0, slot1, 0)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj)
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) fa0[bi] = na0[bi];
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) fb0[bj] = nb0[bj];
         }
-        if (s + 1 < s1) MSM_IMG_STORE(ra, rb, buf ^ 1)
+        MSM_IMG_STORE(ra, rb, slot2)           // K-step s + 2 (loaded one step ago) -> the free slot
         __syncthreads();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             ra[h] = na[h];
             rb[h] = nb[h];
         }
+        slot = slot1;
         // fp64 merge into the private slabs of the four 128 x 128 sub-tiles (upper ones only)
         if (++steps_acc >= P.kflush_steps || s + 1 == s1) {
             steps_acc = 0;
@@ -1638,6 +1671,7 @@ __global__ __launch_bounds__(IMG_NT, 1) void tica_img_mfma_kernel(ImgMfmaArgs P)
     }
 #undef MSM_IMG_LOAD
 #undef MSM_IMG_STORE
+#undef MSM_IMG_FRAGS
 }
 
 // ---------------------------------------------------------------------------

@@ -47,5 +47,10 @@ solve) stats solve python $ROOT/scripts/solveprof.py
        timeout 200 python $ROOT/scripts/solvetime.py > $OUT/solvetime.txt 2>&1; grep -v amdgpu $OUT/solvetime.txt ;;
 kc)    pmc pmc_kc_valu "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" python $ROOT/scripts/kcperf.py
        pmc pmc_kc_wait "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD" python $ROOT/scripts/kcperf.py ;;
+bf16)  stats bf16 python $ROOT/scripts/bf16prof.py bf16
+       pmc pmc_bf16_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" python $ROOT/scripts/bf16prof.py bf16
+       pmc pmc_bf16_wait "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" python $ROOT/scripts/bf16prof.py bf16
+       pmc pmc_bf16_clk "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD" python $ROOT/scripts/bf16prof.py bf16
+       grep -A7 "img_mfma" $OUT/pmc_bf16_lds.txt $OUT/pmc_bf16_wait.txt $OUT/pmc_bf16_clk.txt ;;
 assign) timeout 200 python $ROOT/scripts/assignperf.py 2>&1 | grep assign_nearest > $OUT/assignperf.txt; cat $OUT/assignperf.txt ;;
 esac; done
