@@ -232,3 +232,27 @@ def test_library_rccl_world_of_one(gpu, tmp_path):
     script.write_text(_RCCL1.format(root=ROOT))
     p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "rccl world-of-one ok" in p.stdout, p.stdout[-3000:]
+
+
+def test_bench_self_launches_its_ranks(gpu):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command form) starts its own two
+    ranks under torch.distributed.run and prints ONE JSON line; on a one-GPU box the ranks share the device and the
+    library's collectives run on the host transport (`comm` = "host", `rccl_ranks` = 0), on a multi-GPU node over RCCL."""
+    import json
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames", "400000", "--no-extras", "--no-mbk", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["total_frames"] == 400000
+    assert out["config"]["frames_per_gpu"] == 200000
+    if torch.cuda.device_count() >= 2:
+        assert out["comm"] == "rccl" and out["rccl_ranks"] == 2
+    else:
+        assert out["comm"] == "host" and out["rccl_ranks"] == 0
+    assert out["value"] > 0 and set(out["phases_ms"]) >= {"fit", "allreduce", "solve", "transform", "kcenters_fit", "kcenters_predict"}
+    assert out["clustering"]["kcenters_plain_passes"] + out["clustering"]["kcenters_screened_passes"] == 200
