@@ -523,14 +523,23 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         KcPartial q;
         q.v = rv[0];
         q.i = ri[0];
-        P.next[blockIdx.x] = q;
+        if (P.cand_out) {
+            // sharded fit: the last block to arrive reads every block's partial -- published WRITE-THROUGH (agent-scope
+            // relaxed atomics = sc1 stores, drained before the arrival counter is bumped; the reader uses sc1 loads): no L2
+            // write-back / invalidate per block, which cost the 1,024 blocks of a pass more than the pass itself on a
+            // small shard (MI355X_MICROARCH.md, "valid forms": sc1 payload -> vmcnt(0) -> sc1 counter)
+            __hip_atomic_store(&P.next[blockIdx.x].v, q.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&P.next[blockIdx.x].i, q.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            P.next[blockIdx.x] = q;
+        }
     }
     if (P.cand_out) {
-        // fused candidate record: the last block to arrive reduces all partials (agent-scope release on the way in,
-        // acquire for the block that reads the others' partials)
+        // fused candidate record: the last block to arrive reduces all partials (published write-through above)
         __shared__ int am_last;
         if (tid == 0) {
-            const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             am_last = prev == gridDim.x - 1;
         }
         __syncthreads();
@@ -538,7 +547,9 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
             double cv = -1.0;
             long long ci = -1;
             for (int k = tid; k < (int)gridDim.x; k += DT) {
-                const KcPartial q = P.next[k];
+                KcPartial q;
+                q.v = __hip_atomic_load(&P.next[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.i = __hip_atomic_load(&P.next[k].i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (q.i >= 0 && (ci < 0 || kc_better(q.v, q.i, cv, ci))) {
                     cv = q.v;
                     ci = q.i;
@@ -1778,13 +1789,23 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         KcPartial q;
         q.v = rv[0];
         q.i = ri[0];
-        P.next[blockIdx.x] = q;
+        if (P.cand_out) {
+            // sharded fit: the last block to arrive reads every block's partial -- published WRITE-THROUGH (agent-scope
+            // relaxed atomics = sc1 stores, drained before the arrival counter is bumped; the reader uses sc1 loads): no L2
+            // write-back / invalidate per block, which cost the 1,024 blocks of a pass more than the pass itself on a
+            // small shard (MI355X_MICROARCH.md, "valid forms": sc1 payload -> vmcnt(0) -> sc1 counter)
+            __hip_atomic_store(&P.next[blockIdx.x].v, q.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&P.next[blockIdx.x].i, q.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            P.next[blockIdx.x] = q;
+        }
     }
     if (P.cand_out) {
         // sharded fit: the last block to arrive reduces all partials to the shard's candidate record (as in kcenters_pass_kernel)
         __shared__ int am_last;
         if (tid == 0) {
-            const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             am_last = prev == gridDim.x - 1;
         }
         __syncthreads();
@@ -1792,7 +1813,9 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
             double cv = -1.0;
             long long ci = -1;
             for (int k = tid; k < (int)gridDim.x; k += DT) {
-                const KcPartial q = P.next[k];
+                KcPartial q;
+                q.v = __hip_atomic_load(&P.next[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.i = __hip_atomic_load(&P.next[k].i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (q.i >= 0 && (ci < 0 || kc_better(q.v, q.i, cv, ci))) {
                     cv = q.v;
                     ci = q.i;

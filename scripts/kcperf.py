@@ -17,3 +17,15 @@ for name, Z in (("tICA projection", Y), ("white noise", torch.randn_like(Y))):
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     print("%s: KCenters(200).fit 10M x 10 f64: %.2f ms (MSM_KC_PRUNE=%s) inertia %.6e ids[:4] %s" % (
         name, 1e3 * min(ts[1:]), os.environ.get("MSM_KC_PRUNE", "1"), kc.inertia_, kc.cluster_ids_[:4]))
+# one rank's share of an 8-GPU run (1.25M rows): the single-process fit against the row-sharded library loop (a world of one)
+Z = Y[:1_250_000].contiguous()
+for name, env in (("single-process fit", None), ("sharded loop, world of one", "1")):
+    if env:
+        os.environ["MSMBUILDER_AMD_FORCE_SHARDED"] = env
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        kc = KCenters(n_clusters=200, random_state=0).fit([Z])
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    os.environ.pop("MSMBUILDER_AMD_FORCE_SHARDED", None)
+    print("1.25M x 10 f64, %s: KCenters(200).fit %.2f ms  ids[:4] %s" % (name, 1e3 * min(ts[1:]), kc.cluster_ids_[:4]))
