@@ -239,3 +239,35 @@ def test_config5_per_gpu_share_6250000_x_2048_bf16_stored(gpu, monkeypatch):
         np.testing.assert_allclose(m._sum_tau_to_T, st, rtol=1e-11)
         del m
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode,rtol", [("f32", 1e-5), ("f64", 1e-10)])
+def test_config3_tica_half_28_x_10000_x_171_vs_oracle(gpu, monkeypatch, mode, rtol):
+    """BASELINE configs[2] (Fs peptide: 28 trajectories, contact features) at its full size on the tICA side: 28 x 10,000
+    x 171 float32 (171 = the 21-residue contact count, NOT a multiple of 4: the C/G kernel's unaligned-row path),
+    tICA(n_components=10, lag_time=1 -- the constructor default the config uses) against the float64 ORACLE, then the
+    projection that feeds KCenters(k=200) (whose full-size half is tests/test_gpu_fullsize.py::test_config3_kcenters_280k_bit_exact)."""
+    rs = np.random.RandomState(171)
+    F, k = 171, 10
+    M = rs.randn(6, F) / np.sqrt(6)
+    a = np.exp(-1.0 / np.array([400.0, 150.0, 60.0, 25.0, 10.0, 4.0]))
+    offs = np.abs(rs.randn(F)) * 0.3 + 0.5                              # contact distances: positive, un-centred
+    seqs = []
+    for _ in range(28):
+        e = rs.randn(10_000, 6)
+        z = np.empty_like(e)
+        z[0] = e[0]
+        for t in range(1, len(e)):
+            z[t] = a * z[t - 1] + np.sqrt(1 - a * a) * e[t]
+        seqs.append((0.1 * (z @ M) + 0.05 * rs.randn(10_000, F) + offs).astype(np.float32))
+    m, o = _fit(seqs, mode, monkeypatch, n_components=k, lag_time=1)
+    assert (m.n_observations_, m.n_sequences_, m.n_features) == (280_000, 28, 171)
+    np.testing.assert_allclose(m.eigenvalues_, o.eigenvalues_, rtol=rtol)
+    np.testing.assert_allclose(m.means_, o.means_, rtol=1e-10)
+    np.testing.assert_allclose(m.covariance_, o.covariance_, rtol=0, atol=rtol * np.abs(o.covariance_).max())
+    np.testing.assert_allclose(m.offset_correlation_, o.offset_correlation_, rtol=0, atol=rtol * np.abs(o.offset_correlation_).max())
+    Y, Yo = m.transform(seqs[:3]), o.transform(seqs[:3])
+    for yh, yo in zip(Y, Yo):
+        sign = np.sign((yh * yo).sum(0))
+        scale = np.abs(yo).max(0)
+        assert yh.shape == (10_000, k) and np.all(np.abs(yh * sign - yo) <= (2e-3 if mode == "f32" else 1e-7) * scale)
