@@ -424,3 +424,55 @@ def test_kcenters_screen_margin_is_safe(scale, offset, m):
             assert np.all(dref[ok] >= cur[ok]), (scale, offset, m)
             worst = min(worst, float(np.min((dref[ok] - cur[ok]) / np.maximum(eps[ok].astype(np.float64), 1e-300))))
     assert worst >= 0.0
+
+
+def test_dir_npy_dataset_payload_reader(tmp_path):
+    """The container's host reads go through the native header parser (msm_npy_info) + memmap / fromfile; payloads the
+    parser does not describe (structured dtypes) fall back to numpy's reader; writes are atomic renames; keys iterate in
+    numeric order whatever order the files were created in; stray files are ignored."""
+    from msmbuilder_amd.dataset import dataset
+    rs = np.random.RandomState(3)
+    path = str(tmp_path / "d")
+    arrays = {7: rs.randn(5, 3), 0: rs.randint(0, 9, (4, 2)).astype(np.int32), 11: np.zeros((0, 3), np.float32),
+              3: np.asfortranarray(rs.randn(4, 5)), 2: np.array([True, False, True]),
+              5: np.array([(1, 2.0)], dtype=[("a", "<i4"), ("b", "<f8")]), 6: rs.randn(6).astype(np.float16)}
+    with dataset(path, mode="w") as ds:
+        for k, a in arrays.items():
+            ds[k] = a
+    open(os.path.join(path, "notes.txt"), "w").write("x")
+    open(os.path.join(path, "123.npy"), "w").write("x")                  # not an 8-digit name: not a trajectory
+    ro = dataset(path)
+    assert list(ro.keys()) == sorted(arrays) and len(ro) == len(arrays)
+    assert not [f for f in os.listdir(path) if f.endswith(".part")]     # no temporary files left behind
+    for k, v in ro.items():
+        a = arrays[k]
+        assert v.dtype == a.dtype and v.shape == a.shape and np.array_equal(v, a)
+        if a.dtype.names is None and a.size:
+            mm = ro.get(k, mmap=True)
+            assert isinstance(mm, np.memmap) and not mm.flags.writeable and np.array_equal(mm, a)
+            assert mm.flags.f_contiguous == a.flags.f_contiguous or a.ndim < 2
+    assert ro.get(11, mmap=True).shape == (0, 3)
+    with pytest.raises(IndexError):
+        ro.get(4)
+    # append mode adds to an existing store and keeps its provenance file
+    with dataset(path, mode="a") as ap:
+        ap[4] = np.ones((2, 2))
+    assert list(dataset(path).keys()) == sorted(list(arrays) + [4])
+    with pytest.raises(NotImplementedError):
+        dataset(path, fmt="hdf5")
+    with pytest.raises(ValueError):
+        dataset(path, mode="x")
+
+
+def test_bench_cpu_baseline_runs_on_the_host():
+    """bench.py's cpu_baseline leg (the oracle on the host cores, the reference's libdistance for the clustering legs when
+    oracle/_ref is present): structure of what it reports, on a tiny sample."""
+    import bench
+    rs = np.random.RandomState(0)
+    X = [(np.cumsum(rs.randn(1500, 32), 0) * 0.01 + rs.randn(1500, 32)).astype(np.float32) for _ in range(5)]
+    out, oracle_model, used = bench.cpu_baseline(X, 10, 4, 12, budget_s=0.5)
+    assert out["unit"] == "frames/s" and out["value"] > 0 and out["cores"] == os.cpu_count()
+    assert out["kind"] == "port" and set(out["kinds"]) == {"tica", "clustering"}
+    assert out["tica_fit_best_frames_per_s"] >= max(out["tica_fit_frames_per_s"], out["tica_fit_1thread_frames_per_s"]) * 0.999
+    assert out["threadpool_info"] and all(p["num_threads"] == 1 for p in out["threadpool_info_limited"] if p["user_api"] == "blas")
+    assert len(used) >= 1 and oracle_model.n_sequences_ == len(used)
