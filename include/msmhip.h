@@ -150,6 +150,11 @@ int msm_tica_lagged_symmetrised(msm_tica_t* h, int* flag);
 int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
 /* bf16 modes: duration (ms) of the packed-image pre-pass that preceded that MFMA launch (0 when there was none) */
 int msm_tica_last_prepass_ms(msm_tica_t* h, float* ms);
+/* 1 when the most recent accumulation launch had no column-sum pass over X of its own: the sum/difference kernel's
+ * staging lanes summed the left frames (float32 input, whole trajectories of >= 2 lag frames, n_features % 128 == 0, at
+ * least MSM_TICA_FOLD_MIN = 2^26 elements; MSM_TICA_FOLD=0 disables).  The sums (tica.py:418-419) and the finite check
+ * (utils/validation.py:68-74; a rejected launch is undone) are the same either way. */
+int msm_tica_last_folded(msm_tica_t* h, int* flag);
 /* profiling: {shader-clock start, end, 100 MHz wall-clock start, end} of workgroup 0 of that launch */
 int msm_tica_debug_clocks(msm_tica_t* h, long long* out4);
 /* profiling builds (csrc built with -DMSM_TICA_PROFILE) only: out64[8 + 8*slot + i] = shader cycles wave 0 of

@@ -62,6 +62,7 @@ struct TicaArgs {
     long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
     const float* shift; // [F] per-column reference row r (or nullptr): the fp32 / bf16 kernels accumulate (x - r), see "mean shift"
     int kflush;         // sum/difference kernel: frames accumulated in fp32 registers before the fp64 slab merge
+    double* colA;       // sum/difference kernel with folded column sums: [S][T][F] fp64 sums of the LEFT frames per cohort and serving tile
 };
 
 __device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
@@ -693,7 +694,14 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(flo
 #ifndef MSM_SYM_PRIO_ON2
 #define MSM_SYM_PRIO_ON2 99
 #endif
-template <bool PARTIAL>
+// FOLD: the staging lanes also sum the LEFT frames x_t of the valid pairs in fp64, so the separate column-sum pass over X
+// goes.  Every tile stages column block I (x side) and column block J (y side) of every frame, so a block is staged by T + 1
+// tile sides; the sums of a block are shared out: a tile serves ONE side (x when J - I is even, else y), the tiles serving
+// a block take its staged half-steps in turn (a counter every tile of a cohort advances alike), and eight registers per
+// thread hold the sums (two instructions per element, on 2 / T of the half-steps at most).  Each serving tile writes its
+// share to P.colA[cohort][rank].  A NaN or an infinity anywhere in those frames ends up in a sum, which is the finite check
+// of the pass this replaces.
+template <bool PARTIAL, bool FOLD>
 __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -750,6 +758,19 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
     // the kernel has no registers to spare) and is read, 16 bytes per thread, inside the MFMA stream one k-pair
     // before the packed subtractions that use it.  No shift = zeros (x - 0 is exact: bit-identical sums).
     float* rs = lds + 2 * 4 * PAN;
+    // FOLD: which side this tile serves, how many tiles serve that block, and this tile's turn among them
+    const int fside = (J - I) & 1, fblk = fside ? J : I;
+    const int fnx = (P.T - 1 - fblk) / 2 + 1, fn = fnx + (fblk + 1) / 2;
+    const int frank = fside ? fnx + (fblk - 1 - I) / 2 : (J - I) / 2;
+    int fphase = 0;
+    double cs0 = 0.0, cs1 = 0.0, cs2 = 0.0, cs3 = 0.0;
+#define MSM_SYM_COLADD(V)                                                                              \
+    {                                                                                                  \
+        cs0 += (double)(V).x;                                                                          \
+        cs1 += (double)(V).y;                                                                          \
+        cs2 += (double)(V).z;                                                                          \
+        cs3 += (double)(V).w;                                                                          \
+    }
     if (tid < 64) {
         const int col = (tid < 32 ? I0 : J0) + (tid & 31) * 4;
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -815,6 +836,12 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                 sc_[j] = (kr < cx.hi) ? 1.f : 0.f;                                                     \
             }                                                                                          \
             const f4v rx_ = *reinterpret_cast<const f4v*>(rs + scol), ry_ = *reinterpret_cast<const f4v*>(rs + TM + scol); \
+            if (FOLD && fphase == frank) {                                                             \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+                    if (sc_[j] != 0.f) {                                                               \
+                        if (fside) MSM_SYM_COLADD(ya[j]) else MSM_SYM_COLADD(xa[j])                    \
+                    }                                                                                  \
+            }                                                                                          \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
                 const float4 wa = PARTIAL ? make_float4(sc_[j] * ma.x, sc_[j] * ma.y, sc_[j] * ma.z, sc_[j] * ma.w) \
                                           : make_float4(sc_[j], sc_[j], sc_[j], sc_[j]);               \
@@ -843,6 +870,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     pu = npu; pd = npd; qu = nqu; qd = nqd;
         __syncthreads();  // every wave is done with both buffers (previous chunk)
         MSM_STAGE_EDGE(0, 0)
+        if (FOLD) fphase = fphase + 1 == fn ? 0 : fphase + 1;
         if (P.cosync && chunks_done > 0 && tid == 0) {  // cohort pacing (opt-in, see the C/G kernel): bounded wait
             const unsigned target = (unsigned)P.ntiles * (unsigned)chunks_done;
             const long long t0 = clock64();
@@ -889,11 +917,19 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     } else if (kk == 4) {
                         rsh = *reinterpret_cast<const f4v*>(rs + scol);  // r, I columns (waited on with the fragments)
                     } else if (kk == 5) {
+                        if (FOLD && fast && fside == 0 && fphase == frank) {  // uniform
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) MSM_SYM_COLADD(xa[j])
+                        }
 #pragma unroll
                         for (int j = 0; j < 2; ++j) MSM_SYM_UD(xa[j], xb[j], rsh, ma, PARTIAL)
                         rsh = *reinterpret_cast<const f4v*>(rs + TM + scol);  // r, J columns
                     } else if (kk == 6) {
                         MSM_STORE_X(b ^ 1)
+                        if (FOLD && fast && fside == 1 && fphase == frank) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) MSM_SYM_COLADD(ya[j])
+                        }
 #pragma unroll
                         for (int j = 0; j < 2; ++j) MSM_SYM_UD(ya[j], yb[j], rsh, mb, PARTIAL)
                     } else if (kk == 7) {
@@ -904,6 +940,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     MSM_SYM_MFMAS
                 }
                 if (more && !fast) MSM_STAGE_EDGE(k1, b ^ 1)
+                if (FOLD && more) fphase = fphase + 1 == fn ? 0 : fphase + 1;
                 PROF_MARK(2)
                 __syncthreads();  // buffer b ^ 1 is complete, buffer b is free
                 if (MSM_SYM_PRIO) __builtin_amdgcn_s_setprio(MSM_SYM_PRIO);  // first fragment reads + MFMAs of the new half-step first
@@ -951,6 +988,21 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
         }
     }
     PROF_MARK(4)
+    if (FOLD) {
+        __syncthreads();  // the panels are free
+        double* cs = reinterpret_cast<double*>(smem);   // [4 elements][NT threads]
+        cs[0 * NT + tid] = cs0;
+        cs[1 * NT + tid] = cs1;
+        cs[2 * NT + tid] = cs2;
+        cs[3 * NT + tid] = cs3;
+        __syncthreads();
+        if (tid < TM) {  // column tid of the block = element tid & 3 of the threads (srow, tid >> 2), srow = 0..7
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a += cs[(tid & 3) * NT + r * 32 + (tid >> 2)];
+            P.colA[((size_t)cohort * P.T + frank) * P.F + fblk * TM + tid] = a;
+        }
+    }
 #ifdef MSM_TICA_PROFILE
     if (P.dbg && tid == 0 && blockIdx.x < 5) {
         for (int i = 0; i < 6; ++i) P.dbg[8 + 8 * blockIdx.x + i] = pf_acc[i];
@@ -963,6 +1015,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 }
 #undef MSM_F2
 #undef MSM_SYM_UD
+#undef MSM_SYM_COLADD
 
 // packed C and G contributions of the symmetric kernel's slabs: G += (H + D) / 2 and "C" += (H - D) / 4
 // (a symmetric matrix whose symmetrisation (C + C^T) / 2 is the lagged moment's).  One thread per element of an UPPER tile
@@ -1781,6 +1834,67 @@ __global__ void tica_colmerge_kernel(double* __restrict__ dst, double* __restric
     }
 }
 
+// ---- folded column sums (sum/difference kernel, FOLD) ---------------------------------------------------------------
+// r for a handle's first launch when no column-sum pass runs ahead of the MFMA kernel: the mean of up to FOLD_NS frames
+// spread evenly over the launch's chunks (any r within a fraction of sigma of the mean serves: the shifted moments are
+// restored exactly whatever r is).  One block per 64 columns, four row lanes, fp64.
+constexpr int FOLD_NS = 4096, FOLD_NB = 32;   // samples, and the blocks (per 64 columns) that share them
+__global__ __launch_bounds__(256) void tica_fold_sample_kernel(TicaArgs P, double* __restrict__ part)
+{
+    __shared__ double red[256];
+    constexpr int PER = FOLD_NS / FOLD_NB / 4;   // samples per row lane
+    const int tid = threadIdx.x, col = blockIdx.x * 64 + (tid & 63), rl = tid >> 6;
+    double a = 0.0;
+    if (col < P.F)
+        for (int i0 = 0; i0 < PER; i0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = (blockIdx.y * 4 + rl) * PER + i0 + u;
+                const TicaChunk ch = get_chunk(P, ((long long)s * P.nchunks) / FOLD_NS);
+                const int row = (int)((((unsigned)s * 2654435761u) >> 8) % (unsigned)ch.n);
+                v[u] = as_global<float>(ch.base)[(ch.row0 + row) * P.ld + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)v[u];
+        }
+    red[tid] = a;
+    __syncthreads();
+    if (rl == 0 && col < P.F) part[(size_t)blockIdx.y * P.F + col] = a + red[tid + 64] + red[tid + 128] + red[tid + 192];
+}
+
+__global__ void tica_fold_setr_kernel(const double* __restrict__ part, float* __restrict__ r, int F)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= F) return;
+    double v[FOLD_NB], a = 0.0;
+#pragma unroll
+    for (int k = 0; k < FOLD_NB; ++k) v[k] = part[(size_t)k * F + col];
+#pragma unroll
+    for (int k = 0; k < FOLD_NB; ++k) a += v[k];
+    r[col] = (float)(a / (double)FOLD_NS);
+}
+
+// After the FOLD kernel: colA[c][i][:] = the share of cohort c's left-frame sums that serving tile i of a block took; tmp (the [NCB][2][F] temporary partials) holds what a
+// column-sum pass over the trajectories' first and last tau rows left there: [k][0] = a_k (rows [0, tau)), [k][1] = b_k
+// (rows [len - tau, len)).  s0 = sum A, stau = sum of the right frames = A - a + b, so slot k becomes
+// [A_k | A_k - a_k + b_k] (A_k = 0 beyond the S cohorts) -- the layout an ordinary column-sum pass leaves.  A non-finite
+// A_k raises the flag (the boundary pass checked its own rows element by element).
+__global__ void tica_fold_fix_kernel(double* __restrict__ tmp, const double* __restrict__ colA, int F, int S, int T, int* flag)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)NCB * F) return;
+    const int k = (int)(idx / F), col = (int)(idx - (size_t)k * F);
+    double A = 0.0;
+    if (k < S)
+        for (int i = 0; i < T; ++i) A += colA[((size_t)k * T + i) * F + col];   // the serving tiles' shares, in rank order
+    double* t = tmp + (size_t)k * 2 * F;
+    const double a = t[col], b = t[F + col];
+    t[col] = A;
+    t[F + col] = (A - a) + b;
+    if (!isfinite(A)) atomicOr(flag, 1);
+}
+
 // ---------------------------------------------------------------------------
 // Mean shift.  The covariance is G / 2N - mu mu^T (tica.py:228-259): an error of eps * |G| in an fp32-accumulated
 // G is a RELATIVE covariance error of eps * (mu / sigma)^2, i.e. 1e-3 for features whose mean is 100 standard
@@ -2256,6 +2370,10 @@ struct msm_tica {
     float* shift = nullptr;     // [F] reference row r of the mean shift (fp32 / bf16 kernels); valid once have_shift
     double* shsum = nullptr;    // [3F] raw column sums [A | B | W] of everything accumulated under the shift
     bool shift_on = true, have_shift = false;
+    double* fold = nullptr;     // folded column sums: [S_sym][T][F] per-cohort, per-serving-tile sums of the left frames | [FOLD_NB][F] sample partials
+    bool last_folded = false;   // the most recent launch took the folded path
+    bool slabs_dirty = false;   // slabs_sym hold something since the last reset (a rejected folded launch must be able to undo itself)
+    DevBuf snap;                // ... from this copy
     long long n_sh = 0, nw_sh = 0;  // shifted pairs, and the total weight of their Gram terms (2 n_sh for whole trajectories)
     long long n_obs = 0, n_seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
@@ -2299,6 +2417,7 @@ int tica_zero(msm_tica* h)
     MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, 2 * sizeof(int), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->shsum, 0, 3 * (size_t)h->F * sizeof(double), stream()));
     h->have_shift = false;
+    h->slabs_dirty = false;
     h->reduced = false;
     h->n_sh = h->nw_sh = 0;
     {
@@ -2435,52 +2554,119 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         P.nchunks = (long long)tab.size();
     }
 
-    // 1) column sums + finite check into the temporary partials
-    if (dtype_bytes == 4)
-        hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), P);
-    else if (dtype_bytes == 2)
-        hipLaunchKernelGGL(tica_colsum_kernel<__bf16>, dim3(NCB), dim3(NT), 0, stream(), P);
-    else
-        hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), P);
-    MSM_HIP_CHECK(hipGetLastError());
-    if (check_finite) {
-        int f[2] = {0, 0};
-        MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
-        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-        if (f[0]) {
-            MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
-            MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, sizeof(int), stream()));
-            return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
-        }
+    // Folded column sums (sum/difference kernel, whole trajectories of >= 2 lag frames, full tiles, launches big enough
+    // for a pass over X to matter): no column-sum pass over X ahead of the MFMA kernel -- the kernel's staging lanes sum the
+    // left frames, a column-sum pass over the first and last `lag` rows of every trajectory supplies what separates the
+    // right frames' sums from the left frames' (and checks those rows), and the finite check is made on the sums afterwards.
+    bool fold = false;
+    if (usesym && !useimg && !segs && h->fold && h->F % TM == 0) {
+        const char* fe = getenv("MSM_TICA_FOLD");       // read per launch (A/B switch for tests and scripts)
+        const char* fm = getenv("MSM_TICA_FOLD_MIN");   // elements (frames x features) from which a launch folds
+        const double fmin = fm ? atof(fm) : 67108864.0;
+        fold = !(fe && atoi(fe) == 0) && (double)total * h->F >= fmin;
+        for (msm_idx_t s = 0; s < n_seq && fold; ++s)
+            if (n_rows[s] > h->lag && n_rows[s] < 2 * (long long)h->lag) fold = false;
     }
-    // 1b) mean shift bookkeeping (fp32 / bf16 kernels): the raw column sums of what this launch accumulates under the
-    //     shift, and -- first shifted launch of the handle -- the reference row r = this launch's column means
     const bool shifted = h->shift_on && (use32 || useb || useimg);
-    long long n_call = 0, nw_call = 0, nmean = 0;
-    if (shifted) {
-        for (msm_idx_t s = 0; s < n_seq; ++s) {
-            const SegInfo g = seg_of(s);
-            if (g.len <= h->lag || g.oe <= g.ob) continue;
-            const long long n0 = std::max<long long>(0, std::min<long long>(g.oe, g.len - h->lag) - g.ob);
-            const long long nt = std::max<long long>(0, g.oe - std::max<long long>(g.ob, h->lag));
-            n_call += n0;
-            nmean += n0 + nt;
-            nw_call += (segs && !usesym) ? n0 + nt : 2 * n0;
+    // 1b) mean shift bookkeeping (fp32 / bf16 kernels): the raw column sums of what this launch accumulates under the
+    //     shift, and -- first shifted launch of the handle, `set_r` -- the reference row r = this launch's column means
+    auto shift_and_merge = [&](int set_r) -> int {
+        if (shifted) {
+            long long n_call = 0, nw_call = 0, nmean = 0;
+            for (msm_idx_t s = 0; s < n_seq; ++s) {
+                const SegInfo g = seg_of(s);
+                if (g.len <= h->lag || g.oe <= g.ob) continue;
+                const long long n0 = std::max<long long>(0, std::min<long long>(g.oe, g.len - h->lag) - g.ob);
+                const long long nt = std::max<long long>(0, g.oe - std::max<long long>(g.ob, h->lag));
+                n_call += n0;
+                nmean += n0 + nt;
+                nw_call += (segs && !usesym) ? n0 + nt : 2 * n0;
+            }
+            const int what = !segs ? (SH_A_a | SH_B_b | SH_W_ab) : usesym ? (SH_A_a | SH_W_a) : (SH_A_a | SH_W_ab);
+            hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(256), 0, stream(), h->coltmp,
+                               h->shsum, h->shift, h->F, 1.0 / (double)std::max<long long>(1, nmean), set_r, what);
+            MSM_HIP_CHECK(hipGetLastError());
+            h->have_shift = true;
+            h->n_sh += n_call;
+            h->nw_sh += nw_call;
         }
-        const int what = !segs ? (SH_A_a | SH_B_b | SH_W_ab) : usesym ? (SH_A_a | SH_W_a) : (SH_A_a | SH_W_ab);
-        hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(256), 0, stream(), h->coltmp,
-                           h->shsum, h->shift, h->F, 1.0 / (double)std::max<long long>(1, nmean), h->have_shift ? 0 : 1, what);
-        MSM_HIP_CHECK(hipGetLastError());
-        h->have_shift = true;
-        h->n_sh += n_call;
-        h->nw_sh += nw_call;
-        P.shift = h->shift;
-    }
-    {
         const size_t n = (size_t)NCB * 2 * h->F;
         hipLaunchKernelGGL(tica_colmerge_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
                            h->colpart, h->coltmp, n);
         MSM_HIP_CHECK(hipGetLastError());
+        return MSM_OK;
+    };
+    bool snapshot = false;
+    const size_t slab_bytes = usesym && h->slabs_sym ? (size_t)h->S_sym * h->ntiles_sym * 2 * TM * TM * sizeof(double) : 0;
+    if (!fold) {
+        // 1) column sums + finite check into the temporary partials
+        if (dtype_bytes == 4)
+            hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), P);
+        else if (dtype_bytes == 2)
+            hipLaunchKernelGGL(tica_colsum_kernel<__bf16>, dim3(NCB), dim3(NT), 0, stream(), P);
+        else
+            hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), P);
+        MSM_HIP_CHECK(hipGetLastError());
+        if (check_finite) {
+            int f[2] = {0, 0};
+            MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
+            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+            if (f[0]) {
+                MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
+                MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, sizeof(int), stream()));
+                return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
+            }
+        }
+        if (shifted) P.shift = h->shift;
+        int rc = shift_and_merge(h->have_shift ? 0 : 1);
+        if (rc) return rc;
+    } else {
+        // 1') the boundary rows: [0, lag) count as left frames only (chunk length "infinite"), [len - lag, len) as right
+        //     frames only, so the temporary partials receive a = sum of the first rows | b = sum of the last rows
+        std::vector<TicaChunk> tab;
+        for (msm_idx_t s = 0; s < n_seq; ++s) {
+            const long long len = n_rows[s];
+            if (len <= h->lag) continue;
+            for (int side = 0; side < 2; ++side) {
+                const long long b0 = side ? len - h->lag : 0, b1 = b0 + h->lag;
+                for (long long r0 = b0; r0 < b1; r0 += kc) {
+                    TicaChunk ch;
+                    ch.base = ptrs[s];
+                    ch.row0 = r0;
+                    ch.len = side ? len : (long long)1 << 60;
+                    ch.n = (int)std::min<long long>(kc, b1 - r0);
+                    ch.pad = 0;
+                    ch.last = len - 1;
+                    ch.g0 = 0;
+                    tab.push_back(ch);
+                }
+            }
+        }
+        int rc = h->table2.reserve(tab.size() * sizeof(TicaChunk));
+        if (rc) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->table2.p, tab.data(), tab.size() * sizeof(TicaChunk), hipMemcpyHostToDevice, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        TicaArgs Q = P;
+        Q.chunks = h->table2.as<TicaChunk>();
+        Q.nchunks = (long long)tab.size();
+        hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), Q);
+        MSM_HIP_CHECK(hipGetLastError());
+        if (shifted) {
+            if (!h->have_shift) {
+                double* sp = h->fold + (size_t)h->S_sym * h->T * h->F;
+                hipLaunchKernelGGL(tica_fold_sample_kernel, dim3((unsigned)ceil_div(h->F, 64), FOLD_NB), dim3(256), 0, stream(), P, sp);
+                hipLaunchKernelGGL(tica_fold_setr_kernel, dim3((unsigned)ceil_div(h->F, 256)), dim3(256), 0, stream(), sp, h->shift, h->F);
+                MSM_HIP_CHECK(hipGetLastError());
+            }
+            P.shift = h->shift;
+        }
+        P.colA = h->fold;
+        MSM_HIP_CHECK(hipMemsetAsync(h->fold, 0, (size_t)h->S_sym * h->T * h->F * sizeof(double), stream()));
+        if (check_finite && h->slabs_dirty) {   // a rejected launch leaves the state untouched (utils/validation.py:68-74 raises
+            if ((rc = h->snap.reserve(slab_bytes))) return rc;   // before tica.py:401 accumulates anything)
+            MSM_HIP_CHECK(hipMemcpyAsync(h->snap.p, h->slabs_sym, slab_bytes, hipMemcpyDeviceToDevice, stream()));
+            snapshot = true;
+        }
     }
     if (shifted && segs) {
         // a trajectory split over ranks: the RIGHT frames of the owned pairs, rows [own_begin + lag, min(own_end, len - lag)
@@ -2585,10 +2771,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
         }
     } else if (usesym) {
-        if (h->F % TM == 0)
-            hipLaunchKernelGGL((tica_sym_f32_kernel<false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+        if (fold)
+            hipLaunchKernelGGL((tica_sym_f32_kernel<false, true>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+        else if (h->F % TM == 0)
+            hipLaunchKernelGGL((tica_sym_f32_kernel<false, false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
         else
-            hipLaunchKernelGGL((tica_sym_f32_kernel<true>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+            hipLaunchKernelGGL((tica_sym_f32_kernel<true, false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
     } else if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
         if (aligned && h->F % TM == 0)
             hipLaunchKernelGGL((tica_mfma_f32_kernel<true, false>), dim3(G), dim3(NT), LDS32, stream(), P);
@@ -2617,6 +2805,31 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipEventRecord(h->ev1, stream()));
         h->timed = true;
     }
+    if (fold) {
+        // 3') temporary partials -> [left sums | right sums] per slot, finite check of the folded sums
+        hipLaunchKernelGGL(tica_fold_fix_kernel, dim3((unsigned)ceil_div((size_t)NCB * h->F, 256)), dim3(256), 0, stream(),
+                           h->coltmp, h->fold, h->F, h->S_sym, h->T, h->flag);
+        MSM_HIP_CHECK(hipGetLastError());
+        if (check_finite) {
+            int f[2] = {0, 0};
+            MSM_HIP_CHECK(hipMemcpyAsync(f, h->flag, sizeof(f), hipMemcpyDeviceToHost, stream()));
+            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+            if (f[0]) {   // undo the launch: the slabs as they were, nothing of it in the column sums or the shift
+                if (snapshot)
+                    MSM_HIP_CHECK(hipMemcpyAsync(h->slabs_sym, h->snap.p, slab_bytes, hipMemcpyDeviceToDevice, stream()));
+                else
+                    MSM_HIP_CHECK(hipMemsetAsync(h->slabs_sym, 0, slab_bytes, stream()));
+                MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
+                MSM_HIP_CHECK(hipMemsetAsync(h->flag, 0, sizeof(int), stream()));
+                MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
+            }
+        }
+        int rc = shift_and_merge(0);
+        if (rc) return rc;
+    }
+    if (usesym) h->slabs_dirty = true;
+    h->last_folded = fold;
     for (msm_idx_t s = 0; s < n_seq; ++s) {
         const SegInfo g = seg_of(s);
         if (g.len > h->lag && g.oe > g.ob) {
@@ -2727,14 +2940,17 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
         const char* tmax_env = getenv("MSM_TICA_SYM_TMAX");
         const int tmax = tmax_env ? atoi(tmax_env) : 64;  // and one resident cohort must fit (checked below)
         if (mode == MSM_TICA_F32 && !sym_off && h->T >= 2 && h->T <= tmax && n_features % 4 == 0) {
-            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false>),
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
-            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<true>),
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<true, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
-            int sa = 0, sb = 0;
-            if ((rc = query_slots(tica_sym_f32_kernel<false>, LDSSYM, &sa))) { delete h; return rc; }
-            if ((rc = query_slots(tica_sym_f32_kernel<true>, LDSSYM, &sb))) { delete h; return rc; }
-            h->S_sym = std::min(sa, sb) / h->ntiles_sym;
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
+            int sa = 0, sb = 0, sc = 0;
+            if ((rc = query_slots(tica_sym_f32_kernel<false, false>, LDSSYM, &sa))) { delete h; return rc; }
+            if ((rc = query_slots(tica_sym_f32_kernel<true, false>, LDSSYM, &sb))) { delete h; return rc; }
+            if ((rc = query_slots(tica_sym_f32_kernel<false, true>, LDSSYM, &sc))) { delete h; return rc; }
+            h->S_sym = std::min(std::min(sa, sb), sc) / h->ntiles_sym;
             h->sym = h->S_sym >= 1;  // at least one whole cohort resident (F <= 3968 on 256 CUs), else the C/G kernel
         }
     }
@@ -2770,6 +2986,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->cosync, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void**)&h->shift, (size_t)h->F * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->shsum, 3 * (size_t)h->F * sizeof(double));
+    if (e == hipSuccess && h->sym) e = hipMalloc((void**)&h->fold, (size_t)(h->S_sym * h->T + FOLD_NB) * h->F * sizeof(double));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreate(&h->evp);
@@ -2801,6 +3018,7 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->cosync) (void)hipFree(h->cosync);
     if (h->shift) (void)hipFree(h->shift);
     if (h->shsum) (void)hipFree(h->shsum);
+    if (h->fold) (void)hipFree(h->fold);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->evp) (void)hipEventDestroy(h->evp);
@@ -2939,6 +3157,13 @@ int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms)
     if (!h->timed) return fail(MSM_ERR_STATE, "no accumulation launch recorded yet");
     MSM_HIP_CHECK(hipEventSynchronize(h->ev1));
     MSM_HIP_CHECK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MSM_OK;
+}
+
+int msm_tica_last_folded(msm_tica_t* h, int* flag)
+{
+    if (!h || !flag) return fail(MSM_ERR_STATE, "null argument");
+    *flag = h->last_folded ? 1 : 0;
     return MSM_OK;
 }
 
