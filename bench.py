@@ -354,6 +354,9 @@ def main():
             if record is not None:
                 record.setdefault("mfma_ms", []).append(kernel_ms_of(tica, _lib))
                 record["sym"] = tica._lagged_symmetrised
+                fl = C.c_int(0)
+                _lib.check(_lib.lib().msm_tica_last_folded(tica._handle, C.byref(fl)))
+                record["folded"] = bool(fl.value)
             t = mark("fit", t)
             if world > 1:
                 tica.allreduce()
@@ -413,6 +416,7 @@ def main():
         el_w, _r = timed(rec_w, seqsw, Xw, 1, 2)
         del _r
         rec_w.pop("sym", None)
+        rec_w.pop("folded", None)
         weak = {"frames_per_gpu": n_seq_total * T, "ms_per_step": 1e3 * el_w / 2,
                 "value": world * n_seq_total * T / (el_w / 2), "unit": "frames/s",
                 "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in rec_w.items() if k != "mfma_ms"}}
@@ -425,6 +429,7 @@ def main():
         value = total_frames / (elapsed / args.steps)
         mfma_ms = float(np.mean(times["mfma_ms"]))
         sym = bool(times.pop("sym", False))
+        folded = bool(times.pop("folded", False))
         alg_flop = 4.0 * F * F                      # two dense F x F rank-1 updates per frame
         exe_flop, tiles = executed_flop_per_frame(F, sym)
         kernel = "tica_sym_f32_kernel" if sym else "tica_mfma_%s_kernel" % args.mode
@@ -470,8 +475,12 @@ def main():
                          "traffic_note": "bytes/launch at the L2 fabric side (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes); "
                                          "includes Infinity-Cache hits; algorithmic bytes/launch = %d" % (frames * F * 4),
                          "kernel_ms": mfma_ms, "frames_per_launch": frames,
+                         "column_sums_folded": folded,
+                         "column_sums_note": "true: the kernel's staging lanes also sum the left frames in fp64 (msm_tica_last_folded) and "
+                                             "no column-sum pass reads X ahead of it; MSM_TICA_FOLD=0 restores that pass (kernel 49.2 ms + pass 3.6 ms "
+                                             "against 51.1 ms at 10M x 512)",
                          "tica_accumulate_frames_per_s": frames / (mfma_ms * 1e-3)},
-            "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k not in ("mfma_ms", "sym")},
+            "phases_ms": {k: 1e3 * float(np.mean(v)) for k, v in times.items() if k not in ("mfma_ms", "sym", "folded")},
             "top_eigenvalues": [float(x) for x in ev[:3]],
         }
         if weak is not None:
@@ -591,6 +600,7 @@ def main():
                 step(rec8, seqs8, X8)
             os.environ.pop("MSMBUILDER_AMD_FORCE_SHARDED", None)
             rec8.pop("sym", None)
+            rec8.pop("folded", None)
             ph8 = {k: 1e3 * float(np.mean(v)) for k, v in rec8.items() if k != "mfma_ms"}
             step8 = sum(ph8.values())
             comm_us = {"allreduce_4MB": 150.0, "allgather_per_centre": 25.0}   # assumed RCCL latencies over xGMI (not measured here)

@@ -62,7 +62,8 @@ struct TicaArgs {
     long long* dbg;   // profiling only: [shader clock start, end, 100 MHz wall start, end] of workgroup 0
     const float* shift; // [F] per-column reference row r (or nullptr): the fp32 / bf16 kernels accumulate (x - r), see "mean shift"
     int kflush;         // sum/difference kernel: frames accumulated in fp32 registers before the fp64 slab merge
-    double* colA;       // sum/difference kernel with folded column sums: [S][T][F] fp64 sums of the LEFT frames per cohort and serving tile
+    const float* zrow;  // [F] zeros: where the dummy loads of a non-staging half-step read when the column sums are folded
+    double* colA;       // sum/difference kernel with folded column sums: [S][F] fp64 sums of the LEFT frames, one row per cohort
 };
 
 __device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
@@ -695,12 +696,12 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(flo
 #define MSM_SYM_PRIO_ON2 99
 #endif
 // FOLD: the staging lanes also sum the LEFT frames x_t of the valid pairs in fp64, so the separate column-sum pass over X
-// goes.  Every tile stages column block I (x side) and column block J (y side) of every frame, so a block is staged by T + 1
-// tile sides; the sums of a block are shared out: a tile serves ONE side (x when J - I is even, else y), the tiles serving
-// a block take its staged half-steps in turn (a counter every tile of a cohort advances alike), and eight registers per
-// thread hold the sums (two instructions per element, on 2 / T of the half-steps at most).  Each serving tile writes its
-// share to P.colA[cohort][rank].  A NaN or an infinity anywhere in those frames ends up in a sum, which is the finite check
-// of the pass this replaces.
+// goes: eight registers per thread hold the sums of the thread's four x-side columns (two instructions per element: widen,
+// add), every tile adds every half-step it stages, and the diagonal tile (I, I) of a cohort writes the cohort's sums of
+// column block I to P.colA.  NO branch in the MFMA stream decides anything (a version that shared the sums out over the
+// tiles of a block, taking turns, saved the adds and lost 2 ms to the branches): the half-steps whose in-stream loads are
+// dummies (their frames are staged by the edge sequence instead) read a row of zeros.  A NaN or an infinity anywhere in the
+// left frames ends up in a sum, which is the finite check of the pass this replaces.
 template <bool PARTIAL, bool FOLD>
 __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 {
@@ -758,12 +759,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
     // the kernel has no registers to spare) and is read, 16 bytes per thread, inside the MFMA stream one k-pair
     // before the packed subtractions that use it.  No shift = zeros (x - 0 is exact: bit-identical sums).
     float* rs = lds + 2 * 4 * PAN;
-    // FOLD: which side this tile serves, how many tiles serve that block, and this tile's turn among them
-    const int fside = (J - I) & 1, fblk = fside ? J : I;
-    const int fnx = (P.T - 1 - fblk) / 2 + 1, fn = fnx + (fblk + 1) / 2;
-    const int frank = fside ? fnx + (fblk - 1 - I) / 2 : (J - I) / 2;
-    int fphase = 0;
-    double cs0 = 0.0, cs1 = 0.0, cs2 = 0.0, cs3 = 0.0;
+    double cs0 = 0.0, cs1 = 0.0, cs2 = 0.0, cs3 = 0.0;   // FOLD: fp64 sums of this thread's four x-side columns
 #define MSM_SYM_COLADD(V)                                                                              \
     {                                                                                                  \
         cs0 += (double)(V).x;                                                                          \
@@ -836,11 +832,9 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                 sc_[j] = (kr < cx.hi) ? 1.f : 0.f;                                                     \
             }                                                                                          \
             const f4v rx_ = *reinterpret_cast<const f4v*>(rs + scol), ry_ = *reinterpret_cast<const f4v*>(rs + TM + scol); \
-            if (FOLD && fphase == frank) {                                                             \
+            if (FOLD) {                                                                                \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
-                    if (sc_[j] != 0.f) {                                                               \
-                        if (fside) MSM_SYM_COLADD(ya[j]) else MSM_SYM_COLADD(xa[j])                    \
-                    }                                                                                  \
+                    if (sc_[j] != 0.f) MSM_SYM_COLADD(xa[j])                                           \
             }                                                                                          \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
                 const float4 wa = PARTIAL ? make_float4(sc_[j] * ma.x, sc_[j] * ma.y, sc_[j] * ma.z, sc_[j] * ma.w) \
@@ -870,7 +864,6 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     pu = npu; pd = npd; qu = nqu; qd = nqd;
         __syncthreads();  // every wave is done with both buffers (previous chunk)
         MSM_STAGE_EDGE(0, 0)
-        if (FOLD) fphase = fphase + 1 == fn ? 0 : fphase + 1;
         if (P.cosync && chunks_done > 0 && tid == 0) {  // cohort pacing (opt-in, see the C/G kernel): bounded wait
             const unsigned target = (unsigned)P.ntiles * (unsigned)chunks_done;
             const long long t0 = clock64();
@@ -893,7 +886,8 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                 // accumulators): a half-step that must not take the fast staging still runs it, on row 0 of the chunk
                 // (always readable), and the edge sequence after the loop overwrites what it wrote
                 const size_t kb = fast ? (size_t)k1 * cx.ldb : 0, r8 = fast ? (size_t)8 * cx.ldb : 0;  // scalar
-                const global_ptr<char> pa = cx.base + kb, pb = cx.baseB + kb;
+                const global_ptr<char> zb = as_global<char>(P.zrow);
+                const global_ptr<char> pa = FOLD && !fast ? zb : cx.base + kb, pb = FOLD && !fast ? zb : cx.baseB + kb;
                 const unsigned ox = fast ? offx : ca, oy = fast ? offy : cb;
                 f2v pu = MSM_F2(b * 4 * PAN + 0 * PAN + fa), pd = MSM_F2(b * 4 * PAN + 1 * PAN + fa);
                 f2v qu = MSM_F2(b * 4 * PAN + 2 * PAN + fb), qd = MSM_F2(b * 4 * PAN + 3 * PAN + fb);
@@ -917,7 +911,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     } else if (kk == 4) {
                         rsh = *reinterpret_cast<const f4v*>(rs + scol);  // r, I columns (waited on with the fragments)
                     } else if (kk == 5) {
-                        if (FOLD && fast && fside == 0 && fphase == frank) {  // uniform
+                        if (FOLD) {   // (all sixteen here: split over k-pairs 4 and 5 the kernel is 0.7 ms slower)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) MSM_SYM_COLADD(xa[j])
                         }
@@ -926,10 +920,6 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                         rsh = *reinterpret_cast<const f4v*>(rs + TM + scol);  // r, J columns
                     } else if (kk == 6) {
                         MSM_STORE_X(b ^ 1)
-                        if (FOLD && fast && fside == 1 && fphase == frank) {
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) MSM_SYM_COLADD(ya[j])
-                        }
 #pragma unroll
                         for (int j = 0; j < 2; ++j) MSM_SYM_UD(ya[j], yb[j], rsh, mb, PARTIAL)
                     } else if (kk == 7) {
@@ -940,7 +930,6 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     MSM_SYM_MFMAS
                 }
                 if (more && !fast) MSM_STAGE_EDGE(k1, b ^ 1)
-                if (FOLD && more) fphase = fphase + 1 == fn ? 0 : fphase + 1;
                 PROF_MARK(2)
                 __syncthreads();  // buffer b ^ 1 is complete, buffer b is free
                 if (MSM_SYM_PRIO) __builtin_amdgcn_s_setprio(MSM_SYM_PRIO);  // first fragment reads + MFMAs of the new half-step first
@@ -996,11 +985,11 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
         cs[2 * NT + tid] = cs2;
         cs[3 * NT + tid] = cs3;
         __syncthreads();
-        if (tid < TM) {  // column tid of the block = element tid & 3 of the threads (srow, tid >> 2), srow = 0..7
+        if (I == J && tid < TM) {  // column tid of the block = element tid & 3 of the threads (srow, tid >> 2), srow = 0..7
             double a = 0.0;
 #pragma unroll
             for (int r = 0; r < 8; ++r) a += cs[(tid & 3) * NT + r * 32 + (tid >> 2)];
-            P.colA[((size_t)cohort * P.T + frank) * P.F + fblk * TM + tid] = a;
+            P.colA[(size_t)cohort * P.F + I0 + tid] = a;
         }
     }
 #ifdef MSM_TICA_PROFILE
@@ -1875,19 +1864,17 @@ __global__ void tica_fold_setr_kernel(const double* __restrict__ part, float* __
     r[col] = (float)(a / (double)FOLD_NS);
 }
 
-// After the FOLD kernel: colA[c][i][:] = the share of cohort c's left-frame sums that serving tile i of a block took; tmp (the [NCB][2][F] temporary partials) holds what a
+// After the FOLD kernel: colA[c][:] = sums of cohort c's left frames; tmp (the [NCB][2][F] temporary partials) holds what a
 // column-sum pass over the trajectories' first and last tau rows left there: [k][0] = a_k (rows [0, tau)), [k][1] = b_k
 // (rows [len - tau, len)).  s0 = sum A, stau = sum of the right frames = A - a + b, so slot k becomes
 // [A_k | A_k - a_k + b_k] (A_k = 0 beyond the S cohorts) -- the layout an ordinary column-sum pass leaves.  A non-finite
 // A_k raises the flag (the boundary pass checked its own rows element by element).
-__global__ void tica_fold_fix_kernel(double* __restrict__ tmp, const double* __restrict__ colA, int F, int S, int T, int* flag)
+__global__ void tica_fold_fix_kernel(double* __restrict__ tmp, const double* __restrict__ colA, int F, int S, int* flag)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)NCB * F) return;
     const int k = (int)(idx / F), col = (int)(idx - (size_t)k * F);
-    double A = 0.0;
-    if (k < S)
-        for (int i = 0; i < T; ++i) A += colA[((size_t)k * T + i) * F + col];   // the serving tiles' shares, in rank order
+    const double A = k < S ? colA[(size_t)k * F + col] : 0.0;
     double* t = tmp + (size_t)k * 2 * F;
     const double a = t[col], b = t[F + col];
     t[col] = A;
@@ -2370,7 +2357,7 @@ struct msm_tica {
     float* shift = nullptr;     // [F] reference row r of the mean shift (fp32 / bf16 kernels); valid once have_shift
     double* shsum = nullptr;    // [3F] raw column sums [A | B | W] of everything accumulated under the shift
     bool shift_on = true, have_shift = false;
-    double* fold = nullptr;     // folded column sums: [S_sym][T][F] per-cohort, per-serving-tile sums of the left frames | [FOLD_NB][F] sample partials
+    double* fold = nullptr;     // folded column sums: [S_sym][F] per-cohort sums of the left frames | [FOLD_NB][F] sample partials | [F] zeros
     bool last_folded = false;   // the most recent launch took the folded path
     bool slabs_dirty = false;   // slabs_sym hold something since the last reset (a rejected folded launch must be able to undo itself)
     DevBuf snap;                // ... from this copy
@@ -2653,7 +2640,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipGetLastError());
         if (shifted) {
             if (!h->have_shift) {
-                double* sp = h->fold + (size_t)h->S_sym * h->T * h->F;
+                double* sp = h->fold + (size_t)h->S_sym * h->F;
                 hipLaunchKernelGGL(tica_fold_sample_kernel, dim3((unsigned)ceil_div(h->F, 64), FOLD_NB), dim3(256), 0, stream(), P, sp);
                 hipLaunchKernelGGL(tica_fold_setr_kernel, dim3((unsigned)ceil_div(h->F, 256)), dim3(256), 0, stream(), sp, h->shift, h->F);
                 MSM_HIP_CHECK(hipGetLastError());
@@ -2661,7 +2648,8 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             P.shift = h->shift;
         }
         P.colA = h->fold;
-        MSM_HIP_CHECK(hipMemsetAsync(h->fold, 0, (size_t)h->S_sym * h->T * h->F * sizeof(double), stream()));
+        P.zrow = reinterpret_cast<const float*>(h->fold + (size_t)(h->S_sym + FOLD_NB) * h->F);   // zeroed at creation, never written
+        MSM_HIP_CHECK(hipMemsetAsync(h->fold, 0, (size_t)h->S_sym * h->F * sizeof(double), stream()));
         if (check_finite && h->slabs_dirty) {   // a rejected launch leaves the state untouched (utils/validation.py:68-74 raises
             if ((rc = h->snap.reserve(slab_bytes))) return rc;   // before tica.py:401 accumulates anything)
             MSM_HIP_CHECK(hipMemcpyAsync(h->snap.p, h->slabs_sym, slab_bytes, hipMemcpyDeviceToDevice, stream()));
@@ -2808,7 +2796,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     if (fold) {
         // 3') temporary partials -> [left sums | right sums] per slot, finite check of the folded sums
         hipLaunchKernelGGL(tica_fold_fix_kernel, dim3((unsigned)ceil_div((size_t)NCB * h->F, 256)), dim3(256), 0, stream(),
-                           h->coltmp, h->fold, h->F, h->S_sym, h->T, h->flag);
+                           h->coltmp, h->fold, h->F, h->S_sym, h->flag);
         MSM_HIP_CHECK(hipGetLastError());
         if (check_finite) {
             int f[2] = {0, 0};
@@ -2849,7 +2837,6 @@ int tica_export_device(msm_tica* h)
                        h->packed, h->F);
     MSM_HIP_CHECK(hipGetLastError());
     if (h->sym) {
-        const size_t ff2 = 2 * (size_t)h->F * h->F;
         hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div((size_t)h->ntiles_sym * TM * TM, 256)), dim3(256), 0, stream(),
                            h->slabs_sym, h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
         MSM_HIP_CHECK(hipGetLastError());
@@ -2986,7 +2973,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess) e = hipMalloc((void**)&h->cosync, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void**)&h->shift, (size_t)h->F * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->shsum, 3 * (size_t)h->F * sizeof(double));
-    if (e == hipSuccess && h->sym) e = hipMalloc((void**)&h->fold, (size_t)(h->S_sym * h->T + FOLD_NB) * h->F * sizeof(double));
+    if (e == hipSuccess && h->sym) e = hipMalloc((void**)&h->fold, (size_t)(h->S_sym + FOLD_NB + 1) * h->F * sizeof(double));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreate(&h->evp);
@@ -2994,6 +2981,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
         msm_tica_destroy(h);
         return fail(MSM_ERR_HIP, "msm_tica_create: hipMalloc failed: %s", hipGetErrorString(e));
     }
+    if (h->fold) (void)hipMemsetAsync(h->fold, 0, (size_t)(h->S_sym + FOLD_NB + 1) * h->F * sizeof(double), stream());
     rc = tica_zero(h);
     if (rc) {
         msm_tica_destroy(h);
@@ -3315,7 +3303,6 @@ int tica_reduce_device(msm_tica* h, double shrinkage, long long n_rblw, const do
     hipLaunchKernelGGL(tica_export_cols_kernel, dim3((unsigned)ceil_div(2 * (int64_t)h->F, 64)), dim3(256), 0, stream(), h->colpart, h->base,
                        h->packed, h->F);
     if (h->sym) {
-        const size_t ff2 = 2 * (size_t)h->F * h->F;
         hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div((size_t)h->ntiles_sym * TM * TM, 256)), dim3(256), 0, stream(),
                            h->slabs_sym, h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
     }
