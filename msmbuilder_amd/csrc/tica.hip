@@ -2553,6 +2553,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         fold = !(fe && atoi(fe) == 0) && (double)total * h->F >= fmin;
         for (msm_idx_t s = 0; s < n_seq && fold; ++s)
             if (n_rows[s] > h->lag && n_rows[s] < 2 * (long long)h->lag) fold = false;
+        if (2 * (long long)h->lag * nvalid > total / 4) fold = false;   // the boundary rows would be a pass of their own
     }
     const bool shifted = h->shift_on && (use32 || useb || useimg);
     // 1b) mean shift bookkeeping (fp32 / bf16 kernels): the raw column sums of what this launch accumulates under the
