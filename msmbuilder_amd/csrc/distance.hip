@@ -1520,9 +1520,22 @@ __device__ __forceinline__ unsigned ksc_bf16_rne(float f)  // round-to-nearest-e
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <int NP, bool BF16>  // screen row = NP pairs (m rounded up to even, zero padded)
+// Formats of the screen copy (FMT): 0 = float32 coordinates; 1 = bfloat16; 2 = Q8: signed bytes q_j with ONE scale per row,
+// x~_j = q_j sf, sf a bfloat16 >= max_j |x_j - c0_j| / 127 (round 3).  A byte has the 8 significant bits a bfloat16 has, and
+// with the row's own scale ||x~ - (x - c0)|| <= sqrt(m) sf / 2 is only ~2x the bfloat16 copy's bound (measured on a
+// 10-dimensional projection: 2.28 % of the rows of a pass are re-evaluated exactly instead of 2.20 %, 2.12 % really change)
+// -- but a row of ten features is 10 + 2 + 4 = 16 bytes instead of 24, and a pass is HBM-bound.  q_j sf is EXACT in float32
+// (7 + 8 significant bits), so the pass's float32 arithmetic is the bfloat16 copy's: fl(q_j sf - yc_j) by one fma.
+constexpr int ksc_words(int np, int fmt) { return fmt == 0 ? 2 * np : fmt == 1 ? np : (2 * np + 2 + 3) / 4; }
+__device__ __forceinline__ unsigned ksc_bf16_up(float f)  // smallest bfloat16 >= f (f > 0, finite), as its 16 bits
+{
+    return (__float_as_uint(f) + 0xffffu) >> 16;
+}
+
+template <int NP, int FMT>  // screen row = NP pairs (m rounded up to even, zero padded)
 __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
 {
+    constexpr bool BF16 = FMT == 1;
     constexpr int FC = FeatChunk<double>::FC;  // 16
     constexpr int R = 2;                       // rows per thread and tile
     __shared__ double ys[FC];
@@ -1534,8 +1547,8 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     // The tile stream is software-pipelined: a tile's rows (screen copy + rounded-up distance, one stream) are loaded one
     // tile ahead, the first one BEFORE the prologue -- its loads do not depend on the centre, and the prologue's reduction
     // (a few microseconds at the head of every pass) then overlaps the first HBM round trip instead of preceding it.
-    constexpr int NW = BF16 ? NP : 2 * NP;  // 32-bit words of coordinates per row of the copy
-    constexpr int RW = NW + 1;              // + the row's rounded-up distance: ONE stream, 8-byte loads when RW is even
+    constexpr int NW = ksc_words(NP, FMT);  // 32-bit words of coordinates (Q8: + the scale) per row of the copy
+    constexpr int RW = NW + 1;              // + the row's rounded-up distance: ONE stream, 16- or 8-byte loads when RW allows
     const long long ntile = (P.n + (long long)R * DT - 1) / ((long long)R * DT);
     unsigned qn[R][RW];
     auto load_tile = [&](long long t) {
@@ -1544,7 +1557,16 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
             const long long p0 = t * (R * DT) + k * DT + tid;
             const long long pc = p0 < P.n ? p0 : P.n - 1;
             const unsigned* xr = static_cast<const unsigned*>(P.xs) + pc * RW;
-            if ((RW & 1) == 0) {
+            if ((RW & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < RW / 4; ++j) {
+                    const uint4 v = reinterpret_cast<const uint4*>(xr)[j];
+                    qn[k][4 * j] = v.x;
+                    qn[k][4 * j + 1] = v.y;
+                    qn[k][4 * j + 2] = v.z;
+                    qn[k][4 * j + 3] = v.w;
+                }
+            } else if ((RW & 1) == 0) {
 #pragma unroll
                 for (int j = 0; j < RW / 2; ++j) {
                     const uint2 v = reinterpret_cast<const uint2*>(xr)[j];
@@ -1641,6 +1663,12 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
     //                 max ||x - c0|| and ||yc|| are below 1e18 (squares below 1e36, sums of 16 of them below FLT_MAX).
     constexpr float UREL = (float)((BF16 ? 0x1p-8 : 0x1p-24) * 1.02);  // unit roundoff 2^-p: p = 8 significand bits for bfloat16, 24 for float32
     constexpr float E32 = 0x1p-19f;
+    // Q8: eps of a row = 0.51 sqrt(2 NP) sf  [|x_j - c0_j - q_j sf| <= sf / 2 per feature: q_j = rint((x_j - c0_j) / sf) in
+    // float64, |q_j| <= 127 because 127 sf >= max_j |x_j - c0_j|]  +  e32 (||x~|| + ||yc||) with ||x~|| <= 127 sqrt(2 NP) sf
+    // + eps0: one fma per row, no norm of the row to compute.  (The square root of 2 NP <= 16, rounded up by hand.)
+    constexpr float QSQ = NP == 1 ? 1.4143f : NP == 2 ? 2.f : NP == 3 ? 2.4495f : NP == 4 ? 2.8285f : NP == 5 ? 3.1623f
+                        : NP == 6 ? 3.4642f : NP == 7 ? 3.7417f : 4.f;
+    constexpr float QA = 0.51f * 1.02f * QSQ + E32 * 127.f * QSQ * 1.001f;
     float eps0f, ycnf, ycf[2 * NP];
     {
         const double g2 = __longlong_as_double((long long)P.gmax2[0]), r2 = __longlong_as_double((long long)P.gmax2[1]);
@@ -1680,6 +1708,20 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
             if (t + gridDim.x < ntile) load_tile(t + gridDim.x);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
+                if (FMT == 2) {
+                    constexpr int SB = 2 * NP;   // byte offset of the scale
+                    const float sf = __uint_as_float(((q[k][SB >> 2] >> (8 * (SB & 3))) & 0xffffu) << 16);
+                    float a = 0.f;
+#pragma unroll
+                    for (int f = 0; f < 2 * NP; ++f) {
+                        const int qi = (int)(q[k][f >> 2] << (24 - 8 * (f & 3))) >> 24;   // sign-extended byte f
+                        const float d = fmaf((float)qi, sf, -ycf[f]);
+                        a = fmaf(d, d, a);
+                    }
+                    const float eps = fmaf(sf, QA, fmaf(E32, ycnf, eps0f));
+                    cand[k] = pr[k] < P.n && !(sqrtf(a) - eps >= cf[k]);
+                    continue;
+                }
                 float a = 0.f;
                 float n2 = 0.f;  // ||x~||^2
 #pragma unroll
@@ -1742,7 +1784,7 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
                         P.dist[pr[k]] = d;
                         P.labels[pr[k]] = P.it;
                         cf[k] = ksc_round_up(d);
-                        static_cast<unsigned*>(P.xs)[pr[k] * ((BF16 ? NP : 2 * NP) + 1) + (BF16 ? NP : 2 * NP)] = __float_as_uint(cf[k]);
+                        static_cast<unsigned*>(P.xs)[pr[k] * RW + NW] = __float_as_uint(cf[k]);
                     }
                 }
             }
@@ -1846,13 +1888,14 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
 }
 
 // switch-over from the plain kernel: the centred screen copy, rounded-up distances, max ||x - c0||^2 and max ||x||^2
-template <int NP, bool BF16>
+template <int NP, int FMT>
 __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
 {
+    constexpr bool BF16 = FMT == 1;
     __shared__ double rv[DT];
     __shared__ double rw[DT];
     const int tid = threadIdx.x, m = (int)P.m;
-    constexpr int NW = BF16 ? NP : 2 * NP;
+    constexpr int NW = ksc_words(NP, FMT);
     double c0[2 * NP];
 #pragma unroll
     for (int f = 0; f < 2 * NP; ++f) c0[f] = f < m ? P.c0[f] : 0.0;
@@ -1862,7 +1905,7 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
         unsigned* xo = static_cast<unsigned*>(P.xs) + p * (NW + 1);
         double n2 = 0.0, r2 = 0.0;
         float xc[2 * NP];
-        double xv[2 * NP];
+        double xv[2 * NP], xd[2 * NP];
         if (P.vecw == 16 && (m & 1) == 0) {  // 16-byte loads (the per-feature loads fetched 3x the row's bytes)
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -1879,11 +1922,47 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
             const double v = xv[f];
             const double c = f < m ? v - c0[f] : 0.0;
             xc[f] = (float)c;
+            xd[f] = c;
             if (f < m) {
                 n2 = fma(c, c, n2);
                 r2 = fma(v, v, r2);
             }
         }
+        if (FMT == 2) {
+            // one scale per row: the smallest bfloat16 sf with 127 sf >= max |x_j - c0_j| (0 for a row that IS c0: every q_j = 0
+            // is then exact).  A NaN anywhere makes sf NaN -- the pass re-evaluates such a row exactly every time -- and so do
+            // scales that small that q_j sf could be flushed to zero in the pass's float32 arithmetic.
+            double smax = 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int f = 0; f < 2 * NP; ++f) {
+                const double a = fabs(xd[f]);
+                bad = bad || !(a == a);
+                smax = a > smax ? a : smax;
+            }
+            unsigned sbits = 0;
+            if (bad || !(smax < 1e37) || (smax > 0.0 && smax < 1e-30)) {
+                sbits = 0x7fc0u;   // NaN
+            } else if (smax > 0.0) {
+                sbits = ksc_bf16_up((float)(smax * (1.0000002 / 127.0)));
+            }
+            const double sfd = (double)__uint_as_float(sbits << 16);
+            unsigned w[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) w[j] = 0u;
+#pragma unroll
+            for (int f = 0; f < 2 * NP; ++f) {
+                int qi = 0;
+                if (sbits != 0 && sbits != 0x7fc0u) {
+                    const double t = rint(xd[f] / sfd);
+                    qi = (int)(t > 127.0 ? 127.0 : t < -127.0 ? -127.0 : t);
+                }
+                w[f >> 2] |= ((unsigned)qi & 0xffu) << (8 * (f & 3));
+            }
+            w[(2 * NP) >> 2] |= sbits << (8 * ((2 * NP) & 3));
+#pragma unroll
+            for (int j = 0; j < NW; ++j) xo[j] = w[j];
+        } else
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             if (BF16) {
@@ -1929,12 +2008,13 @@ struct KcStats {
 };
 static KcStats g_kc_stats;
 
-static int ksc_mode()  // MSM_KC_SCREEN: 0 = plain passes only, 1 = float32 screen copy, 2 (default) = bfloat16 screen copy
+static int ksc_mode()  // MSM_KC_SCREEN: 0 = plain passes only, 1 = float32 screen copy, 2 = bfloat16, 3 (default) = bytes + a row scale
 {
-    static const int mode = getenv("MSM_KC_SCREEN") ? atoi(getenv("MSM_KC_SCREEN")) : 2;
+    static const int mode = getenv("MSM_KC_SCREEN") ? atoi(getenv("MSM_KC_SCREEN")) : 3;
     return mode;
 }
 static bool ksc_enabled() { return ksc_mode() != 0; }
+static int ksc_fmt() { return ksc_mode() == 1 ? 0 : ksc_mode() == 2 ? 1 : 2; }   // FMT of the screen kernels
 
 struct KscBufs {
     DevBuf xf, curf, misc;
@@ -2466,11 +2546,11 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         }
         const bool use_screen = it < K;
         if (use_screen) {
-            const bool bf16 = ksc_mode() != 1;
+            const int fmt = ksc_fmt();
             g_kc_stats.plain_passes = it;
             g_kc_stats.screened_passes = K - it;
-            g_kc_stats.screen_row_bytes = (long long)((bf16 ? np : 2 * np) * 4 + 4);   // the screen copy's row + curf
-            if ((rc = B.xf.reserve((size_t)n * ((bf16 ? np : 2 * np) + 1) * sizeof(float)))) return rc;
+            g_kc_stats.screen_row_bytes = (long long)(ksc_words(np, fmt) * 4 + 4);   // the screen copy's row + curf
+            if ((rc = B.xf.reserve((size_t)n * (ksc_words(np, fmt) + 1) * sizeof(float)))) return rc;
             KscArgs S;
             memset(&S, 0, sizeof(S));
             S.X = reinterpret_cast<const double*>(P.X);
@@ -2488,8 +2568,9 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
             S.ids = P.ids;
             const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
             switch (np) {
-#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((ksc_convert_kernel<NP_, true>), dim3(gconv), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, false>), dim3(gconv), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 2>), dim3(gconv), dim3(DT), 0, stream(), S); \
+                           else if (fmt == 1) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 1>), dim3(gconv), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, 0>), dim3(gconv), dim3(DT), 0, stream(), S); break;
                 MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
             }
@@ -2498,8 +2579,9 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                 S.prev = part + (size_t)((it + 1) & 1) * nblk;
                 S.next = part + (size_t)(it & 1) * nblk;
                 switch (np) {
-#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, true>), dim3(nblk), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, false>), dim3(nblk), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 2>), dim3(nblk), dim3(DT), 0, stream(), S); \
+                           else if (fmt == 1) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 1>), dim3(nblk), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 0>), dim3(nblk), dim3(DT), 0, stream(), S); break;
                     MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                 }
@@ -2796,11 +2878,11 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
         KscArgs S;
         memset(&S, 0, sizeof(S));
         const int np = (int)((m + 1) / 2);
-        const bool bf16 = ksc_mode() != 1;
+        const int fmt = ksc_fmt();
         if (screen) {
             KscBufs& B = ksc_bufs();
             if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;
-            if ((rc = B.xf.reserve((size_t)n * ((bf16 ? np : 2 * np) + 1) * sizeof(float)))) return rc;
+            if ((rc = B.xf.reserve((size_t)n * (ksc_words(np, fmt) + 1) * sizeof(float)))) return rc;
             MSM_HIP_CHECK(hipMemsetAsync(B.misc.p, 0, 64, stream()));
             S.X = reinterpret_cast<const double*>(X);
             S.xs = B.xf.p;
@@ -2826,7 +2908,7 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
         g_kc_stats = KcStats();
         g_kc_stats.rows = n;
         g_kc_stats.plain_row_bytes = (long long)(m * sizeof(T) + 16);
-        g_kc_stats.screen_row_bytes = (long long)((bf16 ? np : 2 * np) * 4 + 4);
+        g_kc_stats.screen_row_bytes = (long long)(ksc_words(np, fmt) * 4 + 4);
         for (msm_idx_t it = 0; it < K; ++it) {
             if (screen && it >= KSC_PROBE) {
                 if (it == KSC_PROBE) {
@@ -2835,16 +2917,18 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
                                        reinterpret_cast<const double*>(cen));
                     const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
                     switch (np) {
-#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((ksc_convert_kernel<NP_, true>), dim3(gconv), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, false>), dim3(gconv), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 2>), dim3(gconv), dim3(DT), 0, stream(), S); \
+                           else if (fmt == 1) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 1>), dim3(gconv), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, 0>), dim3(gconv), dim3(DT), 0, stream(), S); break;
                         MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                     }
                 }
                 S.it = (int)it;
                 switch (np) {
-#define MSM_KSC(NP_) case NP_: if (bf16) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, true>), dim3(nblk), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, false>), dim3(nblk), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 2>), dim3(nblk), dim3(DT), 0, stream(), S); \
+                           else if (fmt == 1) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 1>), dim3(nblk), dim3(DT), 0, stream(), S); \
+                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 0>), dim3(nblk), dim3(DT), 0, stream(), S); break;
                     MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                 }

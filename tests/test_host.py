@@ -426,6 +426,66 @@ def test_kcenters_screen_margin_is_safe(scale, offset, m):
     assert worst >= 0.0
 
 
+@pytest.mark.parametrize("scale,offset,m", [(1.0, 0.0, 10), (1e-3, 250.0, 7), (3e4, -1e6, 16), (1.0, 3e6, 2), (1e-12, 0.0, 5)])
+def test_kcenters_byte_screen_margin_is_safe(scale, offset, m):
+    """The default screen copy of round 3: signed bytes q_j with one bfloat16 scale sf per row (127 sf >= max |x_j - c0_j|,
+    q_j = rint((x_j - c0_j) / sf) in float64), d~ = sqrtf(sum fl32(q_j sf - yc_j)^2) and
+    ``eps = sf (0.51 * 1.02 sqrt(m') + 2^-19 * 127 sqrt(m') * 1.001) + 2^-19 ||yc|| + eps0`` (m' = m rounded up to even).
+    Numpy emulation of that arithmetic on adversarial `distances_`, as in the bfloat16 test above: the reference's float64
+    distance must never be below the largest float32 the screen still accepts."""
+    f32 = np.float32
+    rs = np.random.RandomState(m + int(abs(offset)) % 89)
+    n = 200_000
+    X = rs.randn(n, m) * scale + offset
+    X[::5] = (rs.randn(len(X[::5]), m) * 6.0) * scale + offset
+    X[1::11, 0] = offset                                                  # coordinates that sit exactly on the origin's
+    c0 = X[0].copy()
+    Y = X[rs.randint(0, n, 48)]
+    R = np.sqrt((X * X).sum(1).max())
+    G2 = ((X - c0) ** 2).sum(1).max()
+    xd = X - c0
+    smax = np.abs(xd).max(1)
+    sf32 = (smax * (1.0000002 / 127.0)).astype(f32)
+    bits = ((sf32.view(np.uint32).astype(np.uint64) + 0xffff) >> 16).astype(np.uint32) << 16   # smallest bfloat16 >= sf32
+    sf = bits.view(f32).copy()
+    sf[smax == 0] = 0
+    small = (smax > 0) & (smax < 1e-30)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(sf[:, None] > 0, np.rint(xd / sf[:, None].astype(np.float64)), 0.0)
+    assert np.abs(q).max() <= 127
+    q = q.astype(f32)
+    mp = m + (m & 1)
+    qsq = {2: 1.4143, 4: 2.0, 6: 2.4495, 8: 2.8285, 10: 3.1623, 12: 3.4642, 14: 3.7417, 16: 4.0}[mp]
+    QA = f32(f32(0.51) * f32(1.02) * f32(qsq) + f32(2.0 ** -19) * f32(127.0) * f32(qsq) * f32(1.001))
+    worst = np.inf
+    with np.errstate(over="ignore", invalid="ignore", under="ignore"):
+        for y in Y:
+            yc = y - c0
+            ycn2 = float((yc * yc).sum())
+            eps0 = (R + np.sqrt((y * y).sum()) + 2.0 * np.sqrt((c0 * c0).sum())) * 2.0 ** -48 + 1e-37
+            if not (G2 < 1e36 and ycn2 < 1e36):
+                continue
+            eps0f = f32(eps0 * 1.000001)
+            ycnf = f32(np.sqrt(ycn2) * 1.000001)
+            ycf = yc.astype(f32)
+            a = np.zeros(n, dtype=f32)
+            for f in range(m):
+                t = ((q[:, f] * sf).astype(f32) - ycf[f]).astype(f32)     # q sf is exact in float32; the kernel's fma rounds once too
+                a = (a + (t * t).astype(f32)).astype(f32)
+            dt = np.sqrt(a).astype(f32)
+            eps = ((sf * QA).astype(f32) + (f32(2.0 ** -19) * ycnf + eps0f).astype(f32)).astype(f32)
+            ar = np.zeros(n)
+            for f in range(m):
+                d = X[:, f] - y[f]
+                ar = ar + d * d
+            dref = np.sqrt(ar)
+            cur = (dt - eps).astype(f32).astype(np.float64)
+            ok = (cur > 0) & ~small                                        # (rows with a scale below 1e-30 carry a NaN scale: never screened)
+            assert np.all(dref[ok] >= cur[ok]), (scale, offset, m)
+            worst = min(worst, float(np.min((dref[ok] - cur[ok]) / np.maximum(eps[ok].astype(np.float64), 1e-300)))) if ok.any() else worst
+    assert worst >= 0.0
+
+
 def test_dir_npy_dataset_payload_reader(tmp_path):
     """The container's host reads go through the native header parser (msm_npy_info) + memmap / fromfile; payloads the
     parser does not describe (structured dtypes) fall back to numpy's reader; writes are atomic renames; keys iterate in
