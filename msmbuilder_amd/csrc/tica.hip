@@ -1444,6 +1444,7 @@ struct ImgArgs {
     bf16x8* d_hi;
     bf16x8* u_mid;  // bf16x2 only
     bf16x8* d_mid;
+    double* colA;   // folded column sums: [nchunks][F] fp64 sums of the chunk's LEFT frames (nullptr: a separate pass made them)
 };
 
 // thread -> 4 consecutive features (one 16-byte load per row for float32, 8 bytes for bfloat16) x the 8 pairs of one group:
@@ -1456,6 +1457,7 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
     const int fq = threadIdx.x & 63, gq = threadIdx.x >> 6;   // feature quad, group within the K-step
     const int f0 = blockIdx.y * 256 + fq * 4;                 // < Fp
     const bool vec = (P.F % 4 == 0) && (P.ld % 4 == 0) && ((((uintptr_t)ch.base) & 15) == 0);
+    const bool vec2 = (P.F % 4 == 0) && (P.ld % 4 == 0) && ((((uintptr_t)ch.base) & 7) == 0);   // bfloat16 rows: 8-byte loads
     float r[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = (P.shift && f0 + q < P.F) ? P.shift[f0 + q] : 0.f;
@@ -1466,6 +1468,7 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
     const size_t esz = (size_t)P.dtype_bytes;
     const global_ptr<char> base = as_global<char>(ch.base);
     const int fc = f0 < P.F ? f0 : (P.F >= 4 ? P.F - 4 : 0);  // clamped column of the vector loads
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};   // P.colA: fp64 sums of the left frames this thread loads (its four features)
     for (long long st = 0; st < nsteps; ++st) {
         const long long gi = st * 4 + gq;
         float a[8][4], b[8][4];
@@ -1479,6 +1482,15 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
                 const raw_f32x4 va = *(global_ptr<raw_f32x4>)(rowa + (size_t)fc * 4), vb = *(global_ptr<raw_f32x4>)(rowb + (size_t)fc * 4);
                 a[e][0] = va.x; a[e][1] = va.y; a[e][2] = va.z; a[e][3] = va.w;
                 b[e][0] = vb.x; b[e][1] = vb.y; b[e][2] = vb.z; b[e][3] = vb.w;
+            } else if (P.dtype_bytes == 2 && vec2) {
+                // four bfloat16 = one 8-byte load (element-wise 2-byte loads made this pre-pass 2.1 TB/s on bfloat16-stored
+                // input against 3.8 TB/s on float32)
+                typedef unsigned raw_u32x2 __attribute__((ext_vector_type(2)));
+                const raw_u32x2 va = *(global_ptr<raw_u32x2>)(rowa + (size_t)fc * 2), vb = *(global_ptr<raw_u32x2>)(rowb + (size_t)fc * 2);
+                a[e][0] = __uint_as_float(va.x << 16); a[e][1] = __uint_as_float(va.x & 0xffff0000u);
+                a[e][2] = __uint_as_float(va.y << 16); a[e][3] = __uint_as_float(va.y & 0xffff0000u);
+                b[e][0] = __uint_as_float(vb.x << 16); b[e][1] = __uint_as_float(vb.x & 0xffff0000u);
+                b[e][2] = __uint_as_float(vb.y << 16); b[e][3] = __uint_as_float(vb.y & 0xffff0000u);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1491,6 +1503,14 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
                         b[e][q] = (float)*(global_ptr<__bf16>)(rowb + col * 2);
                     }
                 }
+            }
+        }
+        if (P.colA) {   // this pre-pass is bandwidth-bound: the 64 widenings and adds per thread and step are free
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool okp = (gi * 8 + e) < nv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cs[q] += okp ? (double)a[e][q] : 0.0;
             }
         }
 #pragma unroll
@@ -1517,6 +1537,18 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
                 P.u_mid[o] = um;
                 P.d_mid[o] = dm;
             }
+        }
+    }
+    if (P.colA) {   // the four groups of a feature quad -> one sum per (chunk, feature): plain stores, one writer each
+        __shared__ double red[4][64][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[gq][fq][q] = cs[q];
+        __syncthreads();
+        if (gq == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (f0 + q < P.F)
+                    P.colA[(size_t)blockIdx.x * P.F + f0 + q] = (red[0][fq][q] + red[1][fq][q]) + (red[2][fq][q] + red[3][fq][q]);
         }
     }
 }
@@ -1828,6 +1860,7 @@ __global__ void tica_colmerge_kernel(double* __restrict__ dst, double* __restric
 // spread evenly over the launch's chunks (any r within a fraction of sigma of the mean serves: the shifted moments are
 // restored exactly whatever r is).  One block per 64 columns, four row lanes, fp64.
 constexpr int FOLD_NS = 4096, FOLD_NB = 32;   // samples, and the blocks (per 64 columns) that share them
+template <typename TIn>
 __global__ __launch_bounds__(256) void tica_fold_sample_kernel(TicaArgs P, double* __restrict__ part)
 {
     __shared__ double red[256];
@@ -1836,16 +1869,16 @@ __global__ __launch_bounds__(256) void tica_fold_sample_kernel(TicaArgs P, doubl
     double a = 0.0;
     if (col < P.F)
         for (int i0 = 0; i0 < PER; i0 += 8) {
-            float v[8];
+            TIn v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int s = (blockIdx.y * 4 + rl) * PER + i0 + u;
                 const TicaChunk ch = get_chunk(P, ((long long)s * P.nchunks) / FOLD_NS);
                 const int row = (int)((((unsigned)s * 2654435761u) >> 8) % (unsigned)ch.n);
-                v[u] = as_global<float>(ch.base)[(ch.row0 + row) * P.ld + col];
+                v[u] = as_global<TIn>(ch.base)[(ch.row0 + row) * P.ld + col];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a += (double)v[u];
+            for (int u = 0; u < 8; ++u) a += to_f64(v[u]);
         }
     red[tid] = a;
     __syncthreads();
@@ -1869,6 +1902,21 @@ __global__ void tica_fold_setr_kernel(const double* __restrict__ part, float* __
 // (rows [len - tau, len)).  s0 = sum A, stau = sum of the right frames = A - a + b, so slot k becomes
 // [A_k | A_k - a_k + b_k] (A_k = 0 beyond the S cohorts) -- the layout an ordinary column-sum pass leaves.  A non-finite
 // A_k raises the flag (the boundary pass checked its own rows element by element).
+// the bf16 image path's variant: colA[c][:] per CHUNK (tica_img_kernel); slot k takes chunks k, k + NCB, ... in order
+__global__ void tica_fold_fix_img_kernel(double* __restrict__ tmp, const double* __restrict__ colA, int F, long long nchunks, int* flag)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)NCB * F) return;
+    const int k = (int)(idx / F), col = (int)(idx - (size_t)k * F);
+    double A = 0.0;
+    for (long long c = k; c < nchunks; c += NCB) A += colA[(size_t)c * F + col];
+    double* t = tmp + (size_t)k * 2 * F;
+    const double a = t[col], b = t[F + col];
+    t[col] = A;
+    t[F + col] = (A - a) + b;
+    if (!isfinite(A)) atomicOr(flag, 1);
+}
+
 __global__ void tica_fold_fix_kernel(double* __restrict__ tmp, const double* __restrict__ colA, int F, int S, int* flag)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2361,6 +2409,7 @@ struct msm_tica {
     bool last_folded = false;   // the most recent launch took the folded path
     bool slabs_dirty = false;   // slabs_sym hold something since the last reset (a rejected folded launch must be able to undo itself)
     DevBuf snap;                // ... from this copy
+    DevBuf foldimg;             // bf16 image path: [nchunks][F] per-chunk sums of the left frames
     long long n_sh = 0, nw_sh = 0;  // shifted pairs, and the total weight of their Gram terms (2 n_sh for whole trajectories)
     long long n_obs = 0, n_seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
@@ -2546,7 +2595,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // left frames, a column-sum pass over the first and last `lag` rows of every trajectory supplies what separates the
     // right frames' sums from the left frames' (and checks those rows), and the finite check is made on the sums afterwards.
     bool fold = false;
-    if (usesym && !useimg && !segs && h->fold && h->F % TM == 0) {
+    if (usesym && !segs && h->fold && (useimg || h->F % TM == 0)) {   // (bf16 image path: the pre-pass sums while it packs)
         const char* fe = getenv("MSM_TICA_FOLD");       // read per launch (A/B switch for tests and scripts)
         const char* fm = getenv("MSM_TICA_FOLD_MIN");   // elements (frames x features) from which a launch folds
         const double fmin = fm ? atof(fm) : 67108864.0;
@@ -2637,20 +2686,30 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         TicaArgs Q = P;
         Q.chunks = h->table2.as<TicaChunk>();
         Q.nchunks = (long long)tab.size();
-        hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), Q);
+        if (dtype_bytes == 4)
+            hipLaunchKernelGGL(tica_colsum_kernel<float>, dim3(NCB), dim3(NT), 0, stream(), Q);
+        else
+            hipLaunchKernelGGL(tica_colsum_kernel<__bf16>, dim3(NCB), dim3(NT), 0, stream(), Q);
         MSM_HIP_CHECK(hipGetLastError());
         if (shifted) {
             if (!h->have_shift) {
                 double* sp = h->fold + (size_t)h->S_sym * h->F;
-                hipLaunchKernelGGL(tica_fold_sample_kernel, dim3((unsigned)ceil_div(h->F, 64), FOLD_NB), dim3(256), 0, stream(), P, sp);
+                if (dtype_bytes == 4)
+                    hipLaunchKernelGGL(tica_fold_sample_kernel<float>, dim3((unsigned)ceil_div(h->F, 64), FOLD_NB), dim3(256), 0, stream(), P, sp);
+                else
+                    hipLaunchKernelGGL(tica_fold_sample_kernel<__bf16>, dim3((unsigned)ceil_div(h->F, 64), FOLD_NB), dim3(256), 0, stream(), P, sp);
                 hipLaunchKernelGGL(tica_fold_setr_kernel, dim3((unsigned)ceil_div(h->F, 256)), dim3(256), 0, stream(), sp, h->shift, h->F);
                 MSM_HIP_CHECK(hipGetLastError());
             }
             P.shift = h->shift;
         }
-        P.colA = h->fold;
-        P.zrow = reinterpret_cast<const float*>(h->fold + (size_t)(h->S_sym + FOLD_NB) * h->F);   // zeroed at creation, never written
-        MSM_HIP_CHECK(hipMemsetAsync(h->fold, 0, (size_t)h->S_sym * h->F * sizeof(double), stream()));
+        if (useimg) {
+            if ((rc = h->foldimg.reserve((size_t)P.nchunks * h->F * sizeof(double)))) return rc;   // every word is written by the pre-pass
+        } else {
+            P.colA = h->fold;
+            P.zrow = reinterpret_cast<const float*>(h->fold + (size_t)(h->S_sym + FOLD_NB) * h->F);   // zeroed at creation, never written
+            MSM_HIP_CHECK(hipMemsetAsync(h->fold, 0, (size_t)h->S_sym * h->F * sizeof(double), stream()));
+        }
         if (check_finite && h->slabs_dirty) {   // a rejected launch leaves the state untouched (utils/validation.py:68-74 raises
             if ((rc = h->snap.reserve(slab_bytes))) return rc;   // before tica.py:401 accumulates anything)
             MSM_HIP_CHECK(hipMemcpyAsync(h->snap.p, h->slabs_sym, slab_bytes, hipMemcpyDeviceToDevice, stream()));
@@ -2723,6 +2782,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         IA.lag = h->lag;
         IA.dtype_bytes = dtype_bytes;
         IA.shift = P.shift;
+        IA.colA = fold ? h->foldimg.as<double>() : nullptr;
         char* ib = h->img.as<char>();
         IA.u_hi = reinterpret_cast<bf16x8*>(ib);
         IA.d_hi = reinterpret_cast<bf16x8*>(ib + one);
@@ -2796,8 +2856,12 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     }
     if (fold) {
         // 3') temporary partials -> [left sums | right sums] per slot, finite check of the folded sums
-        hipLaunchKernelGGL(tica_fold_fix_kernel, dim3((unsigned)ceil_div((size_t)NCB * h->F, 256)), dim3(256), 0, stream(),
-                           h->coltmp, h->fold, h->F, h->S_sym, h->flag);
+        if (useimg)
+            hipLaunchKernelGGL(tica_fold_fix_img_kernel, dim3((unsigned)ceil_div((size_t)NCB * h->F, 256)), dim3(256), 0, stream(),
+                               h->coltmp, h->foldimg.as<double>(), h->F, P.nchunks, h->flag);
+        else
+            hipLaunchKernelGGL(tica_fold_fix_kernel, dim3((unsigned)ceil_div((size_t)NCB * h->F, 256)), dim3(256), 0, stream(),
+                               h->coltmp, h->fold, h->F, h->S_sym, h->flag);
         MSM_HIP_CHECK(hipGetLastError());
         if (check_finite) {
             int f[2] = {0, 0};

@@ -188,3 +188,46 @@ def test_folded_and_plain_launches_add_up(gpu, monkeypatch):
     cov = ((X0 - mu).T @ (X0 - mu) + (X1 - mu).T @ (X1 - mu)) / (2 * len(X0))
     np.testing.assert_allclose(m.covariance_, cov, rtol=0, atol=2e-6 * np.abs(cov).max())
     np.testing.assert_allclose(m._outer_gram_sum, G, rtol=0, atol=ATOL_SCALE * scale)
+
+
+@pytest.mark.parametrize("stored", ["float32", "bfloat16"])
+@pytest.mark.parametrize("mode,F,lag", [("bf16", 300, 7), ("bf16x2", 512, 40), ("bf16", 2048, 3)])
+def test_image_path_folds_its_column_sums_too(gpu, monkeypatch, mode, F, lag, stored):
+    """bf16 modes: the packed-image pre-pass reads every left frame anyway and sums it in fp64 while it packs -- no
+    column-sum pass of its own (any width: the image is padded, not the sums)."""
+    torch = pytest.importorskip("torch")
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    monkeypatch.setenv("MSM_TICA_FOLD_MIN", "0")
+    lens = [5000, 4096 + 2 * lag, lag, 2 * lag, 2 * lag + 33, 700]
+    seqs = _data(F + lag, lens, F)
+    if stored == "bfloat16":
+        dev = [torch.from_numpy(s).cuda().to(torch.bfloat16) for s in seqs]
+        seqs = [d.float().cpu().numpy() for d in dev]          # what the stored values are
+    else:
+        dev = [torch.from_numpy(s).cuda() for s in seqs]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = tICA(n_components=4, lag_time=lag).fit(dev)
+        assert _folded(m) == 1
+        monkeypatch.setenv("MSM_TICA_FOLD", "0")
+        m0 = tICA(n_components=4, lag_time=lag).fit(dev)
+        assert _folded(m0) == 0
+    m._pull(); m0._pull()
+    Cm, G, s0, st, n = _numpy_moments(seqs, lag, F)
+    np.testing.assert_allclose(m._sum_0_to_TminusTau, s0, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(m._sum_tau_to_T, st, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(m.means_, m0.means_, rtol=1e-12, atol=1e-13)
+    tol = (1e-3 if mode == "bf16" else 1e-5) * np.abs(G).max()   # the modes' stated accuracy (DESIGN 3.2b) on ~10,000 frames
+    np.testing.assert_allclose(m._outer_gram_sum, G, rtol=0, atol=tol)
+    np.testing.assert_allclose(m0._outer_gram_sum, G, rtol=0, atol=tol)      # (different shift rows: two roundings of the same sums)
+    # a rejected launch is undone here as well
+    bad = seqs[0].copy()
+    bad[1234, 5] = np.nan
+    before = m._outer_gram_sum.copy()
+    monkeypatch.setenv("MSM_TICA_FOLD", "1")
+    with pytest.raises(ValueError, match="NaN"):
+        m.partial_fit(torch.from_numpy(bad).cuda() if stored == "float32" else torch.from_numpy(bad).cuda().to(torch.bfloat16))
+    m._is_dirty = True
+    m._pull()
+    np.testing.assert_array_equal(m._outer_gram_sum, before)
