@@ -547,6 +547,41 @@ class tICA(BaseEstimator, TransformerMixin):
         except Exception:  # numpy-only hosts
             Tensor, fast_types = (), ()
         lag = self.lag_time
+        # all-fast group (what a 10M-frame fit of device tensors is: 1,000 of them): 2-D contiguous CUDA tensors of ONE fast
+        # dtype and the model's width, each long enough -- one pass collects pointers and lengths, nothing else is touched
+        # per trajectory (the general path below costs ~1.1 us per trajectory, 1.1 ms of such a fit)
+        if Tensor and len(Xs) and type(Xs[0]) is Tensor and Xs[0].dim() == 2:
+            F = self.n_features if self._initialized else Xs[0].shape[1]
+            dt0 = Xs[0].dtype
+            if dt0 in fast_types and Xs[0].is_cuda:
+                dev0 = Xs[0].device
+                ptrs, nrows, ok = [], [], True
+                for X in Xs:
+                    if type(X) is not Tensor:
+                        ok = False
+                        break
+                    sh = X.shape
+                    if (len(sh) != 2 or sh[1] != F or sh[0] <= lag or sh[0] < F or X.dtype is not dt0 or X.device != dev0
+                            or X.stride() != (F, 1)):
+                        ok = False
+                        break
+                    ptrs.append(X.data_ptr())
+                    nrows.append(sh[0])
+                if ok:
+                    n = len(ptrs)
+                    self._initialize(F)
+                    self._ensure_handle()
+                    _lib.ensure_device(dev0.index)
+                    _lib.set_stream(torch.cuda.current_stream(dev0).cuda_stream)
+                    skipped = C.c_int64(0)
+                    check(_lib.lib().msm_tica_accumulate_batch(self._handle, (C.c_void_p * n)(*ptrs), (C.c_int64 * n)(*nrows), n,
+                                                               8 if dt0 is torch.float64 else 4, int(F), 1, 1, C.byref(skipped)))
+                    self.n_observations_ += sum(nrows)
+                    self.n_sequences_ += n
+                    self._host_stale = True
+                    self._is_dirty = True
+                    self._mu_raw = None
+                    return
         for X in Xs:
             # fast path: a 2-D contiguous float32 / float64 CUDA tensor of the model's width that is long enough needs
             # none of the conversions below (a 10M-frame fit is 1,000 of them: the generic path costs 2 us each)
