@@ -1994,6 +1994,430 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Several centres per pass (round 3; byte copy, single process).
+//
+// k-centers is sequential -- centre k+1 is the argmax of the distances AFTER centre k -- but the argmax can usually be
+// read off a short list.  A pass appends every row whose updated, rounded-up distance exceeds a threshold theta to a list
+// (`curf > theta` implies distance > theta; every row NOT listed has distance <= theta =: tau, and distances only
+// shrink).  kcb_select_kernel, one workgroup, then plays the algorithm on the list alone: the listed row of largest
+// distance (lowest row on ties) is the next centre -- it beats every unlisted row strictly; the remaining listed rows get
+// d = min(d, dist(row, centre)) in the pass kernel's exact arithmetic; the largest of them is the centre after that IF it
+// still exceeds tau, and so on, up to KCB_JMAX centres.  The next pass applies them all, in order, to every row it streams
+// (a row's candidate centres by the screen, then the exact `d < distances_` of kcenters.py:93 centre after centre): the
+// centres, labels_ and distances_ of the one-centre-per-pass loop, in a fraction of its passes (simulated on a 10-dimensional
+// projection: 30 passes instead of 199 with lists of 16).  The per-block argmax partials are still written: the first
+// centre of a batch must be the row they name (numpy's argmax under this file's NaN rules), otherwise -- and whenever the
+// list is empty or overflowed -- the batch is that one row.  theta follows the data: a pass also counts the rows above five
+// lower levels, and the selector takes the lowest level that held at most KCB_TARGET rows (counts at a fixed level can only
+// fall from pass to pass, so the next list fits).
+// ---------------------------------------------------------------------------
+constexpr int KCB_JMAX = 16, KCB_CAP = 2048, KCB_NLEV = 6, KCB_TARGET = 768;
+struct KcbState {
+    int k_done;               // centres fixed so far: ids[0 .. k_done)
+    int J;                    // centres the next pass applies: ids[k_done - J .. k_done)
+    int rounds, fallbacks;
+    float theta;              // listing threshold of the last pass = bound on every row it did not list
+    unsigned count;           // rows it listed (more than KCB_CAP: list unusable)
+    unsigned lev[KCB_NLEV];   // rows above theta * kcb_level(l) after it; lev[0] mirrors count
+    double cen[KCB_JMAX][16];
+    long long list[KCB_CAP];
+};
+__device__ __forceinline__ float kcb_level(int l) { return l == 0 ? 1.f : l == 1 ? 0.985f : l == 2 ? 0.97f : l == 3 ? 0.955f : l == 4 ? 0.94f : 0.91f; }
+
+template <int NP>
+__global__ __launch_bounds__(1024) void kcb_select_kernel(KscArgs P, KcbState* S, int K)
+{
+    __shared__ double rv[1024];
+    __shared__ long long ri[1024];
+    __shared__ double cs[16];
+    const int tid = threadIdx.x, m = (int)P.m;
+    const int k0 = S->k_done;
+    if (k0 >= K) {
+        if (tid == 0) S->J = 0;
+        return;
+    }
+    // block argmax (largest value, lowest row on ties; rows < 0 never win): shuffles inside a wave, then every wave reduces the
+    // 16 wave winners by itself -- ONE barrier per call (the selection loop makes up to 17 of them between two passes)
+    auto reduce = [&](double v, long long i, double& ov, long long& oi) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const double v2 = __shfl_xor(v, s);
+            const long long i2 = __shfl_xor(i, s);
+            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
+                v = v2;
+                i = i2;
+            }
+        }
+        __syncthreads();   // the previous call's readers are done with rv / ri
+        if ((tid & 63) == 0) {
+            rv[tid >> 6] = v;
+            ri[tid >> 6] = i;
+        }
+        __syncthreads();
+        const int l = tid & 15;
+        v = rv[l];
+        i = ri[l];
+#pragma unroll
+        for (int s = 8; s > 0; s >>= 1) {
+            const double v2 = __shfl_xor(v, s);
+            const long long i2 = __shfl_xor(i, s);
+            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
+                v = v2;
+                i = i2;
+            }
+        }
+        ov = v;
+        oi = i;
+    };
+    // the row the per-block partials of the last pass name (the one-centre-per-pass loop's choice)
+    double vP;
+    long long iP;
+    {
+        double v = -1.0;
+        long long i = -1;
+        if (tid < P.nblk) {
+            const KcPartial q = P.prev[tid];
+            if (q.i >= 0) {
+                v = q.v;
+                i = q.i;
+            }
+        }
+        reduce(v, i, vP, iP);
+    }
+    const float theta = S->theta;
+    const unsigned cnt = S->count;
+    const bool usable = cnt > 0 && cnt <= (unsigned)KCB_CAP && theta > 0.f && theta < 3e38f;
+    const double tau = (double)theta;
+    // this thread's (up to) two listed rows: index, current distance, coordinates
+    long long ci[2] = {-1, -1};
+    double cv[2] = {-1.0, -1.0}, cx[2][2 * NP];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const unsigned c = (unsigned)tid + 1024u * u;
+        if (usable && c < cnt) {
+            ci[u] = S->list[c];
+            cv[u] = P.dist[ci[u]];
+#pragma unroll
+            for (int f = 0; f < 2 * NP; ++f) cx[u][f] = f < m ? P.X[ci[u] * P.m + f] : 0.0;
+        }
+    }
+    int J = 0, fell = 0;
+    double vlast = vP;
+    for (;;) {
+        double v = -1.0, vb;
+        long long i = -1, ib;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (ci[u] >= 0 && (i < 0 || kc_better(cv[u], ci[u], v, i))) {
+                v = cv[u];
+                i = ci[u];
+            }
+        reduce(v, i, vb, ib);
+        long long centre;
+        if (J == 0) {
+            if (usable && ib == iP) {
+                centre = ib;
+            } else {
+                centre = iP;
+                fell = 1;
+            }
+            vlast = vP;
+        } else {
+            if (!(ib >= 0 && vb > tau)) break;
+            centre = ib;
+            vlast = vb;
+        }
+        if (fell) {
+            if (tid < 16) cs[tid] = tid < m ? P.X[centre * P.m + tid] : 0.0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (ci[u] == centre) {   // the thread that holds the row: no trip to global memory inside the loop
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) cs[f] = f < 2 * NP ? cx[u][f] : 0.0;
+                }
+        }
+        if (tid == 0) P.ids[k0 + J] = centre;
+        __syncthreads();
+        if (tid < 16) S->cen[J][tid] = cs[tid];
+        ++J;
+        if (fell || k0 + J >= K || J >= KCB_JMAX) break;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (ci[u] < 0) continue;
+            if (ci[u] == centre) {
+                ci[u] = -1;
+                continue;
+            }
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int f = 0; f < 2 * NP; ++f) m_update<double, M_EUCLIDEAN>(a, b, cx[u][f], cs[f]);
+            const double d = m_final<M_EUCLIDEAN>(a, b, P.m);
+            if (d < cv[u]) cv[u] = d;   // the pass's own update (kcenters.py:93)
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // threshold of the next list
+        float th;
+        const float vl = ksc_round_up(vlast > 0.0 ? vlast : 0.0);
+        if (!(theta > 0.f) || !(theta < 3e38f)) {
+            th = 0.97f * vl;
+        } else if (cnt > (unsigned)KCB_TARGET) {
+            th = theta * 1.02f;
+        } else {
+            int l = 0;
+            for (int q = 1; q < KCB_NLEV; ++q)
+                if (S->lev[q] <= (unsigned)KCB_TARGET) l = q;
+            th = theta * kcb_level(l);
+        }
+        if (th > vl) th = vl;
+        S->theta = th;
+        S->count = 0;
+        for (int q = 0; q < KCB_NLEV; ++q) S->lev[q] = 0;
+        S->J = J;
+        S->k_done = k0 + J;
+        S->rounds += 1;
+        S->fallbacks += fell;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(DT) void kcenters_batch_pass_kernel(KscArgs P, KcbState* S)
+{
+    constexpr int R = 2;
+    constexpr int NW = ksc_words(NP, 2), RW = NW + 1;
+    constexpr int SB = 2 * NP;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) f32x2 ycf[KCB_JMAX][NP];
+    __shared__ double yd[KCB_JMAX][2 * NP];
+    __shared__ float epsb[KCB_JMAX];
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    __shared__ unsigned slev[KCB_NLEV];
+    const int tid = threadIdx.x, m = (int)P.m;
+    const int J = S->J;
+    if (J == 0) return;
+    const int kbase = S->k_done - J;
+    const float theta = S->theta;
+    const long long ntile = (P.n + (long long)R * DT - 1) / ((long long)R * DT);
+    unsigned qn[R][RW];
+    auto load_tile = [&](long long t) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const long long p0 = t * (R * DT) + k * DT + tid;
+            const long long pc = p0 < P.n ? p0 : P.n - 1;
+            const unsigned* xr = static_cast<const unsigned*>(P.xs) + pc * RW;
+            if ((RW & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < RW / 4; ++j) {
+                    const uint4 v = reinterpret_cast<const uint4*>(xr)[j];
+                    qn[k][4 * j] = v.x;
+                    qn[k][4 * j + 1] = v.y;
+                    qn[k][4 * j + 2] = v.z;
+                    qn[k][4 * j + 3] = v.w;
+                }
+            } else if ((RW & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < RW / 2; ++j) {
+                    const uint2 v = reinterpret_cast<const uint2*>(xr)[j];
+                    qn[k][2 * j] = v.x;
+                    qn[k][2 * j + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < RW; ++j) qn[k][j] = xr[j];
+            }
+        }
+    };
+    if ((long long)blockIdx.x < ntile) load_tile(blockIdx.x);
+    // the batch's centres: exact coordinates, float32 coordinates relative to the copy's origin, and the part of eps that
+    // belongs to the centre (see kcenters_screen_pass_kernel for the terms)
+    if (tid < KCB_NLEV) slev[tid] = 0;
+    if (tid < KCB_JMAX * 2 * NP) {
+        const int j = tid / (2 * NP), f = tid - j * (2 * NP);
+        const double y = j < J ? S->cen[j][f] : 0.0;
+        yd[j][f] = y;
+        reinterpret_cast<float*>(&ycf[j][0])[f] = (float)(y - (f < m ? P.c0[f] : 0.0));
+    }
+    if (tid < KCB_JMAX) {
+        double c0n2 = 0.0, yn2 = 0.0, ycn2 = 0.0;
+        for (int f = 0; f < 2 * NP; ++f) {
+            const double y = tid < J ? S->cen[tid][f] : 0.0, c0f = f < m ? P.c0[f] : 0.0;
+            c0n2 = fma(c0f, c0f, c0n2);
+            yn2 = fma(y, y, yn2);
+            ycn2 = fma(y - c0f, y - c0f, ycn2);
+        }
+        const double g2 = __longlong_as_double((long long)P.gmax2[0]), r2 = __longlong_as_double((long long)P.gmax2[1]);
+        double eps0 = (sqrt(r2) + sqrt(yn2) + 2.0 * sqrt(c0n2)) * 0x1p-48 + 1e-37;
+        if (!(g2 < 1e36) || !(r2 < 1e76) || !(ycn2 < 1e36)) eps0 = NAN;
+        epsb[tid] = fmaf(0x1p-19f, (float)(sqrt(ycn2) * 1.000001), (float)(eps0 * 1.000001));
+    }
+    __syncthreads();
+    constexpr float E32 = 0x1p-19f;
+    constexpr float QSQ = NP == 1 ? 1.4143f : NP == 2 ? 2.f : NP == 3 ? 2.4495f : NP == 4 ? 2.8285f : NP == 5 ? 3.1623f
+                        : NP == 6 ? 3.4642f : NP == 7 ? 3.7417f : 4.f;
+    constexpr float QA = 0.51f * 1.02f * QSQ + E32 * 127.f * QSQ * 1.001f;
+    float bf = -1.f;
+    long long bi = -1;
+    double bx = 0.0;
+    bool bknown = false;
+    unsigned nlev[KCB_NLEV];
+#pragma unroll
+    for (int l = 0; l < KCB_NLEV; ++l) nlev[l] = 0;
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        float cf[R];
+        unsigned cmask[R];
+        long long pr[R];
+        unsigned q[R][RW];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            pr[k] = t * (R * DT) + k * DT + tid;
+#pragma unroll
+            for (int j = 0; j < RW; ++j) q[k][j] = qn[k][j];
+            cf[k] = __uint_as_float(q[k][NW]);
+        }
+        if (t + gridDim.x < ntile) load_tile(t + gridDim.x);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const float sf = __uint_as_float(((q[k][SB >> 2] >> (8 * (SB & 3))) & 0xffffu) << 16);
+            f32x2 xt[NP];
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                xt[g].x = (float)((int)(q[k][(2 * g) >> 2] << (24 - 8 * ((2 * g) & 3))) >> 24) * sf;       // q sf: exact
+                xt[g].y = (float)((int)(q[k][(2 * g + 1) >> 2] << (24 - 8 * ((2 * g + 1) & 3))) >> 24) * sf;
+            }
+            // a row is left alone by centre j when  sqrt(a_j) - eps_j >= curf.  Compared as squares, without the square root:
+            // a_j >= T^2 with T = (curf + eps_j)(1 + 2^-20) evaluated in float32 (three roundings of 2^-24 each, and one more
+            // in the product T T, leave T^2 above the real (curf + eps_j)^2): the real-arithmetic inequality with room to
+            // spare -- eps_j already allows for float32 roundings of the original form
+            const float base = cf[k] + sf * QA;
+            unsigned mk = 0;
+            for (int j = 0; j < J; ++j) {
+                f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < NP; ++g) {
+                    const f32x2 d = xt[g] - ycf[j][g];
+                    acc = __builtin_elementwise_fma(d, d, acc);
+                }
+                const float T = (base + epsb[j]) * (1.f + 0x1p-20f);
+                if (!(acc.x + acc.y >= T * T)) mk |= 1u << j;
+            }
+            cmask[k] = pr[k] < P.n ? mk : 0u;
+        }
+        if (cmask[0] | cmask[1]) {
+            double x[R][2 * NP], cur[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const long long pc = pr[k] < P.n ? pr[k] : P.n - 1;
+                const double* xp = P.X + pc * P.m;
+                if (P.vecw == 16 && (m & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        const raw_f32x4 v = *reinterpret_cast<const raw_f32x4*>(xp + 2 * j);
+                        x[k][2 * j] = reinterpret_cast<const double*>(&v)[0];
+                        x[k][2 * j + 1] = reinterpret_cast<const double*>(&v)[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 2 * NP; ++f) x[k][f] = xp[f < m ? f : m - 1];
+#pragma unroll
+                    for (int f = 0; f < 2 * NP; ++f)
+                        if (f >= m) x[k][f] = 0.0;
+                }
+                cur[k] = P.dist[pc];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                unsigned mk = cmask[k];
+                int lab = -1;
+                double c = cur[k];
+                while (mk) {   // the batch's centres in order, as the separate passes would meet the row
+                    const int j = __builtin_ctz(mk);
+                    mk &= mk - 1;
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int f = 0; f < 2 * NP; ++f) m_update<double, M_EUCLIDEAN>(a, b, x[k][f], yd[j][f]);
+                    const double d = m_final<M_EUCLIDEAN>(a, b, P.m);
+                    if (d < c) {   // strict, kcenters.py:93
+                        c = d;
+                        lab = kbase + j;
+                    }
+                }
+                if (lab >= 0) {
+                    P.dist[pr[k]] = c;
+                    P.labels[pr[k]] = lab;
+                    cf[k] = ksc_round_up(c);
+                    static_cast<unsigned*>(P.xs)[pr[k] * RW + NW] = __float_as_uint(cf[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const long long p = pr[k];
+            const bool in = p < P.n;
+            // the list of the next selection, and the level counts that place its threshold
+            const bool lst = in && cf[k] > theta;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(lst);
+            if (bal) {
+                const int lane = tid & 63, leader = __builtin_ctzll(bal);
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&S->count, (unsigned)__builtin_popcountll(bal));
+                base = __shfl(base, leader);
+                if (lst) {
+                    const unsigned slot = base + (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    if (slot < (unsigned)KCB_CAP) S->list[slot] = p;
+                }
+            }
+#pragma unroll
+            for (int l = 1; l < KCB_NLEV; ++l) nlev[l] += (in && cf[k] > theta * kcb_level(l)) ? 1u : 0u;
+            if (in) {
+                if (cf[k] > bf || bi < 0) {
+                    bf = cf[k];
+                    bi = p;
+                    bknown = false;
+                } else if (cf[k] == bf) {
+                    if (!bknown) {
+                        bx = P.dist[bi];
+                        bknown = true;
+                    }
+                    const double v = P.dist[p];
+                    if (v > bx) {
+                        bx = v;
+                        bi = p;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 1; l < KCB_NLEV; ++l)
+        if (nlev[l]) atomicAdd(&slev[l], nlev[l]);
+    double bvx = -1.0;
+    if (bi >= 0) bvx = bknown ? bx : P.dist[bi];
+    rv[tid] = bvx;
+    ri[tid] = bi;
+    __syncthreads();
+    if (tid >= 1 && tid < KCB_NLEV && slev[tid]) atomicAdd(&S->lev[tid], slev[tid]);
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (tid < k) {
+            const long long oi = ri[tid + k];
+            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + k], oi, rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + k];
+                ri[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        KcPartial q;
+        q.v = rv[0];
+        q.i = ri[0];
+        P.next[blockIdx.x] = q;
+    }
+}
+
 // c0 = coordinates of the first centre (ids[0]), for the copy's origin
 // (sharded fit: `centre0` = the first centre's coordinates as selected from the exchanged records -- it may be another rank's row)
 __global__ void ksc_origin_kernel(const double* __restrict__ X, const msm_idx_t* __restrict__ ids, long long m, double* __restrict__ c0,
@@ -2004,7 +2428,7 @@ __global__ void ksc_origin_kernel(const double* __restrict__ X, const msm_idx_t*
 
 // what the last k-centers fit streamed (for bench.py's bytes-per-pass figure): pass counts and the bytes a pass reads per row
 struct KcStats {
-    long long rows = 0, plain_passes = 0, screened_passes = 0, plain_row_bytes = 0, screen_row_bytes = 0;
+    long long rows = 0, plain_passes = 0, screened_passes = 0, plain_row_bytes = 0, screen_row_bytes = 0, batch_fallbacks = 0;
 };
 static KcStats g_kc_stats;
 
@@ -2573,6 +2997,46 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                            else hipLaunchKernelGGL((ksc_convert_kernel<NP_, 0>), dim3(gconv), dim3(DT), 0, stream(), S); break;
                 MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
+            }
+            const char* be = getenv("MSM_KC_BATCH");   // 0: one centre per pass (A/B switch; read per fit)
+            if (fmt == 2 && !(be && atoi(be) == 0) && nblk <= 1024) {
+                // several centres per pass (kcb_select_kernel / kcenters_batch_pass_kernel): rounds of {selector, pass} are
+                // queued four at a time -- a round whose selector finds all K centres fixed is two empty launches -- and the
+                // host looks at the progress counter between the groups
+                DevBuf& SB = pool(PS_W);
+                if ((rc = SB.reserve(sizeof(KcbState)))) return rc;
+                KcbState* St = SB.as<KcbState>();
+                static KcbState init;   // (18 KiB: not on the stack; only the header is ever written or copied)
+                init.k_done = (int)it;
+                init.J = init.rounds = init.fallbacks = 0;
+                init.theta = INFINITY;
+                init.count = 0;
+                for (int l = 0; l < KCB_NLEV; ++l) init.lev[l] = 0;
+                MSM_HIP_CHECK(hipMemcpyAsync(St, &init, offsetof(KcbState, cen), hipMemcpyHostToDevice, stream()));
+                MSM_HIP_CHECK(hipStreamSynchronize(stream()));   // `init` is pageable host memory
+                int rounds = 0, done = (int)it;
+                while (done < (int)K) {
+                    for (int r = 0; r < 4; ++r, ++rounds) {
+                        S.prev = part + (size_t)((it + 1 + rounds) & 1) * nblk;   // partials of the last pass that ran
+                        S.next = part + (size_t)((it + rounds) & 1) * nblk;
+                        switch (np) {
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL((kcb_select_kernel<NP_>), dim3(1), dim3(1024), 0, stream(), S, St, (int)K); \
+                               hipLaunchKernelGGL((kcenters_batch_pass_kernel<NP_>), dim3(nblk), dim3(DT), 0, stream(), S, St); break;
+                            MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
+#undef MSM_KSC
+                        }
+                    }
+                    MSM_HIP_CHECK(hipGetLastError());
+                    MSM_HIP_CHECK(hipMemcpyAsync(&done, &St->k_done, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                    if (rounds > 4 * (int)K) return fail(MSM_ERR_HIP, "k-centers: the batched passes made no progress");
+                }
+                int rf[2] = {0, 0};
+                MSM_HIP_CHECK(hipMemcpyAsync(rf, &St->rounds, sizeof(rf), hipMemcpyDeviceToHost, stream()));
+                MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                g_kc_stats.screened_passes = rf[0];   // passes that streamed the copy (the empty rounds of the last group are not counted)
+                g_kc_stats.batch_fallbacks = rf[1];
+                it = K;
             }
             for (; it < K; ++it) {
                 S.it = (int)it;
