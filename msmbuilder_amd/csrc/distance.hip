@@ -2418,6 +2418,267 @@ __global__ __launch_bounds__(DT) void kcenters_batch_pass_kernel(KscArgs P, KcbS
     }
 }
 
+// ---- row-sharded fit: the same rounds with ONE exchange per round -----------------------------------------------------
+// A rank's round record (doubles): [0] rows it listed (more than KCB_CAPR: list unusable), [1..5] level counts, [8] value and
+// [9] GLOBAL row of its per-block-partials argmax (-1: none), [10..25] that row's coordinates, then from [32] on the listed
+// rows as {distance, global row, coordinates[m]}.  The records are all-gathered and every rank runs the same selection on
+// the same numbers: no rank learns anything another does not, so the batches -- and the number of rounds -- agree.
+constexpr int KCB_CAPR = 256, KCB_HDR = 32;
+__host__ __device__ constexpr size_t kcb_rec_doubles(long long m) { return (size_t)KCB_HDR + (size_t)KCB_CAPR * (size_t)(2 + m); }
+
+// the records of the first round, made from the one-centre protocol's gathered candidates {value, global row, coordinates}
+__global__ void kcb_boot_records_kernel(const double* __restrict__ cands, int world, long long m, double* __restrict__ recs)
+{
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (r >= world) return;
+    const double* c = cands + (size_t)r * (2 + m);
+    double* o = recs + (size_t)r * kcb_rec_doubles(m);
+    if (tid < KCB_HDR) {
+        double v = 0.0;
+        if (tid == 8) v = c[0];
+        else if (tid == 9) v = c[1];
+        else if (tid >= 10 && tid < 10 + 16) v = tid - 10 < m ? c[2 + tid - 10] : 0.0;
+        o[tid] = v;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(DT) void kcb_pack_kernel(KscArgs P, KcbState* S, double* __restrict__ rec)
+{
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    const int tid = threadIdx.x, m = (int)P.m;
+    if (S->J == 0) return;   // an empty round: nobody reads the record
+    double bv = -1.0;
+    long long bi = -1;
+    for (int k = tid; k < P.nblk; k += DT) {
+        const KcPartial q = P.next[k];
+        if (q.i >= 0 && (bi < 0 || kc_better(q.v, q.i, bv, bi))) {
+            bv = q.v;
+            bi = q.i;
+        }
+    }
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (tid < k) {
+            const long long oi = ri[tid + k];
+            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + k], oi, rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + k];
+                ri[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const long long w = ri[0];
+    const unsigned cnt = S->count;
+    if (tid < KCB_HDR) {
+        double v = 0.0;
+        if (tid == 0) v = (double)cnt;
+        else if (tid < KCB_NLEV) v = (double)S->lev[tid];
+        else if (tid == 8) v = w >= 0 ? rv[0] : -1.0;
+        else if (tid == 9) v = w >= 0 ? (double)(P.row_offset + w) : -1.0;
+        else if (tid >= 10 && tid < 26) v = (w >= 0 && tid - 10 < m) ? P.X[w * P.m + (tid - 10)] : 0.0;
+        rec[tid] = v;
+    }
+    const unsigned ne = cnt <= (unsigned)KCB_CAPR ? cnt : 0u;
+    for (unsigned e = tid; e < ne; e += DT) {
+        const long long p = S->list[e];
+        double* o = rec + KCB_HDR + (size_t)e * (2 + m);
+        o[0] = P.dist[p];
+        o[1] = (double)(P.row_offset + p);
+        for (int f = 0; f < m; ++f) o[2 + f] = P.X[p * P.m + f];
+    }
+}
+
+// a rank without rows: nothing listed, no argmax
+__global__ void kcb_empty_record_kernel(double* __restrict__ rec)
+{
+    if (threadIdx.x < KCB_HDR) rec[threadIdx.x] = (threadIdx.x == 8 || threadIdx.x == 9) ? -1.0 : 0.0;
+}
+
+template <int NP>
+__global__ __launch_bounds__(1024) void kcb_select_sharded_kernel(const double* __restrict__ recs, int world, long long mm, KcbState* S, int K,
+                                                                   double* __restrict__ cen_out, msm_idx_t* __restrict__ ids_out)
+{
+    __shared__ double rv[1024];
+    __shared__ long long ri[1024];
+    __shared__ double cs[16];
+    const int tid = threadIdx.x, m = (int)mm;
+    const size_t RD = kcb_rec_doubles(mm);
+    const int k0 = S->k_done;
+    if (k0 >= K) {
+        if (tid == 0) S->J = 0;
+        return;
+    }
+    auto reduce = [&](double v, long long i, double& ov, long long& oi) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const double v2 = __shfl_xor(v, s);
+            const long long i2 = __shfl_xor(i, s);
+            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
+                v = v2;
+                i = i2;
+            }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            rv[tid >> 6] = v;
+            ri[tid >> 6] = i;
+        }
+        __syncthreads();
+        const int l = tid & 15;
+        v = rv[l];
+        i = ri[l];
+#pragma unroll
+        for (int s = 8; s > 0; s >>= 1) {
+            const double v2 = __shfl_xor(v, s);
+            const long long i2 = __shfl_xor(i, s);
+            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
+                v = v2;
+                i = i2;
+            }
+        }
+        ov = v;
+        oi = i;
+    };
+    // the row the one-centre protocol would take: best of the ranks' own argmax records (value, lowest GLOBAL row on ties)
+    double vP;
+    long long iP;
+    int rP = -1;
+    {
+        double v = -1.0;
+        long long i = -1;
+        if (tid < world) {
+            const double* h = recs + (size_t)tid * RD;
+            if (h[9] >= 0.0) {
+                v = h[8];
+                i = (long long)h[9];
+            }
+        }
+        reduce(v, i, vP, iP);
+        for (int r = 0; r < world; ++r)
+            if (iP >= 0 && (long long)recs[(size_t)r * RD + 9] == iP) rP = r;
+    }
+    // union of the ranks' lists, level counts summed
+    unsigned total = 0, truecount = 0;
+    bool fits = true;
+    unsigned lev[KCB_NLEV];
+#pragma unroll
+    for (int q = 0; q < KCB_NLEV; ++q) lev[q] = 0;
+    for (int r = 0; r < world; ++r) {
+        const double* h = recs + (size_t)r * RD;
+        const unsigned c = (unsigned)h[0];
+        truecount += c;
+        if (c > (unsigned)KCB_CAPR) fits = false;
+        else total += c;
+#pragma unroll
+        for (int q = 1; q < KCB_NLEV; ++q) lev[q] += (unsigned)h[q];
+    }
+    const float theta = S->theta;
+    const bool usable = fits && total > 0 && total <= (unsigned)KCB_CAP && theta > 0.f && theta < 3e38f;
+    const double tau = (double)theta;
+    long long ci[2] = {-1, -1};
+    double cv[2] = {-1.0, -1.0}, cx[2][2 * NP];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        unsigned c = (unsigned)tid + 1024u * u;
+        if (usable && c < total) {
+            int r = 0;
+            for (; r < world; ++r) {
+                const unsigned cr = (unsigned)recs[(size_t)r * RD];
+                if (c < cr) break;
+                c -= cr;
+            }
+            const double* e = recs + (size_t)r * RD + KCB_HDR + (size_t)c * (2 + m);
+            cv[u] = e[0];
+            ci[u] = (long long)e[1];
+#pragma unroll
+            for (int f = 0; f < 2 * NP; ++f) cx[u][f] = f < m ? e[2 + f] : 0.0;
+        }
+    }
+    int J = 0, fell = 0;
+    double vlast = vP;
+    for (;;) {
+        double v = -1.0, vb;
+        long long i = -1, ib;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (ci[u] >= 0 && (i < 0 || kc_better(cv[u], ci[u], v, i))) {
+                v = cv[u];
+                i = ci[u];
+            }
+        reduce(v, i, vb, ib);
+        long long centre;
+        if (J == 0) {
+            if (usable && ib == iP) {
+                centre = ib;
+            } else {
+                centre = iP;
+                fell = 1;
+            }
+            vlast = vP;
+        } else {
+            if (!(ib >= 0 && vb > tau)) break;
+            centre = ib;
+            vlast = vb;
+        }
+        if (fell) {
+            if (tid < 16) cs[tid] = (rP >= 0 && tid < m) ? recs[(size_t)rP * RD + 10 + tid] : 0.0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (ci[u] == centre) {
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) cs[f] = f < 2 * NP ? cx[u][f] : 0.0;
+                }
+        }
+        if (tid == 0) ids_out[k0 + J] = centre;
+        __syncthreads();
+        if (tid < 16) S->cen[J][tid] = cs[tid];
+        if (tid < m) cen_out[(size_t)(k0 + J) * m + tid] = cs[tid];
+        ++J;
+        if (fell || k0 + J >= K || J >= KCB_JMAX) break;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (ci[u] < 0) continue;
+            if (ci[u] == centre) {
+                ci[u] = -1;
+                continue;
+            }
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int f = 0; f < 2 * NP; ++f) m_update<double, M_EUCLIDEAN>(a, b, cx[u][f], cs[f]);
+            const double d = m_final<M_EUCLIDEAN>(a, b, mm);
+            if (d < cv[u]) cv[u] = d;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float th;
+        const float vl = ksc_round_up(vlast > 0.0 ? vlast : 0.0);
+        if (!(theta > 0.f) || !(theta < 3e38f)) {
+            th = 0.97f * vl;
+        } else if (truecount > (unsigned)KCB_CAPR) {
+            th = theta * 1.02f;
+        } else {
+            int l = 0;
+            for (int q = 1; q < KCB_NLEV; ++q)
+                if (lev[q] <= (unsigned)KCB_CAPR) l = q;
+            th = theta * kcb_level(l);
+        }
+        if (th > vl) th = vl;
+        S->theta = th;
+        S->count = 0;
+        for (int q = 0; q < KCB_NLEV; ++q) S->lev[q] = 0;
+        S->J = J;
+        S->k_done = k0 + J;
+        S->rounds += 1;
+        S->fallbacks += fell;
+    }
+}
+
 // c0 = coordinates of the first centre (ids[0]), for the copy's origin
 // (sharded fit: `centre0` = the first centre's coordinates as selected from the exchanged records -- it may be another rank's row)
 __global__ void ksc_origin_kernel(const double* __restrict__ X, const msm_idx_t* __restrict__ ids, long long m, double* __restrict__ c0,
@@ -3306,7 +3567,143 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
     if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
     static const bool unfused = getenv("MSM_KC_UNFUSED") != nullptr;  // A/B switch: pass + candidate + select kernels
     const bool fused = !unfused && n > 0 && row_vecw<T>(X, m, false) > 0;  // register path (m <= FC): one kernel per centre
-    if (fused) {
+    // Several centres per exchange (kcb_*: threshold lists, an identical selection on every rank): float64 rows of <= 16
+    // features, euclidean.  The decision uses nothing a rank knows alone -- not its shard size, which may be zero --, because
+    // it changes the exchange pattern: PROBE all-gathers of one candidate, then one all-gather of a round record per round.
+    bool batched = false;
+    if constexpr (sizeof(T) == 8) {
+        const int probe = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 4;
+        const char* be = getenv("MSM_KC_BATCH");
+        batched = !unfused && mid == M_EUCLIDEAN && m <= FeatChunk<T>::FC && K > 8 && K > probe && ksc_enabled() && ksc_fmt() == 2 &&
+                  !(be && atoi(be) == 0);
+        if (batched) {
+            const msm_idx_t PROBE = probe;
+            const int np = (int)((m + 1) / 2);
+            const int nblk = (int)std::min<long long>(std::max<long long>(ceil_div(std::max<long long>(n, 1), DT), 1), KC_MAXBLK);
+            DevBuf& dPart = pool(PS_PART);
+            if ((rc = dPart.reserve((size_t)nblk * sizeof(KcPartial) + 16))) return rc;
+            unsigned* counter = reinterpret_cast<unsigned*>(dPart.as<KcPartial>() + nblk);
+            MSM_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned), stream()));
+            g_kc_stats = KcStats();
+            g_kc_stats.rows = n;
+            g_kc_stats.plain_row_bytes = (long long)(m * sizeof(T) + 16);
+            g_kc_stats.screen_row_bytes = (long long)(ksc_words(np, 2) * 4 + 4);
+            g_kc_stats.plain_passes = PROBE;
+            // ---- the first PROBE centres: one candidate per exchange, plain passes (a rank without rows keeps the pattern) ----
+            if (n > 0) {
+                KcArgs P;
+                memset(&P, 0, sizeof(P));
+                P.X = X;
+                P.n = n;
+                P.m = m;
+                P.nblk = nblk;
+                P.next = dPart.as<KcPartial>();
+                P.dist = distances;
+                P.labels = labels;
+                P.vecw = row_vecw<T>(X, m, false);
+                P.centers = cen;
+                P.prune = kc_prune_enabled();
+                P.sel_cands = cands;
+                P.sel_world = world;
+                P.sel_centers = cen;
+                P.sel_ids = dids;
+                P.cand_out = cand;
+                P.row_offset = row_offset;
+                P.counter = counter;
+                for (msm_idx_t it = 0; it < PROBE; ++it) {
+                    P.it = (int)it;
+                    launch_kc<T>(mid, nblk, P);
+                    if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
+                }
+            } else {
+                if ((rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, 0))) return rc;
+                for (msm_idx_t it = 0; it < PROBE; ++it) {
+                    if ((rc = kcenters_pass_dev_impl<T>(X, n, m, y, it, metric, labels, distances, row_offset, cand, cen))) return rc;
+                    if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
+                    if (it + 1 < PROBE && (rc = kcenters_select_impl<T>(cands, world, m, y, cen, dids, it + 1))) return rc;
+                }
+            }
+            MSM_HIP_CHECK(hipGetLastError());
+            // ---- rounds ----
+            const size_t RD = kcb_rec_doubles(m);
+            DevBuf& W = pool(PS_W);
+            const size_t stb = (sizeof(KcbState) + 15) / 16 * 16;
+            if ((rc = W.reserve(stb + (size_t)(1 + world) * RD * sizeof(double)))) return rc;
+            KcbState* St = W.as<KcbState>();
+            double* recL = reinterpret_cast<double*>(static_cast<char*>(W.p) + stb);
+            double* recsG = comm_active() ? recL + RD : recL;   // a world of one: the gathered records ARE the rank's record
+            static KcbState init;
+            init.k_done = (int)PROBE;
+            init.J = init.rounds = init.fallbacks = 0;
+            init.theta = INFINITY;
+            init.count = 0;
+            for (int l = 0; l < KCB_NLEV; ++l) init.lev[l] = 0;
+            MSM_HIP_CHECK(hipMemcpyAsync(St, &init, offsetof(KcbState, cen), hipMemcpyHostToDevice, stream()));
+            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+            hipLaunchKernelGGL(kcb_boot_records_kernel, dim3((unsigned)world), dim3(64), 0, stream(), cands, world, (long long)m, recsG);
+            KscArgs S;
+            memset(&S, 0, sizeof(S));
+            if (n > 0) {
+                KscBufs& B = ksc_bufs();
+                if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;
+                if ((rc = B.xf.reserve((size_t)n * (ksc_words(np, 2) + 1) * sizeof(float)))) return rc;
+                MSM_HIP_CHECK(hipMemsetAsync(B.misc.p, 0, 64, stream()));
+                S.X = reinterpret_cast<const double*>(X);
+                S.xs = B.xf.p;
+                S.gmax2 = B.misc.as<unsigned long long>();
+                S.c0 = reinterpret_cast<double*>(static_cast<char*>(B.misc.p) + 64);
+                S.n = n;
+                S.m = m;
+                S.nblk = nblk;
+                S.vecw = row_vecw<T>(X, m, false);
+                S.seed = seed;
+                S.dist = distances;
+                S.labels = labels;
+                S.ids = dids;
+                S.next = dPart.as<KcPartial>();
+                S.row_offset = row_offset;
+                hipLaunchKernelGGL(ksc_origin_kernel, dim3(1), dim3(64), 0, stream(), S.X, dids, (long long)m, S.c0,
+                                   reinterpret_cast<const double*>(cen));
+                const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
+                switch (np) {
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL((ksc_convert_kernel<NP_, 2>), dim3(gconv), dim3(DT), 0, stream(), S); break;
+                    MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
+#undef MSM_KSC
+                }
+            }
+            MSM_HIP_CHECK(hipGetLastError());
+            int rounds = 0, done = (int)PROBE;
+            while (done < (int)K) {
+                for (int r = 0; r < 4; ++r, ++rounds) {
+                    switch (np) {
+#define MSM_KSC(NP_) case NP_: \
+                        hipLaunchKernelGGL((kcb_select_sharded_kernel<NP_>), dim3(1), dim3(1024), 0, stream(), recsG, world, (long long)m, St, (int)K, \
+                                           reinterpret_cast<double*>(cen), dids); \
+                        if (n > 0) { \
+                            hipLaunchKernelGGL((kcenters_batch_pass_kernel<NP_>), dim3(nblk), dim3(DT), 0, stream(), S, St); \
+                            hipLaunchKernelGGL((kcb_pack_kernel<NP_>), dim3(1), dim3(DT), 0, stream(), S, St, recL); \
+                        } \
+                        break;
+                        MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
+#undef MSM_KSC
+                    }
+                    if (n <= 0) hipLaunchKernelGGL(kcb_empty_record_kernel, dim3(1), dim3(64), 0, stream(), recL);
+                    MSM_HIP_CHECK(hipGetLastError());
+                    if ((rc = comm_allgather(recL, recsG, RD * sizeof(double)))) return rc;
+                }
+                MSM_HIP_CHECK(hipMemcpyAsync(&done, &St->k_done, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                if (rounds > 4 * (int)K) return fail(MSM_ERR_HIP, "k-centers: the batched rounds made no progress");
+            }
+            int rf[2] = {0, 0};
+            MSM_HIP_CHECK(hipMemcpyAsync(rf, &St->rounds, sizeof(rf), hipMemcpyDeviceToHost, stream()));
+            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+            g_kc_stats.screened_passes = rf[0];
+            g_kc_stats.batch_fallbacks = rf[1];
+        }
+    }
+    if (batched) {
+    } else if (fused) {
         // every rank must take the same path or the all-gathers would not match: rows are a property of the data type and
         // width only, except for an EMPTY shard -- which therefore runs the generic kernels but keeps the exchange pattern
         DevBuf &dPart = pool(PS_PART);
