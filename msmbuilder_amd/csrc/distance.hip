@@ -2013,6 +2013,44 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
 // fall from pass to pass, so the next list fits).
 // ---------------------------------------------------------------------------
 constexpr int KCB_JMAX = 16, KCB_CAP = 2048, KCB_NLEV = 6, KCB_TARGET = 768;
+// ---- wave argmax of (value, row): largest value, lowest row among equal values; rows < 0 do not take part ---------------
+// The value goes through DPP row operations and readlanes (a 64-bit __shfl_xor is two ds_bpermute round trips per step:
+// the selection kernels make ~35 block reductions between two passes and were 30-45 us, most of it shuffles).
+template <int CTRL>
+__device__ __forceinline__ double kcb_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double kcb_readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ void kcb_wave_argmax(double v, long long i, double& ov, long long& oi)
+{
+    const double w = i >= 0 ? v : -1.0;     // distances are >= 0; a NaN loses every fmax
+    double x = w;
+    x = fmax(x, kcb_dpp_f64<0xB1>(x));      // quad_perm [1,0,3,2]
+    x = fmax(x, kcb_dpp_f64<0x4E>(x));      // quad_perm [2,3,0,1]
+    x = fmax(x, kcb_dpp_f64<0x141>(x));     // row_half_mirror
+    x = fmax(x, kcb_dpp_f64<0x140>(x));     // row_mirror: every lane holds the maximum of its row of 16
+    const double vm = fmax(fmax(kcb_readlane_f64(x, 0), kcb_readlane_f64(x, 16)), fmax(kcb_readlane_f64(x, 32), kcb_readlane_f64(x, 48)));
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(i >= 0 && w == vm);
+    if (!mask) mask = __builtin_amdgcn_ballot_w64(i >= 0);   // only NaN values took part: the lowest row, like a scan that never sees `>`
+    long long best = -1;
+    while (mask) {   // one lane, except on exact ties
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const long long c = ((long long)__builtin_amdgcn_readlane((int)(i >> 32), l) << 32) |
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(i & 0xffffffffLL), l);
+        if (best < 0 || c < best) best = c;
+    }
+    ov = vm;
+    oi = best;
+}
+
+
 struct KcbState {
     int k_done;               // centres fixed so far: ids[0 .. k_done)
     int J;                    // centres the next pass applies: ids[k_done - J .. k_done)
@@ -2037,38 +2075,20 @@ __global__ __launch_bounds__(1024) void kcb_select_kernel(KscArgs P, KcbState* S
         if (tid == 0) S->J = 0;
         return;
     }
-    // block argmax (largest value, lowest row on ties; rows < 0 never win): shuffles inside a wave, then every wave reduces the
-    // 16 wave winners by itself -- ONE barrier per call (the selection loop makes up to 17 of them between two passes)
+    // block argmax (largest value, lowest row on ties; rows < 0 never win): inside a wave by kcb_wave_argmax, then every wave
+    // reduces the 16 wave winners by itself -- two barriers per call (the selection loop makes up to 17 calls between passes)
     auto reduce = [&](double v, long long i, double& ov, long long& oi) {
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            const double v2 = __shfl_xor(v, s);
-            const long long i2 = __shfl_xor(i, s);
-            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
-                v = v2;
-                i = i2;
-            }
-        }
+        double wv;
+        long long wi;
+        kcb_wave_argmax(v, i, wv, wi);
         __syncthreads();   // the previous call's readers are done with rv / ri
         if ((tid & 63) == 0) {
-            rv[tid >> 6] = v;
-            ri[tid >> 6] = i;
+            rv[tid >> 6] = wv;
+            ri[tid >> 6] = wi;
         }
         __syncthreads();
-        const int l = tid & 15;
-        v = rv[l];
-        i = ri[l];
-#pragma unroll
-        for (int s = 8; s > 0; s >>= 1) {
-            const double v2 = __shfl_xor(v, s);
-            const long long i2 = __shfl_xor(i, s);
-            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
-                v = v2;
-                i = i2;
-            }
-        }
-        ov = v;
-        oi = i;
+        const int l = tid & 63;
+        kcb_wave_argmax(l < 16 ? rv[l] : -1.0, l < 16 ? ri[l] : -1, ov, oi);
     };
     // the row the per-block partials of the last pass name (the one-centre-per-pass loop's choice)
     double vP;
@@ -2513,35 +2533,17 @@ __global__ __launch_bounds__(1024) void kcb_select_sharded_kernel(const double* 
         return;
     }
     auto reduce = [&](double v, long long i, double& ov, long long& oi) {
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            const double v2 = __shfl_xor(v, s);
-            const long long i2 = __shfl_xor(i, s);
-            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
-                v = v2;
-                i = i2;
-            }
-        }
-        __syncthreads();
+        double wv;
+        long long wi;
+        kcb_wave_argmax(v, i, wv, wi);
+        __syncthreads();   // the previous call's readers are done with rv / ri
         if ((tid & 63) == 0) {
-            rv[tid >> 6] = v;
-            ri[tid >> 6] = i;
+            rv[tid >> 6] = wv;
+            ri[tid >> 6] = wi;
         }
         __syncthreads();
-        const int l = tid & 15;
-        v = rv[l];
-        i = ri[l];
-#pragma unroll
-        for (int s = 8; s > 0; s >>= 1) {
-            const double v2 = __shfl_xor(v, s);
-            const long long i2 = __shfl_xor(i, s);
-            if (i2 >= 0 && (i < 0 || kc_better(v2, i2, v, i))) {
-                v = v2;
-                i = i2;
-            }
-        }
-        ov = v;
-        oi = i;
+        const int l = tid & 63;
+        kcb_wave_argmax(l < 16 ? rv[l] : -1.0, l < 16 ? ri[l] : -1, ov, oi);
     };
     // the row the one-centre protocol would take: best of the ranks' own argmax records (value, lowest GLOBAL row on ties)
     double vP;
