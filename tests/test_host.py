@@ -486,6 +486,68 @@ def test_kcenters_byte_screen_margin_is_safe(scale, offset, m):
     assert worst >= 0.0
 
 
+@pytest.mark.parametrize("kind", ["gaussian", "lattice", "duplicates", "trajectory"])
+def test_kcenters_batched_selection_equals_the_sequential_scan(kind):
+    """The rule behind several k-centers centres per pass (csrc/distance.hip, kcb_select_kernel), played in numpy: list the
+    rows whose distance exceeds theta; the listed row of largest distance (lowest row on ties) is the next centre; the other
+    listed rows take d = min(d, dist(row, centre)); the next largest is the centre after that IF it is strictly above theta
+    (every unlisted row is at most theta, and distances only shrink) -- else a new pass.  The centre sequence must be the
+    one-centre-per-pass loop's (kcenters.py:79-102: argmax of distances_, first occurrence), also on integer lattices and
+    duplicated rows where ties are everywhere, whatever theta is."""
+    rs = np.random.RandomState({"gaussian": 1, "lattice": 2, "duplicates": 3, "trajectory": 4}[kind])
+    n, m, K = 6000, 4, 60
+    if kind == "gaussian":
+        X = rs.randn(n, m)
+    elif kind == "lattice":
+        X = rs.randint(-4, 5, size=(n, m)).astype(np.float64)
+    elif kind == "duplicates":
+        X = rs.randn(n // 6, m)[rs.randint(0, n // 6, n)]
+    else:
+        X = np.cumsum(rs.randn(n, m) * 0.1, axis=0)
+    def dist_to(c):
+        d = X - X[c]
+        return np.sqrt((d * d).sum(1))
+    # the reference loop
+    ref = [0]
+    dref = dist_to(0)
+    for _ in range(K - 1):
+        c = int(np.argmax(dref))
+        ref.append(c)
+        dref = np.minimum(dref, dist_to(c))
+    for theta_rule in (0.97, 0.8, 1.5, 0.0):
+        ids = [0]
+        dist = dist_to(0)
+        passes = 0
+        while len(ids) < K:
+            passes += 1
+            vmax = dist.max()
+            theta = theta_rule * vmax                                     # any threshold will do for correctness
+            listed = np.flatnonzero(dist > theta)
+            if len(listed) == 0 or len(listed) > 512:                      # empty / overflowed list: the partials' argmax alone
+                batch = [int(np.argmax(dist))]
+            else:
+                cv = dist[listed].copy()
+                alive = np.ones(len(listed), bool)
+                batch = []
+                while len(ids) + len(batch) < K and len(batch) < 16:
+                    if not alive.any():
+                        break
+                    v = np.where(alive, cv, -1.0)
+                    j = int(np.flatnonzero(v == v.max())[0])               # largest value, lowest row (listed is ascending)
+                    if batch and not (v[j] > theta):
+                        break
+                    batch.append(int(listed[j]))
+                    alive[j] = False
+                    d = X[listed] - X[listed[j]]
+                    cv = np.minimum(cv, np.sqrt((d * d).sum(1)))
+            for c in batch:                                                # the pass applies the batch in order
+                dist = np.minimum(dist, dist_to(c))
+            ids += batch
+        assert ids == ref, (kind, theta_rule)
+        if theta_rule == 0.97 and kind in ("gaussian", "trajectory"):
+            assert passes < K // 2                                         # and it does batch
+
+
 def test_dir_npy_dataset_payload_reader(tmp_path):
     """The container's host reads go through the native header parser (msm_npy_info) + memmap / fromfile; payloads the
     parser does not describe (structured dtypes) fall back to numpy's reader; writes are atomic renames; keys iterate in
