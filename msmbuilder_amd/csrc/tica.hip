@@ -2513,6 +2513,30 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
     if (kc < bk) kc = bk;
+    if (kc == KCMAX && total < 16LL * KCMAX * S && !useimg) {
+        // Few chunks per cohort (one rank's share of a strong-scaled fit: 1.25M frames = 7.35 chunks of 4096 per cohort, the
+        // busiest cohort does 8): cohorts take chunks round-robin, so the launch lasts as long as the fullest one.  Try smaller
+        // chunks and keep the size whose fullest cohort -- plus ~16 frames' worth of prologue per chunk -- is lightest.
+        long long best = -1, best_kc = kc;
+        std::vector<long long> load((size_t)S);
+        for (long long cand : {4096LL, 3072LL, 2560LL, 2048LL, 1536LL, 1024LL}) {
+            std::fill(load.begin(), load.end(), 0LL);
+            long long c = 0;
+            for (msm_idx_t s = 0; s < n_seq; ++s) {
+                const SegInfo g = seg_of(s);
+                if (g.len <= h->lag || g.oe <= g.ob) continue;
+                const long long own = g.oe - g.ob, nch = ceil_div(own, cand);
+                const long long piece = ceil_div(ceil_div(own, nch), bk) * bk;
+                for (long long r0 = 0; r0 < own; r0 += piece, ++c) load[(size_t)(c % S)] += std::min(piece, own - r0) + 16;
+            }
+            const long long worst = *std::max_element(load.begin(), load.end());
+            if (best < 0 || worst < best) {
+                best = worst;
+                best_kc = cand;
+            }
+        }
+        kc = best_kc;
+    }
 
     TicaArgs P;
     memset(&P, 0, sizeof(P));

@@ -4,7 +4,7 @@ import ctypes as C, os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from msmbuilder_amd import tICA, _lib
-F, T, n_seq = 512, 10000, 1000
+F, T, n_seq = 512, 10000, int(os.environ.get("N_SEQ", "1000"))
 X = torch.randn(n_seq * T, F, device="cuda")
 X += torch.rand(F, device="cuda") * 2 - 1
 seqs = list(X.view(n_seq, T, F).unbind(0))
