@@ -3219,7 +3219,10 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         // plain / screened from pass 16 / from pass 4 / from pass 1: tICA projection 26.6 / 13.1 / 11.8 / 11.8 ms, white
         // noise 33.7 / 15.1 / 13.3 / 17.6 ms, 40 separated blobs (where per-row pruning is at its best) 17.9 / 17.1 / 17.1 /
         // 17.5 ms -- so no decision is needed.
-        static const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 4;
+        // (with several centres per pass the early centres are cheap on the copy too -- one pass applies a batch of them to
+        //  every row, whatever fraction changes: 2 plain passes, tICA projection 4.53 -> 4.26 ms; 4 for one centre per pass)
+        const bool kcb_on = ksc_fmt() == 2 && !(getenv("MSM_KC_BATCH") && atoi(getenv("MSM_KC_BATCH")) == 0) && nblk <= 1024;
+        const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : (kcb_on ? 2 : 4);
         KscBufs& B = ksc_bufs();
         const int np = (int)((m + 1) / 2);
         if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;  // [gmax2[2] | ... | c0[16]]
@@ -3574,7 +3577,7 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
     // it changes the exchange pattern: PROBE all-gathers of one candidate, then one all-gather of a round record per round.
     bool batched = false;
     if constexpr (sizeof(T) == 8) {
-        const int probe = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 4;
+        const int probe = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 2;
         const char* be = getenv("MSM_KC_BATCH");
         batched = !unfused && mid == M_EUCLIDEAN && m <= FeatChunk<T>::FC && K > 8 && K > probe && ksc_enabled() && ksc_fmt() == 2 &&
                   !(be && atoi(be) == 0);
