@@ -548,6 +548,64 @@ def test_kcenters_batched_selection_equals_the_sequential_scan(kind):
             assert passes < K // 2                                         # and it does batch
 
 
+@pytest.mark.parametrize("scale,offset,m", [(1.0, 0.0, 10), (1e-3, 250.0, 7), (3e4, -1e6, 16), (1.0, 3e6, 2), (1e-12, 0.0, 5), (1e15, 0.0, 9)])
+def test_assign_screen_bound_holds(scale, offset, m):
+    """The float32 sweep of the screened assign_nearest (csrc/distance_small.hip, assign_screen_kernel): rows and centres
+    centred on centre 0 and rounded to float32, ``w_k = |c~_k|^2 - 2 x~.c~_k + (|x~|^2 + 2 Eh)`` with two partial dot products
+    (even / odd features), ``Eh = 1.01 (m' + 8) 2^-24 ((|x~| + max|c~|) 1.001)^2``.  What the kernel relies on, checked in
+    numpy with every float32 operation rounded (two roundings where the kernel has one fma: the bound covers both) against
+    extended-precision distances of the float64 data: ``|w_k - 2 Eh - D_k^2| <= Eh``, ``w_k >= 0``, and therefore for every
+    row ``v2 - 4 Eh <= min over k != k1 of D_k^2`` with v2 the second smallest key value, its low 8 bits cleared."""
+    f32 = np.float32
+    rs = np.random.RandomState(m + int(abs(offset)) % 83)
+    n, K = 20000, 48
+    X = rs.randn(n, m) * scale + offset
+    X[::9] = (rs.randn(len(X[::9]), m) * 5.0) * scale + offset
+    Y = X[rs.randint(0, n, K)].copy()
+    Y[5] = Y[2]                                                            # a duplicated centre
+    o = Y[0]
+    mp = m + (m & 1)
+    xt = np.zeros((n, mp), f32); xt[:, :m] = (X - o).astype(f32)
+    ct = np.zeros((K, mp), f32); ct[:, :m] = (Y - o).astype(f32)
+    def sq(v):
+        a = np.zeros(len(v), f32)
+        for f in range(mp):
+            a = (a + (v[:, f] * v[:, f]).astype(f32)).astype(f32)
+        return a
+    nx, nc = sq(xt), sq(ct)
+    if not (nc.max() <= 3e37 and np.all(nx <= 3e37)):
+        pytest.skip("beyond the float32 range: the kernel does not screen such data")
+    rnc = np.sqrt(nc.max()).astype(f32)
+    cE = f32((mp + 8) * 2.0 ** -24)
+    S = ((np.sqrt(nx).astype(f32) + rnc).astype(f32) * f32(1.001)).astype(f32)
+    Eh = (((cE * S).astype(f32) * S).astype(f32) * f32(1.01)).astype(f32)
+    off = (nx + (f32(2.0) * Eh).astype(f32)).astype(f32)
+    W = np.zeros((n, K), f32)
+    for k in range(K):
+        sx = (f32(-0.5) * off).astype(f32)
+        sy = np.zeros(n, f32)
+        for g in range(mp // 2):
+            sx = (sx + (xt[:, 2 * g] * ct[k, 2 * g]).astype(f32)).astype(f32)
+            sy = (sy + (xt[:, 2 * g + 1] * ct[k, 2 * g + 1]).astype(f32)).astype(f32)
+        w = (nc[k] + (f32(-2.0) * (sx + sy).astype(f32)).astype(f32)).astype(f32)
+        W[:, k] = np.maximum(w, f32(0.0))
+    Xl, Yl = X.astype(np.longdouble), Y.astype(np.longdouble)
+    D2 = np.stack([((Xl - Yl[k]) ** 2).sum(1) for k in range(K)], 1)
+    Ehl = Eh.astype(np.longdouble)[:, None]
+    err = np.abs(W.astype(np.longdouble) - 2 * Ehl - D2)
+    assert np.all(err <= Ehl), float((err / np.maximum(Ehl, np.longdouble(1e-300))).max())
+    assert np.all(W >= 0)
+    # the two smallest keys (index in the low 8 bits) and the bound the fast path uses
+    keys = (W.view(np.uint32) & np.uint32(0xffffff00)) | np.arange(K, dtype=np.uint32)[None, :]
+    order = np.argsort(keys, axis=1, kind="stable")
+    k1 = order[:, 0]
+    v2 = np.take_along_axis(keys, order[:, 1:2], 1)[:, 0]
+    v2 = (v2 & np.uint32(0xffffff00)).view(f32).astype(np.longdouble)
+    D2o = D2.copy()
+    D2o[np.arange(n), k1] = np.inf
+    assert np.all(v2 - 4 * Ehl[:, 0] <= D2o.min(1))
+
+
 def test_dir_npy_dataset_payload_reader(tmp_path):
     """The container's host reads go through the native header parser (msm_npy_info) + memmap / fromfile; payloads the
     parser does not describe (structured dtypes) fall back to numpy's reader; writes are atomic renames; keys iterate in
