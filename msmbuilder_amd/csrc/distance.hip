@@ -2012,7 +2012,7 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
 // lower levels, and the selector takes the lowest level that held at most KCB_TARGET rows (counts at a fixed level can only
 // fall from pass to pass, so the next list fits).
 // ---------------------------------------------------------------------------
-constexpr int KCB_JMAX = 16, KCB_CAP = 2048, KCB_NLEV = 6, KCB_TARGET = 768;
+constexpr int KCB_JMAX = 16, KCB_CAP = 2048, KCB_NLEV = 6, KCB_TARGET = 1536;
 // ---- wave argmax of (value, row): largest value, lowest row among equal values; rows < 0 do not take part ---------------
 // The value goes through DPP row operations and readlanes (a 64-bit __shfl_xor is two ds_bpermute round trips per step:
 // the selection kernels make ~35 block reductions between two passes and were 30-45 us, most of it shuffles).
