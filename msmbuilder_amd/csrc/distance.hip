@@ -2012,7 +2012,7 @@ __global__ __launch_bounds__(DT) void ksc_convert_kernel(KscArgs P)
 // lower levels, and the selector takes the lowest level that held at most KCB_TARGET rows (counts at a fixed level can only
 // fall from pass to pass, so the next list fits).
 // ---------------------------------------------------------------------------
-constexpr int KCB_JMAX = 16, KCB_CAP = 2048, KCB_NLEV = 6, KCB_TARGET = 1536;
+constexpr int KCB_JMAX = 32, KCB_CAP = 2048, KCB_NLEV = 6, KCB_TARGET = 1536;
 // ---- wave argmax of (value, row): largest value, lowest row among equal values; rows < 0 do not take part ---------------
 // The value goes through DPP row operations and readlanes (a 64-bit __shfl_xor is two ds_bpermute round trips per step:
 // the selection kernels make ~35 block reductions between two passes and were 30-45 us, most of it shuffles).
@@ -2255,8 +2255,8 @@ __global__ __launch_bounds__(DT) void kcenters_batch_pass_kernel(KscArgs P, KcbS
     // the batch's centres: exact coordinates, float32 coordinates relative to the copy's origin, and the part of eps that
     // belongs to the centre (see kcenters_screen_pass_kernel for the terms)
     if (tid < KCB_NLEV) slev[tid] = 0;
-    if (tid < KCB_JMAX * 2 * NP) {
-        const int j = tid / (2 * NP), f = tid - j * (2 * NP);
+    for (int e = tid; e < KCB_JMAX * 2 * NP; e += DT) {
+        const int j = e / (2 * NP), f = e - j * (2 * NP);
         const double y = j < J ? S->cen[j][f] : 0.0;
         yd[j][f] = y;
         reinterpret_cast<float*>(&ycf[j][0])[f] = (float)(y - (f < m ? P.c0[f] : 0.0));
