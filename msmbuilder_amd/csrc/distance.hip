@@ -524,12 +524,12 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         q.v = rv[0];
         q.i = ri[0];
         if (P.cand_out) {
-            // sharded fit: the last block to arrive reads every block's partial -- published WRITE-THROUGH (agent-scope
-            // relaxed atomics = sc1 stores, drained before the arrival counter is bumped; the reader uses sc1 loads): no L2
-            // write-back / invalidate per block, which cost the 1,024 blocks of a pass more than the pass itself on a
-            // small shard (MI355X_MICROARCH.md, "valid forms": sc1 payload -> vmcnt(0) -> sc1 counter)
+            // sharded fit: the last block to arrive reads every block's partial -- published write-through (agent-scope
+            // relaxed atomics = sc1 stores, so the release fence finds nothing of this block's dirty in the L2), then an
+            // agent-scope RELEASE fence, drained, before the arrival ticket; the last arriver takes an ACQUIRE fence
             __hip_atomic_store(&P.next[blockIdx.x].v, q.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&P.next[blockIdx.x].i, q.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // round 4: the ticket below is taken behind a release
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             P.next[blockIdx.x] = q;
@@ -541,6 +541,7 @@ __global__ __launch_bounds__(DT) void kcenters_pass_kernel(KcArgs P)
         if (tid == 0) {
             const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             am_last = prev == gridDim.x - 1;
+            if (am_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ... and the last arriver acquires
         }
         __syncthreads();
         if (am_last) {
@@ -1832,12 +1833,12 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         q.v = rv[0];
         q.i = ri[0];
         if (P.cand_out) {
-            // sharded fit: the last block to arrive reads every block's partial -- published WRITE-THROUGH (agent-scope
-            // relaxed atomics = sc1 stores, drained before the arrival counter is bumped; the reader uses sc1 loads): no L2
-            // write-back / invalidate per block, which cost the 1,024 blocks of a pass more than the pass itself on a
-            // small shard (MI355X_MICROARCH.md, "valid forms": sc1 payload -> vmcnt(0) -> sc1 counter)
+            // sharded fit: the last block to arrive reads every block's partial -- published write-through (agent-scope
+            // relaxed atomics = sc1 stores, so the release fence finds nothing of this block's dirty in the L2), then an
+            // agent-scope RELEASE fence, drained, before the arrival ticket; the last arriver takes an ACQUIRE fence
             __hip_atomic_store(&P.next[blockIdx.x].v, q.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&P.next[blockIdx.x].i, q.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // round 4: the ticket below is taken behind a release
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             P.next[blockIdx.x] = q;
@@ -1849,6 +1850,7 @@ __global__ __launch_bounds__(DT) void kcenters_screen_pass_kernel(KscArgs P)
         if (tid == 0) {
             const unsigned prev = __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             am_last = prev == gridDim.x - 1;
+            if (am_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ... and the last arriver acquires
         }
         __syncthreads();
         if (am_last) {

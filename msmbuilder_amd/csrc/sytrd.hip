@@ -57,12 +57,11 @@ __device__ __forceinline__ double trd_block_sum(double x, double* red, int tid)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Exchange buffers are written and read with agent-scope relaxed atomics (`global_store/load_dwordx2 ... sc1`): coherent
-// across the XCDs' L2s by themselves, so the barrier needs no L2 write-back / invalidate of its own (a release that has
-// to walk a write-back L2 costs microseconds, per column).  Measured alternatives: release/acquire atomics on the flags
-// with plain data accesses 4.4 ms at n = 512; a barrier-free variant in which every double carries its step stamp and
-// every wave polls its own elements 5.9 ms (the polling traffic of 128 waves on 16 KiB of lines is the bottleneck);
-// this one 2.8 ms including 4 MB of copies -- two fabric round trips (flags, then data) of ~1.5 us per column.
+// Exchange buffers are written and read with agent-scope relaxed atomics (`global_store/load_dwordx2 ... sc1`: write-through
+// stores, L1-bypassing loads), which keeps the release fence of the grid barrier below cheap -- the L2 holds nothing dirty
+// of this kernel's for it to write back.  Since round 4 the barrier itself is a release fence / acquire fence pair at
+// agent scope (see the loop): the sc1 accesses alone are a form MI355X_MICROARCH.md lists as valid on gfx950, but not one
+// the memory model promises.  The kernel sits on the solve's FALLBACK route only (subspace.hip is the default).
 __device__ __forceinline__ void trd_store(double* p, double x)
 {
     __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -156,11 +155,17 @@ __global__ __launch_bounds__(TRD_NT, 1) void sytrd_coop_kernel(TrdArgs P)
                 }
             }
         }
-        // ---- grid barrier i: stamp = i + 1 (flag per workgroup; one wave polls all flags, one lane each)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's exchange stores have left
+        // ---- grid barrier i: stamp = i + 1 (flag per workgroup; one wave polls all flags, one lane each).
+        // Publication order (round 4): the workgroup's exchange stores -> workgroup barrier -> ONE agent-scope
+        // RELEASE fence (lane 0) -> drained -> flag store; on the other side relaxed polls -> ONE agent-scope ACQUIRE fence
+        // by the polling wave -> workgroup barrier -> the exchange loads.  (Rounds 2-3 published the flag behind a
+        // workgroup-scope fence only and relied on the sc1 form of the data accesses.)
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(P.flags + g, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back is complete before the flag can be seen
+            __hip_atomic_store(P.flags + g, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (wave == 0) {
             const long long t0 = clock64();
             for (;;) {
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(TRD_NT, 1) void sytrd_coop_kernel(TrdArgs P)
                     break;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
         if (bail) return;

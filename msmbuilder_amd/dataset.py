@@ -105,8 +105,9 @@ class NumpyDirDataset(object):
         self._say('reading', name)
         try:
             return _Payload(name).host_array(mmap)
-        except ValueError:
-            # structured / object / big-endian payloads are not device material; numpy still reads them
+        except (ValueError, OSError, _lib.MsmHipError):
+            # structured / object / big-endian payloads are not device material; numpy still reads them -- and a plain
+            # host read of a file (no compute) must not depend on libmsmhip.so being loadable on this machine
             return np.load(name, mmap_mode='r' if mmap else None, allow_pickle=False)
 
     def set(self, i, x):
@@ -120,6 +121,10 @@ class NumpyDirDataset(object):
         try:
             with os.fdopen(fd, 'wb') as f:
                 np.lib.format.write_array(f, np.asanyarray(x), allow_pickle=False)
+            # mkstemp creates 0600 files; np.save (what the reference uses, dataset.py:323) honours the umask
+            umask = os.umask(0)
+            os.umask(umask)
+            os.chmod(tmp, 0o666 & ~umask)
             os.replace(tmp, name)
         except BaseException:
             if os.path.exists(tmp):

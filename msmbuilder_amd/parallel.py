@@ -285,6 +285,7 @@ def allreduce_tica(model, group=None):
     model.n_sequences_ = int(nseq.value)
     model._host_stale = True
     model._is_dirty = True
+    model._mu_raw = None   # a mean cached by a device solve of the LOCAL accumulators is not the reduced model's
     return model
 
 

@@ -35,6 +35,18 @@ assert m.n_observations_ == ref.n_observations_ and m.n_sequences_ == ref.n_sequ
 np.testing.assert_allclose(m.eigenvalues_, ref.eigenvalues_, rtol=1e-11)
 np.testing.assert_allclose(m.means_, ref.means_, rtol=1e-12)
 
+# partial_fit -> read eigenvalues_ (the device solve caches the LOCAL mean) -> allreduce -> means_ / covariance_ must be
+# those of the reduced model (ADVICE r3: the cached mean used to survive the all-reduce)
+m2 = tICA(n_components=3, lag_time=5)
+for i in mine:
+    m2.partial_fit(seqs[i])
+_ = m2.eigenvalues_
+m2.allreduce()
+np.testing.assert_allclose(m2.means_, ref.means_, rtol=1e-12)
+np.testing.assert_allclose(m2.covariance_, ref.covariance_, rtol=1e-10, atol=1e-13)
+np.testing.assert_allclose(m2.offset_correlation_, ref.offset_correlation_, rtol=1e-10, atol=1e-13)
+np.testing.assert_allclose(m2.eigenvalues_, ref.eigenvalues_, rtol=1e-11)
+
 # ---- tICA: SPMD fit of ONE long trajectory cut between the ranks (lag-row right halo)
 long = [(rs.randn(5000, 12) * 0.7 + 0.3).astype(np.float32), seqs[0], seqs[1][:4]]
 ms = tICA(n_components=3, lag_time=7).fit_sharded(long)

@@ -317,6 +317,10 @@ def test_dir_npy_dataset_host_protocol(tmp_path):
     ro = dataset(path, mode="r")
     assert list(ro.keys()) == [0, 1, 2] and len(ro) == 3
     assert sorted(os.listdir(path)) == ["00000000.npy", "00000001.npy", "00000002.npy", "PROVENANCE.txt"]
+    umask = os.umask(0)
+    os.umask(umask)
+    for name in ("00000000.npy", "00000002.npy"):          # np.save's permissions (umask), not mkstemp's 0600
+        assert (os.stat(os.path.join(path, name)).st_mode & 0o777) == (0o666 & ~umask)
     for a, b in zip(arrays, ro):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(ro.get(2, mmap=True)[7], arrays[2][7])
