@@ -146,10 +146,9 @@ int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until 
  * X[:-tau].T @ X[tau:] is not kept. */
 int msm_tica_lagged_symmetrised(msm_tica_t* h, int* flag);
 /* HIP-event duration (ms) of the most recent MFMA accumulation launch of this handle,
- * measured on the stream it ran on (bench.py's roofline leg); synchronises on it. */
+ * measured on the stream it ran on (bench.py's roofline leg); synchronises on it.  bf16 modes: the whole
+ * pack-and-multiply pipeline (the packing of super-chunk k + 1 overlaps the MFMA kernel of super-chunk k). */
 int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
-/* bf16 modes: duration (ms) of the packed-image pre-pass that preceded that MFMA launch (0 when there was none) */
-int msm_tica_last_prepass_ms(msm_tica_t* h, float* ms);
 /* 1 when the most recent accumulation launch had no column-sum pass over X of its own: the sum/difference kernel's
  * staging lanes summed the left frames (float32 input, whole trajectories of >= 2 lag frames, n_features % 128 == 0, at
  * least MSM_TICA_FOLD_MIN = 2^26 elements; MSM_TICA_FOLD=0 disables).  The sums (tica.py:418-419) and the finite check

@@ -87,7 +87,6 @@ def _declare(lib):
     f("msm_tica_export_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_import_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_project", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, _i64, _p, C.c_int, C.c_int)
-    f("msm_tica_last_prepass_ms", C.c_int, _p, C.POINTER(C.c_float))
     f("msm_tica_last_folded", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_allreduce", C.c_int, _p)
     f("msm_tica_counts", C.c_int, _p, _i64p, _i64p)

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -246,6 +247,28 @@ DevBuf& pool(int slot)
 {
     static DevBuf* slots = new DevBuf[PS_COUNT];  // intentionally leaked (outlives HIP teardown)
     return slots[slot];
+}
+
+// The bf16 image path's ring (tica.hip): ONE buffer per process, created with the first bf16-mode handle, never per fit --
+// round 3 reserved a whole-input image per handle inside the timed fit (an 8 - 16 GB hipMalloc = 0.25 - 0.5 s).
+ImgRing* img_ring()
+{
+    static ImgRing* P = nullptr;   // intentionally leaked
+    if (P) return P;
+    ImgRing* q = new ImgRing();
+    const char* e = getenv("MSM_TICA_IMG_RING_MB");
+    size_t mb = e ? (size_t)atoll(e) : 1024;
+    if (mb < 64) mb = 64;
+    if (mb > 65536) mb = 65536;
+    q->bytes = mb << 20;
+    const hipError_t err = hipMalloc((void**)&q->p, q->bytes);
+    if (err != hipSuccess) {
+        set_error("bf16 image ring: hipMalloc(%zu MB) failed: %s", mb, hipGetErrorString(err));
+        delete q;
+        return nullptr;
+    }
+    P = q;
+    return P;
 }
 
 int metric_id(const char* name)

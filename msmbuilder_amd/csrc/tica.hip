@@ -19,6 +19,7 @@
 // The cohort's workgroups read the same frames at the same time and are placed on
 // one XCD where possible, so the 13x panel re-read (F=512) is L2 traffic, not HBM.
 #include "common.h"
+#include "tica_img_dev.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1228,192 +1229,6 @@ __global__ __launch_bounds__(NT, 2) void tica_mfma_f64_kernel(TicaArgs P)
 }
 
 // ---------------------------------------------------------------------------
-// bf16 kernels (BASELINE config 5: "bf16-MFMA covariance vs fp32"): v_mfma_f32_32x32x16_bf16,
-// fp32 accumulate, 16x the fp32 MFMA rate.
-//   X3 = false ("bf16")  : inputs rounded to bf16 (RNE), one product   (eigenvalue rtol 1e-3)
-//   X3 = true  ("bf16x2"): split x = hi + mid (two bf16 terms, 16 significant bits), all four
-//               products hi*hi + hi*mid + mid*hi + mid*mid: what is dropped is the 2^-17-relative,
-//               random-signed remainder x - hi - mid, so sums over frames keep fp32-class accuracy
-//               at 4/16 of the fp32 MFMA time.  (Without mid*mid the Gram diagonal is biased low by
-//               sum(mid^2): measured 2.9e-6 relative.)
-// The bf16 MFMA wants 8 CONSECUTIVE FRAMES of one feature per lane, i.e. a column walk of the
-// frame-major data.  The transpose is done in registers while staging: a thread loads the same
-// float4 (4 features) from 8 consecutive frames, converts, and writes one 16-byte
-// [8 frames] packet per feature into an LDS image [frame-group][feature][8]; fragments are then
-// plain conflict-free ds_read_b128.  With the MFMA phase this short the kernel is bound by the
-// L2 -> LDS staging path, not by the matrix pipe.
-// ---------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BKB = 32;  // frames per K-step: 4 groups of 8
-
-template <bool X3>
-struct StageB {
-    float4 v[8];  // 8 consecutive frames x 4 features of this thread's panel (A for threads 0-127, B for 128-255)
-    float sc[8];  // A-side weights
-};
-
-template <bool VEC4>
-__device__ __forceinline__ void stageB_load(float4 (&v)[8], float (&sc)[8], const ChunkCtx& cx, int F, int k0,
-                                            int isG, int col0, bool isB, int tid)
-{
-    const int c4 = (tid & 31) * 4;
-    const int kg = (tid >> 5) & 3;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int kr = k0 + kg * 8 + r;
-        float w = (kr < cx.hi) ? 1.f : 0.f;
-        if (isG) w += (kr >= cx.lo && kr < cx.n) ? 1.f : 0.f;
-        const int lim = isB ? cx.nmaxB : cx.nmax;
-        const int rr = kr < lim ? kr : lim;
-        v[r] = load_row4<VEC4>(isB ? cx.baseB : cx.base, (unsigned)rr * cx.ldb, col0 + c4, F);
-        sc[r] = isB ? 1.f : w;
-    }
-}
-
-template <bool X3>
-__device__ __forceinline__ void stageB_store(const float4 (&v)[8], const float (&sc)[8], bf16x8* hi, bf16x8* mid,
-                                             float4 colmask, float4 shift, int tid)
-{
-    const int c4 = (tid & 31) * 4;
-    const int kg = (tid >> 5) & 3;
-    const float m4[4] = {colmask.x, colmask.y, colmask.z, colmask.w};
-    const float r4[4] = {shift.x, shift.y, shift.z, shift.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bf16x8 h, m;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            // mean shift BEFORE the bf16 rounding: 8 (16) significant bits are spent on x - r, not on the column mean
-            const float x = ((q == 0 ? v[r].x : q == 1 ? v[r].y : q == 2 ? v[r].z : v[r].w) - r4[q]) * (sc[r] * m4[q]);
-            const __bf16 xh = (__bf16)x;
-            h[r] = xh;
-            if (X3) m[r] = (__bf16)(x - (float)xh);
-        }
-        hi[kg * TM + c4 + q] = h;
-        if (X3) mid[kg * TM + c4 + q] = m;
-    }
-}
-
-template <bool VEC4, bool X3>
-__global__ __launch_bounds__(NT, 2) void tica_mfma_bf16_kernel(TicaArgs P)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // per buffer: Ah [4][128] packets, Bh [4][128], (X3: Am, Bm)
-    constexpr int PK = 4 * TM;                     // packets per panel image
-    constexpr int IMG = (X3 ? 4 : 2) * PK;         // packets per buffer
-    bf16x8* L = reinterpret_cast<bf16x8*>(smem);   // [2][IMG]
-
-    const int tid = threadIdx.x;
-    const int p = xcd_linear_id();
-    const int cohort = p / P.ntiles, tile = p % P.ntiles;
-    int I, J, isG;
-    decode_tile(tile, P.T, I, J, isG);
-    const int I0 = I * TM, J0 = J * TM;
-    const int tauB = isG ? 0 : P.lag;
-    const bool isB = tid >= 128;                   // this thread stages the B panel
-    const int col0 = isB ? J0 : I0;
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int kl = lane >> 5, cl = lane & 31;
-    double* slab = P.slabs + (size_t)p * (TM * TM);
-    const int c4 = (tid & 31) * 4;
-    const float4 cm = make_float4(col0 + c4 + 0 < P.F ? 1.f : 0.f, col0 + c4 + 1 < P.F ? 1.f : 0.f,
-                                  col0 + c4 + 2 < P.F ? 1.f : 0.f, col0 + c4 + 3 < P.F ? 1.f : 0.f);
-
-    const float4 rsh = load_shift4(P.shift, col0 + c4, P.F);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-        for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
-    int rows_acc = 0;
-
-    for (long long c = cohort; c < P.nchunks; c += P.S) {
-        const TicaChunk ch = get_chunk(P, c);
-        const int nsteps = (ch.n + BKB - 1) / BKB;
-        ChunkCtx cx = make_ctx(P, ch);
-        set_lag(cx, tauB, sizeof(float), P.ld);
-
-        StageB<X3> s0, s1;
-        stageB_load<VEC4>(s0.v, s0.sc, cx, P.F, 0, isG, col0, isB, tid);
-        stageB_store<X3>(s0.v, s0.sc, L + (isB ? PK : 0), L + (isB ? PK : 0) + 2 * PK, cm, rsh, tid);
-        stageB_load<VEC4>(s0.v, s0.sc, cx, P.F, BKB, isG, col0, isB, tid);
-        __syncthreads();
-#define MSM_TICA_STEPB(SNEXT, SLOAD, BUF)                                                         \
-        {                                                                                         \
-            stageB_load<VEC4>(SLOAD.v, SLOAD.sc, cx, P.F, (s + 2) * BKB, isG, col0, isB, tid);    \
-            const bf16x8* Ah = L + (BUF) * IMG;                                                   \
-            const bf16x8* Bh = Ah + PK;                                                           \
-            _Pragma("unroll") for (int q = 0; q < BKB / 16; ++q) {                                \
-                const int kg = 2 * q + kl;                                                        \
-                const bf16x8 a0 = Ah[kg * TM + wr * 64 + cl], a1 = Ah[kg * TM + wr * 64 + 32 + cl]; \
-                const bf16x8 b0 = Bh[kg * TM + wc * 64 + cl], b1 = Bh[kg * TM + wc * 64 + 32 + cl]; \
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);  \
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);  \
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);  \
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);  \
-                if (X3) {                                                                         \
-                    const bf16x8* Am = Ah + 2 * PK;                                               \
-                    const bf16x8* Bm = Am + PK;                                                   \
-                    const bf16x8 am0 = Am[kg * TM + wr * 64 + cl], am1 = Am[kg * TM + wr * 64 + 32 + cl]; \
-                    const bf16x8 bm0 = Bm[kg * TM + wc * 64 + cl], bm1 = Bm[kg * TM + wc * 64 + 32 + cl]; \
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bm0, acc[0][0], 0, 0, 0); \
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bm1, acc[0][1], 0, 0, 0); \
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bm0, acc[1][0], 0, 0, 0); \
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bm1, acc[1][1], 0, 0, 0); \
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, b0, acc[0][0], 0, 0, 0); \
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, b1, acc[0][1], 0, 0, 0); \
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, b0, acc[1][0], 0, 0, 0); \
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, b1, acc[1][1], 0, 0, 0); \
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, bm0, acc[0][0], 0, 0, 0); \
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, bm1, acc[0][1], 0, 0, 0); \
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bm0, acc[1][0], 0, 0, 0); \
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bm1, acc[1][1], 0, 0, 0); \
-                }                                                                                 \
-            }                                                                                     \
-            if (s + 1 < nsteps) {                                                                 \
-                bf16x8* dst = L + ((BUF) ^ 1) * IMG + (isB ? PK : 0);                             \
-                stageB_store<X3>(SNEXT.v, SNEXT.sc, dst, dst + 2 * PK, cm, rsh, tid);             \
-            }                                                                                     \
-            __syncthreads();                                                                      \
-        }
-        for (int s = 0; s < nsteps; s += 2) {
-            MSM_TICA_STEPB(s0, s1, 0)
-            ++s;
-            if (s < nsteps) MSM_TICA_STEPB(s1, s0, 1)
-            --s;
-        }
-#undef MSM_TICA_STEPB
-        rows_acc += ch.n;
-        if (rows_acc + P.kc > KFLUSH || c + P.S >= P.nchunks) {
-            rows_acc = 0;
-            unsigned toff = (unsigned)((wr * 64 + 4 * kl) * TM + wc * 64 + cl);
-            asm volatile("" : "+v"(toff));
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi) {
-                double old[2][16];
-#pragma unroll
-                for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        old[bj][r] = (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff];
-#pragma unroll
-                for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff] = old[bj][r] + (double)acc[bi][bj][r];
-                        acc[bi][bj][r] = 0.f;
-                    }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // bf16 image path (modes `bf16` / `bf16x2`, BASELINE configs[4]): the sum/difference form of 3.1b on the bf16 matrix
 // pipe, in two kernels.
 //
@@ -1440,6 +1255,7 @@ struct ImgArgs {
     long long ld;
     int F, Fp, lag, dtype_bytes;
     const float* shift;
+    long long g_off; // first 8-pair group of the super-chunk being packed: the ring slot holds groups [g_off, g_off + G)
     bf16x8* u_hi;   // [G][Fp] packets
     bf16x8* d_hi;
     bf16x8* u_mid;  // bf16x2 only
@@ -1530,7 +1346,7 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
                     dm[e] = (__bf16)(d - (float)d1);
                 }
             }
-            const size_t o = (size_t)(ch.g0 + gi) * (size_t)P.Fp + (size_t)(f0 + q);
+            const size_t o = (size_t)(ch.g0 - P.g_off + gi) * (size_t)P.Fp + (size_t)(f0 + q);
             P.u_hi[o] = uh;
             P.d_hi[o] = dh;
             if (X2) {
@@ -1553,200 +1369,7 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
     }
 }
 
-struct ImgMfmaArgs {
-    const bf16x8* u_hi;
-    const bf16x8* d_hi;
-    const bf16x8* u_mid;
-    const bf16x8* d_mid;
-    long long nsteps;  // K-steps in the image (bf16: 4 groups = 32 pairs each; bf16x2: 2 groups = 16 pairs each)
-    int Fp, T, T2, ntiles_sym, ntile2, S, kflush_steps;
-    double* slabs;     // sum/difference layout: [S * ntiles_sym][2][TM * TM]
-};
-
-constexpr int IMG_NT = 512;                       // 8 waves: 4 (rows) x 2 (columns), each 64 x 128 outputs
-constexpr int IMG_SLOTS = 3;                      // LDS ring: K-steps s (being multiplied), s + 1 (complete), s + 2 (being written)
-constexpr size_t IMG_LDS = (size_t)IMG_SLOTS * 2 * 4 * 256 * 16;  // 96 KiB: [3 slots][A, B][4 packet rows][256 features] 16-byte packets
-
-// Round 3: fragments PREFETCHED ACROSS THE BARRIER.  With two LDS buffers every K-step began, for all eight waves at once,
-// with its fragment reads behind the barrier (and the second k-half's reads behind the first half's MFMAs): the matrix
-// pipe idled for two LDS round trips per step (MFMA busy 0.43, 2,500 cycles per step against 1,024 of MFMA work).  With a
-// ring of three slots step s + 1 is complete in LDS while step s is multiplied, so a wave reads the FIRST fragment set of
-// step s + 1 during step s and starts its MFMAs right behind the barrier; the second set is read at the top of the step,
-// under those MFMAs.  The accumulation order per accumulator is unchanged (bit-identical sums).
-template <bool X2>
-__global__ __launch_bounds__(IMG_NT, 1) void tica_img_mfma_kernel(ImgMfmaArgs P)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16x8* L = reinterpret_cast<bf16x8*>(smem);   // [3][2][4][256]
-    constexpr int PAN = 4 * 256;                   // packets per panel
-    const int tid = threadIdx.x;
-    const int p = xcd_linear_id();
-    const int cohort = p / P.ntile2, tile = p % P.ntile2;
-    const int which = tile & 1;                    // 0: H = sum u u^T, 1: D = sum d d^T
-    int I = 0, uix = tile >> 1;
-    while (uix >= P.T2 - I) {
-        uix -= P.T2 - I;
-        ++I;
-    }
-    const int J = I + uix;
-    const bf16x8* hi = which ? P.d_hi : P.u_hi;
-    const bf16x8* mid = which ? P.d_mid : P.u_mid;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int kl = lane >> 5, cl = lane & 31;
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-        for (int bj = 0; bj < 4; ++bj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
-
-    // this cohort's contiguous share of the K-steps
-    const long long s0 = P.nsteps * cohort / P.S, s1 = P.nsteps * (cohort + 1) / P.S;
-    // staging: panel = 4 packet rows x 256 features; thread -> packets tid and tid + 512 of A and of B
-    //   bf16  : packet rows = pair groups 4 s .. 4 s + 3 of the hi image
-    //   bf16x2: rows 0-1 = groups 2 s, 2 s + 1 of the hi image, rows 2-3 = the same groups of the mid image
-    const int c0 = tid & 255, q0 = tid >> 8;  // q0 in {0, 1}: packet rows q0 and q0 + 2
-    raw_f32x4 ra[2], rb[2], na[2], nb[2];
-    // (steps beyond the share are clamped to its last one: never out of the image, loaded and stored but not multiplied)
-#define MSM_IMG_LOAD(RA, RB, S_)                                                                   \
-    {                                                                                              \
-        const long long sc_ = (S_) < s1 ? (S_) : s1 - 1;                                           \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                            \
-            const int row = q0 + 2 * h;                                                            \
-            const bf16x8* src = (X2 && row >= 2) ? mid : hi;                                       \
-            const long long g = X2 ? sc_ * 2 + (row & 1) : sc_ * 4 + row;                          \
-            const global_ptr<raw_f32x4> base = as_global<raw_f32x4>(src + (size_t)g * (size_t)P.Fp); \
-            RA[h] = base[I * 256 + c0];                                                            \
-            RB[h] = base[J * 256 + c0];                                                            \
-        }                                                                                          \
-    }
-#define MSM_IMG_STORE(RA, RB, SLOT)                                                                \
-    {                                                                                              \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                            \
-            const int row = q0 + 2 * h;                                                            \
-            *reinterpret_cast<raw_f32x4*>(L + (SLOT) * 2 * PAN + row * 256 + c0) = RA[h];          \
-            *reinterpret_cast<raw_f32x4*>(L + (SLOT) * 2 * PAN + PAN + row * 256 + c0) = RB[h];    \
-        }                                                                                          \
-    }
-    // fragment sets of a K-step in slot SLOT: set 0 is what the step's first MFMAs need (bf16: the k-half of pairs 0-15;
-    // bf16x2: the mid images), set 1 the rest (pairs 16-31; the hi images)
-#define MSM_IMG_FRAGS(FA, FB, SLOT, SET)                                                           \
-    {                                                                                              \
-        const bf16x8* Ah_ = L + (SLOT) * 2 * PAN;                                                  \
-        const bf16x8* Bh_ = Ah_ + PAN;                                                             \
-        const int kg_ = X2 ? ((SET) == 0 ? 2 + kl : kl) : 2 * (SET) + kl;                          \
-        _Pragma("unroll") for (int bi = 0; bi < 2; ++bi) FA[bi] = Ah_[kg_ * 256 + wr * 64 + bi * 32 + cl];   \
-        _Pragma("unroll") for (int bj = 0; bj < 4; ++bj) FB[bj] = Bh_[kg_ * 256 + wc * 128 + bj * 32 + cl];  \
-    }
-    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
-    if (s1 > s0) {
-        MSM_IMG_LOAD(ra, rb, s0)
-        MSM_IMG_STORE(ra, rb, 0)
-        MSM_IMG_LOAD(ra, rb, s0 + 1)
-        MSM_IMG_STORE(ra, rb, 1)
-        MSM_IMG_LOAD(ra, rb, s0 + 2)
-    }
-    __syncthreads();
-    if (s1 > s0) MSM_IMG_FRAGS(fa0, fb0, 0, 0)
-    int steps_acc = 0;
-    int slot = 0;   // slot of step s; s + 1 -> slot + 1, s + 2 -> slot + 2 (mod 3)
-    for (long long s = s0; s < s1; ++s) {
-        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
-        MSM_IMG_LOAD(na, nb, s + 3)            // K-step s + 3 -> the other register set
-        MSM_IMG_FRAGS(fa1, fb1, slot, 1)       // this step's second fragment set: lands under the first set's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        if (!X2) {
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int bj = 0; bj < 4; ++bj)
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8 na0[2], nb0[4];
-            MSM_IMG_FRAGS(na0, nb0, slot1, 0)  // the NEXT step's first set (its slot has been complete since the last barrier)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int bj = 0; bj < 4; ++bj)
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi) fa0[bi] = na0[bi];
-#pragma unroll
-            for (int bj = 0; bj < 4; ++bj) fb0[bj] = nb0[bj];
-        } else {
-            // set 0 = (am, bm), set 1 = (ah, bh); per accumulator the products come in the order mm, hm, mh, hh as before
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int bj = 0; bj < 4; ++bj)
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int bj = 0; bj < 4; ++bj) {
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8 na0[2], nb0[4];
-            MSM_IMG_FRAGS(na0, nb0, slot1, 0)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int bj = 0; bj < 4; ++bj)
-                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi) fa0[bi] = na0[bi];
-#pragma unroll
-            for (int bj = 0; bj < 4; ++bj) fb0[bj] = nb0[bj];
-        }
-        MSM_IMG_STORE(ra, rb, slot2)           // K-step s + 2 (loaded one step ago) -> the free slot
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            ra[h] = na[h];
-            rb[h] = nb[h];
-        }
-        slot = slot1;
-        // fp64 merge into the private slabs of the four 128 x 128 sub-tiles (upper ones only)
-        if (++steps_acc >= P.kflush_steps || s + 1 == s1) {
-            steps_acc = 0;
-            const int ti = 2 * I + (wr >> 1), tj = 2 * J + wc;   // 128-blocks of this wave's outputs
-            if (ti <= tj && tj < P.T) {
-                const int st = ti * P.T - ti * (ti - 1) / 2 + (tj - ti);
-                double* slab = P.slabs + ((size_t)cohort * P.ntiles_sym + st) * (2 * TM * TM) + (size_t)which * (TM * TM);
-                unsigned toff = (unsigned)(((wr & 1) * 64 + 4 * kl) * TM + cl);
-                asm volatile("" : "+v"(toff));
-#pragma unroll
-                for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                    for (int bj = 0; bj < 4; ++bj) {
-                        double old[16];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) old[r] = (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * TM + bj * 32)[toff] = old[r] + (double)acc[bi][bj][r];
-                    }
-            }
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int bj = 0; bj < 4; ++bj)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
-        }
-    }
-#undef MSM_IMG_LOAD
-#undef MSM_IMG_STORE
-#undef MSM_IMG_FRAGS
-}
+// (ImgMfmaArgs and the MFMA kernels of the image path: tica_img_dev.h)
 
 // ---------------------------------------------------------------------------
 // Column sums s0 / stau (tica.py:418-419) + the finite check of
@@ -2391,7 +2014,7 @@ using namespace msm;
 
 struct msm_tica {
     int F = 0, lag = 0, mode = 0, T = 0, ntiles = 0;
-    int S32 = 0, S64 = 0, SB = 0, SB3 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
+    int S32 = 0, S64 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
     int sym = 0, ntiles_sym = 0, S_sym = 0;                // symmetric fp32 kernel: upper tiles, cohorts (1 workgroup per CU)
     double* slabs_sym = nullptr;                           // [S_sym * ntiles_sym][2][TM*TM]: H and D blocks
     double* slabs = nullptr;    // [G][TM*TM]
@@ -2412,12 +2035,10 @@ struct msm_tica {
     DevBuf foldimg;             // bf16 image path: [nchunks][F] per-chunk sums of the left frames
     long long n_sh = 0, nw_sh = 0;  // shifted pairs, and the total weight of their Gram terms (2 n_sh for whole trajectories)
     long long n_obs = 0, n_seq = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch
-    hipEvent_t evp = nullptr;                 // bf16 image path: start of the image pre-pass (ev0 then sits between the two kernels)
-    bool timed = false, timed_pre = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch (bf16 image path: the whole pack + multiply pipeline)
+    bool timed = false;
     DevBuf table, table2, staging;
-    DevBuf img;                  // bf16 image path: [u_hi | d_hi | (u_mid | d_mid)] packets, grow-only
-    int img_on = 0, T2 = 0, ntile2 = 0, S_img = 0;  // 256-wide tiles per side, H and D tiles of the upper triangle, cohorts
+    int img_on = 0, T2 = 0, ntile2 = 0, S_img = 0, img_grid = 0;  // 256-wide tiles per side, H and D tiles of the upper triangle, whole cohorts, workgroups
     DevBuf solve;                // device-resident solve: [A (F*F) | B (F*F) | mu F | D F | E F | scal 4 | part 2*nblk | scale F | Y k*F | vals F | ints]
     bool reduced = false;        // solve.A / solve.B hold the reduced matrix and the Cholesky factor of the current state
     size_t packed_len() const { return 2 * (size_t)F * F + 2 * (size_t)F + 2; }
@@ -2437,8 +2058,8 @@ int query_slots(K kernel, size_t lds, int* slots)
 
 constexpr size_t LDS32 = 2 * 2 * BK32 * TM * sizeof(float);  // 64 KiB
 constexpr size_t LDSSYM = 4 * BK32 * TM * sizeof(float) + 2 * TM * sizeof(float);  // 64 KiB: the (u, d) images for columns I and J, + 1 KiB: the shift row
-constexpr size_t LDSB = 2 * 2 * 4 * TM * 16;                  // 32 KiB: [2 bufs][A,B][4 groups][128] 16-byte packets
-constexpr size_t LDSB3 = 2 * 4 * 4 * TM * 16;                 // 64 KiB: + mid images
+constexpr int IMG_LAG = 1;                                    // tica_img_pp_kernel: load batches left in flight (tica_img_dev.h)
+constexpr size_t IMG_PP_LDS = (size_t)(3 + IMG_LAG) * IMG_SLOT;  // 128 KiB: a ring of four K-steps
 constexpr size_t LDS64 = 2 * 2 * BK64 * P64 * sizeof(double);  // 72 KiB (double-buffered, pitch 144)
 
 int tica_zero(msm_tica* h)
@@ -2501,17 +2122,19 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     h->reduced = false;
 
     // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
-    const bool use32 = (h->mode == MSM_TICA_F32 && dtype_bytes == 4);
     const bool bfmode = (h->mode == MSM_TICA_BF16 || h->mode == MSM_TICA_BF16X2);
     const bool useimg = bfmode && h->img_on && (dtype_bytes == 4 || dtype_bytes == 2);  // packed bf16 image + 256 x 256 tiles
-    const bool useb = bfmode && dtype_bytes == 4 && !useimg;                            // round 1's in-register transpose kernels
-    const int bk = (use32 || useb || useimg) ? BK32 : BK64;
-    const bool usesym = (use32 && h->sym && aligned) || useimg;  // pair semantics: sum/difference slabs (H/D kernel: 16-byte aligned rows only)
-    const int S = useimg ? h->S_img : usesym ? h->S_sym : use32 ? h->S32 : useb ? (h->mode == MSM_TICA_BF16 ? h->SB : h->SB3) : h->S64;  // one resident round
+    // (a bf16 mode whose 256-wide tiles do not fit one resident round -- beyond 3,840 features -- runs the fp32 C/G kernel:
+    //  the mode is an accuracy floor, not a promise of the bf16 pipe; bfloat16-stored rows there take the fp64 kernel)
+    const bool use32 = dtype_bytes == 4 && (h->mode == MSM_TICA_F32 || (bfmode && !useimg));
+    const int bk = (use32 || useimg) ? BK32 : BK64;
+    const bool usesym = (use32 && h->mode == MSM_TICA_F32 && h->sym && aligned) || useimg;  // pair semantics: sum/difference slabs (H/D kernel: 16-byte aligned rows only)
+    const int S = useimg ? h->S_img : usesym ? h->S_sym : use32 ? h->S32 : h->S64;  // one resident round
     const int G = S * (usesym ? h->ntiles_sym : h->ntiles);
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
+    if (useimg && kc > 2048) kc = 2048;   // a chunk = one workgroup column of the packing pre-pass: finer chunks, more of them in flight
     if (kc < bk) kc = bk;
     if (kc == KCMAX && total < 16LL * KCMAX * S && !useimg) {
         // Few chunks per cohort (one rank's share of a strong-scaled fit: 1.25M frames = 7.35 chunks of 4096 per cohort, the
@@ -2569,6 +2192,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     }
 
     long long img_groups = 0;  // bf16 image path: 8-pair groups of the packed image (whole K-steps per chunk)
+    std::vector<TicaChunk> img_tab;   // ... and its chunk table (the super-chunk loop below cuts it into ring slots)
     if (nvalid == 1 && n_seq == 1 && !segs && !useimg) {
         P.chunks = nullptr;
         P.single.base = ptrs[0];
@@ -2612,6 +2236,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // `tab` is pageable host memory
         P.chunks = h->table.as<TicaChunk>();
         P.nchunks = (long long)tab.size();
+        if (useimg) img_tab.swap(tab);
     }
 
     // Folded column sums (sum/difference kernel, whole trajectories of >= 2 lag frames, full tiles, launches big enough
@@ -2628,7 +2253,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             if (n_rows[s] > h->lag && n_rows[s] < 2 * (long long)h->lag) fold = false;
         if (2 * (long long)h->lag * nvalid > total / 4) fold = false;   // the boundary rows would be a pass of their own
     }
-    const bool shifted = h->shift_on && (use32 || useb || useimg);
+    const bool shifted = h->shift_on && (use32 || useimg);
     // 1b) mean shift bookkeeping (fp32 / bf16 kernels): the raw column sums of what this launch accumulates under the
     //     shift, and -- first shifted launch of the handle, `set_r` -- the reference row r = this launch's column means
     auto shift_and_merge = [&](int set_r) -> int {
@@ -2783,65 +2408,85 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     }
     // 2) the MFMA pass
     MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned), stream()));
-    h->timed_pre = false;
-    if (useimg && h->evp) {
-        MSM_HIP_CHECK(hipEventRecord(h->evp, stream()));
-        h->timed_pre = true;
-    } else if (h->ev0) {
-        MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
-    }
+    if (!useimg && h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));   // (image path: recorded below, around the whole pipeline)
     if (useimg) {
+        // The image is produced and consumed in SUPER-CHUNKS through a ring that the library owns (runtime.hip, img_ring):
+        // tica_img_kernel packs as many chunks as the ring holds, tica_img_pp_kernel multiplies them, and so on, all on
+        // stream().  Round 3 packed the WHOLE input into a per-handle image first (2x - 4x the input bytes of scratch,
+        // reserved inside the timed fit).  (Packing super-chunk k + 1 WHILE super-chunk k is multiplied was built and
+        // measured this round -- CU-masked streams, the MFMA kernel on the other CUs -- and is slower than taking turns:
+        // the packing pass needs the whole chip's memory pipelines, 40 - 64 CUs deliver 1.0 - 1.6 TB/s)
         const bool x2 = h->mode == MSM_TICA_BF16X2;
         const int Fp = h->T2 * 256;
-        const size_t one = (size_t)std::max<long long>(img_groups, 4) * (size_t)Fp * 16;  // bytes of one image
-        int rc = h->img.reserve(one * (x2 ? 4 : 2));
-        if (rc) return rc;
-        ImgArgs IA;
-        memset(&IA, 0, sizeof(IA));
-        IA.chunks = P.chunks;
-        IA.nchunks = P.nchunks;
-        IA.ld = ld;
-        IA.F = h->F;
-        IA.Fp = Fp;
-        IA.lag = h->lag;
-        IA.dtype_bytes = dtype_bytes;
-        IA.shift = P.shift;
-        IA.colA = fold ? h->foldimg.as<double>() : nullptr;
-        char* ib = h->img.as<char>();
-        IA.u_hi = reinterpret_cast<bf16x8*>(ib);
-        IA.d_hi = reinterpret_cast<bf16x8*>(ib + one);
-        IA.u_mid = x2 ? reinterpret_cast<bf16x8*>(ib + 2 * one) : nullptr;
-        IA.d_mid = x2 ? reinterpret_cast<bf16x8*>(ib + 3 * one) : nullptr;
-        if (img_groups > 0) {
-            const dim3 g1((unsigned)P.nchunks, (unsigned)h->T2);
+        ImgRing* ring = img_ring();
+        if (!ring) return MSM_ERR_HIP;
+        const int nimg = x2 ? 4 : 2;
+        const size_t gbytes = (size_t)Fp * 16;                                  // one 8-pair group of ONE image
+        long long slot_groups = (long long)(ring->bytes / (gbytes * nimg));
+        slot_groups -= slot_groups % 4;
+        const long long max_chunk_groups = ceil_div(kc, 32) * 4;
+        if (slot_groups < max_chunk_groups)
+            return fail(MSM_ERR_INVALID, "bf16 image ring too small for %d features (MSM_TICA_IMG_RING_MB)", h->F);
+        const size_t one = (size_t)slot_groups * gbytes;                        // bytes of one image inside the ring
+        if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
+        const std::vector<TicaChunk>& tab = img_tab;
+        for (size_t c0 = 0; c0 < tab.size() && img_groups > 0;) {
+            // chunks [c0, c1): as many as fit the ring
+            const long long g_start = tab[c0].g0;
+            size_t c1 = c0;
+            long long g_end = g_start;
+            while (c1 < tab.size()) {
+                const long long ge = c1 + 1 < tab.size() ? tab[c1 + 1].g0 : img_groups;
+                if (ge - g_start > slot_groups) break;
+                g_end = ge;
+                ++c1;
+            }
+            ImgArgs IA;
+            memset(&IA, 0, sizeof(IA));
+            IA.chunks = P.chunks + c0;
+            IA.nchunks = (long long)(c1 - c0);
+            IA.ld = ld;
+            IA.F = h->F;
+            IA.Fp = Fp;
+            IA.lag = h->lag;
+            IA.dtype_bytes = dtype_bytes;
+            IA.shift = P.shift;
+            IA.colA = fold ? h->foldimg.as<double>() + c0 * (size_t)h->F : nullptr;
+            IA.g_off = g_start;
+            IA.u_hi = reinterpret_cast<bf16x8*>(ring->p);
+            IA.d_hi = reinterpret_cast<bf16x8*>(ring->p + one);
+            IA.u_mid = x2 ? reinterpret_cast<bf16x8*>(ring->p + 2 * one) : nullptr;
+            IA.d_mid = x2 ? reinterpret_cast<bf16x8*>(ring->p + 3 * one) : nullptr;
+            const dim3 g1((unsigned)(c1 - c0), (unsigned)h->T2);
             if (x2)
                 hipLaunchKernelGGL(tica_img_kernel<true>, g1, dim3(256), 0, stream(), IA);
             else
                 hipLaunchKernelGGL(tica_img_kernel<false>, g1, dim3(256), 0, stream(), IA);
             MSM_HIP_CHECK(hipGetLastError());
-            if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
             ImgMfmaArgs MA;
             memset(&MA, 0, sizeof(MA));
             MA.u_hi = IA.u_hi;
             MA.d_hi = IA.d_hi;
             MA.u_mid = IA.u_mid;
             MA.d_mid = IA.d_mid;
-            MA.nsteps = x2 ? img_groups / 2 : img_groups / 4;
+            MA.nsteps = x2 ? (g_end - g_start) / 2 : (g_end - g_start) / 4;
             MA.Fp = Fp;
             MA.T = h->T;
             MA.T2 = h->T2;
             MA.ntiles_sym = h->ntiles_sym;
             MA.ntile2 = h->ntile2;
             MA.S = h->S_img;
-            MA.kflush_steps = std::max(1, P.kflush / (x2 ? 16 : 32));
+            MA.main_steps = img_main_steps(MA.nsteps, h->img_grid, h->ntile2);
+            // fp32 partials: bf16 inputs carry 8 significant bits, their products' partial sums can run 8x longer than the
+            // fp32 kernels' before the merge costs accuracy that matters (stated tolerance of the mode: 1e-3)
+            MA.kflush_steps = std::max(1, x2 ? P.kflush / 16 : 8 * P.kflush / 32);
             MA.slabs = h->slabs_sym;
-            const unsigned g2 = (unsigned)(h->S_img * h->ntile2);
             if (x2)
-                hipLaunchKernelGGL(tica_img_mfma_kernel<true>, dim3(g2), dim3(IMG_NT), IMG_LDS, stream(), MA);
+                hipLaunchKernelGGL((tica_img_pp_kernel<true, IMG_LAG>), dim3((unsigned)h->img_grid), dim3(IMG_NT), IMG_PP_LDS, stream(), MA);
             else
-                hipLaunchKernelGGL(tica_img_mfma_kernel<false>, dim3(g2), dim3(IMG_NT), IMG_LDS, stream(), MA);
-        } else if (h->ev0) {
-            MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
+                hipLaunchKernelGGL((tica_img_pp_kernel<false, IMG_LAG>), dim3((unsigned)h->img_grid), dim3(IMG_NT), IMG_PP_LDS, stream(), MA);
+            MSM_HIP_CHECK(hipGetLastError());
+            c0 = c1;
         }
     } else if (usesym) {
         if (fold)
@@ -2850,24 +2495,13 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             hipLaunchKernelGGL((tica_sym_f32_kernel<false, false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
         else
             hipLaunchKernelGGL((tica_sym_f32_kernel<true, false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
-    } else if (h->mode == MSM_TICA_F32 && dtype_bytes == 4) {
+    } else if (use32) {
         if (aligned && h->F % TM == 0)
             hipLaunchKernelGGL((tica_mfma_f32_kernel<true, false>), dim3(G), dim3(NT), LDS32, stream(), P);
         else if (aligned)
             hipLaunchKernelGGL((tica_mfma_f32_kernel<true, true>), dim3(G), dim3(NT), LDS32, stream(), P);
         else
             hipLaunchKernelGGL((tica_mfma_f32_kernel<false, true>), dim3(G), dim3(NT), LDS32, stream(), P);
-    } else if (useb) {
-        const bool x3 = h->mode == MSM_TICA_BF16X2;
-        const size_t lds = x3 ? LDSB3 : LDSB;
-        if (aligned && x3)
-            hipLaunchKernelGGL((tica_mfma_bf16_kernel<true, true>), dim3(G), dim3(NT), lds, stream(), P);
-        else if (aligned)
-            hipLaunchKernelGGL((tica_mfma_bf16_kernel<true, false>), dim3(G), dim3(NT), lds, stream(), P);
-        else if (x3)
-            hipLaunchKernelGGL((tica_mfma_bf16_kernel<false, true>), dim3(G), dim3(NT), lds, stream(), P);
-        else
-            hipLaunchKernelGGL((tica_mfma_bf16_kernel<false, false>), dim3(G), dim3(NT), lds, stream(), P);
     } else if (dtype_bytes == 4) {
         hipLaunchKernelGGL(tica_mfma_f64_kernel<float>, dim3(G), dim3(NT), LDS64, stream(), P);
     } else {
@@ -2985,29 +2619,11 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
         if ((rc = query_slots(tica_mfma_f64_kernel<double>, LDS64, &sb))) { delete h; return rc; }
         slots64 = sa < sb ? sa : sb;
     }
-    int slotsb = 0, slotsb3 = 0;
-    {
-        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_bf16_kernel<true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB3));
-        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_mfma_bf16_kernel<false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB3));
-        int sa = 0, sb = 0;
-        if ((rc = query_slots(tica_mfma_bf16_kernel<true, false>, LDSB, &sa))) { delete h; return rc; }
-        if ((rc = query_slots(tica_mfma_bf16_kernel<false, false>, LDSB, &sb))) { delete h; return rc; }
-        slotsb = sa < sb ? sa : sb;
-        if ((rc = query_slots(tica_mfma_bf16_kernel<true, true>, LDSB3, &sa))) { delete h; return rc; }
-        if ((rc = query_slots(tica_mfma_bf16_kernel<false, true>, LDSB3, &sb))) { delete h; return rc; }
-        slotsb3 = sa < sb ? sa : sb;
-    }
     // one resident round per launch: S cohorts of ntiles workgroups, per kernel flavour
     h->S32 = slots32 / h->ntiles;
     h->S64 = slots64 / h->ntiles;
-    h->SB = slotsb / h->ntiles;
-    h->SB3 = slotsb3 / h->ntiles;
     if (h->S32 < 1) h->S32 = 1;
     if (h->S64 < 1) h->S64 = 1;
-    if (h->SB < 1) h->SB = 1;
-    if (h->SB3 < 1) h->SB3 = 1;
     {
         // symmetric fp32 kernel (H/D blocks of the upper tiles): two 64-KiB workgroups per CU
         const char* sym_env = getenv("MSM_TICA_SYM");
@@ -3032,22 +2648,22 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     }
     {
         // bf16 image path (256 x 256 tiles of H and D on the upper triangle, one 8-wave workgroup per CU)
-        const char* img_env = getenv("MSM_TICA_BF16_IMG");
-        const bool img_off = img_env && atoi(img_env) == 0;   // A/B switch: round 1's bf16 kernels
         h->T2 = (int)ceil_div(n_features, 256);
         h->ntile2 = h->T2 * (h->T2 + 1);
-        if ((mode == MSM_TICA_BF16 || mode == MSM_TICA_BF16X2) && !img_off && h->ntile2 <= num_cus()) {
-            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_mfma_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_LDS));
-            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_mfma_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_LDS));
+        if ((mode == MSM_TICA_BF16 || mode == MSM_TICA_BF16X2) && h->ntile2 <= num_cus()) {
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<false, IMG_LAG>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<true, IMG_LAG>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_LDS));
+            if (!img_ring()) { delete h; return MSM_ERR_HIP; }   // the process's image ring exists before any fit is timed
             h->img_on = 1;
-            h->S_img = num_cus() / h->ntile2;
+            h->img_grid = std::max(num_cus(), h->ntile2);   // one workgroup per CU: whole cohorts + a remainder cohort (tica_img_dev.h)
+            h->S_img = h->img_grid / h->ntile2;
             h->sym = 1;                 // the exported lagged moment is the symmetrised one
-            h->S_sym = h->S_img;
+            h->S_sym = h->S_img + 1;    // slab rows: the cohorts' and the remainder cohort's
         }
     }
-    h->S = std::max(std::max(h->S32, h->S64), std::max(h->SB, h->SB3));  // slabs exist for the largest; unused ones stay zero
+    h->S = std::max(h->S32, h->S64);  // slabs exist for the largest; unused ones stay zero
     h->G = h->S * h->ntiles;
     const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipError_t e = hipSuccess;
@@ -3065,7 +2681,6 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (e == hipSuccess && h->sym) e = hipMalloc((void**)&h->fold, (size_t)(h->S_sym + FOLD_NB + 1) * h->F * sizeof(double));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-    if (e == hipSuccess) e = hipEventCreate(&h->evp);
     if (e != hipSuccess) {
         msm_tica_destroy(h);
         return fail(MSM_ERR_HIP, "msm_tica_create: hipMalloc failed: %s", hipGetErrorString(e));
@@ -3098,7 +2713,6 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->fold) (void)hipFree(h->fold);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->evp) (void)hipEventDestroy(h->evp);
     delete h;
     return MSM_OK;
 }
@@ -3241,16 +2855,6 @@ int msm_tica_last_folded(msm_tica_t* h, int* flag)
 {
     if (!h || !flag) return fail(MSM_ERR_STATE, "null argument");
     *flag = h->last_folded ? 1 : 0;
-    return MSM_OK;
-}
-
-int msm_tica_last_prepass_ms(msm_tica_t* h, float* ms)
-{
-    if (!h || !ms) return fail(MSM_ERR_STATE, "null argument");
-    *ms = 0.f;
-    if (!h->timed_pre) return MSM_OK;  // no image pre-pass in the most recent launch
-    MSM_HIP_CHECK(hipEventSynchronize(h->ev0));
-    MSM_HIP_CHECK(hipEventElapsedTime(ms, h->evp, h->ev0));
     return MSM_OK;
 }
 

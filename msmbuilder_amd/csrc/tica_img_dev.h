@@ -1,0 +1,301 @@
+// tica_img_dev.h -- device side of the bf16 image path's MFMA pass (modes `bf16` / `bf16x2`, BASELINE configs[4]).
+//
+// H = sum u u^T and D = sum d d^T on the upper 256 x 256 tiles, straight from the packed image that tica_img_kernel
+// writes: 16-byte packets [8 consecutive pairs] of one feature, [pair group][feature][8] (tica.hip).  Included by
+// tica.hip (the product) and by scripts/micro/img_mfma.hip (the kernel alone, next to round 3's, on one box).
+//
+// Round 4: the ping-pong kernel.  Round 3's kernel ran its eight waves in lockstep -- all of them read fragments, then all
+// of them multiply -- and moved every packet global -> registers -> ds_write_b128 -> LDS; its matrix pipes were busy 0.53
+// of the time (profiles/r03_pmc_bf16_kernel.txt: 44 % of the wave cycles stalled behind the co-resident wave's MFMAs,
+// 32 % at barriers and waitcnts).  Here
+//   * packets go global -> LDS directly (`global_load_lds_dwordx4`: the image layout IS the LDS layout, a wave-instruction
+//     moves 64 packets = one packet row of 64 features, 1 KiB contiguous on both sides): no staging registers, no
+//     ds_write pass, a ring of NS slots of 32 KiB;
+//   * the two waves of a SIMD alternate roles (MI355X_MICROARCH.md, "Two waves per SIMD"): while waves 0-3 multiply
+//     K-step s, waves 4-7 read their fragments of step s and issue a quarter each of a panel's loads; after a barrier they
+//     swap.  One wave per SIMD is in its MFMA cluster at any time, at raised priority, and its partner's LDS / VMEM
+//     instructions issue beside it.
+// The accumulation order per accumulator is the lockstep kernel's (bit-identical slabs; the micro-benchmark checks it).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace msm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float img_f32x16 __attribute__((ext_vector_type(16)));
+typedef float img_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int IMG_TM = 128;                       // slab sub-tile (the sum/difference slab layout of tica.hip)
+constexpr int IMG_NT = 512;                       // 8 waves: 4 (rows) x 2 (columns), each 64 x 128 outputs
+constexpr int IMG_SLOT = 2 * 4 * 256 * 16;        // one K-step in LDS: [A, B][4 packet rows][256 features] 16-byte packets = 32 KiB
+
+struct ImgMfmaArgs {
+    const bf16x8* u_hi;
+    const bf16x8* d_hi;
+    const bf16x8* u_mid;
+    const bf16x8* d_mid;
+    long long nsteps;  // K-steps in the image (bf16: 4 groups = 32 pairs each; bf16x2: 2 groups = 16 pairs each)
+    int Fp, T, T2, ntiles_sym, ntile2, S, kflush_steps;
+    int main_steps;    // ping-pong kernel: K-steps of each full cohort (see img_main_steps); the remainder cohort takes the rest
+    double* slabs;     // sum/difference layout: [(S + 1) * ntiles_sym][2][TM * TM]
+    long long wrap;    // micro-benchmark only (WRAP kernels): K-step s is READ from step s % wrap -- a cache-resident image
+};
+
+// persistent block id -> XCD-contiguous linear id (blocks land on XCD blockIdx % 8); bijective for any grid
+__device__ __forceinline__ int img_xcd_linear_id()
+{
+    const int G = gridDim.x, b = blockIdx.x;
+    const int q = G / 8, r = G % 8, xcd = b % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+}
+
+// K-steps per full cohort for `nsteps` steps over `grid` workgroups and `units` units (host and device agree through the
+// kernel argument): rounds x the remainder cohort's share, or an even split when the grid is a whole number of cohorts
+inline int img_main_steps(long long nsteps, int grid, int units)
+{
+    const int S = grid / units, R = grid - S * units;
+    if (S == 0) return 0;
+    if (R == 0) return (int)(nsteps / S);
+    const int rounds = (units + R - 1) / R;
+    return (int)(nsteps / ((long long)S * rounds + 1)) * rounds;
+}
+
+// unit id of a cohort -> (which matrix, I <= J).  H units first, then D units: an XCD's share of a cohort then reads
+// (mostly) ONE image, and consecutive units share their row panel I.
+__device__ __forceinline__ void img_decode_unit(int unit, int T2, int& which, int& I, int& J)
+{
+    const int half = T2 * (T2 + 1) / 2;
+    which = unit >= half ? 1 : 0;
+    int uix = unit - which * half;
+    I = 0;
+    while (uix >= T2 - I) {
+        uix -= T2 - I;
+        ++I;
+    }
+    J = I + uix;
+}
+
+// fp64 merge of a wave's 64 x 128 accumulators into the private slabs of the 128 x 128 sub-tiles (upper ones only)
+__device__ __forceinline__ void img_flush(img_f32x16 (&acc)[2][4], const ImgMfmaArgs& P, int cohort, int which, int I, int J,
+                                          int wr, int wc, int kl, int cl)
+{
+    const int ti = 2 * I + (wr >> 1), tj = 2 * J + wc;   // 128-blocks of this wave's outputs
+    if (ti <= tj && tj < P.T) {
+        const int st = ti * P.T - ti * (ti - 1) / 2 + (tj - ti);
+        double* slab = P.slabs + ((size_t)cohort * P.ntiles_sym + st) * (2 * IMG_TM * IMG_TM) + (size_t)which * (IMG_TM * IMG_TM);
+        unsigned toff = (unsigned)(((wr & 1) * 64 + 4 * kl) * IMG_TM + cl);
+        asm volatile("" : "+v"(toff));
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) {
+                double old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * IMG_TM + bj * 32)[toff];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    (slab + (bi * 32 + (r & 3) + 8 * (r >> 2)) * IMG_TM + bj * 32)[toff] = old[r] + (double)acc[bi][bj][r];
+            }
+    }
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The ping-pong kernel.  Phases are separated by workgroup barriers; K-step s of a cohort's share occupies phases 2n and
+// 2n + 1 (n = s - s0):
+//     phase 2n    : waves 0-3  MFMA(s)                      | waves 4-7  fragments(s),     issue panel A of step s + D
+//     phase 2n + 1: waves 4-7  MFMA(s)                      | waves 0-3  fragments(s + 1), issue panel B of step s + D
+// A wave waits for its own loads at the END of its MFMA phase, allowing the newest LAG batches (of 4 loads) to stay in
+// flight; with D = 2 + LAG and NS = D + 1 ring slots
+//   * panel A of step t is issued in phase 2 (t - D), complete (waited for + barrier) by the end of phase 2 (t - D) + 1 + 2 LAG,
+//     panel B one phase later: both <= 2 t - 2, and the first reader of step t is phase 2 t - 1;                      (RAW)
+//   * the slot of step t was last read in phase 2 (t - NS) + 0 ... it is rewritten from phase 2 (t - D) > 2 (t - NS). (WAR)
+// LAG = 0: a load has one phase (~600 cycles) to land before its issuer waits for it; LAG = 1: three phases.
+// ---------------------------------------------------------------------------------------------------------------------
+// One SEGMENT of a workgroup's work: K-steps [s0, s1) of one unit, merged into slab row `cohort`.
+template <bool X2, int LAG, bool WRAP, int ABL>
+__device__ __forceinline__ void img_pp_segment(const ImgMfmaArgs& P, char* smem, int unit, int cohort, int s0, int s1)
+{
+    constexpr int D = 2 + LAG, NS = D + 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: scalar branches on the role
+    const int grp = wave >> 2, wi = wave & 3;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kl = lane >> 5, cl = lane & 31;
+    int which, I, J;
+    img_decode_unit(unit, P.T2, which, I, J);
+    const bf16x8* hi = which ? P.d_hi : P.u_hi;
+    const bf16x8* mid = which ? P.d_mid : P.u_mid;
+
+    img_f32x16 acc[2][4];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+
+    // (s0, s1 are scalars: the step clamp of the loads must not cost VALU instructions; 32-bit: the scalar unit has no
+    //  64-bit ordered compare, the host keeps nsteps per launch far below 2^31)
+    if (s1 <= s0) return;   // uniform over the workgroup
+
+    // ---- loads: this wave moves packet row `wi` of ONE panel per step (waves 4-7: panel A = columns I; waves 0-3: panel B =
+    //      columns J), four 64-feature segments = four wave-instructions.  Address = a scalar base per step + ONE per-lane
+    //      32-bit offset + an immediate per segment: while the partner wave streams MFMAs a VALU instruction of this wave
+    //      waits for a gap in that stream, so the load phase must not need any (first version: two 64-bit VALU adds per
+    //      load and 24 register moves per step -- the phase took 890 cycles against 512 of MFMA).
+    const int mypanel = grp == 1 ? 0 : 1;
+    const bf16x8* rowimg = (X2 && wi >= 2) ? mid : hi;                  // bf16x2: packet rows 0-1 = hi groups, 2-3 = mid groups
+    const long long gmul = X2 ? 2 : 4;
+    const int grow = X2 ? (wi & 1) : wi;
+    const size_t colbase = (size_t)(mypanel == 0 ? I : J) * 256;       // first packet column of the panel
+    const unsigned lds_my = (unsigned)(mypanel * 16384 + wi * 4096);    // byte offset inside a slot
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // (a diagonal unit, I == J, could load ONE panel: measured 4 % SLOWER -- its waves 0-3 then idle through their load phase
+    //  and the unit drifts away from the cohort whose panels it shares in L2)
+    auto issue = [&](int step, int slot) {
+        if (ABL & 1) return;
+        int sc = step < s1 ? step : s1 - 1;                             // beyond the share: a harmless re-load (counts stay uniform)
+        if (WRAP) sc %= (int)P.wrap;
+        const char* sbase = reinterpret_cast<const char*>(rowimg + (size_t)((long long)sc * gmul + grow) * (size_t)P.Fp + colbase);   // uniform
+        char* dst = smem + (unsigned)slot * IMG_SLOT + lds_my;
+        // the instruction's immediate offset advances BOTH addresses (global: vaddr + offset; LDS: M0 + offset + 16 lane):
+        // one address computation and one M0 write serve the four segments
+        const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(sbase + lane16);
+        __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)dst;
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+    };
+    // ---- fragments of a step: set 0 is what the step's first MFMAs take (bf16: pairs 0-15; bf16x2: the mid images),
+    //      set 1 the rest (pairs 16-31; the hi images)
+    const unsigned fragA = (unsigned)((kl * 256 + wr * 64 + cl) * 16);
+    const unsigned fragB = (unsigned)(16384 + (kl * 256 + wc * 128 + cl) * 16);
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
+    auto frags = [&](int slot, bool force = false) {
+        if ((ABL & 2) && !force) return;
+        const char* base = smem + (unsigned)slot * IMG_SLOT;
+        constexpr int k0 = X2 ? 2 : 0, k1 = X2 ? 0 : 2;   // first packet row of set 0 / set 1
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            fa0[bi] = *reinterpret_cast<const bf16x8*>(base + fragA + (k0 * 256 + bi * 32) * 16);
+            fa1[bi] = *reinterpret_cast<const bf16x8*>(base + fragA + (k1 * 256 + bi * 32) * 16);
+        }
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+            fb0[bj] = *reinterpret_cast<const bf16x8*>(base + fragB + (k0 * 256 + bj * 32) * 16);
+            fb1[bj] = *reinterpret_cast<const bf16x8*>(base + fragB + (k1 * 256 + bj * 32) * 16);
+        }
+    };
+    auto mfmas = [&]() {
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+                acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
+        if (X2) {   // per accumulator: mid.mid, hi.mid, mid.hi, hi.hi -- round 3's order
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj) {
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+                acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+    };
+    auto wait_loads = [&]() {
+        if (LAG == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (LAG == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+#define IMG_PP_BARRIER() do { if (!(ABL & 4)) __builtin_amdgcn_s_barrier(); } while (0)
+
+    // ---- prologue: steps s0 .. s0 + D - 1 into slots 0 .. D - 1
+#pragma unroll
+    for (int q = 0; q < D; ++q) issue(s0 + q, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IMG_PP_BARRIER();
+
+    // Two role-specific loops (same barrier count): one code path per wave, so a step's fragments are read straight into
+    // the registers its MFMAs take -- a shared loop body made the compiler read into temporaries and move them.
+    int slot = 0, slot_ld = D;   // slot of step s; slot of step s + D (NS = D + 1: the one "behind" slot)
+    int steps_acc = 0;
+    if (grp == 0) {
+        frags(0, true);
+        for (int s = s0; s < s1; ++s) {
+            const int slot1 = slot + 1 == NS ? 0 : slot + 1;
+            mfmas();                                   // phase 2n
+            wait_loads();
+            IMG_PP_BARRIER();
+            if (s + 1 < s1) frags(slot1);              // phase 2n + 1
+            issue(s + D, slot_ld);
+            IMG_PP_BARRIER();
+            slot = slot1;
+            slot_ld = slot_ld + 1 == NS ? 0 : slot_ld + 1;
+            if (++steps_acc >= P.kflush_steps || s + 1 == s1) {
+                steps_acc = 0;
+                img_flush(acc, P, cohort, which, I, J, wr, wc, kl, cl);
+            }
+        }
+    } else {
+        if (ABL & 2) frags(0, true);
+        for (int s = s0; s < s1; ++s) {
+            frags(slot);                               // phase 2n
+            issue(s + D, slot_ld);
+            IMG_PP_BARRIER();
+            mfmas();                                   // phase 2n + 1
+            wait_loads();
+            IMG_PP_BARRIER();
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            slot_ld = slot_ld + 1 == NS ? 0 : slot_ld + 1;
+            if (++steps_acc >= P.kflush_steps || s + 1 == s1) {
+                steps_acc = 0;
+                img_flush(acc, P, cohort, which, I, J, wr, wc, kl, cl);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads: nothing may still be writing LDS ...
+    IMG_PP_BARRIER();                                  // ... when the next segment's prologue refills the ring (or at exit)
+#undef IMG_PP_BARRIER
+}
+
+// Work split (round 4): with U = ntile2 units and G workgroups (one per CU of the stream), S = G / U COHORTS take a share of
+// `main_steps` K-steps each, all units side by side -- workgroups that read the same panels at the same time, next to each
+// other in the XCD-linear order.  The other R = G % U workgroups (40 of 256 at 2,048 features, which round 3 left idle)
+// form a REMAINDER cohort that takes the rest of the steps in ceil(U / R) rounds of R units (slab row S): with
+// main_steps = rounds x (remainder's steps) every workgroup multiplies for the same time.
+template <bool X2, int LAG, bool WRAP = false, int ABL = 0>   // ABL: micro-benchmark ablations (1: no loads, 2: no fragment reads, 4: no barriers, 8: no priority)
+__global__ __launch_bounds__(IMG_NT, 1) void tica_img_pp_kernel(ImgMfmaArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][A, B][4][256] packets -- the ONLY LDS object
+    const int U = P.ntile2, G = (int)gridDim.x;
+    const int S = G / U, R = G - S * U;
+    const int p = img_xcd_linear_id();
+    if (p < S * U) {
+        const int cohort = p / U;
+        const int s1 = (R == 0 && cohort == S - 1) ? (int)P.nsteps : (cohort + 1) * P.main_steps;   // (no remainder cohort: the last one takes the odd steps)
+        img_pp_segment<X2, LAG, WRAP, ABL>(P, smem, p - cohort * U, cohort, cohort * P.main_steps, s1);
+    } else {
+        const int r = p - S * U;
+        for (int unit = r; unit < U; unit += R)
+            img_pp_segment<X2, LAG, WRAP, ABL>(P, smem, unit, S, S * P.main_steps, (int)P.nsteps);
+    }
+}
+
+}  // namespace msm
