@@ -64,7 +64,8 @@ struct TicaArgs {
     const float* shift; // [F] per-column reference row r (or nullptr): the fp32 / bf16 kernels accumulate (x - r), see "mean shift"
     int kflush;         // sum/difference kernel: frames accumulated in fp32 registers before the fp64 slab merge
     const float* zrow;  // [F] zeros: where the dummy loads of a non-staging half-step read when the column sums are folded
-    double* colA;       // sum/difference kernel with folded column sums: [S][F] fp64 sums of the LEFT frames, one row per cohort
+    double* colA;       // sum/difference kernel with folded column sums: [S (+ 1)][F] fp64 sums of the LEFT frames, one row per cohort
+    long long n_main;   // sum/difference kernel, REM: chunks [0, n_main) belong to the whole cohorts, the rest to the remainder cohort
 };
 
 __device__ __forceinline__ TicaChunk get_chunk(const TicaArgs& P, long long c)
@@ -703,7 +704,11 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(flo
 // tiles of a block, taking turns, saved the adds and lost 2 ms to the branches): the half-steps whose in-stream loads are
 // dummies (their frames are staged by the edge sequence instead) read a row of zeros.  A NaN or an infinity anywhere in the
 // left frames ends up in a sum, which is the finite check of the pass this replaces.
-template <bool PARTIAL, bool FOLD>
+// REM (round 4): the grid is ALL resident slots -- P.S whole cohorts of P.ntiles workgroups, which take the chunks
+// [0, P.n_main) round-robin as before, plus R = gridDim.x - P.S * P.ntiles workgroups that round 3 left idle (104 of 512 at
+// 2,048 features): a REMAINDER cohort that takes the chunks [P.n_main, P.nchunks) in ceil(ntiles / R) rounds of R tiles
+// (slab / column-sum row P.S).  The host picks n_main so that every workgroup is busy for the same time.
+template <bool PARTIAL, bool FOLD, bool REM = false>
 __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -735,7 +740,13 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 
     const int tid = threadIdx.x;
     const int p = xcd_linear_id();
-    const int cohort = p / P.ntiles, tile = p % P.ntiles;  // ntiles = T (T + 1) / 2 upper tiles
+    const bool rem = REM && p >= P.S * P.ntiles;             // a workgroup of the remainder cohort (uniform)
+    const int remR = REM ? (int)gridDim.x - P.S * P.ntiles : 1;
+    PROF_DECL;
+  for (int round = 0; round < (rem ? (P.ntiles + remR - 1) / remR : 1); ++round) {   // (REM = false: one trip, folded away)
+    const int cohort = rem ? P.S : p / P.ntiles;
+    const int tile = rem ? p - P.S * P.ntiles + round * remR : p % P.ntiles;  // ntiles = T (T + 1) / 2 upper tiles
+    if (rem && tile >= P.ntiles) break;
     int I = 0, u = tile;
     while (u >= P.T - I) {
         u -= P.T - I;
@@ -747,7 +758,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int kl = lane >> 5, cl = lane & 31;
-    double* slabH = P.slabs + (size_t)p * (2 * TM * TM);
+    double* slabH = P.slabs + ((size_t)cohort * P.ntiles + tile) * (2 * TM * TM);
     double* slabD = slabH + TM * TM;
 
     const int c4 = (tid & 31) * 4;
@@ -788,8 +799,8 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
         P.dbg[2] = wall_clock64();
     }
 
-    PROF_DECL;
-    for (long long c = cohort; c < P.nchunks; c += P.S) {
+    const long long c_end = REM ? (rem ? P.nchunks : P.n_main) : P.nchunks, c_step = rem ? 1 : P.S;
+    for (long long c = rem ? P.n_main : cohort; c < c_end; c += c_step) {
         PROF_MARK(5)
         const TicaChunk ch = get_chunk(P, c);
         const int nsteps = (ch.n + BK32 - 1) / BK32;
@@ -865,7 +876,7 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
                     pu = npu; pd = npd; qu = nqu; qd = nqd;
         __syncthreads();  // every wave is done with both buffers (previous chunk)
         MSM_STAGE_EDGE(0, 0)
-        if (P.cosync && chunks_done > 0 && tid == 0) {  // cohort pacing (opt-in, see the C/G kernel): bounded wait
+        if (P.cosync && !rem && chunks_done > 0 && tid == 0) {  // cohort pacing (opt-in, see the C/G kernel): bounded wait
             const unsigned target = (unsigned)P.ntiles * (unsigned)chunks_done;
             const long long t0 = clock64();
             while (__hip_atomic_load(P.cosync + cohort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -942,12 +953,12 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 #undef MSM_SYM_FRAGS
 #undef MSM_STORE_X
 #undef MSM_STORE_Y
-        if (P.cosync) {
+        if (P.cosync && !rem) {
             ++chunks_done;
             if (tid == 0) __hip_atomic_fetch_add(P.cosync + cohort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         rows_acc += ch.n;
-        if (rows_acc + P.kc > P.kflush || c + P.S >= P.nchunks) {
+        if (rows_acc + P.kc > P.kflush || c + c_step >= c_end) {
             rows_acc = 0;
             // accumulator register r of block (bi, bj), lane (kl, cl) = tile row wr*64 + 2*rho + bi with
             // rho = (r & 3) + 8 (r >> 2) + 4 kl, tile column wc*64 + 2*cl + bj: the two bj of a lane are adjacent doubles
@@ -992,7 +1003,9 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
             for (int r = 0; r < 8; ++r) a += cs[(tid & 3) * NT + r * 32 + (tid >> 2)];
             P.colA[(size_t)cohort * P.F + I0 + tid] = a;
         }
+        __syncthreads();  // (the next round's first staging writes the panels this sum was read from)
     }
+  }   // round
 #ifdef MSM_TICA_PROFILE
     if (P.dbg && tid == 0 && blockIdx.x < 5) {
         for (int i = 0; i < 6; ++i) P.dbg[8 + 8 * blockIdx.x + i] = pf_acc[i];
@@ -2015,7 +2028,8 @@ using namespace msm;
 struct msm_tica {
     int F = 0, lag = 0, mode = 0, T = 0, ntiles = 0;
     int S32 = 0, S64 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
-    int sym = 0, ntiles_sym = 0, S_sym = 0;                // symmetric fp32 kernel: upper tiles, cohorts (1 workgroup per CU)
+    int sym = 0, ntiles_sym = 0, S_sym = 0;                // symmetric fp32 kernel: upper tiles, slab / column-sum ROWS (cohorts, + 1 with a remainder cohort)
+    int sym_cohorts = 0, sym_grid = 0;                     // ... whole cohorts, workgroups of a launch (sym_grid > sym_cohorts * ntiles_sym: remainder cohort)
     double* slabs_sym = nullptr;                           // [S_sym * ntiles_sym][2][TM*TM]: H and D blocks
     double* slabs = nullptr;    // [G][TM*TM]
     double* base = nullptr;     // packed [2FF+2F] imported state
@@ -2129,8 +2143,9 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     const bool use32 = dtype_bytes == 4 && (h->mode == MSM_TICA_F32 || (bfmode && !useimg));
     const int bk = (use32 || useimg) ? BK32 : BK64;
     const bool usesym = (use32 && h->mode == MSM_TICA_F32 && h->sym && aligned) || useimg;  // pair semantics: sum/difference slabs (H/D kernel: 16-byte aligned rows only)
-    const int S = useimg ? h->S_img : usesym ? h->S_sym : use32 ? h->S32 : h->S64;  // one resident round
-    const int G = S * (usesym ? h->ntiles_sym : h->ntiles);
+    const int S = useimg ? h->S_img : usesym ? h->sym_cohorts : use32 ? h->S32 : h->S64;  // one resident round
+    const bool symrem = usesym && !useimg && h->sym_grid > S * h->ntiles_sym;              // ... + a remainder cohort
+    const int G = symrem ? h->sym_grid : S * (usesym ? h->ntiles_sym : h->ntiles);
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
@@ -2237,6 +2252,15 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         P.chunks = h->table.as<TicaChunk>();
         P.nchunks = (long long)tab.size();
         if (useimg) img_tab.swap(tab);
+    }
+
+    P.n_main = P.nchunks;
+    if (symrem) {
+        // chunks of the remainder cohort: its R workgroups walk them once per round, the whole cohorts share the others
+        // S ways -- equal time when n_rem x rounds = n_main / S
+        const int R = G - S * h->ntiles_sym, rounds = (int)ceil_div(h->ntiles_sym, R);
+        const long long n_rem = (P.nchunks + ((long long)S * rounds + 1) / 2) / ((long long)S * rounds + 1);
+        P.n_main = P.nchunks - n_rem;
     }
 
     // Folded column sums (sum/difference kernel, whole trajectories of >= 2 lag frames, full tiles, launches big enough
@@ -2489,7 +2513,14 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             c0 = c1;
         }
     } else if (usesym) {
-        if (fold)
+        if (symrem) {
+            if (fold)
+                hipLaunchKernelGGL((tica_sym_f32_kernel<false, true, true>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+            else if (h->F % TM == 0)
+                hipLaunchKernelGGL((tica_sym_f32_kernel<false, false, true>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+            else
+                hipLaunchKernelGGL((tica_sym_f32_kernel<true, false, true>), dim3(G), dim3(NT), LDSSYM, stream(), P);
+        } else if (fold)
             hipLaunchKernelGGL((tica_sym_f32_kernel<false, true>), dim3(G), dim3(NT), LDSSYM, stream(), P);
         else if (h->F % TM == 0)
             hipLaunchKernelGGL((tica_sym_f32_kernel<false, false>), dim3(G), dim3(NT), LDSSYM, stream(), P);
@@ -2642,8 +2673,26 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
             if ((rc = query_slots(tica_sym_f32_kernel<false, false>, LDSSYM, &sa))) { delete h; return rc; }
             if ((rc = query_slots(tica_sym_f32_kernel<true, false>, LDSSYM, &sb))) { delete h; return rc; }
             if ((rc = query_slots(tica_sym_f32_kernel<false, true>, LDSSYM, &sc))) { delete h; return rc; }
-            h->S_sym = std::min(std::min(sa, sb), sc) / h->ntiles_sym;
-            h->sym = h->S_sym >= 1;  // at least one whole cohort resident (F <= 3968 on 256 CUs), else the C/G kernel
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false, false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<true, false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false, true, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
+            int sd = 0, se = 0, sf = 0;
+            if ((rc = query_slots(tica_sym_f32_kernel<false, false, true>, LDSSYM, &sd))) { delete h; return rc; }
+            if ((rc = query_slots(tica_sym_f32_kernel<true, false, true>, LDSSYM, &se))) { delete h; return rc; }
+            if ((rc = query_slots(tica_sym_f32_kernel<false, true, true>, LDSSYM, &sf))) { delete h; return rc; }
+            const int slots = std::min(std::min(std::min(sa, sb), sc), std::min(std::min(sd, se), sf));
+            h->sym_cohorts = slots / h->ntiles_sym;
+            h->sym = h->sym_cohorts >= 1;  // at least one whole cohort resident (F <= 3968 on 256 CUs), else the C/G kernel
+            // remainder cohort: the slots beyond the whole cohorts, when they are worth a launch flavour of their own --
+            // at least a sixteenth of the chip and at most three rounds over the tiles (2,048 features: 104 of 512 slots,
+            // two rounds; 512 features: 2 slots, not worth it)
+            const int R = slots - h->sym_cohorts * h->ntiles_sym;
+            const bool rem = h->sym && R * 16 >= slots && 3 * R >= h->ntiles_sym;
+            h->sym_grid = rem ? slots : h->sym_cohorts * h->ntiles_sym;
+            h->S_sym = h->sym_cohorts + (rem ? 1 : 0);
         }
     }
     {
@@ -2661,6 +2710,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
             h->S_img = h->img_grid / h->ntile2;
             h->sym = 1;                 // the exported lagged moment is the symmetrised one
             h->S_sym = h->S_img + 1;    // slab rows: the cohorts' and the remainder cohort's
+            h->sym_cohorts = h->S_img;
         }
     }
     h->S = std::max(h->S32, h->S64);  // slabs exist for the largest; unused ones stay zero
