@@ -395,6 +395,11 @@ def main():
     comm_ok = True
     if world > 1:
         comm_ok = ci[1].value == world and (torch.cuda.device_count() < world or (comm_kind == "rccl" and rccl_ranks == world))
+    comm_failed_ranks = [f["rank"] for f in parallel._comm_failures]
+    if world > 1 and not comm_ok and rank == 0:
+        sys.stderr.write("bench.py: the library's collectives did not run over RCCL with all %d ranks (transport %s, %d ranks%s)\n"
+                         % (world, comm_kind, ci[1].value, ", RCCL join / self-test failed on ranks %s" % comm_failed_ranks
+                            if comm_failed_ranks else ""))
     kst = (C.c_int64 * 5)()
     _lib.check(_lib.lib().msm_kcenters_last_stats(kst))
 
@@ -449,14 +454,14 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
             "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
-            "rccl_ranks": rccl_ranks, "comm": comm_kind, "comm_ok": comm_ok,
+            "rccl_ranks": rccl_ranks, "comm": comm_kind, "comm_ok": comm_ok, "comm_failed_ranks": comm_failed_ranks,
             "config": {"workload": "BASELINE configs[3]: %d x %d fp32 as %d trajectories x %d (%d frames on each of %d GPU%s), "
                                    "tICA(n_components=%d, lag_time=%d) fit+solve+transform -> KCenters(k=%d) fit+predict"
                                    % (total_frames, F, total_frames // T, T, frames, world, "s" if world > 1 else "",
                                       args.components, args.lag, args.clusters),
                        "total_frames": total_frames, "frames_per_gpu": frames, "n_features": F, "lag_time": args.lag,
                        "n_components": args.components, "n_clusters": args.clusters,
-                       "parallelism": "whole trajectories dealt over %d rank%s, 1 all-reduce (tICA) + 1 all-gather per centre (KCenters)"
+                       "parallelism": "whole trajectories dealt over %d rank%s, 1 all-reduce (tICA) + 1 all-gather per ROUND of centres (KCenters: ~35 per fit)"
                                       % (world, "s" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": executed, "peak": peak, "unit": "TFLOP/s",
                          "frac": executed / peak, "traffic": traffic, "traffic_source": traffic_source,
@@ -635,6 +640,32 @@ def main():
                               "accumulate_frames_per_s": 1e6 / ms2 * 1e3, "fit_plus_solve_ms": 1e3 * t2,
                               "top_eigenvalues": [float(x) for x in e2[:3]]}
             del X2, m2
+            # --- SURVEY 8(d)'s C3 stress variant: KCenters(200) and assign_nearest on RAW contact-like features, 280,000 x 171
+            # float32 as 28 trajectories x 10,000, no tICA in front (odd row length: the scalar-staged exact kernels)
+            gC = torch.Generator(device=dev).manual_seed(171)
+            XC = (torch.linspace(0.4, 2.5, 171, device=dev) + 0.2 * torch.randn(280_000, 171, generator=gC, device=dev)).abs().float().contiguous()
+            seqsC = list(XC.view(28, 10_000, 171).unbind(0))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                kcC = KCenters(n_clusters=200, random_state=0).fit(seqsC)
+                torch.cuda.synchronize()
+                tC = time.perf_counter()
+                kcC = KCenters(n_clusters=200, random_state=0).fit(seqsC)
+                torch.cuda.synchronize()
+                tC = time.perf_counter() - tC
+                kcC.predict(seqsC)
+                torch.cuda.synchronize()
+                tP = time.perf_counter()
+                labC = kcC.predict(seqsC)
+                torch.cuda.synchronize()
+                tP = time.perf_counter() - tP
+            out["config3_stress"] = {"workload": "280,000 x 171 fp32 (28 x 10,000), KCenters(k=200, euclidean) fit + predict, no tICA",
+                                     "kcenters_fit_ms": 1e3 * tC, "fit_frames_per_s": 280_000 / tC,
+                                     "fit_pass_TBps_if_every_pass_read_X": 200 * 280_000 * 171 * 4 / tC / 1e12,
+                                     "assign_nearest_ms": 1e3 * tP, "assign_frames_per_s": 280_000 / tP,
+                                     "assign_pair_elements_per_s": 280_000 * 200 * 171 / tP,
+                                     "inertia": float(kcC.inertia_)}
+            del XC, seqsC, kcC, labC
             # --- BASELINE configs[4] width: F = 2048, fp32 vs bf16x2 vs bf16 MFMA
             n5 = 100
             X5 = synth(torch, n5, T, 2048, 7, dev)

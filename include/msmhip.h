@@ -100,8 +100,13 @@ int msm_comm_rccl_available(void); /* 1: librccl loadable and a device visible. 
                                       MIN over the bootstrap channel) before ANY of them calls msm_comm_init_rccl, because
                                       ncclCommInitRank blocks until every rank has joined */
 int msm_comm_unique_id(char* id128);
-int msm_comm_init_rccl(const char* id128, int rank, int world);
+int msm_comm_init_rccl(const char* id128, int rank, int world); /* gives up after MSM_COMM_TIMEOUT_S seconds (180) with
+                                      MSM_ERR_STATE and a message naming the rank: ncclCommInitRank cannot be cancelled, a rank
+                                      that never joins must not hang the others for good */
 int msm_comm_init_host(msm_host_collective_fn fn, int rank, int world);
+int msm_comm_selftest(int timeout_s); /* one all-reduce + one all-gather of a few doubles through the installed communicator,
+                                      checked and time-limited (0 ok; MSM_ERR_STATE: wrong numbers / no answer, message names the
+                                      rank).  Every rank calls it right after the communicator is built */
 int msm_comm_destroy(void);
 int msm_comm_info(int* rank, int* world, int* kind); /* kind: 0 none, 1 RCCL, 2 host callback */
 int msm_comm_allreduce_f64(double* dbuf, msm_idx_t n);                    /* device buffer, in place; synchronises */
@@ -346,6 +351,13 @@ int msm_kcenters_last_stats(msm_idx_t* out5);
  * labels int32 (sklearn's dtype) follow on_device; *inertia fp64 sum of fp32 terms. */
 int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* centers,
                          msm_idx_t K, int32_t* labels, double* inertia, int on_device);
+/* k-means++ seeds (scikit-learn `_kmeans_plusplus`, sklearn/cluster/_kmeans.py:163-259; reached from
+ * msmbuilder/cluster/__init__.py:67-69) of the n x F float32 rows X (host or device per on_device): centre 0 = row
+ * `first`, then K - 1 rounds of L candidates drawn by inverse-CDF sampling of the current squared distances with the
+ * uniforms u[(K - 1) * L] (host float64 in [0, 1): the caller's RandomState stream), the candidate of lowest potential
+ * wins.  Distances in scikit-learn's float64-upcast arithmetic.  centers[K * F] float32 and ids[K] (rows of X): host. */
+int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t K, msm_idx_t first, const double* u, int L,
+                            float* centers, msm_idx_t* ids, int on_device);
 /* One MiniBatchKMeans step on the rows X[batch_idx[b]] (batch_idx host int64, length B):
  * label, then per-centre streaming mean c <- (c*w + sum x)/(w + n) with cumulative
  * counts (sklearn _k_means_minibatch.pyx:59-109, unit sample weights).  centers
@@ -384,6 +396,11 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
 int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
                 msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
                 msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
+/* msm_mbk_run in two halves: _begin queues the run and returns, _end waits and fetches (the host draws the next run's
+ * indices in between); one run in flight per handle */
+int msm_mbk_run_begin(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                      msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, const double* state6);
+int msm_mbk_run_end(msm_mbk_t* h, double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
 /* The same for a ROW-SHARDED fit (one process per GPU, rows in consecutive blocks): the S batches are global and identical
  * on every rank; a rank passes the rows of each batch that IT owns as local row numbers -- local_idx (host) back to back,
  * offsets[S + 1] (host) delimiting the steps -- and the size B of the whole batch.  Per step: label + fp64 sums / counts /

@@ -95,6 +95,7 @@ def _declare(lib):
     f("msm_comm_init_rccl", C.c_int, _p, C.c_int, C.c_int)
     f("msm_comm_init_host", C.c_int, _p, C.c_int, C.c_int)
     f("msm_comm_destroy", C.c_int)
+    f("msm_comm_selftest", C.c_int, C.c_int)
     f("msm_comm_info", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
     f("msm_comm_allreduce_f64", C.c_int, _p, _i64)
     f("msm_comm_allgather", C.c_int, _p, _p, _i64)
@@ -141,12 +142,15 @@ def _declare(lib):
         f("msm_kcenters_pass_dev_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, C.c_char_p, _p, _p, _i64, _p)
         f("msm_kcenters_select_" + sfx, C.c_int, _p, _i64, _i64, _p, _p, _p, _i64)
     f("msm_kmeans_label_f32", C.c_int, _p, _i64, _i64, _p, _i64, _p, _f64p, C.c_int)
+    f("msm_kmeans_plusplus_f32", C.c_int, _p, _i64, _i64, _i64, _i64, _p, C.c_int, _p, _p, C.c_int)
     f("msm_mbk_create", C.c_int, C.POINTER(_p), _i64, _i64)
     f("msm_mbk_destroy", C.c_int, _p)
     f("msm_mbk_set", C.c_int, _p, _p, _p)
     f("msm_mbk_set_counts", C.c_int, _p, _p)
     f("msm_mbk_get", C.c_int, _p, _p, _p)
     f("msm_mbk_step", C.c_int, _p, _p, _i64, _p, _i64, _f64p, _p, C.c_int, C.c_int)
+    f("msm_mbk_run_begin", C.c_int, _p, _p, _i64, _p, _i64, _i64, _i64, C.c_double, _i64, _p)
+    f("msm_mbk_run_end", C.c_int, _p, _p, C.POINTER(C.c_int64), C.POINTER(C.c_int), _p, _p)
     f("msm_mbk_run", C.c_int, _p, _p, _i64, _p, _i64, _i64, _i64, C.c_double, _i64, _p, C.POINTER(C.c_int64),
       C.POINTER(C.c_int), _p, _p)
     f("msm_mbk_run_sharded", C.c_int, _p, _p, _i64, _p, _p, _i64, _i64, _i64, C.c_double, _i64, _p, C.POINTER(C.c_int64),

@@ -59,52 +59,23 @@ def label_inertia(X, centers):
 
 
 def kmeans_plusplus(X, n_clusters, random_state):
-    """Greedy k-means++ seeding on a (small, host) sample, mirroring scikit-learn's
-    ``_kmeans_plusplus`` draw for draw (sklearn/cluster/_kmeans.py:163-259): first centre by
-    ``choice``, then ``2 + log(k)`` candidates per round drawn by inverse-CDF sampling of the
-    current squared distances, keeping the candidate with the lowest potential."""
-    n_samples, n_features = X.shape
-    centers = np.empty((n_clusters, n_features), dtype=X.dtype)
+    """Greedy k-means++ seeding of the rows ``X`` (numpy float32 or a torch CUDA tensor), scikit-learn's
+    ``_kmeans_plusplus`` draw for draw (sklearn/cluster/_kmeans.py:163-259): first centre by ``choice``, then
+    ``2 + log(k)`` candidates per round drawn by inverse-CDF sampling of the current squared distances, keeping the
+    candidate with the lowest potential.  The rounds run on the device (``msm_kmeans_plusplus_f32``, csrc/kpp.hip); the
+    draws -- one ``choice`` and ``(k - 1) x (2 + log k)`` uniforms -- come from ``random_state`` in scikit-learn's order
+    (legacy ``RandomState.uniform`` draws element by element, so one call for all rounds is the same stream as one call
+    per round).  Returns the centres as a host float32 array."""
+    ax = X if isinstance(X, Arr) else Arr(X, np.float32)
+    n_samples, n_features = ax.shape
     n_local_trials = 2 + int(np.log(n_clusters))
-    sample_weight = np.ones(n_samples, dtype=X.dtype)
-    center_id = random_state.choice(n_samples, p=sample_weight / sample_weight.sum())
-    centers[0] = X[center_id]
-    xsq = np.einsum("ij,ij->i", X, X)
-    Xm2 = np.ascontiguousarray(-2.0 * X)  # -2 x.c as c.(-2 x): an exact scaling, one pass less per round
-    d = np.empty((n_local_trials, n_samples), dtype=X.dtype)
-
-    def sqdist(c, out):  # [len(c), n_samples], same ||x||^2 - 2 x.c + ||c||^2 form as sklearn
-        np.dot(c, Xm2.T, out=out)
-        out += xsq[None, :]
-        out += np.einsum("ij,ij->i", c, c)[:, None]
-        np.maximum(out, 0, out=out)
-        return out
-
-    import os
-    from ..decomposition._moments import _blas_limit
-    closest = sqdist(centers[0:1], np.empty((1, n_samples), dtype=X.dtype))[0].copy()
-    current_pot = closest @ sample_weight
-    cum = np.empty(n_samples)
-    # a thousand tiny sgemms: a large BLAS pool costs more in wake-ups than it computes (and keeps spinning afterwards)
-    with _blas_limit(int(os.environ.get("MSMBUILDER_AMD_KPP_THREADS", "8"))):
-        _kpp_rounds(X, centers, n_clusters, n_local_trials, sample_weight, random_state, sqdist, d, closest, current_pot, cum)
-    return centers
-
-
-def _kpp_rounds(X, centers, n_clusters, n_local_trials, sample_weight, random_state, sqdist, d, closest, current_pot, cum):
-    n_samples = X.shape[0]
-    for c in range(1, n_clusters):
-        rand_vals = random_state.uniform(size=n_local_trials) * current_pot
-        np.cumsum(closest, dtype=np.float64, out=cum)   # sample_weight == 1
-        candidate_ids = np.searchsorted(cum, rand_vals)
-        np.clip(candidate_ids, None, n_samples - 1, out=candidate_ids)
-        d_cand = sqdist(X[candidate_ids], d)
-        np.minimum(closest, d_cand, out=d_cand)
-        pots = d_cand @ sample_weight
-        best = np.argmin(pots)
-        current_pot = pots[best]
-        closest = d_cand[best].copy()
-        centers[c] = X[candidate_ids[best]]
+    sample_weight = np.ones(n_samples, dtype=np.float32)
+    center_id = int(random_state.choice(n_samples, p=sample_weight / sample_weight.sum()))
+    u = np.ascontiguousarray(random_state.uniform(size=(max(n_clusters - 1, 0), n_local_trials)), dtype=np.float64)
+    centers = np.empty((n_clusters, n_features), dtype=np.float32)
+    ids = np.empty(n_clusters, dtype=np.int64)
+    check(_lib.lib().msm_kmeans_plusplus_f32(ax.vp, n_samples, n_features, n_clusters, center_id, u.ctypes.data,
+                                             n_local_trials, centers.ctypes.data, ids.ctypes.data, ax.on_device))
     return centers
 
 
@@ -165,14 +136,23 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         """_kmeans.py:955-1045 (the init subsample is drawn even for an explicit array)."""
         n_samples = shard.n_total
         Xs = None
+        from .. import parallel as _par
+        # k-means++ runs on the device: rows that already live there are gathered there (no trip through the host)
+        on_dev = ax.on_device and not _par.active() and isinstance(self.init, str) and self.init == "k-means++"
+
+        def rows(idx):
+            if on_dev:
+                import torch
+                return ax.keep[torch.as_tensor(np.ascontiguousarray(idx, dtype=np.int64), device=ax.keep.device)]
+            return self._rows(ax, shard, idx)
         if self._init_size is not None and self._init_size < n_samples:
             init_indices = random_state.randint(0, n_samples, self._init_size)
             if isinstance(self.init, str) or callable(self.init):
-                Xs = self._rows(ax, shard, init_indices)
+                Xs = rows(init_indices)
         elif isinstance(self.init, str) or callable(self.init):
-            Xs = self._rows(ax, shard, np.arange(n_samples))
+            Xs = ax.keep if on_dev else self._rows(ax, shard, np.arange(n_samples))
         if isinstance(self.init, str) and self.init == "k-means++":
-            centers = kmeans_plusplus(Xs, self.n_clusters, random_state)
+            centers = kmeans_plusplus(Xs, self.n_clusters, random_state)   # on the device (csrc/kpp.hip)
         elif isinstance(self.init, str) and self.init == "random":
             w = np.ones(len(Xs), dtype=Xs.dtype)
             seeds = random_state.choice(len(Xs), size=self.n_clusters, replace=False, p=w / w.sum())
@@ -278,6 +258,7 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                 to_reassign[keep] = False
             n_reassigns = int(to_reassign.sum())
             if n_reassigns:
+                self._drop_prefetch(random_state)   # the next run's indices were drawn ahead: this draw comes BEFORE them
                 new_centers = random_state.choice(B, replace=False, size=n_reassigns)
                 if self.verbose:
                     print("[MiniBatchKMeans] Reassigning %d cluster centers." % n_reassigns)
@@ -295,6 +276,12 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                     weight_sums[to_reassign] = mn
                     check(L.msm_mbk_set_counts(self._mbk, weight_sums.ctypes.data))
 
+    def _drop_prefetch(self, random_state):
+        """Indices drawn ahead for a run that will not happen: put the generator back in front of that draw."""
+        pre = self.__dict__.pop("_prefetched", None)
+        if pre is not None:
+            random_state.set_state(pre[0])
+
     def _run(self, ax, shard, first_step, n_steps, n_samples, random_state):
         """Steps ``first_step ...`` up to and including the next one that looks at the counts for a random
         reassignment, queued on the device in one go (``msm_mbk_run``): the batches are drawn up front, the
@@ -304,20 +291,30 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         generator is rewound to where scikit-learn would have left it."""
         L = _lib.lib()
         B = self._batch_size
-        plan, since = [], self._n_since_last_reassign
-        while first_step + len(plan) < n_steps and len(plan) < 256:
-            since += B
-            hit = since >= 10 * self.n_clusters
-            plan.append(hit)
-            if hit:
-                break
+
+        def plan_from(step0, since):
+            plan = []
+            while step0 + len(plan) < n_steps and len(plan) < 256:
+                since += B
+                hit = since >= 10 * self.n_clusters
+                plan.append(hit)
+                if hit:
+                    break
+            return plan
+        plan = plan_from(first_step, self._n_since_last_reassign)
         S = len(plan)
         # the S batches in ONE call: legacy RandomState.randint draws element by element from the bit stream, so this is
         # the same stream (and leaves the same state) as scikit-learn's S calls of size B -- checked by the n_steps_ /
         # generator-state comparisons against scikit-learn in the tests; S calls + S state snapshots cost 0.47 ms per run
         # on the host, more than the run's 0.23 ms on the GPU
-        state0 = random_state.get_state()
-        idx = np.ascontiguousarray(random_state.randint(0, n_samples, (S, B)), dtype=np.int64)
+        pre = self.__dict__.pop("_prefetched", None)
+        if pre is not None and pre[1].shape == (S, B):
+            state0, idx = pre          # drawn while the previous run executed; the generator already stands behind it
+        else:
+            if pre is not None:
+                random_state.set_state(pre[0])
+            state0 = random_state.get_state()
+            idx = np.ascontiguousarray(random_state.randint(0, n_samples, (S, B)), dtype=np.int64)
         alpha = min(B * 2.0 / (n_samples + 1), 1)
         st = np.array([self._ewa_inertia or 0.0, self._ewa_inertia_min or 0.0, float(self._no_improvement),
                        0.0 if self._ewa_inertia is None else 1.0, 0.0 if self._ewa_inertia_min is None else 1.0, 0.0])
@@ -338,8 +335,16 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                                         alpha, mni, st.ctypes.data, C.byref(done), C.byref(conv), inertias.ctypes.data,
                                         self._counts.ctypes.data))
         else:
-            check(L.msm_mbk_run(self._mbk, ax.vp, ax.shape[0], idx.ctypes.data, S, B, first_step, alpha, mni,
-                                st.ctypes.data, C.byref(done), C.byref(conv), inertias.ctypes.data, self._counts.ctypes.data))
+            check(L.msm_mbk_run_begin(self._mbk, ax.vp, ax.shape[0], idx.ctypes.data, S, B, first_step, alpha, mni, st.ctypes.data))
+            # while the device runs: the NEXT run's batch indices, assuming this run completes (what it does but once per
+            # fit).  The generator is left behind that draw; whoever needs it in between (the rewind below, a random
+            # reassignment in `_reassign`) first puts it back to `_prefetched[0]`.
+            nxt = plan_from(first_step + S, 0 if plan[-1] else self._n_since_last_reassign + S * B)
+            if nxt:
+                st_n = random_state.get_state()
+                self._prefetched = (st_n, np.ascontiguousarray(random_state.randint(0, n_samples, (len(nxt), B)), dtype=np.int64))
+            check(L.msm_mbk_run_end(self._mbk, st.ctypes.data, C.byref(done), C.byref(conv), inertias.ctypes.data,
+                                    self._counts.ctypes.data))
         done = int(done.value)
         self._ewa_inertia = float(st[0]) if st[3] else None
         self._ewa_inertia_min = float(st[1]) if st[4] else None
@@ -349,6 +354,7 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
             self._n_since_last_reassign = 0
             self._reassign(ax, shard, idx[-1], random_state)
         elif done < S:  # the criterion fired early: leave the generator where scikit-learn would (rare: once per fit)
+            self.__dict__.pop("_prefetched", None)
             random_state.set_state(state0)
             random_state.randint(0, n_samples, (done, B))
         return done, bool(conv.value)
@@ -448,6 +454,7 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                     i += done
                 else:  # one step at a time: starved centres (the first steps), tol > 0, verbose, host data
                     i += 1
+                    self._drop_prefetch(random_state)
                     minibatch_indices = random_state.randint(0, n_samples, self._batch_size)
                     minibatch_indices = np.ascontiguousarray(minibatch_indices, dtype=np.int64)
                     if self._tol > 0.0:  # the tol criterion needs the centres on the host every step
@@ -464,6 +471,7 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                     break
         finally:
             centers = self._mbk_close()
+        self._drop_prefetch(random_state)   # leave the generator where scikit-learn does
 
         self.cluster_centers_ = centers
         self.n_steps_ = i + 1

@@ -18,9 +18,16 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
+#include <chrono>
+#include <cstdlib>
+#include <future>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 namespace msm {
 
@@ -186,8 +193,30 @@ int msm_comm_init_rccl(const char* id128, int rank, int world)
     msm_comm_destroy();
     nccl_uid id;
     memcpy(id.internal, id128, 128);
-    nccl_comm c = nullptr;
-    const int st = r.init_rank(&c, world, id, rank);  // uses the calling thread's current device (msm_init)
+    // ncclCommInitRank blocks until EVERY rank has joined: a rank that died, took another branch or cannot reach the
+    // others would hang the job for good.  It runs on a helper thread (on the caller's device); the caller gives up after
+    // MSM_COMM_TIMEOUT_S seconds (180) with an error that names the rank -- the Python side then agrees on the host
+    // transport with the ranks that are still there (the helper stays parked inside RCCL: there is no cancelling it).
+    int dev = 0;
+    MSM_HIP_CHECK(hipGetDevice(&dev));
+    typedef std::pair<int, nccl_comm> InitResult;
+    auto prom = std::make_shared<std::promise<InitResult>>();
+    std::future<InitResult> fut = prom->get_future();
+    const fn_init_rank init = r.init_rank;
+    std::thread([prom, init, dev, world, id, rank] {
+        (void)hipSetDevice(dev);
+        nccl_comm c = nullptr;
+        const int st = init(&c, world, id, rank);
+        prom->set_value(InitResult(st, c));
+    }).detach();
+    const char* te = getenv("MSM_COMM_TIMEOUT_S");
+    const int tmo = te && atoi(te) > 0 ? atoi(te) : 180;
+    if (fut.wait_for(std::chrono::seconds(tmo)) != std::future_status::ready)
+        return fail(MSM_ERR_STATE, "ncclCommInitRank timed out after %d s on rank %d of %d (device %d): not every rank joined", tmo, rank,
+                    world, dev);
+    const InitResult res = fut.get();
+    const int st = res.first;
+    nccl_comm c = res.second;
     if (st != 0) return fail(MSM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, nccl_err(st));
     g_comm.kind = 1;
     g_comm.rank = rank;
@@ -224,6 +253,48 @@ int msm_comm_info(int* rank, int* world, int* kind)
     if (world) *world = comm_world();
     if (kind) *kind = g_comm.kind;
     return MSM_OK;
+}
+
+/* One all-reduce and one all-gather of a few doubles through the installed communicator, checked against what they must
+ * return, with a time limit: 0 = the transport works, MSM_ERR_STATE = wrong numbers or no answer within `timeout_s`
+ * (message names the rank).  Called by every rank right after the communicator is built, BEFORE any fit depends on it. */
+int msm_comm_selftest(int timeout_s)
+{
+    if (g_comm.kind == 0) return MSM_OK;
+    const int W = g_comm.world, me = g_comm.rank, tmo = timeout_s > 0 ? timeout_s : 60;
+    // d[0..1]: all-reduced {rank + 1, 1}; d[2]: this rank's tag; d[3 .. 3 + W): the gathered tags
+    double* d = nullptr;
+    MSM_HIP_CHECK(hipMalloc((void**)&d, (size_t)(3 + W) * sizeof(double)));
+    const double mine[3] = {(double)(me + 1), 1.0, 1000.0 + me};
+    MSM_HIP_CHECK(hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, stream()));
+    int rc = comm_allreduce_f64(d, 2);
+    if (!rc) rc = comm_allgather(d + 2, d + 3, sizeof(double));
+    if (!rc) {
+        hipEvent_t ev = nullptr;
+        MSM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        MSM_HIP_CHECK(hipEventRecord(ev, stream()));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipEventQuery(ev)) == hipErrorNotReady) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(tmo)) break;
+            usleep(200);
+        }
+        if (q == hipErrorNotReady)   // the stream is wedged: the buffer and the event are leaked on purpose
+            return fail(MSM_ERR_STATE, "rank %d of %d: the communicator's first collectives did not complete within %d s", me, W, tmo);
+        (void)hipEventDestroy(ev);
+        if (q != hipSuccess) rc = fail(MSM_ERR_HIP, "rank %d of %d: collective self-test: %s", me, W, hipGetErrorString(q));
+    }
+    if (!rc) {
+        std::vector<double> host((size_t)(3 + W), 0.0);
+        MSM_HIP_CHECK(hipMemcpy(host.data(), d, (size_t)(3 + W) * sizeof(double), hipMemcpyDeviceToHost));
+        bool ok = host[0] == 0.5 * W * (W + 1) && host[1] == (double)W;
+        for (int r = 0; r < W && ok; ++r) ok = host[3 + r] == 1000.0 + r;
+        if (!ok)
+            rc = fail(MSM_ERR_STATE, "rank %d of %d: the communicator's first collectives returned wrong numbers (sum %g, count %g)", me, W,
+                      host[0], host[1]);
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 /* test / bootstrap helpers on caller-owned DEVICE buffers */

@@ -1374,6 +1374,8 @@ struct msm_mbk {
     int* stop = nullptr;
     char* pinned = nullptr;
     size_t pinned_bytes = 0;
+    const char* run_out = nullptr;   // msm_mbk_run_begin .. _end: where the run in flight leaves its results (in `pinned`)
+    size_t run_st_bytes = 0;
 };
 
 namespace {
@@ -1644,12 +1646,14 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
     return MSM_OK;
 }
 
-int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
-                msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
-                msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
+/* msm_mbk_run in two halves: _begin queues the whole run (indices in, S steps, results out) and returns without waiting,
+ * _end waits for it and hands the results over.  Between the two the host is free -- MiniBatchKMeans draws the NEXT run's
+ * batch indices there (a quarter of a millisecond per 65,536 indices with the legacy RandomState, as long as a large-batch
+ * step takes on the device). */
+int msm_mbk_run_begin(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                      msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, const double* state6)
 {
-    if (!h || !X || !batch_idx || !state6 || !steps_done || !converged || !inertias)
-        return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
+    if (!h || !X || !batch_idx || !state6) return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
     if (n < 1 || B < 1 || S < 1 || S > 4096) return fail(MSM_ERR_INVALID, "msm_mbk_run: bad shape");
     for (msm_idx_t b = 0; b < S * B; ++b)
         if (batch_idx[b] < 0 || batch_idx[b] >= n) return fail(MSM_ERR_INVALID, "mbk: batch index out of range");
@@ -1717,7 +1721,19 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
     MSM_HIP_CHECK(hipMemcpyAsync(o, st, st_bytes, hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes, h->stop, sizeof(int), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes + 8, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    h->run_out = o;
+    h->run_st_bytes = st_bytes;
+    return MSM_OK;
+}
+
+int msm_mbk_run_end(msm_mbk_t* h, double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
+{
+    if (!h || !state6 || !steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run_end: null argument");
+    if (!h->run_out) return fail(MSM_ERR_STATE, "msm_mbk_run_end: no run in flight");
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    const char* o = h->run_out;
+    const size_t st_bytes = h->run_st_bytes;
+    h->run_out = nullptr;
     const double* so = reinterpret_cast<const double*>(o);
     for (int i = 0; i < 5; ++i) state6[i] = so[i];
     state6[5] = so[5];
@@ -1726,6 +1742,16 @@ int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batc
     *converged = *reinterpret_cast<const int*>(o + st_bytes);
     if (counts_out) memcpy(counts_out, o + st_bytes + 8, (size_t)h->K * sizeof(float));
     return MSM_OK;
+}
+
+int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
+                msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
+{
+    if (!steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
+    const int rc = msm_mbk_run_begin(h, X, n, batch_idx, S, B, first_step, alpha, max_no_improvement, state6);
+    if (rc) return rc;
+    return msm_mbk_run_end(h, state6, steps_done, converged, inertias, counts_out);
 }
 
 /* msm_mbk_run for a ROW-SHARDED fit (one process per GPU): the S batches are GLOBAL (identical on every rank); this rank

@@ -15,6 +15,7 @@ tICA buffer is exported device-to-device, never staged through the host); with `
 (CPU-only test runs of the host logic) they go through host tensors.
 """
 import os
+import warnings
 
 import numpy as np
 
@@ -77,6 +78,7 @@ def init_from_env(backend=None):
 # form a communicator, so the library is given a host-side transport instead: same library code above it.
 # ---------------------------------------------------------------------------------------------------
 _lib_comm_kind = None      # None | "rccl" | "host"
+_comm_failures = []        # ranks whose RCCL join / self-test failed when the communicator was last built (then: host transport)
 _host_cb_keepalive = None
 _lib_comm_key = None       # (backend, world, rank, default group identity) the communicator belongs to
 _atexit_registered = False
@@ -145,6 +147,7 @@ def library_comm():
     dist = _dist()
     L = _lib.lib()
     r, w = dist.get_rank(), dist.get_world_size()
+    _comm_failures[:] = []
     want = os.environ.get("MSMBUILDER_AMD_COMM", "auto")     # auto | rccl | host
     kind = None
     if want != "host" and _backend_is_nccl():
@@ -162,19 +165,33 @@ def library_comm():
             dist.broadcast(t, src=0)
             raw = bytes(t.cpu().numpy().tolist())
             if raw[128]:
+                # 2) join (time-limited inside the library), then 3) one checked all-reduce + all-gather through the new
+                #    communicator before any fit depends on it.  Every rank reports; the ranks that failed are named in
+                #    `comm_failures` (bench.py prints them) and everybody falls back to the host transport together.
                 rc = L.msm_comm_init_rccl(raw[:128], r, w)
-                flag = torch.tensor([1.0 if rc == 0 else 0.0], device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if flag.item() > 0:
+                err = _lib.last_error() if rc else ""
+                if rc == 0:
+                    rc = L.msm_comm_selftest(int(os.environ.get("MSM_COMM_TIMEOUT_S", "180")))
+                    err = _lib.last_error() if rc else ""
+                flags = torch.zeros(w, device="cuda")
+                flags[r] = 1.0 if rc == 0 else 0.0
+                dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+                bad = [i for i, v in enumerate(flags.cpu().tolist()) if v < 0.5]
+                if not bad:
                     kind = "rccl"
                 else:
+                    _comm_failures[:] = [{"rank": i, "error": err if i == r else None} for i in bad]
+                    if rc:
+                        warnings.warn("libmsmhip RCCL communicator, rank %d of %d: %s" % (r, w, err))
                     L.msm_comm_destroy()
         if kind is None and want == "rccl":
-            raise RuntimeError("libmsmhip could not create its RCCL communicator: " + _lib.last_error())
+            raise RuntimeError("libmsmhip could not create its RCCL communicator (failed ranks: %s): %s"
+                               % ([f["rank"] for f in _comm_failures], _lib.last_error()))
     if kind is None:
         cbt = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
         _host_cb_keepalive = cbt(_host_collective)
         _lib.check(L.msm_comm_init_host(C.cast(_host_cb_keepalive, C.c_void_p), r, w))
+        _lib.check(L.msm_comm_selftest(int(os.environ.get("MSM_COMM_TIMEOUT_S", "180"))))
         kind = "host"
     _lib_comm_kind, _lib_comm_key = kind, key
     global _atexit_registered

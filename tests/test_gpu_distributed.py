@@ -278,3 +278,29 @@ def test_bench_self_launches_its_ranks(gpu):
     assert out["value"] > 0 and set(out["phases_ms"]) >= {"fit", "allreduce", "solve", "transform", "kcenters_fit", "kcenters_predict"}
     # (several centres per exchange: at most one round per centre)
     assert out["clustering"]["kcenters_plain_passes"] == 2 and 1 <= out["clustering"]["kcenters_screened_passes"] <= 198
+
+
+def test_bench_world_of_eight_on_the_box(gpu):
+    """The driver's 8-GPU command form, `python bench.py --gpus 8`, with EIGHT ranks before the driver's node is the first
+    to try: on a one-GPU box the ranks share the device over the host transport, so the sharded code -- the dealing of the
+    trajectories, the packed all-reduce, the k-centers round records of eight shards, the barrier / max-over-ranks timing,
+    the single JSON line -- meets world = 8 here (VERDICT r3 #2d).  On an 8-GPU node the same command runs over RCCL."""
+    import json
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                        "--frames", "800000", "--no-extras", "--no-mbk", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["total_frames"] == 800000
+    assert out["config"]["frames_per_gpu"] == 100000 and out["comm_ok"] and out["comm_failed_ranks"] == []
+    if torch.cuda.device_count() >= 8:
+        assert out["comm"] == "rccl" and out["rccl_ranks"] == 8
+    else:
+        assert out["comm"] == "host" and out["rccl_ranks"] == 0
+    assert out["value"] > 0 and set(out["phases_ms"]) >= {"fit", "allreduce", "solve", "transform", "kcenters_fit", "kcenters_predict"}
+    ev = out["top_eigenvalues"] if "top_eigenvalues" in out else None
+    assert ev is None or (0.0 < ev[0] < 1.0)

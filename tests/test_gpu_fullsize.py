@@ -153,6 +153,42 @@ def test_config3_kcenters_280k_bit_exact(gpu):
         assert np.array_equal(pred, labels)
 
 
+def test_config3_stress_280k_x_171_without_tica_bit_exact(gpu):
+    """SURVEY 8(d)'s C3 stress variant: KCenters(200).fit and assign_nearest on the RAW contact features, 280,000 x 171
+    float32 (28 trajectories x 10,000), no tICA in front -- the wide-row kernels (171 is odd: no 16-byte aligned rows, the
+    scalar-staged pair kernel) at full size.  Bit for bit against the C oracle and, where it is built, against the
+    reference's own headers compiled from where they lie (oracle/_ref; assign.hpp:50-91)."""
+    from msmbuilder_amd import KCenters, libdistance
+    from oracle.libdistance_oracle import Oracle, Ref
+    o = Oracle()
+    rs = np.random.RandomState(171)
+    n, F, K = 280_000, 171, 200
+    # contact-distance-like features: positive, column means 0.4 - 2.5 nm, slow drift along each trajectory + noise
+    base = np.linspace(0.4, 2.5, F).astype(np.float32)
+    Y = np.empty((n, F), dtype=np.float32)
+    for t in range(28):
+        drift = np.cumsum(rs.randn(10_000, 8).astype(np.float32) * 0.01, axis=0) @ rs.randn(8, F).astype(np.float32)
+        Y[t * 10_000:(t + 1) * 10_000] = np.abs(base + 0.3 * drift + 0.05 * rs.randn(10_000, F).astype(np.float32))
+    Y[123_456] = Y[7]                                      # a duplicate row: an exact tie for assign_nearest's strict <
+    seqs = [Y[i * 10_000:(i + 1) * 10_000] for i in range(28)]
+    m = KCenters(n_clusters=K, random_state=0).fit(seqs)
+    ids, labels, dist = o.kcenters_fit(Y, K, "euclidean", m.cluster_ids_[0])
+    assert m.cluster_ids_ == list(ids)
+    assert np.array_equal(np.concatenate(m.labels_), labels)
+    assert np.array_equal(np.concatenate(m.distances_), dist)
+    assert m.inertia_ == np.sum(dist)
+    assert m.cluster_centers_.dtype == np.float32 and np.array_equal(m.cluster_centers_, Y[ids])
+    centres = np.ascontiguousarray(Y[ids])
+    got, inertia = libdistance.assign_nearest(Y, centres, "euclidean")
+    want = o.assign_nearest(Y, centres, "euclidean")
+    assert np.array_equal(got, want[0]) and abs(inertia - want[1]) <= 1e-13 * want[1]
+    assert np.array_equal(np.concatenate(m.predict(seqs)), want[0])
+    if Ref.available():
+        ref = Ref().assign_nearest(Y, centres, "euclidean")
+        assert np.array_equal(got, ref[0]) and abs(inertia - ref[1]) <= 1e-13 * ref[1]
+    assert got[123_456] == got[7] and np.array_equal(got[ids], np.arange(K))
+
+
 @pytest.mark.parametrize("metric", ["euclidean", "cityblock", "chebyshev"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_kcenters_label_sorted_path_clustered(gpu, metric, dtype, monkeypatch):

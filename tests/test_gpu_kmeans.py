@@ -170,3 +170,51 @@ def test_small_batch_step_kernels_equal_general_kernels(gpu, K, F, B):
     if F > 32:  # (rows of <= 32 features take mbk_small_label_kernel, whose fp32 summation order is its own)
         assert run({"MSM_MBK_LABEL64": "0"}) == base
         assert run({"MSM_MBK_SMALL": "0"}) == base
+
+
+@pytest.mark.parametrize("n,F,k", [(500, 8, 10), (3072, 64, 50), (1000, 3, 25), (3072, 512, 200), (1, 4, 1), (7, 2, 7)])
+def test_device_kmeans_plusplus_draws_scikit_learns_seeds(gpu, n, F, k):
+    """The device seeding (msm_kmeans_plusplus_f32: scikit-learn's float64-upcast distance arithmetic, the caller's
+    RandomState stream) against `sklearn.cluster.kmeans_plusplus` ITSELF, live: the same rows are chosen and the generator
+    ends in the same state -- at MiniBatchKMeans' default init sample (3 x 1024 rows) and at the smallest shapes, host rows
+    and device rows alike."""
+    sk = pytest.importorskip("sklearn.cluster")
+    import torch
+    from msmbuilder_amd.cluster.minibatchkmeans import kmeans_plusplus
+    from oracle.kpp_oracle import kmeans_plusplus as kpp_oracle
+    rs = np.random.RandomState(n + k)
+    X = (rs.randn(n, F) * rs.uniform(0.5, 3, F) + rs.randn(F)).astype(np.float32)
+    g_ref = np.random.RandomState(7)
+    ref, ref_ids = sk.kmeans_plusplus(X, k, random_state=g_ref)
+    tail = g_ref.randint(0, 1 << 30, 5)
+    for rows in (X, torch.from_numpy(X).cuda()):
+        g_mine = np.random.RandomState(7)
+        mine = kmeans_plusplus(rows, k, g_mine)
+        np.testing.assert_array_equal(mine, ref)
+        np.testing.assert_array_equal(g_mine.randint(0, 1 << 30, 5), tail)
+    np.testing.assert_array_equal(kpp_oracle(X, k, np.random.RandomState(7)), ref)   # ... and so does the oracle restatement
+
+
+def test_device_kmeans_plusplus_large_sample(gpu):
+    """The bench's large-batch init sample, 3 x 65,536 rows, K = 1000.  scikit-learn sums its potentials in float32 over
+    the 196,608 rows (a BLAS dot: ~1e-5 relative, order-dependent), and every inverse-CDF draw is scaled by that sum -- a
+    1e-5 change of scale moves a draw by two rows -- so at this size its picks are those of one BLAS build, not of the
+    algorithm.  The device seeding keeps scikit-learn's draws and distance arithmetic with float64 potentials: it must
+    equal the float64 restatement in oracle/kpp_oracle.py row for row, and seed as well as scikit-learn does (potential
+    of the chosen seeds within 5 % of scikit-learn's on the same data and stream)."""
+    sk = pytest.importorskip("sklearn.cluster")
+    import torch
+    from msmbuilder_amd.cluster.minibatchkmeans import kmeans_plusplus
+    from oracle.kpp_oracle import kmeans_plusplus_f64
+    n, F, k = 196_608, 10, 1000
+    rs = np.random.RandomState(5)
+    X = (rs.randn(n, F) * np.linspace(3, 0.3, F)).astype(np.float32)
+    mine = kmeans_plusplus(torch.from_numpy(X).cuda(), k, np.random.RandomState(7))
+    want, _ = kmeans_plusplus_f64(X, k, np.random.RandomState(7))
+    np.testing.assert_array_equal(mine, want)
+    ref, _ = sk.kmeans_plusplus(X, k, random_state=np.random.RandomState(7))
+
+    def potential(C):
+        from msmbuilder_amd.cluster.minibatchkmeans import label_inertia
+        return label_inertia(X, C)[1]
+    assert 0.95 < potential(mine) / potential(ref) < 1.05
