@@ -1348,6 +1348,51 @@ static int sum_partials_host(const double* dpartial, int n, double* out)
     return MSM_OK;
 }
 
+// Rows whose length is not a multiple of 16 bytes (171 float32 contact features: SURVEY 8(d)'s C3 stress variant) cannot take
+// the wide-row streaming kernels and fell to the scalar-staged pair kernel -- 20x slower per pair-element (280,000 x 171 x
+// K = 200: assign_nearest 32.7 ms, a k-centers pass 134 us at 1.4 TB/s; profiles/r04_pmc_all_first.txt).  For the NORM
+// metrics a zero column is an exact no-op in the reference's arithmetic (a float difference 0 - 0 = +0, then s + 0*0 = s,
+// s + |0| = s, max(s, 0) = s for s >= 0), so such rows are copied once into a buffer zero-padded to the next multiple of 16
+// bytes -- one streaming pass, 2 x the input bytes -- and everything downstream sees aligned rows.  Bit-identical outputs.
+template <typename T>
+static bool pad_rows_pays(int mid, long long m, long long n, bool has_indices)
+{
+    constexpr int E = 16 / (int)sizeof(T);
+    return !has_indices && (mid == M_EUCLIDEAN || mid == M_SQEUCLIDEAN || mid == M_CITYBLOCK || mid == M_CHEBYSHEV) &&
+           m > FeatChunk<T>::FC && (m % E) != 0 && n * m >= (1LL << 20);
+}
+
+template <typename T>
+__global__ void pad_rows_kernel(const T* __restrict__ X, long long n, long long m, long long mp, T* __restrict__ out)
+{
+    constexpr int E = 16 / (int)sizeof(T);
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x, per = mp / E;   // 16-byte groups
+    if (g >= n * per) return;
+    const long long i = g / per, c = (g - i * per) * E;
+    T v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = c + e < m ? X[i * m + c + e] : (T)0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[i * mp + c + e] = v[e];
+}
+
+template <typename T>
+static int pad_rows(const T* X, long long n, long long m, DevBuf& buf, const T** out, long long* mp_out)
+{
+    constexpr int E = 16 / (int)sizeof(T);
+    const long long mp = (m + E - 1) / E * E;
+    int rc = buf.reserve((size_t)std::max<long long>(n, 1) * mp * sizeof(T));
+    if (rc) return rc;
+    if (n > 0) {
+        const long long groups = n * (mp / E);
+        hipLaunchKernelGGL(pad_rows_kernel<T>, dim3((unsigned)ceil_div(groups, 256)), dim3(256), 0, stream(), X, n, m, mp, buf.as<T>());
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    *out = buf.as<T>();
+    *mp_out = mp;
+    return MSM_OK;
+}
+
 template <typename T>
 int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_idx_t* X_indices,
                         msm_idx_t n_X, msm_idx_t n_Y, msm_idx_t m, msm_idx_t n_idx,
@@ -1395,6 +1440,15 @@ int assign_nearest_impl(const T* X, const T* Y, const char* metric, const msm_id
             if ((rc = dMin.reserve((size_t)n * sizeof(double)))) return rc;
             P.min_dist = dMin.as<double>();
         }
+    }
+    if (pad_rows_pays<T>(mid, m, n_X, P.X_indices != nullptr)) {
+        const T *xp = nullptr, *yp = nullptr;
+        long long mp = m;
+        if ((rc = pad_rows<T>(static_cast<const T*>(P.X), n_X, m, pool(PS_PADX), &xp, &mp))) return rc;
+        if ((rc = pad_rows<T>(static_cast<const T*>(P.Y), n_Y, m, pool(PS_PADY), &yp, &mp))) return rc;
+        P.X = xp;
+        P.Y = yp;
+        P.m = m = mp;
     }
     P.vecw = row_vecw<T>(P.X, m, P.X_indices != nullptr);
     if (P.vecw == 0 && wide_ok<T>(P.X, P.Y, m, P.X_indices != nullptr)) grid = wide_grid(n);
@@ -3202,6 +3256,13 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         P.X = dX.p;
         P.labels = dLab.as<msm_idx_t>();
         P.dist = dDist.as<double>();
+    }
+    if (pad_rows_pays<T>(mid, m, n, false)) {   // odd rows, norm metric: a zero-padded aligned copy (see pad_rows_pays)
+        const T* xp = nullptr;
+        long long mp = m;
+        if ((rc = pad_rows<T>(static_cast<const T*>(P.X), n, m, pool(PS_PADX), &xp, &mp))) return rc;
+        P.X = xp;
+        P.m = m = mp;
     }
     P.vecw = row_vecw<T>(P.X, m, false);
     if (P.vecw == 0 && wide_ok<T>(P.X, P.X, m, false)) P.nblk = nblk = std::min(nblk, wide_grid(n));
