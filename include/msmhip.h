@@ -204,33 +204,20 @@ int msm_tica_export_sums(msm_tica_t* h, double* s0, double* stau);
  * from F ~ 1024) and returns the k largest eigenvalues (descending) and their eigenvectors as rows. */
 int msm_tica_reduce(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* Cs, double* mu,
                     double* info);
-/* msm_tica_reduce followed by the Householder tridiagonalisation of the reduced matrix ON THE DEVICE (msm_sytrd's
- * cooperative kernel, n_features <= 1024): the host receives LAPACK dsytrd(lower) outputs d[F], e[F-1], tau[F-1] and the
- * reflectors V[(F-1)*(F-1)] (the block A(2:n, 1:n-1), column-major: dormqr's argument) and finishes with dstemr (selected eigenpairs of the tridiagonal) and dormqr
- * (reflectors applied to the k vectors) before msm_tica_backsolve.  *status = 1: the cooperative kernel could not keep
- * its workgroups resident -- Cs (host, F x F) then holds the reduced matrix for the msm_tica_reduce route. */
-int msm_tica_reduce_tridiag(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* d, double* e,
-                            double* tau, double* V, double* Cs, double* mu, double* info, int* status);
-/* The tridiagonalisation on its own: symmetric A (n x n, host or device per on_device), n <= 1024. */
-int msm_sytrd(const double* A, msm_idx_t n, double* d, double* e, double* tau, double* V, int* status, int on_device);
 int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V);
-/* The whole top-k solve without LAPACK and with ONE synchronisation (n_features <= 1024, k <= 64): msm_tica_reduce's
- * finalisation and reduction (Cholesky by the library's own blocked kernel), the cooperative tridiagonalisation, the k
- * largest eigenpairs of the tridiagonal matrix by multisection + inverse iteration (msm_tridiag_topk), the Householder
- * back-transform, v = L^-T y.  For n_features >= 128 and k <= 16 a Chebyshev-filtered subspace iteration on the reduced
- * matrix (csrc/subspace.hip; its 32 x 32 Rayleigh-Ritz problems are solved on the host, so it synchronises a few times)
- * is tried first and the tridiagonalisation runs only when it stalls.  vals[k] descending, vecs[k][F] rows B-orthonormal
- * like dsygvx's, mu[F], info[12]: [0..5] as msm_tica_reduce, info[6] = max_j ||Cs y_j - lambda_j y_j||_inf, info[7] =
- * max_j | ||y_j||^2 - 1 |, info[8] = 1 if the pairs came from the subspace iteration, info[9] = its filtered iterations.
- * *status = 0: pairs returned and verified on the reduced matrix; 1: the cooperative kernel gave up; 2: the residual
- * check failed -- in both cases Cs (host, F x F) holds the reduced matrix for the caller's LAPACK route
- * (msm_tica_backsolve afterwards), as with msm_tica_reduce_tridiag. */
+/* The top-k solve on the device (128 <= n_features <= 1024, k <= 16): msm_tica_reduce's finalisation and reduction
+ * (Cholesky by the library's own blocked kernel), a Chebyshev-filtered subspace iteration on the reduced matrix
+ * (csrc/subspace.hip; its 32 x 32 Rayleigh-Ritz problems are solved on the host, so it synchronises a few times),
+ * v = L^-T y.  vals[k] descending, vecs[k][F] rows B-orthonormal like dsygvx's, mu[F], info[12]: [0..5] as
+ * msm_tica_reduce, info[6] = max_j ||Cs y_j - lambda_j y_j||_inf, info[7] = max(max_j | ||y_j||^2 - 1 |, max_{i<j} |y_i.y_j|),
+ * info[8] = 1 if pairs were returned, info[9] = filtered iterations spent.
+ * *status = 0: pairs returned and verified on the reduced matrix (residual, norm, mutual orthogonality); 1: the iteration
+ * did not converge (flat spectra); 2: the check failed -- in both cases Cs (host, F x F) holds the reduced matrix for the
+ * caller's LAPACK route (msm_tica_backsolve afterwards). */
 int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k, double* vals,
                         double* vecs, double* Cs, double* mu, double* info, int* status);
-/* Building blocks, exported for the tests: k largest eigenpairs of the symmetric tridiagonal (d[n], e[n-1]), n <= 1024,
- * k <= 64 (vals descending, vecs[k][n] orthonormal rows); Cholesky B = U^T U on the row-major upper triangle (LAPACK
- * dpotrf 'L' on the column-major view), *info = first non-positive pivot (1-based) or 0. */
-int msm_tridiag_topk(const double* d, const double* e, msm_idx_t n, msm_idx_t k, double* vals, double* vecs, int on_device);
+/* Building block, exported for the tests: Cholesky B = U^T U on the row-major upper triangle (LAPACK dpotrf 'L' on the
+ * column-major view), *info = first non-positive pivot (1-based) or 0. */
 int msm_potrf(double* B, msm_idx_t n, int* info, int on_device);
 int msm_tica_solve_device(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k,
                           double* vals, double* vecs, double* mu, double* info);
@@ -243,7 +230,8 @@ int msm_tica_counts(msm_tica_t* h, msm_idx_t* n_observations, msm_idx_t* n_seque
 
 /* out[n, k] (float64) = (X - mean) @ comps.T, comps is k x F row-major, mean/comps host
  * float64 (tica.py:329-333; any kinetic/commute column scaling is folded into comps by
- * the caller).  X / out follow on_device.  check_finite as above. */
+ * the caller).  X / out follow on_device.  check_finite as above.  dtype_bytes = 2: bfloat16-STORED rows, widened
+ * (exactly) inside the kernel -- the result equals the projection of their float32 images. */
 int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features,
                      msm_idx_t ld, const double* mean, const double* comps, msm_idx_t k,
                      double* out, int on_device, int check_finite);

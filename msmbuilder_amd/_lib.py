@@ -107,11 +107,8 @@ def _declare(lib):
     f("msm_tica_export_sums", C.c_int, _p, _p, _p)
     f("msm_tica_reduce", C.c_int, _p, C.c_double, _i64, _p, _p, _p, _p)
     f("msm_tica_backsolve", C.c_int, _p, _p, _i64, _p)
-    f("msm_tica_reduce_tridiag", C.c_int, _p, C.c_double, _i64, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int))
     f("msm_tica_solve_topk", C.c_int, _p, C.c_double, _i64, _p, _i64, _p, _p, _p, _p, _p, C.POINTER(C.c_int))
-    f("msm_tridiag_topk", C.c_int, _p, _p, _i64, _i64, _p, _p, C.c_int)
     f("msm_potrf", C.c_int, _p, _i64, C.POINTER(C.c_int), C.c_int)
-    f("msm_sytrd", C.c_int, _p, _i64, _p, _p, _p, _p, C.POINTER(C.c_int), C.c_int)
     f("msm_tica_solve_device", C.c_int, _p, C.c_double, _i64, _p, _i64, _p, _p, _p, _p)
 
     f("msm_label_range", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64p, _i64p, _i64p)

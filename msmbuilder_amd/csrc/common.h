@@ -85,18 +85,12 @@ int comm_allgather(const void* dsend, void* drecv, size_t bytes);   // drecv[r *
 int sygv_reduce_device(double* A, double* B, int n, int* dinfo);   // B = L L^T (lower, col-major), A <- L^-1 A L^-T
 int sygv_back_device(const double* L, double* Y, int n, int k);    // Y[n x k col-major] <- L^-T Y
 int syevd_device(double* A, int n, double* D, double* E, int* dinfo);
-// sytrd.hip: cooperative Householder tridiagonalisation (n <= 1024), queued on stream(); work8n: 8n doubles of
-// exchange records; *status (device int) = 1 if the kernel gave up
-int sytrd_device(const double* A, int n, double* d, double* e, double* tau, double* V, double* work8n, int* status);
-
-// toppairs.hip: the LAPACK-free tail of the solve, queued on stream(), nothing synchronised
+// toppairs.hip: own Cholesky and the residual check of the solve, queued on stream(), nothing synchronised
 int potrf_upper_device(double* B, int n, int* dinfo);   // B = U^T U on the row-major upper triangle (== dpotrf 'L', col-major)
-int tri_topk_device(const double* d, const double* e, int n, int k, double* vals, double* S);   // n <= 1024, k <= 64; e has n entries
-int apply_q_device(const double* V, const double* tau, int n, int k, const double* S, double* Y);
 int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res2k);
 
 // subspace.hip: k largest eigenpairs of a symmetric matrix with spectrum in [lower, inf) by Chebyshev-filtered subspace
-// iteration (block of 32, Rayleigh-Ritz on the host); synchronises; *converged = 0 -> outputs meaningless, use the direct route
+// iteration (block of 32, Rayleigh-Ritz on the host); synchronises; *converged = 0 -> outputs meaningless, use the fallback
 int subspace_topk_device(const double* Cm, int n, int k, double lower, double tol, int degree, int max_outer, double* lam,
                          double* Yk, double* work, int* converged, int* outer_used);
 size_t subspace_work_doubles(int n);

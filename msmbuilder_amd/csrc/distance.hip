@@ -1186,11 +1186,6 @@ __global__ __launch_bounds__(DT) void sum_partial_kernel(const double* __restric
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-static int kc_prune_enabled()
-{
-    static const int on = !(getenv("MSM_KC_PRUNE") && atoi(getenv("MSM_KC_PRUNE")) == 0);  // A/B switch for scripts / tests
-    return on;
-}
 
 // ---- host-side dispatch ----------------------------------------------------
 // widest aligned per-lane vector load for a [*, m] row-major array, 0 if the fast path does not apply
@@ -1206,15 +1201,12 @@ static int row_vecw(const void* X, long long m, bool has_indices)
 }
 
 constexpr size_t wide_lds(int ncl) { return (size_t)2 * DT * WP * 4 + (size_t)2 * ncl * 32 * 4 + (size_t)DT * 16; }
-constexpr size_t WIDE_LDS = wide_lds(WNC);
 
 // wide-row streaming path applies: long rows, 16-byte aligned vectors, no row gather
 template <typename T>
 static bool wide_ok(const void* X, const void* Y, long long m, bool has_indices)
 {
     constexpr int E = 16 / (int)sizeof(T);
-    static const bool disabled = getenv("MSM_DIST_NO_WIDE") != nullptr;  // A/B switch for scripts/distperf.py
-    if (disabled) return false;
     return !has_indices && m > FeatChunk<T>::FC && (m % E) == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0 &&
            (size_t)m * sizeof(T) < ((size_t)1 << 24);
 }
@@ -1240,9 +1232,8 @@ static void launch_wide_nc(int grid, const WideArgs& A)
 template <typename T, int MM, int MODE>
 static void launch_wide(int grid, const WideArgs& A)
 {
-    // assign_nearest picks its centre-group size by shape (MSM_WIDE_NC=16 keeps the general one, for A/B runs)
-    static const bool fixed = getenv("MSM_WIDE_NC") && atoi(getenv("MSM_WIDE_NC")) == 16;
-    if (MODE == 0 && !fixed) {
+    // assign_nearest picks its centre-group size by shape
+    if (MODE == 0) {
         if (A.pa.K <= 8) return launch_wide_nc<T, MM, 0, 8>(grid, A);
         // (32-centre groups for float64 rows were measured too: 2M x 256 x K = 100 8.74 ms against 8.31 ms with 16 -- the
         //  4 KiB of extra LDS cost the second workgroup of a CU and more than the halved re-streaming of the row tile gains)
@@ -1254,16 +1245,14 @@ template <typename T, int MODE>
 void launch_pair(int metric, int grid, const PairArgs& P)
 {
     const bool wide = wide_ok<T>(P.X, P.Y, P.m, P.X_indices != nullptr);
-    static const bool small1 = getenv("MSM_DIST_SMALL1") != nullptr;  // A/B switch: one row per lane (round 1's kernel)
-    static const bool small2 = getenv("MSM_DIST_SMALL2") != nullptr;  // A/B switch: generic two-rows kernel for the euclidean family too
     WideArgs A;
     memset(&A, 0, sizeof(A));
     A.pa = P;
 #define MSM_CASE(MM)                                                                              \
     case MM:                                                                                      \
-        if (P.vecw > 0 && MODE == 0 && !small1 && !small2 && (MM == M_EUCLIDEAN || MM == M_SQEUCLIDEAN) &&  \
+        if (P.vecw > 0 && MODE == 0 && (MM == M_EUCLIDEAN || MM == M_SQEUCLIDEAN) &&              \
             (sizeof(T) == 4 ? launch_small3_f32(MM, grid, P) : launch_small3_f64(MM, grid, P))) { \
-        } else if (P.vecw > 0 && MODE == 0 && !small1)                                            \
+        } else if (P.vecw > 0 && MODE == 0)                                                       \
             hipLaunchKernelGGL((assign_small2_kernel<T, MM>), dim3(grid), dim3(DT), 0, stream(), P); /* every block writes its partial */ \
         else if (P.vecw > 0)                                                                      \
             hipLaunchKernelGGL((pair_small_kernel<T, MM, MODE>), dim3(grid), dim3(DT), 0, stream(), P); \
@@ -2751,13 +2740,9 @@ struct KcStats {
 };
 static KcStats g_kc_stats;
 
-static int ksc_mode()  // MSM_KC_SCREEN: 0 = plain passes only, 1 = float32 screen copy, 2 = bfloat16, 3 (default) = bytes + a row scale
-{
-    static const int mode = getenv("MSM_KC_SCREEN") ? atoi(getenv("MSM_KC_SCREEN")) : 3;
-    return mode;
-}
-static bool ksc_enabled() { return ksc_mode() != 0; }
-static int ksc_fmt() { return ksc_mode() == 1 ? 0 : ksc_mode() == 2 ? 1 : 2; }   // FMT of the screen kernels
+// The screen copy in use is FMT 2 (bytes + a row scale); the float32 / bfloat16 formats of the kernels' FMT parameter were
+// measured in round 3 and are no longer instantiated.
+constexpr int KSC_FMT = 2;
 
 struct KscBufs {
     DevBuf xf, curf, misc;
@@ -2766,456 +2751,6 @@ static KscBufs& ksc_bufs()
 {
     static KscBufs b;
     return b;
-}
-
-// ---------------------------------------------------------------------------
-// Label-sorted k-centers (single GPU, rows in registers, norm metrics).
-//
-// The per-row triangle-inequality test above saves arithmetic, not bytes: rows that cannot change are scattered through
-// the array, every 128-byte line still holds one that can, and a pass stays at ~130 us of HBM time (10M x 10 float64).
-// Here the fit works on a PERMUTED copy of the rows (with their distance, label and original index), re-sorted by label
-// (a counting sort) after a few chosen passes, and keeps a summary per tile of KS_TILE rows: the label its rows had at
-// the last sort if they all shared one (else "mixed"), the largest current distance among those rows and among the
-// rows that joined a newer centre since, and the tile's argmax candidate.  A pass reads the summary first:
-//     d(new centre, centre L) >= 2(1+eps) max_old   and   min_{j newer} d(new centre, centre j) >= 2(1+eps) max_new
-// is the per-row test for every row of the tile at once (cur_i <= the tile's maximum), so none can change and the whole
-// tile -- rows, distances, labels -- is not read.  Once the data is clustered most tiles go that way.  Results are exact:
-// a tile is skipped only when the per-row test would skip each of its rows, the argmax tie rule uses the ORIGINAL row
-// index, and the order of rows inside a label is irrelevant.  labels / distances are scattered back at the end.
-// ---------------------------------------------------------------------------
-constexpr int KS_TILE = 1024;  // rows per tile (4 per thread)
-
-struct KsSummary {
-    int lab;            // >= 0: label shared by the tile's pre-sort rows; -1: mixed (always processed); -2: no such rows
-    int pad;
-    double max_old;     // largest current distance among the pre-sort rows (-1: none)
-    double max_new;     // ... among rows that joined a centre chosen after the last sort (-1: none)
-    double best_v;      // argmax candidate of the tile
-    long long best_i;   // its ORIGINAL row index
-};
-
-struct KsArgs {
-    const void* X0;          // rows in the caller's order (centre coordinates are read from here)
-    const void* Xc;          // rows in the current order (X0 before the first sort)
-    const long long* orig;   // current position -> original row (nullptr: identity)
-    long long n, m;
-    int it, epoch, nblk, vecw;
-    long long seed;
-    double* dist;            // current order
-    int* lab;
-    KsSummary* sum;          // [tiles]
-    void* centers;           // T [K][m]
-    msm_idx_t* ids;          // [K]
-    const KcPartial* prev;   // [nblk] candidates of pass it-1
-    KcPartial* next;         // [nblk]
-};
-
-template <typename T, int M>
-__global__ __launch_bounds__(DT) void kcenters_sorted_pass_kernel(KsArgs P)
-{
-    constexpr int FC = FeatChunk<T>::FC;
-    __shared__ T ys[FC];
-    __shared__ double Dc[KC_PRUNE_MAX];
-    __shared__ double rv[DT];
-    __shared__ long long ri[DT];
-    __shared__ double wmo[4], wmn[4], wbv[4];
-    __shared__ long long wbi[4];
-    __shared__ int wl0[4], wl1[4];
-    const T* X0 = static_cast<const T*>(P.X0);
-    const T* Xc = static_cast<const T*>(P.Xc);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double F = PruneMargin<T>::F;
-
-    // ---- prologue: this pass's centre, its distances to the earlier centres ----
-    long long cidx = P.seed;
-    if (P.it > 0) {  // numpy argmax over the previous pass's per-workgroup candidates: largest, then lowest original row
-        double fv = -1.0;
-        long long fi = -1;
-        for (int k = tid; k < P.nblk; k += DT) {
-            const KcPartial q = P.prev[k];
-            if (q.i >= 0 && (fi < 0 || kc_better(q.v, q.i, fv, fi))) {
-                fv = q.v;
-                fi = q.i;
-            }
-        }
-        rv[tid] = fv;
-        ri[tid] = fi;
-        __syncthreads();
-        for (int k = DT / 2; k > 0; k >>= 1) {
-            if (tid < k && ri[tid + k] >= 0 && (ri[tid] < 0 || kc_better(rv[tid + k], ri[tid + k], rv[tid], ri[tid]))) {
-                rv[tid] = rv[tid + k];
-                ri[tid] = ri[tid + k];
-            }
-            __syncthreads();
-        }
-        cidx = ri[0] < 0 ? 0 : ri[0];
-        __syncthreads();
-    }
-    if (tid < FC) ys[tid] = tid < P.m ? X0[cidx * P.m + tid] : (T)0;
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid == 0) P.ids[P.it] = cidx;
-        if (tid < P.m) static_cast<T*>(P.centers)[(long long)P.it * P.m + tid] = ys[tid];
-    }
-    double mdn = INFINITY;  // min over the centres chosen since the last sort
-    for (int j = tid; j < P.it; j += DT) {
-        const T* cj = static_cast<const T*>(P.centers) + (long long)j * P.m;
-        double a = 0.0, b = 0.0;
-        for (int f = 0; f < (int)P.m; ++f) m_update<T, M>(a, b, cj[f], ys[f]);
-        const double d = m_final<M>(a, b, P.m);
-        Dc[j] = d;
-        if (j >= P.epoch) mdn = d < mdn ? d : mdn;  // (a NaN distance never prunes: comparisons with it are false)
-        if (j >= P.epoch && !(d == d)) mdn = -INFINITY;
-    }
-    rv[tid] = mdn;
-    __syncthreads();
-    for (int k = DT / 2; k > 0; k >>= 1) {
-        if (tid < k) rv[tid] = rv[tid + k] < rv[tid] ? rv[tid + k] : rv[tid];
-        __syncthreads();
-    }
-    mdn = rv[0];
-    __syncthreads();
-
-    double bv = -1.0;  // this workgroup's argmax candidate (thread 0 keeps it)
-    long long bi = -1;
-    const long long ntile = (P.n + KS_TILE - 1) / KS_TILE;
-    for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
-        if (P.it > 0) {  // uniform: the whole tile at once
-            const KsSummary S = P.sum[t];
-            bool skip = S.lab != -1;
-            if (skip && S.lab >= 0) skip = Dc[S.lab] >= F * S.max_old;
-            if (skip && S.max_new >= 0.0) skip = mdn >= F * S.max_new;
-            if (skip) {
-                if (tid == 0 && S.best_i >= 0 && (bi < 0 || kc_better(S.best_v, S.best_i, bv, bi))) {
-                    bv = S.best_v;
-                    bi = S.best_i;
-                }
-                continue;
-            }
-        }
-        double tbv = -1.0, tmo = -1.0, tmn = -1.0;
-        long long tbi = -1;
-        int l0 = 0x7fffffff, l1 = -1;
-#pragma unroll
-        for (int k = 0; k < KS_TILE / DT; ++k) {
-            const long long p = t * KS_TILE + k * DT + tid;
-            if (p < P.n) {
-                double cur = (P.it == 0) ? INFINITY : P.dist[p];  // distances_.fill(inf), kcenters.py:87-88
-                int lab = (P.it == 0) ? 0 : P.lab[p];
-                const bool rowskip = P.it > 0 && Dc[lab] >= F * cur;
-                if (!rowskip) {
-                    T x[FC];
-                    load_row_regs<T>(x, Xc + p * P.m, (int)P.m, P.vecw);
-                    double a = 0.0, b = 0.0;
-#pragma unroll
-                    for (int g = 0; g < FC / 4; ++g)
-                        if (g * 4 < P.m) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) m_update<T, M>(a, b, x[g * 4 + q], ys[g * 4 + q]);
-                        }
-                    const double d = m_final<M>(a, b, P.m);
-                    const bool upd = d < cur;  // strict, kcenters.py:93
-                    if (upd) {
-                        cur = d;
-                        lab = P.it;
-                    }
-                    if (upd || P.it == 0) {
-                        P.dist[p] = cur;
-                        P.lab[p] = lab;
-                    }
-                }
-                const long long o = P.orig ? P.orig[p] : p;
-                if (tbi < 0 || kc_better(cur, o, tbv, tbi)) {
-                    tbv = cur;
-                    tbi = o;
-                }
-                if (lab < P.epoch) {
-                    l0 = lab < l0 ? lab : l0;
-                    l1 = lab > l1 ? lab : l1;
-                    tmo = cur > tmo ? cur : tmo;
-                    if (!(cur == cur)) tmo = INFINITY;
-                } else {
-                    tmn = cur > tmn ? cur : tmn;
-                    if (!(cur == cur)) tmn = INFINITY;
-                }
-            }
-        }
-        // tile summary: butterflies inside the wave, then the 4 waves through LDS
-#pragma unroll
-        for (int msk = 32; msk > 0; msk >>= 1) {
-            const double ov = __shfl_xor(tbv, msk, 64);
-            const long long oi = __shfl_xor(tbi, msk, 64);
-            if (oi >= 0 && (tbi < 0 || kc_better(ov, oi, tbv, tbi))) {
-                tbv = ov;
-                tbi = oi;
-            }
-            const double omo = __shfl_xor(tmo, msk, 64), omn = __shfl_xor(tmn, msk, 64);
-            tmo = omo > tmo ? omo : tmo;
-            tmn = omn > tmn ? omn : tmn;
-            const int ol0 = __shfl_xor(l0, msk, 64), ol1 = __shfl_xor(l1, msk, 64);
-            l0 = ol0 < l0 ? ol0 : l0;
-            l1 = ol1 > l1 ? ol1 : l1;
-        }
-        if (lane == 0) {
-            wbv[wave] = tbv;
-            wbi[wave] = tbi;
-            wmo[wave] = tmo;
-            wmn[wave] = tmn;
-            wl0[wave] = l0;
-            wl1[wave] = l1;
-        }
-        __syncthreads();
-        if (tid == 0) {
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                if (wbi[w] >= 0 && (tbi < 0 || kc_better(wbv[w], wbi[w], tbv, tbi))) {
-                    tbv = wbv[w];
-                    tbi = wbi[w];
-                }
-                tmo = wmo[w] > tmo ? wmo[w] : tmo;
-                tmn = wmn[w] > tmn ? wmn[w] : tmn;
-                l0 = wl0[w] < l0 ? wl0[w] : l0;
-                l1 = wl1[w] > l1 ? wl1[w] : l1;
-            }
-            KsSummary S;
-            S.lab = (l1 < 0) ? -2 : (l0 == l1 ? l0 : -1);
-            S.pad = 0;
-            S.max_old = tmo;
-            S.max_new = tmn;
-            S.best_v = tbv;
-            S.best_i = tbi;
-            P.sum[t] = S;
-            if (tbi >= 0 && (bi < 0 || kc_better(tbv, tbi, bv, bi))) {
-                bv = tbv;
-                bi = tbi;
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {  // this workgroup's candidate for the next centre; the next pass's prologue reduces them
-        KcPartial q;
-        q.v = bv;
-        q.i = bi;
-        P.next[blockIdx.x] = q;
-    }
-}
-
-// counting sort by label, 1/3: label histogram (per-workgroup in LDS, then one atomic per label)
-__global__ __launch_bounds__(DT) void ks_hist_kernel(const int* __restrict__ lab, long long n, int K,
-                                                     unsigned long long* __restrict__ counts)
-{
-    __shared__ unsigned h[KC_PRUNE_MAX];
-    for (int j = threadIdx.x; j < K; j += DT) h[j] = 0u;
-    __syncthreads();
-    for (long long p = (long long)blockIdx.x * DT + threadIdx.x; p < n; p += (long long)gridDim.x * DT) atomicAdd(&h[lab[p]], 1u);
-    __syncthreads();
-    for (int j = threadIdx.x; j < K; j += DT)
-        if (h[j]) atomicAdd(&counts[j], (unsigned long long)h[j]);
-}
-
-// 2/3: exclusive scan of the K counts -> write cursors; clears the counts for the next sort
-__global__ __launch_bounds__(DT) void ks_scan_kernel(unsigned long long* __restrict__ counts, int K,
-                                                     unsigned long long* __restrict__ cursor)
-{
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int j = 0; j < K; ++j) {
-            cursor[j] = run;
-            run += counts[j];
-            counts[j] = 0;
-        }
-    }
-}
-
-// 3/3: every workgroup takes chunks of KS_CH rows, reserves a run per label in the output (one global atomic per label
-// present) and moves its rows there -- coordinates, distance, label, original index.  The order inside a label is arbitrary.
-constexpr int KS_CH = 2048;
-template <typename T>
-__global__ __launch_bounds__(DT) void ks_scatter_kernel(const T* __restrict__ Xc, const long long* __restrict__ orig,
-                                                        const double* __restrict__ dist, const int* __restrict__ lab,
-                                                        long long n, long long m, int K, int vecw,
-                                                        unsigned long long* __restrict__ cursor, T* __restrict__ Xn,
-                                                        long long* __restrict__ orign, double* __restrict__ distn,
-                                                        int* __restrict__ labn)
-{
-    __shared__ unsigned h[KC_PRUNE_MAX];
-    __shared__ unsigned long long base[KC_PRUNE_MAX];
-    const long long nch = (n + KS_CH - 1) / KS_CH;
-    for (long long ch = blockIdx.x; ch < nch; ch += gridDim.x) {
-        for (int j = threadIdx.x; j < K; j += DT) h[j] = 0u;
-        __syncthreads();
-        int l[KS_CH / DT];
-        unsigned r[KS_CH / DT];
-#pragma unroll
-        for (int k = 0; k < KS_CH / DT; ++k) {
-            const long long p = ch * KS_CH + k * DT + threadIdx.x;
-            l[k] = p < n ? lab[p] : -1;
-            r[k] = l[k] >= 0 ? atomicAdd(&h[l[k]], 1u) : 0u;
-        }
-        __syncthreads();
-        for (int j = threadIdx.x; j < K; j += DT)
-            if (h[j]) base[j] = atomicAdd(&cursor[j], (unsigned long long)h[j]);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < KS_CH / DT; ++k) {
-            const long long p = ch * KS_CH + k * DT + threadIdx.x;
-            if (l[k] >= 0) {
-                const long long q = (long long)(base[l[k]] + r[k]);
-                const T* src = Xc + p * m;
-                T* dst = Xn + q * m;
-                if (vecw == 16) {
-                    for (long long f = 0; f < m; f += 16 / (long long)sizeof(T))
-                        *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(src + f);
-                } else if (vecw == 8) {
-                    for (long long f = 0; f < m; f += 8 / (long long)sizeof(T))
-                        *reinterpret_cast<float2*>(dst + f) = *reinterpret_cast<const float2*>(src + f);
-                } else {
-                    for (long long f = 0; f < m; ++f) dst[f] = src[f];
-                }
-                orign[q] = orig ? orig[p] : p;
-                distn[q] = dist[p];
-                labn[q] = l[k];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// back to the caller's order
-__global__ __launch_bounds__(DT) void ks_unpermute_kernel(const long long* __restrict__ orig, const double* __restrict__ dist,
-                                                          const int* __restrict__ lab, long long n,
-                                                          double* __restrict__ dist_out, msm_idx_t* __restrict__ lab_out)
-{
-    for (long long p = (long long)blockIdx.x * DT + threadIdx.x; p < n; p += (long long)gridDim.x * DT) {
-        const long long o = orig ? orig[p] : p;
-        dist_out[o] = dist[p];
-        lab_out[o] = lab[p];
-    }
-}
-
-template <typename T>
-static void launch_ks_pass(int mid, int grid, const KsArgs& P)
-{
-    switch (mid) {
-        case M_EUCLIDEAN: hipLaunchKernelGGL((kcenters_sorted_pass_kernel<T, M_EUCLIDEAN>), dim3(grid), dim3(DT), 0, stream(), P); break;
-        case M_CITYBLOCK: hipLaunchKernelGGL((kcenters_sorted_pass_kernel<T, M_CITYBLOCK>), dim3(grid), dim3(DT), 0, stream(), P); break;
-        case M_CHEBYSHEV: hipLaunchKernelGGL((kcenters_sorted_pass_kernel<T, M_CHEBYSHEV>), dim3(grid), dim3(DT), 0, stream(), P); break;
-    }
-}
-
-// passes after which the rows are re-sorted by label (MSM_KC_SORT="15,31,..." overrides; MSM_KC_SORTED=0: plain passes)
-static const std::vector<int>& ks_schedule()
-{
-    static std::vector<int> sch;
-    static bool init = false;
-    if (!init) {
-        init = true;
-        const char* e = getenv("MSM_KC_SORT");
-        std::string str = e ? e : "11,23,47,95,143";
-        size_t pos = 0;
-        while (pos < str.size()) {
-            sch.push_back(atoi(str.c_str() + pos));
-            pos = str.find(',', pos);
-            if (pos == std::string::npos) break;
-            ++pos;
-        }
-    }
-    return sch;
-}
-
-// Opt-in (MSM_KC_SORTED=1, read per call).  Measured on 10M x 10 float64, K = 200 (scripts/kcblobs.py, kcperf.py): 40
-// well-separated blobs 18.4 ms against 17.8 ms for plain per-row pruning, the bench's unclustered tICA projection 36.9
-// against 25.3 ms -- the counting sorts and the heavier pass cost more than the skipped tiles return, because a tile that
-// holds ANY row of a newer centre is tested against the minimum over ALL newer centres.  Kept for the exactness test and
-// as the base for per-tile newer-label lists.
-static bool ks_enabled()
-{
-    const char* e = getenv("MSM_KC_SORTED");
-    return e && atoi(e) != 0;
-}
-
-struct KsBufs {
-    DevBuf x[2], dist[2], orig[2], lab[2], sum, centers, misc;
-};
-static KsBufs& ks_bufs()
-{
-    static KsBufs b;
-    return b;
-}
-
-// device pointers throughout: Xd [n][m], labels_d / dist_d outputs in the caller's order, ids_d [K]
-template <typename T>
-int kcenters_sorted_run(int mid, const T* Xd, msm_idx_t n, msm_idx_t m, msm_idx_t K, msm_idx_t seed, int vecw,
-                        msm_idx_t* ids_d, msm_idx_t* labels_d, double* dist_d)
-{
-    KsBufs& B = ks_bufs();
-    int rc;
-    const long long ntile = ceil_div(n, KS_TILE);
-    const int nblk = (int)std::min<long long>(ntile, 4LL * num_cus());
-    for (int k = 0; k < 2; ++k) {
-        if ((rc = B.dist[k].reserve((size_t)n * sizeof(double)))) return rc;
-        if ((rc = B.lab[k].reserve((size_t)n * sizeof(int)))) return rc;
-    }
-    if ((rc = B.sum.reserve((size_t)ntile * sizeof(KsSummary)))) return rc;
-    if ((rc = B.centers.reserve((size_t)K * m * sizeof(T)))) return rc;
-    // misc: [2 x nblk candidates | K counts | K cursors]
-    const size_t off_counts = (size_t)2 * nblk * sizeof(KcPartial), off_cursor = off_counts + (size_t)K * 8,
-                 misc_bytes = off_cursor + (size_t)K * 8;
-    if ((rc = B.misc.reserve(misc_bytes))) return rc;
-    char* misc = static_cast<char*>(B.misc.p);
-    MSM_HIP_CHECK(hipMemsetAsync(misc + off_counts, 0, misc_bytes - off_counts, stream()));
-    KsArgs P;
-    memset(&P, 0, sizeof(P));
-    P.X0 = Xd;
-    P.Xc = Xd;
-    P.orig = nullptr;
-    P.n = n;
-    P.m = m;
-    P.seed = seed;
-    P.nblk = nblk;
-    P.vecw = vecw;
-    P.epoch = (int)K + 1;  // before the first sort every label counts as "pre-sort"
-    P.dist = B.dist[0].as<double>();
-    P.lab = B.lab[0].as<int>();
-    P.sum = B.sum.as<KsSummary>();
-    P.centers = B.centers.p;
-    P.ids = ids_d;
-    KcPartial* part = reinterpret_cast<KcPartial*>(misc);
-    unsigned long long* counts = reinterpret_cast<unsigned long long*>(misc + off_counts);
-    unsigned long long* cursor = reinterpret_cast<unsigned long long*>(misc + off_cursor);
-    const std::vector<int>& sch = ks_schedule();
-    int cur = 0;
-    for (msm_idx_t it = 0; it < K; ++it) {
-        P.it = (int)it;
-        P.prev = part + (size_t)((it + 1) & 1) * nblk;
-        P.next = part + (size_t)(it & 1) * nblk;
-        launch_ks_pass<T>(mid, nblk, P);
-        if (it + 1 < K && std::find(sch.begin(), sch.end(), (int)it) != sch.end()) {
-            const int nxt = cur ^ 1;
-            if ((rc = B.x[nxt].reserve((size_t)n * m * sizeof(T)))) return rc;
-            if ((rc = B.orig[nxt].reserve((size_t)n * sizeof(long long)))) return rc;
-            const int nlab = (int)it + 1;
-            const int g = (int)std::min<long long>(ceil_div(n, KS_CH), 8LL * num_cus());
-            hipLaunchKernelGGL(ks_hist_kernel, dim3(g), dim3(DT), 0, stream(), P.lab, (long long)n, nlab, counts);
-            hipLaunchKernelGGL(ks_scan_kernel, dim3(1), dim3(DT), 0, stream(), counts, nlab, cursor);
-            hipLaunchKernelGGL((ks_scatter_kernel<T>), dim3(g), dim3(DT), 0, stream(), static_cast<const T*>(P.Xc), P.orig,
-                               P.dist, P.lab, (long long)n, (long long)m, nlab, vecw, cursor, B.x[nxt].as<T>(),
-                               B.orig[nxt].as<long long>(), B.dist[nxt].as<double>(), B.lab[nxt].as<int>());
-            cur = nxt;
-            P.Xc = B.x[cur].p;
-            P.orig = B.orig[cur].as<long long>();
-            P.dist = B.dist[cur].as<double>();
-            P.lab = B.lab[cur].as<int>();
-            P.epoch = nlab;
-            // the summaries describe the old order: mark every tile "mixed" so the next pass rebuilds them
-            MSM_HIP_CHECK(hipMemsetAsync(P.sum, 0xff, (size_t)ntile * sizeof(KsSummary), stream()));
-        }
-    }
-    MSM_HIP_CHECK(hipGetLastError());
-    const int g = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
-    hipLaunchKernelGGL(ks_unpermute_kernel, dim3(g), dim3(DT), 0, stream(), P.orig, P.dist, P.lab, (long long)n, dist_d, labels_d);
-    MSM_HIP_CHECK(hipGetLastError());
-    return MSM_OK;
 }
 
 template <typename T>
@@ -3243,7 +2778,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     P.seed = seed;
     P.nblk = nblk;
     P.ids = dIds.as<msm_idx_t>();
-    P.prune = kc_prune_enabled();
+    P.prune = 1;
     if (on_device) {
         P.X = X;
         P.labels = labels;
@@ -3267,16 +2802,12 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     P.vecw = row_vecw<T>(P.X, m, false);
     if (P.vecw == 0 && wide_ok<T>(P.X, P.X, m, false)) P.nblk = nblk = std::min(nblk, wide_grid(n));
     KcPartial* part = dPart.as<KcPartial>();
-    const bool sorted = ks_enabled() && P.prune && P.vecw > 0 && K <= KC_PRUNE_MAX && K >= 16 && n >= (1 << 18) &&
-                        (mid == M_EUCLIDEAN || mid == M_CITYBLOCK || mid == M_CHEBYSHEV);
-    const bool screen = !sorted && ksc_enabled() && sizeof(T) == 8 && mid == M_EUCLIDEAN && P.vecw > 0 && n >= 65536 && K > 8;
+    const bool screen = sizeof(T) == 8 && mid == M_EUCLIDEAN && P.vecw > 0 && n >= 65536 && K > 8;
     g_kc_stats = KcStats();
     g_kc_stats.rows = n;
     g_kc_stats.plain_row_bytes = (long long)(m * sizeof(T) + 16);   // the row, distances_, labels_ (pruning test)
     g_kc_stats.plain_passes = K;
-    if (sorted) {
-        if ((rc = kcenters_sorted_run<T>(mid, static_cast<const T*>(P.X), n, m, K, seed, P.vecw, P.ids, P.labels, P.dist))) return rc;
-    } else if (screen) {
+    if (screen) {
         // A few plain passes first (in the first passes most rows change, and a candidate costs the screen's bytes on top of
         // the plain pass's), then the screened ones.  Measured on 10M x 10 float64, K = 200 (scripts/kcperf.py, kcblobs.py),
         // plain / screened from pass 16 / from pass 4 / from pass 1: tICA projection 26.6 / 13.1 / 11.8 / 11.8 ms, white
@@ -3284,8 +2815,8 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         // 17.5 ms -- so no decision is needed.
         // (with several centres per pass the early centres are cheap on the copy too -- one pass applies a batch of them to
         //  every row, whatever fraction changes: 2 plain passes, tICA projection 4.53 -> 4.26 ms; 4 for one centre per pass)
-        const bool kcb_on = ksc_fmt() == 2 && !(getenv("MSM_KC_BATCH") && atoi(getenv("MSM_KC_BATCH")) == 0) && nblk <= 1024;
-        const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : (kcb_on ? 2 : 4);
+        const bool kcb_on = !(getenv("MSM_KC_BATCH") && atoi(getenv("MSM_KC_BATCH")) == 0) && nblk <= 1024;  // read per fit
+        const int KSC_PROBE = kcb_on ? 2 : 4;
         KscBufs& B = ksc_bufs();
         const int np = (int)((m + 1) / 2);
         if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;  // [gmax2[2] | ... | c0[16]]
@@ -3299,7 +2830,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         }
         const bool use_screen = it < K;
         if (use_screen) {
-            const int fmt = ksc_fmt();
+            constexpr int fmt = KSC_FMT;
             g_kc_stats.plain_passes = it;
             g_kc_stats.screened_passes = K - it;
             g_kc_stats.screen_row_bytes = (long long)(ksc_words(np, fmt) * 4 + 4);   // the screen copy's row + curf
@@ -3321,14 +2852,11 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
             S.ids = P.ids;
             const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
             switch (np) {
-#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 2>), dim3(gconv), dim3(DT), 0, stream(), S); \
-                           else if (fmt == 1) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 1>), dim3(gconv), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, 0>), dim3(gconv), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL((ksc_convert_kernel<NP_, fmt>), dim3(gconv), dim3(DT), 0, stream(), S); break;
                 MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
             }
-            const char* be = getenv("MSM_KC_BATCH");   // 0: one centre per pass (A/B switch; read per fit)
-            if (fmt == 2 && !(be && atoi(be) == 0) && nblk <= 1024) {
+            if (kcb_on) {
                 // several centres per pass (kcb_select_kernel / kcenters_batch_pass_kernel): rounds of {selector, pass} are
                 // queued four at a time -- a round whose selector finds all K centres fixed is two empty launches -- and the
                 // host looks at the progress counter between the groups
@@ -3372,9 +2900,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                 S.prev = part + (size_t)((it + 1) & 1) * nblk;
                 S.next = part + (size_t)(it & 1) * nblk;
                 switch (np) {
-#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 2>), dim3(nblk), dim3(DT), 0, stream(), S); \
-                           else if (fmt == 1) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 1>), dim3(nblk), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 0>), dim3(nblk), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, fmt>), dim3(nblk), dim3(DT), 0, stream(), S); break;
                     MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                 }
@@ -3561,7 +3087,7 @@ int kcenters_pass_dev_impl(const T* X, msm_idx_t n, msm_idx_t m, const T* y_dev,
     P.ids = dIds.as<msm_idx_t>();
     P.ycenter = y_dev;
     P.centers = centers_dev;                        // centres 0 .. it of the fit (pruning table); null: no pruning
-    P.prune = centers_dev ? kc_prune_enabled() : 0;
+    P.prune = centers_dev ? 1 : 0;
     if (n > 0) {
         P.vecw = row_vecw<T>(P.X, m, false);
         if (P.vecw == 0 && wide_ok<T>(P.X, P.ycenter, m, false)) nblk = std::min(nblk, wide_grid(n));
@@ -3633,16 +3159,15 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
     hipLaunchKernelGGL((kc_seed_candidate_kernel<T>), dim3(1), dim3(DT), 0, stream(), X, (long long)m, local_seed, (long long)seed, cand);
     MSM_HIP_CHECK(hipGetLastError());
     if ((rc = comm_allgather(cand, cands, rec * sizeof(double)))) return rc;
-    static const bool unfused = getenv("MSM_KC_UNFUSED") != nullptr;  // A/B switch: pass + candidate + select kernels
-    const bool fused = !unfused && n > 0 && row_vecw<T>(X, m, false) > 0;  // register path (m <= FC): one kernel per centre
+    const bool fused = n > 0 && row_vecw<T>(X, m, false) > 0;  // register path (m <= FC): one kernel per centre
     // Several centres per exchange (kcb_*: threshold lists, an identical selection on every rank): float64 rows of <= 16
     // features, euclidean.  The decision uses nothing a rank knows alone -- not its shard size, which may be zero --, because
     // it changes the exchange pattern: PROBE all-gathers of one candidate, then one all-gather of a round record per round.
     bool batched = false;
     if constexpr (sizeof(T) == 8) {
-        const int probe = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 2;
-        const char* be = getenv("MSM_KC_BATCH");
-        batched = !unfused && mid == M_EUCLIDEAN && m <= FeatChunk<T>::FC && K > 8 && K > probe && ksc_enabled() && ksc_fmt() == 2 &&
+        constexpr int probe = 2;
+        const char* be = getenv("MSM_KC_BATCH");   // 0: one centre per exchange (A/B switch of the tests; read per fit)
+        batched = mid == M_EUCLIDEAN && m <= FeatChunk<T>::FC && K > 8 && K > probe &&
                   !(be && atoi(be) == 0);
         if (batched) {
             const msm_idx_t PROBE = probe;
@@ -3670,7 +3195,7 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
                 P.labels = labels;
                 P.vecw = row_vecw<T>(X, m, false);
                 P.centers = cen;
-                P.prune = kc_prune_enabled();
+                P.prune = 1;
                 P.sel_cands = cands;
                 P.sel_world = world;
                 P.sel_centers = cen;
@@ -3790,7 +3315,7 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
         P.labels = labels;
         P.vecw = row_vecw<T>(X, m, false);
         P.centers = cen;
-        P.prune = kc_prune_enabled();
+        P.prune = 1;
         P.sel_cands = cands;
         P.sel_world = world;
         P.sel_centers = cen;
@@ -3801,13 +3326,13 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
         // Screened passes (float64 rows, euclidean; see kcenters_screen_pass_kernel) after a few plain ones, as in the
         // single-process fit.  The decision is LOCAL to a rank: the exchange pattern (one all-gather per centre) is the same
         // for both kernels, so a rank with a small shard may keep the plain kernel while its peers screen.
-        static const int KSC_PROBE = getenv("MSM_KC_PROBE") ? std::max(1, atoi(getenv("MSM_KC_PROBE"))) : 4;
-        static const long long KSC_MIN_ROWS = getenv("MSM_KC_SCREEN_MIN_ROWS") ? atoll(getenv("MSM_KC_SCREEN_MIN_ROWS")) : 65536;
-        const bool screen = ksc_enabled() && sizeof(T) == 8 && mid == M_EUCLIDEAN && n >= KSC_MIN_ROWS && K > 8 && K > KSC_PROBE;
+        constexpr int KSC_PROBE = 4;
+        constexpr long long KSC_MIN_ROWS = 65536;
+        const bool screen = sizeof(T) == 8 && mid == M_EUCLIDEAN && n >= KSC_MIN_ROWS && K > 8 && K > KSC_PROBE;
         KscArgs S;
         memset(&S, 0, sizeof(S));
         const int np = (int)((m + 1) / 2);
-        const int fmt = ksc_fmt();
+        constexpr int fmt = KSC_FMT;
         if (screen) {
             KscBufs& B = ksc_bufs();
             if ((rc = B.misc.reserve(64 + 16 * sizeof(double)))) return rc;
@@ -3846,18 +3371,14 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
                                        reinterpret_cast<const double*>(cen));
                     const int gconv = (int)std::min<long long>(ceil_div(n, DT), 8LL * num_cus());
                     switch (np) {
-#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 2>), dim3(gconv), dim3(DT), 0, stream(), S); \
-                           else if (fmt == 1) hipLaunchKernelGGL((ksc_convert_kernel<NP_, 1>), dim3(gconv), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((ksc_convert_kernel<NP_, 0>), dim3(gconv), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL((ksc_convert_kernel<NP_, fmt>), dim3(gconv), dim3(DT), 0, stream(), S); break;
                         MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                     }
                 }
                 S.it = (int)it;
                 switch (np) {
-#define MSM_KSC(NP_) case NP_: if (fmt == 2) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 2>), dim3(nblk), dim3(DT), 0, stream(), S); \
-                           else if (fmt == 1) hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 1>), dim3(nblk), dim3(DT), 0, stream(), S); \
-                           else hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, 0>), dim3(nblk), dim3(DT), 0, stream(), S); break;
+#define MSM_KSC(NP_) case NP_: hipLaunchKernelGGL((kcenters_screen_pass_kernel<NP_, fmt>), dim3(nblk), dim3(DT), 0, stream(), S); break;
                     MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                 }

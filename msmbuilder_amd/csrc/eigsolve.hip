@@ -82,9 +82,8 @@ int sygv_reduce_device(double* A, double* B, int n, int* dinfo)
     const double one = 1.0;
     int st;
     // B = L L^T: the library's own blocked kernel up to n = 1024 (one launch per 32 rows; rocSOLVER's dpotrf is launch-
-    // latency bound there: 1.3 ms at n = 512), rocSOLVER beyond.  MSM_POTRF=rocsolver|own forces one of them.
-    static const char* pf = getenv("MSM_POTRF");
-    const bool own = pf ? (pf[0] == 'o') : n <= 1024;
+    // latency bound there: 1.3 ms at n = 512), rocSOLVER beyond.
+    const bool own = n <= 1024;
     if (own) {
         int rc = potrf_upper_device(B, n, dinfo);
         if (rc) return rc;

@@ -1389,13 +1389,11 @@ bool mbk_small_off()
 bool mbk_small_ok(const msm_mbk* h, long long n) { return !mbk_small_off() && h->m <= 32 && n <= 65536; }  // label kernel
 bool mbk_small_update_ok(long long n)                                                                      // update kernel
 {
-    static const bool off = getenv("MSM_MBK_UPDATE_WAVE") && atoi(getenv("MSM_MBK_UPDATE_WAVE")) == 0;  // A/B switch
-    return !off && !mbk_small_off() && n <= MSU_CAP;
+    return !mbk_small_off() && n <= MSU_CAP;
 }
 bool mbk_label64_ok(const msm_mbk* h, long long n)                                                         // 64 x 64 label tiles
 {
-    static const bool off = getenv("MSM_MBK_LABEL64") && atoi(getenv("MSM_MBK_LABEL64")) == 0;  // A/B switch
-    return !off && !mbk_small_off() && n <= 4096 && h->m > 32;
+    return !mbk_small_off() && n <= 4096 && h->m > 32;
 }
 
 // centre update of a step: one wave per centre for small batches, else one workgroup per centre

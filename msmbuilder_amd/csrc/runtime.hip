@@ -122,8 +122,6 @@ struct BulkH2D {
     }
     static int pool_threads()
     {
-        const char* env = getenv("MSM_H2D_THREADS");
-        if (env && atoi(env) > 0) return std::min(64, atoi(env));
         const unsigned hw = std::thread::hardware_concurrency();
         return (int)std::max(2u, std::min(8u, hw / 2));
     }
@@ -139,8 +137,7 @@ BulkH2D* bulk_instance()
 
 int h2d_bulk(void* dst_device, const void* src_host, size_t bytes)
 {
-    static const bool disabled = [] { const char* e = getenv("MSM_H2D_BULK"); return e && atoi(e) == 0; }();
-    if (bytes < ((size_t)8 << 20) || disabled) {
+    if (bytes < ((size_t)8 << 20)) {
         MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));
         return MSM_OK;
     }
@@ -171,9 +168,8 @@ int h2d_bulk(void* dst_device, const void* src_host, size_t bytes)
 
 int d2h_bulk(void* dst_host, const void* src_device, size_t bytes)
 {
-    static const bool disabled = [] { const char* e = getenv("MSM_H2D_BULK"); return e && atoi(e) == 0; }();
     BulkH2D* B = nullptr;
-    if (bytes >= ((size_t)8 << 20) && !disabled) {
+    if (bytes >= ((size_t)8 << 20)) {
         BulkH2D* inst = bulk_instance();
         if (inst->ok) B = inst;
     }

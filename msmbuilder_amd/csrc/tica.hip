@@ -1709,6 +1709,16 @@ __global__ __launch_bounds__(256) void tica_export_cols_kernel(const double* __r
     if (wave == 0 && in) out[2 * FF + e] = base[2 * FF + e] + ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
+// Element types of the projection kernels: float32, float64, and bfloat16-STORED rows (BASELINE configs[4]) as raw 16-bit
+// words that the kernels widen themselves -- an exact widening, so bfloat16 rows project like their float32 images.
+struct Bf16Raw { unsigned short bits; };
+__device__ __forceinline__ double pj_widen(float x) { return (double)x; }
+__device__ __forceinline__ double pj_widen(double x) { return x; }
+__device__ __forceinline__ double pj_widen(Bf16Raw x) { return (double)__uint_as_float((unsigned)x.bits << 16); }
+__device__ __forceinline__ bool pj_finite(float x) { return isfinite(x); }
+__device__ __forceinline__ bool pj_finite(double x) { return isfinite(x); }
+__device__ __forceinline__ bool pj_finite(Bf16Raw x) { return (x.bits & 0x7f80u) != 0x7f80u; }
+
 // out[n,k] = (X - mean) @ comps^T in fp64 (tica.py:329-333), evaluated as X @ comps^T - (mean @ comps^T)
 // with the k constants mean @ comps^T precomputed on the host in fp64.  HBM-bound: reads
 // F*sizeof(T) and writes 8k bytes per frame.  A workgroup owns 128 rows; X tiles [128][FC] arrive
@@ -1743,12 +1753,12 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
                     const long long r = row0 + rr;
                     TIn v[CW];
 #pragma unroll
-                    for (int q = 0; q < CW; ++q) v[q] = (TIn)0;
+                    for (int q = 0; q < CW; ++q) v[q] = TIn{};
                     if (r < n && f0 + cc < F)
                         *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(X + r * ld + f0 + cc);
 #pragma unroll
                     for (int q = 0; q < CW; ++q) {
-                        bad |= !isfinite(v[q]);
+                        bad |= !pj_finite(v[q]);
                         Xs[(cc + q) * RP + rr] = v[q];
                     }
                 }
@@ -1756,9 +1766,9 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
                 for (int e = tid; e < RW * FC; e += NT) {
                     const int rr = e / FC, ff = e % FC;
                     const long long r = row0 + rr;
-                    TIn v = (TIn)0;
+                    TIn v = TIn{};
                     if (r < n && f0 + ff < F) v = X[r * ld + f0 + ff];
-                    bad |= !isfinite(v);
+                    bad |= !pj_finite(v);
                     Xs[ff * RP + rr] = v;
                 }
             }
@@ -1770,8 +1780,8 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
             const int fw = (F - f0) < FC ? (F - f0) : FC;
 #pragma unroll 4
             for (int ff = 0; ff < fw; ++ff) {
-                const double x0 = (double)Xs[ff * RP + lane];
-                const double x1 = (double)Xs[ff * RP + lane + 64];
+                const double x0 = pj_widen(Xs[ff * RP + lane]);
+                const double x1 = pj_widen(Xs[ff * RP + lane + 64]);
 #pragma unroll
                 for (int a = 0; a < NPW; ++a) {
                     const double v = Vs[wave * NPW + a][ff];
@@ -1819,8 +1829,9 @@ __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __r
                                                                   int kbase, int ktot, double* __restrict__ out,
                                                                   int* flag)
 {
-    constexpr int FCH = 128 / (int)sizeof(TIn);  // features per chunk (32 f32 / 16 f64)
-    constexpr int NT4 = FCH / 4;                 // MFMAs per chunk and row block (8 / 4)
+    constexpr int FCH = 128 / (int)sizeof(TIn);  // features per chunk (64 bf16 / 32 f32 / 16 f64)
+    constexpr int NT4 = FCH / 4;                 // MFMAs per chunk and row block (16 / 8 / 4)
+    constexpr int NV = (FCH + 31) / 32;          // Vp rows a thread stages per chunk
     constexpr int RB = 4;                        // row blocks of 16 per wave
     __shared__ double Vs[2][FCH * PVP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1849,7 +1860,7 @@ __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[b][q] = 0.0;
 
-    raw_f32x4 xs0[RB][2], xs1[RB][2], vreg;
+    raw_f32x4 xs0[RB][2], xs1[RB][2], vreg[NV];
     // byte offsets of this lane's two 16-byte halves of chunk c inside a row; a half that lies past the
     // row (partial last chunk) re-reads the row's last 16 bytes instead: finite data against zero Vp rows
 #define MSM_PJ_LOAD(XS, C)                                                                        \
@@ -1861,12 +1872,15 @@ __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __r
             XS[b][0] = *(global_ptr<raw_f32x4>)(Xg + (xo[b] + a0));                               \
             XS[b][1] = *(global_ptr<raw_f32x4>)(Xg + (xo[b] + a1));                               \
         }                                                                                         \
-        const int feat = (C) * FCH + vf;                                                          \
-        vreg = *(global_ptr<raw_f32x4>)(Vg + (size_t)(feat < F ? feat : F - 1) * 128 + vc * 8);    \
-        if (feat >= F || vf >= FCH) vreg = raw_f32x4{0.f, 0.f, 0.f, 0.f};                         \
+        _Pragma("unroll") for (int j = 0; j < NV; ++j) {                                          \
+            const int lf = vf + 32 * j, feat = (C) * FCH + lf;                                    \
+            vreg[j] = *(global_ptr<raw_f32x4>)(Vg + (size_t)(feat < F ? feat : F - 1) * 128 + vc * 8); \
+            if (feat >= F || lf >= FCH) vreg[j] = raw_f32x4{0.f, 0.f, 0.f, 0.f};                  \
+        }                                                                                         \
     }
 #define MSM_PJ_VSTORE(BUF)                                                                        \
-    if (vf < FCH) *reinterpret_cast<raw_f32x4*>(&Vs[BUF][vf * PVP + vc]) = vreg;
+    _Pragma("unroll") for (int j = 0; j < NV; ++j)                                                \
+        if (vf + 32 * j < FCH) *reinterpret_cast<raw_f32x4*>(&Vs[BUF][(vf + 32 * j) * PVP + vc]) = vreg[j];
     MSM_PJ_LOAD(xs0, 0)
     MSM_PJ_VSTORE(0)
     __syncthreads();
@@ -1878,7 +1892,7 @@ __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __r
             const double bv = vb[t * PVP];                                                        \
             _Pragma("unroll") for (int b = 0; b < RB; ++b) {                                      \
                 const TIn* xe = reinterpret_cast<const TIn*>(&XCUR[b][0]);                        \
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xe[t], bv, acc[b], 0, 0, 0); \
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj_widen(xe[t]), bv, acc[b], 0, 0, 0); \
             }                                                                                     \
         }                                                                                         \
         if (c + 1 < nch) MSM_PJ_VSTORE((BUF) ^ 1)                                                 \
@@ -2192,17 +2206,15 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     {
         // fp32 partial sums of the SHIFTED frames are sigma^2-sized, so two chunks (8192 frames) can share a merge; raw
         // moments (no shift) keep the 4096-frame partials of round 1
-        static const char* kf = getenv("MSM_TICA_KFLUSH");
-        P.kflush = kf ? atoi(kf) : (h->shift_on ? 2 * KFLUSH_SYM : KFLUSH_SYM);
+        P.kflush = h->shift_on ? 2 * KFLUSH_SYM : KFLUSH_SYM;
     }
     {
         // Cohort pacing (the workgroups of a cohort wait for each other at chunk boundaries, bounded).  C/G kernel, measured
         // at 10M x 512: the L2 fabric-side fetch drops from 207 GB to 79-82 GB per launch but the kernel is 4 % slower
         // (78.4 -> 81.7 ms): opt-in there.  Sum/difference kernel WITH the wave-priority window (round 2): 110 GB -> 32 GB
         // fetched per launch (1.8x the algorithmic bytes instead of 5.5x) AND 1 % faster (50.45 -> 49.8 ms; without the
-        // priority window pacing cost 2 %): on by default there.  MSM_TICA_COHORT_PACING=0 / 1 forces it either way.
-        const char* e = getenv("MSM_TICA_COHORT_PACING");
-        const bool pace = e ? atoi(e) != 0 : (usesym && !useimg);
+        // priority window pacing cost 2 %): on there.
+        const bool pace = usesym && !useimg;
         P.cosync = pace ? h->cosync : nullptr;
     }
 
@@ -2269,10 +2281,11 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // right frames' sums from the left frames' (and checks those rows), and the finite check is made on the sums afterwards.
     bool fold = false;
     if (usesym && !segs && h->fold && (useimg || h->F % TM == 0)) {   // (bf16 image path: the pre-pass sums while it packs)
-        const char* fe = getenv("MSM_TICA_FOLD");       // read per launch (A/B switch for tests and scripts)
-        const char* fm = getenv("MSM_TICA_FOLD_MIN");   // elements (frames x features) from which a launch folds
-        const double fmin = fm ? atof(fm) : 67108864.0;
-        fold = !(fe && atoi(fe) == 0) && (double)total * h->F >= fmin;
+        // MSM_TICA_FOLD, read per launch (A/B switch of the tests): 0 = never, 2 = whatever the size; default: launches of
+        // at least 2^26 elements (frames x features)
+        const char* fe = getenv("MSM_TICA_FOLD");
+        const int fmode = fe ? atoi(fe) : 1;
+        fold = fmode != 0 && (fmode == 2 || (double)total * h->F >= 67108864.0);
         for (msm_idx_t s = 0; s < n_seq && fold; ++s)
             if (n_rows[s] > h->lag && n_rows[s] < 2 * (long long)h->lag) fold = false;
         if (2 * (long long)h->lag * nvalid > total / 4) fold = false;   // the boundary rows would be a pass of their own
@@ -2660,8 +2673,7 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
         const char* sym_env = getenv("MSM_TICA_SYM");
         const bool sym_off = sym_env && atoi(sym_env) == 0;
         h->ntiles_sym = h->T * (h->T + 1) / 2;
-        const char* tmax_env = getenv("MSM_TICA_SYM_TMAX");
-        const int tmax = tmax_env ? atoi(tmax_env) : 64;  // and one resident cohort must fit (checked below)
+        constexpr int tmax = 64;  // and one resident cohort must fit (checked below)
         if (mode == MSM_TICA_F32 && !sym_off && h->T >= 2 && h->T <= tmax && n_features % 4 == 0) {
             MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_sym_f32_kernel<false, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSSYM));
@@ -3107,96 +3119,81 @@ int msm_tica_reduce(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const dou
     return tica_reduce_status(scal, ints, info);
 }
 
-int msm_tica_reduce_tridiag(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, double* d, double* e,
-                            double* tau, double* V, double* Cs, double* mu, double* info, int* status)
-{
-    if (!h || !d || !e || !tau || !V || !Cs || !mu || !status) return fail(MSM_ERR_STATE, "msm_tica_reduce_tridiag: null argument");
-    if (h->F > 1024) return fail(MSM_ERR_INVALID, "msm_tica_reduce_tridiag: n_features > 1024");
-    SolveBufs b;
-    int rc = tica_reduce_device(h, shrinkage, n_rblw, scale, &b);
-    if (rc) return rc;
-    const int n = h->F;
-    const size_t FF = (size_t)n * n;
-    // A holds Cs = L^-1 OC L^-T (both triangles, equal up to rounding); reflectors go to the Y slot
-    if ((rc = sytrd_device(b.A, n, b.D, b.E, b.vals, b.Y, b.trdw, b.ints + 8))) return rc;
-    double scal[4];
-    int ints[8], st = 0;
-    MSM_HIP_CHECK(hipMemcpyAsync(d, b.D, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    if (n > 1) MSM_HIP_CHECK(hipMemcpyAsync(e, b.E, (n - 1) * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    if (n > 1) MSM_HIP_CHECK(hipMemcpyAsync(tau, b.vals, (n - 1) * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    if (n > 1) MSM_HIP_CHECK(hipMemcpyAsync(V, b.Y, (size_t)(n - 1) * (n - 1) * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(&st, b.ints + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    *status = st;
-    if (st) {  // the cooperative kernel gave up: hand the reduced matrix to the host route
-        MSM_HIP_CHECK(hipMemcpyAsync(Cs, b.A, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
-        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    }
-    return tica_reduce_status(scal, ints, info);
-}
-
 int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const double* scale, msm_idx_t k, double* vals,
                         double* vecs, double* Cs, double* mu, double* info, int* status)
 {
     if (!h || !vals || !vecs || !Cs || !mu || !status) return fail(MSM_ERR_STATE, "msm_tica_solve_topk: null argument");
-    if (h->F > 1024 || h->F < 3) return fail(MSM_ERR_INVALID, "msm_tica_solve_topk: need 3 <= n_features <= 1024");
-    if (k < 1 || k > h->F || k > 64) return fail(MSM_ERR_INVALID, "msm_tica_solve_topk: need 1 <= k <= min(n_features, 64)");
+    if (h->F > 1024 || h->F < 128) return fail(MSM_ERR_INVALID, "msm_tica_solve_topk: need 128 <= n_features <= 1024");
+    if (k < 1 || k > 16) return fail(MSM_ERR_INVALID, "msm_tica_solve_topk: need 1 <= k <= 16");
     SolveBufs b;
     int rc = tica_reduce_device(h, shrinkage, n_rblw, scale, &b);
     if (rc) return rc;
     const int n = h->F;
     const size_t FF = (size_t)n * n;
-    // 1) Chebyshev-filtered subspace iteration (subspace.hip): a few short launch chains when the spectrum has the gap
-    //    tICA is run for; the reduced tICA matrix has its spectrum in [-1, 1].  MSM_SOLVE_SUBSPACE=0 skips it.
-    const char* ssenv = getenv("MSM_SOLVE_SUBSPACE");
-    const int ssdeg = getenv("MSM_SOLVE_SUBSPACE_DEGREE") ? std::max(2, atoi(getenv("MSM_SOLVE_SUBSPACE_DEGREE"))) : 10;
+    // Chebyshev-filtered subspace iteration (subspace.hip): a few short launch chains when the spectrum has the gap tICA is
+    // run for; the reduced tICA matrix has its spectrum in [-1, 1].  When it does not converge (flat spectra: white-noise
+    // features) the reduced matrix goes back to the caller, whose verified fallback is LAPACK's dsyevr on it (round 3 had a
+    // second device route in between -- cooperative tridiagonalisation + multisection + inverse iteration; removed in round
+    // 4: two routes, one fallback).
     int conv = 0, outer = 0;
-    if (!(ssenv && ssenv[0] == '0') && n >= 128 && k <= 16) {
-        if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, ssdeg, 6, b.lam, b.Yk, b.sswork, &conv, &outer))) return rc;
-    }
-    // 2) the direct route: A = Cs = L^-1 OC L^-T stays intact (sytrd copies it into registers); reflectors -> Y slot, tau -> vals slot
+    if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, 10, 6, b.lam, b.Yk, b.sswork, &conv, &outer))) return rc;
     if (!conv) {
-        if ((rc = sytrd_device(b.A, n, b.D, b.E, b.vals, b.Y, b.trdw, b.ints + 8))) return rc;
-        if ((rc = tri_topk_device(b.D, b.E, n, (int)k, b.lam, b.S))) return rc;
-        if ((rc = apply_q_device(b.Y, b.vals, n, (int)k, b.S, b.Yk))) return rc;
+        double scal[4];
+        int ints[8];
+        MSM_HIP_CHECK(hipMemcpyAsync(Cs, b.A, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        rc = tica_reduce_status(scal, ints, info);
+        if (rc) return rc;
+        if (info) {
+            info[8] = 0.0;
+            info[9] = (double)outer;
+        }
+        *status = 1;
+        return MSM_OK;
     }
     if ((rc = pair_residual_device(b.A, n, b.Yk, b.lam, (int)k, b.res))) return rc;
     // the residual kernel has read Yk; L^-T in place for the k vectors
     MSM_HIP_CHECK(hipMemcpyAsync(b.S, b.Yk, (size_t)k * n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
     if ((rc = sygv_back_device(b.B, b.S, n, (int)k))) return rc;
     double scal[4], res[128];
-    int ints[8], st = 0;
+    int ints[8];
+    std::vector<double> yk((size_t)k * n);
+    MSM_HIP_CHECK(hipMemcpyAsync(yk.data(), b.Yk, (size_t)k * n * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(vecs, b.S, (size_t)k * n * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(vals, b.lam, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(res, b.res, 2 * (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
-    if (!conv) MSM_HIP_CHECK(hipMemcpyAsync(&st, b.ints + 8, sizeof(int), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     rc = tica_reduce_status(scal, ints, info);
     if (rc) return rc;
     if (info) {
-        info[8] = conv ? 1.0 : 0.0;   // 1: the pairs came from the subspace iteration, 0: from the tridiagonalisation
+        info[8] = 1.0;                // the pairs came from the subspace iteration
         info[9] = (double)outer;      // filtered iterations spent (also when they did not converge)
     }
-    // self-check on the reduced matrix: every returned pair must satisfy C y = lambda y to rounding and be normalised.
-    // A failure (the cooperative tridiagonalisation gave up or exchanged a stale value, the inverse iteration stalled)
+    // self-check on the reduced matrix: every returned pair must satisfy C y = lambda y to rounding, be normalised, and the
+    // k vectors must be mutually orthogonal (a rank-deficient block would pass the per-pair checks).  A failure
     // hands the reduced matrix to the caller's LAPACK route instead of returning a wrong pair.
-    double lmax = 1.0, rmax = 0.0, nmax = 0.0;
+    double lmax = 1.0, rmax = 0.0, nmax = 0.0, omax = 0.0;
     for (int j = 0; j < (int)k; ++j) {
         lmax = std::max(lmax, std::fabs(vals[j]));
         rmax = std::max(rmax, res[j]);
         nmax = std::max(nmax, res[k + j]);
+        for (int i = 0; i < j; ++i) {
+            double dot = 0.0;
+            for (int c = 0; c < n; ++c) dot += yk[(size_t)i * n + c] * yk[(size_t)j * n + c];
+            omax = std::max(omax, std::fabs(dot));
+        }
     }
     if (info) {
         info[6] = rmax;
-        info[7] = nmax;
+        info[7] = std::max(nmax, omax);
     }
-    *status = st ? 1 : ((!(rmax <= 1e-11 * lmax) || !(nmax <= 1e-10)) ? 2 : 0);
+    *status = (!(rmax <= 1e-11 * lmax) || !(nmax <= 1e-10) || !(omax <= 1e-8)) ? 2 : 0;
     if (*status) {
         MSM_HIP_CHECK(hipMemcpyAsync(Cs, b.A, FF * sizeof(double), hipMemcpyDeviceToHost, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
@@ -3290,7 +3287,8 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
                      double* out, int on_device, int check_finite)
 {
     if (!X || !mean || !comps || !out) return fail(MSM_ERR_INVALID, "msm_tica_project: null pointer");
-    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (dtype_bytes != 2 && dtype_bytes != 4 && dtype_bytes != 8)
+        return fail(MSM_ERR_INVALID, "dtype_bytes must be 2 (bfloat16), 4 or 8");
     if (n_rows < 0 || n_features < 1 || k < 1 || ld < n_features) return fail(MSM_ERR_INVALID, "bad shape");
     if (n_rows == 0) return MSM_OK;
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
@@ -3329,8 +3327,7 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     const unsigned grid = (unsigned)ceil_div(n_rows, 128);
     const int cw = 16 / dtype_bytes;
     const int vec = (((uintptr_t)Xd) % 16 == 0) && (ldd % cw == 0) && (n_features % cw == 0);
-    static const bool no_mfma = getenv("MSM_PROJECT_NO_MFMA") != nullptr;  // A/B switch for scripts
-    if (vec && !no_mfma && (size_t)256 * ldd * dtype_bytes < ((size_t)1 << 32)) {
+    if (vec && (size_t)256 * ldd * dtype_bytes < ((size_t)1 << 32)) {
         // fp64-MFMA path: components in blocks of 16, panel Vp[F][16] (feature-major, zero padded)
         DevBuf& dVp = pool(PS_W);
         const msm_idx_t nkb = ceil_div(k, 16);
@@ -3344,7 +3341,11 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
         for (msm_idx_t kb = 0; kb < nkb; ++kb) {
             const int kk = (int)std::min<msm_idx_t>(16, k - kb * 16);
             const double* vpk = dVp.as<double>() + (size_t)kb * n_features * 16;
-            if (dtype_bytes == 4)
+            if (dtype_bytes == 2)
+                hipLaunchKernelGGL((tica_project_mfma_kernel<Bf16Raw>), dim3(g2), dim3(NT), 0, stream(), (const Bf16Raw*)Xd,
+                                   (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
+                                   outd, dflag);
+            else if (dtype_bytes == 4)
                 hipLaunchKernelGGL((tica_project_mfma_kernel<float>), dim3(g2), dim3(NT), 0, stream(), (const float*)Xd,
                                    (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
                                    outd, dflag);
@@ -3379,7 +3380,9 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     case 7: MSM_PROJ(TT, 7); break;                                                                   \
     default: MSM_PROJ(TT, 8); break;                                                                  \
     }
-    if (dtype_bytes == 4) {
+    if (dtype_bytes == 2) {
+        MSM_PROJ_T(Bf16Raw)
+    } else if (dtype_bytes == 4) {
         MSM_PROJ_T(float)
     } else {
         MSM_PROJ_T(double)

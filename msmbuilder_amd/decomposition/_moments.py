@@ -72,10 +72,6 @@ def _blas_threads(F):
     ms after the call, which starves the thread that is about to enqueue hundreds of small
     kernel launches (the 200 k-centers launches went from 31 ms to 48-90 ms right after a
     256-thread solve)."""
-    import os
-    env = os.environ.get("MSMBUILDER_AMD_SOLVE_THREADS")
-    if env:
-        return max(1, int(env))
     return 4 if F <= 768 else 8
 
 
@@ -119,43 +115,10 @@ def top_standard_eigenpairs(Cs, k):
     return vals[order], np.ascontiguousarray(vecs[:, order].T)
 
 
-def use_device_tridiagonalisation(F):
-    """Hybrid solve: tridiagonalise the reduced matrix on the device (csrc/sytrd.hip, F <= 1024) instead of inside the host's
-    dsyevr.  MSMBUILDER_AMD_DEVICE_TRD=0 keeps it on the host."""
-    import os
-    return F <= 1024 and os.environ.get("MSMBUILDER_AMD_DEVICE_TRD", "1") != "0"
-
-
-def use_device_topk(F, k):
-    """Hybrid solve, all of it on the device (csrc/toppairs.hip: own Cholesky, cooperative tridiagonalisation, multisection +
-    inverse iteration on the tridiagonal matrix, Householder back-transform; one synchronisation, no LAPACK), for
-    3 <= F <= 1024 and k <= 64.  MSMBUILDER_AMD_DEVICE_TOPK=0 keeps dstemr / dormqr on the host."""
-    import os
-    return (3 <= F <= 1024 and 1 <= k <= min(F, 64) and use_device_tridiagonalisation(F)
-            and os.environ.get("MSMBUILDER_AMD_DEVICE_TOPK", "1") != "0")
-
-
-def eigenpairs_from_tridiagonal(d, e, tau, V, k):
-    """k largest eigenpairs of the symmetric matrix whose LAPACK dsytrd(lower) factors are (d, e, tau, V = the reflector
-    block A(2:n, 1:n-1), flat column-major): dstemr on the tridiagonal for the selected pairs (O(k n)), then Q = H(0) ... H(n-2) applied to the k vectors with
-    dormqr (dormtr's lower case: the reflectors act on rows 1 .. n-1).  Eigenvalues descending, eigenvectors as ROWS."""
-    import scipy.linalg.lapack as lp
-    n = len(d)
-    with _blas_limit(1):
-        if n == 1:
-            return np.array([d[0]]), np.ones((1, 1))
-        w, z = scipy.linalg.eigh_tridiagonal(d, e, select='i', select_range=(n - k, n - 1), lapack_driver='stemr',
-                                             check_finite=False)
-        z = np.asfortranarray(z)
-        if n > 2:
-            a = V[:(n - 1) * (n - 1)].reshape((n - 1, n - 1), order='F')   # LAPACK's A(2:n, 1:n-1) as the kernel packed it
-            c = np.asfortranarray(z[1:, :])
-            cq, _work, info = lp.dormqr('L', 'N', a, np.ascontiguousarray(tau[:n - 1]), c, max(1, c.shape[1]) * 64)
-            if info != 0:
-                raise np.linalg.LinAlgError("dormqr failed (info = %d)" % info)
-            z[1:, :] = cq
-    order = np.argsort(w)[::-1]
-    return w[order], np.ascontiguousarray(z[:, order].T)
+def use_subspace_solve(F, k):
+    """The device route of the hybrid solve (csrc/subspace.hip behind ``msm_tica_solve_topk``) applies to up to 16
+    components of 128 .. 1,024 features; everything else takes LAPACK's dsyevr on the reduced matrix."""
+    return 128 <= F <= 1024 and 1 <= k <= 16
 
 
 def device_generalized_eigenpairs(lhs, rhs, k):

@@ -289,11 +289,12 @@ class tICA(BaseEstimator, TransformerMixin):
     # --------------------------------------------------------------------- solve
     def _solve(self):
         """Top ``n_components`` generalized eigenpairs of (offset_correlation_, covariance_), cached until the
-        accumulators change (tica.py:167-199).  The finalisation of the moments, the shrinkage estimate, the Cholesky
-        reduction and the back-substitution run on the device (``msm_tica_reduce`` / ``msm_tica_backsolve``); only the
-        reduced F x F standard problem visits the host for LAPACK's dsyevr (its tridiagonalisation is latency-bound on
-        a GPU at F = 512), and from ``_moments.DEVICE_SOLVE_MIN_FEATURES`` the device does that too (``msm_tica_solve_device``).
-        ``MSMBUILDER_AMD_DEVICE_SOLVE=0`` restores the all-host numpy / dsygvx path of round 1."""
+        accumulators change (tica.py:167-199).  Three routes: the finalisation of the moments, the shrinkage estimate, the
+        Cholesky reduction, a subspace iteration for the top pairs and the back-substitution on the device
+        (``msm_tica_solve_topk``: up to 16 components of 128 .. 1,024 features); the same with LAPACK's dsyevr on the
+        reduced matrix where that does not apply or does not converge (``msm_tica_reduce`` / ``msm_tica_backsolve``);
+        rocSOLVER from ``_moments.DEVICE_SOLVE_MIN_FEATURES`` (``msm_tica_solve_device``).
+        ``MSMBUILDER_AMD_DEVICE_SOLVE=0`` is the all-host numpy / dsygvx path of the reference."""
         if not self._is_dirty:
             # n_components may have been raised since the last solve
             if len(self._eigenvalues_) >= self.n_components:
@@ -351,38 +352,27 @@ class tICA(BaseEstimator, TransformerMixin):
             Cs = np.empty((F, F))
             done = False
             V = None
-            if _moments.use_device_topk(F, k):
-                # everything on the device, one synchronisation: reduction, cooperative tridiagonalisation, the k largest
-                # pairs of the tridiagonal matrix, Householder back-transform, L^-T (csrc/toppairs.hip); the pairs are
-                # verified against the reduced matrix there -- status != 0 hands Cs to the LAPACK route below
+            if _moments.use_subspace_solve(F, k):
+                # reduction + Chebyshev-filtered subspace iteration + L^-T on the device (csrc/subspace.hip); the pairs are
+                # verified against the reduced matrix there -- status != 0 (no convergence on a flat spectrum, or a failed
+                # check) hands Cs to the LAPACK route below
                 vals = np.empty(k)
                 V = np.empty((k, F))
                 status = C.c_int(0)
                 run(L.msm_tica_solve_topk(self._handle, shrink, int(self.n_observations_),
                                           None if scale_p is None else scale_p.ctypes.data, k, vals.ctypes.data, V.ctypes.data,
                                           Cs.ctypes.data, mu.ctypes.data, info.ctypes.data, C.byref(status)))
-                self._solve_route = ("subspace" if info[8] else "tridiagonal", int(info[9]), status.value)
+                self._solve_route = ("subspace" if status.value == 0 else "lapack", int(info[9]), status.value)
                 if status.value == 0:
                     done = True
                 else:
                     V = None
-            elif _moments.use_device_tridiagonalisation(F):
-                # the reduced matrix is tridiagonalised on the device too (cooperative Householder kernel, sytrd.hip);
-                # the host only runs dstemr on the tridiagonal and applies the reflectors to the k vectors
-                d, e, tau, Vr = np.empty(F), np.empty(max(F - 1, 1)), np.empty(max(F - 1, 1)), np.empty(max(F - 1, 1) ** 2)
-                status = C.c_int(0)
-                run(L.msm_tica_reduce_tridiag(self._handle, shrink, int(self.n_observations_),
-                                              None if scale_p is None else scale_p.ctypes.data, d.ctypes.data, e.ctypes.data,
-                                              tau.ctypes.data, Vr.ctypes.data, Cs.ctypes.data, mu.ctypes.data,
-                                              info.ctypes.data, C.byref(status)))
-                if status.value == 0:
-                    vals, Y = _moments.eigenpairs_from_tridiagonal(d, e[:F - 1], tau[:F - 1], Vr, k)
-                    done = True
             else:
                 run(L.msm_tica_reduce(self._handle, shrink, int(self.n_observations_),
                                       None if scale_p is None else scale_p.ctypes.data, Cs.ctypes.data, mu.ctypes.data,
                                       info.ctypes.data))
-            if not done:   # host dsyevr on the reduced matrix (also the fallback when the cooperative kernel gave up)
+                self._solve_route = ("lapack", 0, 0)
+            if not done:   # host dsyevr on the reduced matrix: the verified fallback
                 vals, Y = _moments.top_standard_eigenpairs(Cs, k)   # Y: k x F, rows = eigenvectors of the reduced problem
             if V is None:
                 V = np.empty((k, F))
@@ -520,12 +510,12 @@ class tICA(BaseEstimator, TransformerMixin):
         if is_device_array(X):
             import torch
             if X.dtype == torch.bfloat16:
-                # bf16-STORED trajectories (BASELINE configs[4]: half the bytes) feed the bf16 modes as they are;
-                # the other modes take them as float32 (an exact widening)
+                # bf16-STORED trajectories (BASELINE configs[4]: half the bytes) feed the bf16 modes and the projection
+                # kernels (keep_bf16 = "always") as they are; the other modes take them as float32 (an exact widening)
                 # (the mode is the HANDLE's, fixed when it was created; the environment may have changed since)
                 hk = getattr(self, "_handle_key", None)
                 mode = hk[2] if (hk is not None and self._initialized) else _mode_from_env()
-                if not (keep_bf16 and mode in (_lib.TICA_BF16, _lib.TICA_BF16X2)):
+                if not (keep_bf16 == "always" or (keep_bf16 and mode in (_lib.TICA_BF16, _lib.TICA_BF16X2))):
                     X = X.to(torch.float32)
             elif X.dtype not in (torch.float32, torch.float64):
                 X = X.to(torch.float64)
@@ -754,14 +744,25 @@ class tICA(BaseEstimator, TransformerMixin):
         mean, comps = None, None
         L = _lib.lib()
         for X in sequences:
-            X = self._prepare(X)
+            X = self._prepare(X, keep_bf16="always")
             if mean is None:
                 mean, comps = self._projection()
             if X.shape[1] != comps.shape[1]:
                 raise ValueError("shapes (%d,%d) and (%d,%d) not aligned" % (
                     X.shape[0], X.shape[1], comps.shape[1], comps.shape[0]))
-            ax = Arr(X)
             k = comps.shape[0]
+            if is_device_array(X) and str(X.dtype).endswith("bfloat16"):
+                # bfloat16-stored rows: widened inside the projection kernel (2 bytes per value read from HBM)
+                import torch
+                _lib.ensure_device(X.device.index)
+                _lib.set_stream(torch.cuda.current_stream(X.device).cuda_stream)
+                out = torch.empty((X.shape[0], k), dtype=torch.float64, device=X.device)
+                if X.shape[0] > 0:
+                    check(L.msm_tica_project(C.c_void_p(X.data_ptr()), 2, X.shape[0], X.shape[1], X.shape[1],
+                                             mean.ctypes.data, comps.ctypes.data, k, C.c_void_p(out.data_ptr()), 1, 1))
+                sequences_new.append(out)
+                continue
+            ax = Arr(X)
             out = _lib.empty_like_placement(ax, (ax.shape[0], k), np.float64)
             aout = Arr(out, np.float64)
             if ax.shape[0] > 0:

@@ -19,8 +19,8 @@ for name, Z in (("tICA projection", Y), ("white noise", torch.randn_like(Y))):
     from msmbuilder_amd import _lib as _L
     _st = (_C.c_int64 * 5)(); _L.check(_L.lib().msm_kcenters_last_stats(_st))
     print("   passes: %d plain + %d on the screen copy (%d B per row)" % (_st[1], _st[2], _st[4]))
-    print("%s: KCenters(200).fit 10M x 10 f64: %.2f ms (MSM_KC_PRUNE=%s) inertia %.6e ids[:4] %s" % (
-        name, 1e3 * min(ts[1:]), os.environ.get("MSM_KC_PRUNE", "1"), kc.inertia_, kc.cluster_ids_[:4]))
+    print("%s: KCenters(200).fit 10M x 10 f64: %.2f ms inertia %.6e ids[:4] %s" % (
+        name, 1e3 * min(ts[1:]), kc.inertia_, kc.cluster_ids_[:4]))
 # one rank's share of an 8-GPU run (1.25M rows): the single-process fit against the row-sharded library loop (a world of one)
 Z = Y[:1_250_000].contiguous()
 for name, env in (("single-process fit", None), ("sharded loop, world of one", "1")):

@@ -1,5 +1,5 @@
-"""tICA._solve wall time at the bench width (F = 512, k = 10) for the solve routes, plus the pieces of the device tail
-(msm_potrf, msm_sytrd, msm_tridiag_topk) on their own.  Run once per MSM_POTRF setting (the switch is read once)."""
+"""tICA._solve wall time at the bench width (F = 512, k = 10) for the solve routes (host dsygvx; device finalise +
+Cholesky reduction with host dsyevr; subspace iteration on the device; rocSOLVER), plus msm_potrf on its own."""
 import ctypes as C, os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,14 +22,12 @@ def solve_ms(env, n=20):
     return 1e3 * float(np.median(ts[3:])), ev.copy()
 base = None
 for name, env in (("host dsygvx", {"MSMBUILDER_AMD_DEVICE_SOLVE": "0"}),
-                  ("hybrid, host dsyevr", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "0"}),
-                  ("hybrid, device sytrd + host dstemr/dormqr", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1", "MSMBUILDER_AMD_DEVICE_TOPK": "0"}),
-                  ("device tail, tridiagonal route", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1", "MSMBUILDER_AMD_DEVICE_TOPK": "1", "MSM_SOLVE_SUBSPACE": "0"}),
-                  ("device tail, subspace iteration first", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1", "MSMBUILDER_AMD_DEVICE_TOPK": "1", "MSM_SOLVE_SUBSPACE": "1"})):
+                  ("device tail (subspace iteration, LAPACK fallback)", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid"}),
+                  ("rocSOLVER dsyevd", {"MSMBUILDER_AMD_DEVICE_SOLVE": "1"})):
     ms, ev = solve_ms(env)
     print("      route:", getattr(m, "_solve_route", None))
     base = ev if base is None else base
-    print("%-45s %.2f ms   max rel diff vs host %.1e   (MSM_POTRF=%s)" % (name, ms, np.abs(ev / base - 1).max(), os.environ.get("MSM_POTRF", "default")))
+    print("%-50s %.2f ms   max rel diff vs host %.1e" % (name, ms, np.abs(ev / base - 1).max()))
 L = _lib.lib()
 rs = np.random.RandomState(0)
 M = rs.randn(F, F + 8); B = M @ M.T / F + 0.1 * np.eye(F)
@@ -42,9 +40,3 @@ def dev_ms(f, n=20):
 w = dB.clone()
 print("msm_potrf (device buffer, incl. sync)      %.3f ms" % dev_ms(lambda: L.msm_potrf(C.c_void_p(w.copy_(dB).data_ptr()), F, C.byref(info), 1)))
 print("torch.linalg.cholesky                      %.3f ms" % dev_ms(lambda: (torch.linalg.cholesky(dB), torch.cuda.synchronize())))
-S = rs.randn(F, F); S = S + S.T; dS = torch.from_numpy(S).cuda()
-d, e, tau, V = (torch.empty(n_, dtype=torch.float64, device="cuda") for n_ in (F, F, F, F * F)); st = C.c_int()
-p = lambda t: C.c_void_p(t.data_ptr())
-print("msm_sytrd (device buffers)                 %.3f ms" % dev_ms(lambda: L.msm_sytrd(p(dS), F, p(d), p(e), p(tau), p(V), C.byref(st), 1)))
-vals, vecs = torch.empty(k, dtype=torch.float64, device="cuda"), torch.empty(k * F, dtype=torch.float64, device="cuda")
-print("msm_tridiag_topk (device buffers)          %.3f ms" % dev_ms(lambda: L.msm_tridiag_topk(p(d), p(e), F, k, p(vals), p(vecs), 1)))

@@ -191,12 +191,11 @@ def test_config3_stress_280k_x_171_without_tica_bit_exact(gpu):
 
 @pytest.mark.parametrize("metric", ["euclidean", "cityblock", "chebyshev"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_kcenters_label_sorted_path_clustered(gpu, metric, dtype, monkeypatch):
-    """>= 2^18 rows of CLUSTERED data through the opt-in label-sorted fit (MSM_KC_SORTED=1: tiles skipped by their
-    summaries, rows re-sorted by label after chosen passes) against the C oracle, bit for bit -- with duplicate rows (zero
-    distances, argmax ties decided by the original row index) and a row count that is not a multiple of the tile."""
+def test_kcenters_clustered_rows_beyond_2_18(gpu, metric, dtype):
+    """>= 2^18 rows of CLUSTERED data (where the per-row pruning test and, for float64 euclidean rows, the screened and
+    batched passes skip most rows) against the C oracle, bit for bit -- with duplicate rows (zero distances, argmax ties
+    decided by the row index) and a row count that is not a multiple of any tile."""
     from msmbuilder_amd import KCenters
-    monkeypatch.setenv("MSM_KC_SORTED", "1")
     from oracle.libdistance_oracle import Oracle
     o = Oracle()
     rs = np.random.RandomState(11)

@@ -152,7 +152,7 @@ def test_small_batch_step_kernels_equal_general_kernels(gpu, K, F, B):
     """The small-batch step kernels are drop-ins for the general ones: the 64 x 64 label tiles use kmeans_label_v4_kernel's
     feature order (bit-identical dot products, hence labels) and the wave-per-centre update adds a centre's members in
     batch order like the workgroup-per-centre one -- so a whole fit (centres, labels, step count, inertia) must be
-    bit-identical with either switched off.  The switches are read once per process: each variant runs in its own."""
+    bit-identical with them switched off (MSM_MBK_SMALL=0).  The switch is read once per process: each variant runs in its own."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _STEP_AB % dict(root=root, seed=K + F, K=K, F=F, B=B)
@@ -166,10 +166,15 @@ def test_small_batch_step_kernels_equal_general_kernels(gpu, K, F, B):
         return lines[-1]
 
     base = run({})
-    assert run({"MSM_MBK_UPDATE_WAVE": "0"}) == base
-    if F > 32:  # (rows of <= 32 features take mbk_small_label_kernel, whose fp32 summation order is its own)
-        assert run({"MSM_MBK_LABEL64": "0"}) == base
-        assert run({"MSM_MBK_SMALL": "0"}) == base
+    general = run({"MSM_MBK_SMALL": "0"})
+    if F > 32:
+        assert general == base
+    else:
+        # rows of <= 32 features take mbk_small_label_kernel, whose fp32 summation order is its own: the same steps and
+        # labels, the inertia to fp32 rounding
+        b, g = base.split(), general.split()
+        assert b[1] == g[1] and b[3] == g[3]
+        assert abs(float(b[4]) - float(g[4])) <= 1e-5 * abs(float(g[4]))
 
 
 @pytest.mark.parametrize("n,F,k", [(500, 8, 10), (3072, 64, 50), (1000, 3, 25), (3072, 512, 200), (1, 4, 1), (7, 2, 7)])

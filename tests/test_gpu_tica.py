@@ -407,6 +407,53 @@ def test_project_matches_numpy(gpu, dtype, n, F, k):
     assert rc == _lib.MSM_ERR_NONFINITE
 
 
+@pytest.mark.parametrize("n,F,k", [(1, 8, 1), (255, 24, 3), (1000, 104, 16), (513, 512, 17), (300, 136, 40), (700, 2048, 10),
+                                   (257, 36, 10), (64, 6, 6), (129, 71, 5)])
+def test_project_bfloat16_stored_rows(gpu, n, F, k):
+    """bfloat16-STORED rows (BASELINE configs[4]) are widened INSIDE the projection kernels (dtype_bytes = 2; 64-feature
+    chunks on the fp64 matrix pipe for rows of a multiple of 8 features, the lane-per-row kernel otherwise): the widening
+    is exact, so the result equals (X - mu) . V^T of the stored values in float64, and `transform` of a bfloat16 tensor
+    equals `transform` of its float32 image bit for bit.  A non-finite stored value is reported like any other."""
+    import ctypes as C
+    import torch
+    from msmbuilder_amd import _lib, tICA
+    rs = np.random.RandomState(n + F + k)
+    Xb = torch.from_numpy((rs.randn(n, F) * 3 + 1).astype(np.float32)).cuda().to(torch.bfloat16)
+    X32 = Xb.float()
+    mu = rs.randn(F)
+    V = np.ascontiguousarray(rs.randn(k, F))
+    want = (X32.cpu().numpy().astype(np.float64) - mu).dot(V.T)
+    L = _lib.lib()
+    _lib.ensure_device(0)
+    _lib.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def project(t, nbytes):
+        out = torch.empty((n, k), dtype=torch.float64, device="cuda")
+        rc = L.msm_tica_project(C.c_void_p(t.data_ptr()), nbytes, n, F, F, mu.ctypes.data, V.ctypes.data, k,
+                                C.c_void_p(out.data_ptr()), 1, 1)
+        return rc, out
+    rc, got = project(Xb, 2)
+    assert rc == 0
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-12, atol=1e-11 * np.abs(want).max())
+    rc32, got32 = project(X32, 4)
+    assert rc32 == 0
+    if F % 8 == 0 or F % 4 != 0:   # the same kernel family for both element types (both MFMA, or both lane-per-row)
+        np.testing.assert_allclose(got.cpu().numpy(), got32.cpu().numpy(), rtol=1e-13, atol=1e-12 * np.abs(want).max())
+    bad = Xb.clone()
+    bad[n // 2, F - 1] = float("nan")
+    rc, _ = project(bad, 2)
+    assert rc == _lib.MSM_ERR_NONFINITE
+    if n > 64 and F >= 24:
+        m = tICA(n_components=min(3, F), lag_time=2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.fit([X32])
+            ya, yb = m.transform([Xb])[0], m.transform([X32])[0]
+        assert ya.dtype == torch.float64 and ya.is_cuda
+        if F % 8 == 0:
+            np.testing.assert_allclose(ya.cpu().numpy(), yb.cpu().numpy(), rtol=1e-12, atol=1e-12 * float(yb.abs().max()))
+
+
 @pytest.mark.parametrize("F", [132, 256, 388])
 def test_symmetric_kernel_half_step_edges(gpu, monkeypatch, F):
     """Pair counts around the kernel's 16-frame half-steps and 32-frame steps, one trajectory each and all together
@@ -438,53 +485,21 @@ def test_symmetric_kernel_half_step_edges(gpu, monkeypatch, F):
         np.testing.assert_allclose(m._outer_0_to_T_lagged, Cs, rtol=0, atol=ATOL_SCALE["f32"] * scale)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 31, 256, 300, 512, 1000])
-def test_device_tridiagonalisation_vs_lapack(gpu, n):
-    """csrc/sytrd.hip (cooperative Householder kernel, one grid barrier per column) finished with dstemr + dormqr on the host
-    against LAPACK's dsyevr on the same matrix: eigenvalues, residuals, orthonormality."""
-    import ctypes as C
-    import scipy.linalg
-    from msmbuilder_amd import _lib
-    from msmbuilder_amd.decomposition import _moments
-    rs = np.random.RandomState(n)
-    M = rs.randn(n, n)
-    A = (M + M.T) / 2 + np.diag(rs.randn(n) * 3)
-    d, e, tau, V = np.empty(n), np.empty(max(n - 1, 1)), np.empty(max(n - 1, 1)), np.empty(max(n - 1, 1) ** 2)
-    st = C.c_int(0)
-    _lib.check(_lib.lib().msm_sytrd(A.ctypes.data, n, d.ctypes.data, e.ctypes.data, tau.ctypes.data, V.ctypes.data,
-                                    C.byref(st), 0))
-    assert st.value == 0
-    k = min(n, 10)
-    w, Y = _moments.eigenpairs_from_tridiagonal(d, e[:n - 1], tau[:n - 1], V, k)
-    wr = scipy.linalg.eigh(A, subset_by_index=[n - k, n - 1])[0][::-1]
-    scale = np.abs(A).max() * n
-    np.testing.assert_allclose(w, wr, rtol=0, atol=1e-14 * scale)
-    assert np.abs(A @ Y.T - Y.T * w).max() <= 1e-14 * scale
-    assert np.abs(Y @ Y.T - np.eye(k)).max() <= 1e-12
-    # the tridiagonal has the same spectrum as A (all of it)
-    if n > 1:
-        np.testing.assert_allclose(scipy.linalg.eigvalsh_tridiagonal(d, e[:n - 1]), scipy.linalg.eigvalsh(A), rtol=0, atol=1e-14 * scale)
-
-
 def test_solve_paths_agree(gpu, monkeypatch):
-    """host (numpy + dsygvx), hybrid with host dsyevr, hybrid with the device tridiagonalisation (host dstemr / dormqr),
-    the LAPACK-free device tail (csrc/toppairs.hip), all-device rocSOLVER: one model."""
+    """host (numpy + dsygvx), hybrid (device finalise + Cholesky reduction + back-substitution; here 6 features: LAPACK's
+    dsyevr on the reduced matrix), all-device rocSOLVER: one model."""
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
     seqs = _ar1(5, 6, 3000, 200)
     out = {}
     for name, env in (("host", {"MSMBUILDER_AMD_DEVICE_SOLVE": "0"}),
-                      ("evr", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "0"}),
-                      ("trd", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1",
-                               "MSMBUILDER_AMD_DEVICE_TOPK": "0"}),
-                      ("topk", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid", "MSMBUILDER_AMD_DEVICE_TRD": "1",
-                                "MSMBUILDER_AMD_DEVICE_TOPK": "1"}),
+                      ("hybrid", {"MSMBUILDER_AMD_DEVICE_SOLVE": "hybrid"}),
                       ("dev", {"MSMBUILDER_AMD_DEVICE_SOLVE": "1"})):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         m = tICA(n_components=6, lag_time=9).fit(seqs)
         out[name] = (m.eigenvalues_.copy(), m.eigenvectors_.copy(), m.shrinkage_, m.means_.copy())
-    for name in ("evr", "trd", "topk", "dev"):
+    for name in ("hybrid", "dev"):
         np.testing.assert_allclose(out[name][0], out["host"][0], rtol=1e-11)
         sg = np.sign((out[name][1] * out["host"][1]).sum(0))
         np.testing.assert_allclose(out[name][1] * sg, out["host"][1], rtol=0, atol=1e-8 * np.abs(out["host"][1]).max())

@@ -1,6 +1,6 @@
 """The sum/difference kernel with the column sums folded into its staging lanes (no column-sum pass over X ahead of the
 MFMA kernel; csrc/tica.hip, FOLD): same sums (tica.py:418-419), same moments, same finite check with a rejected input
-leaving the state untouched (utils/validation.py:68-74 raises before tica.py:401 accumulates).  MSM_TICA_FOLD_MIN=0
+leaving the state untouched (utils/validation.py:68-74 raises before tica.py:401 accumulates).  MSM_TICA_FOLD=2
 lets small inputs take the path that by default starts at 2^26 elements."""
 import ctypes as C
 import warnings
@@ -46,7 +46,7 @@ def _numpy_moments(seqs, lag, F):
 def test_folded_sums_and_moments_vs_numpy(gpu, monkeypatch, F, lag):
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
-    monkeypatch.setenv("MSM_TICA_FOLD_MIN", "0")
+    monkeypatch.setenv("MSM_TICA_FOLD", "2")
     # chunks that end inside a step, trajectories of exactly 2 lag frames (every frame is a boundary frame), one too short
     # to count (skipped), half-step edges
     lens = [9001, 4096 + 2 * lag, lag, 2 * lag, 33 + 2 * lag, 2 * lag + 5, 4097, 2 * lag + 16, 2 * lag + 17]
@@ -83,7 +83,7 @@ def test_short_trajectory_falls_back_to_the_column_sum_pass(gpu, monkeypatch):
     boundary rows: such a launch keeps the separate pass."""
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
-    monkeypatch.setenv("MSM_TICA_FOLD_MIN", "0")
+    monkeypatch.setenv("MSM_TICA_FOLD", "2")
     F, lag = 256, 40
     seqs = _data(3, [3000, lag + 7, 500], F)
     m = tICA(n_components=3, lag_time=lag).fit(seqs)
@@ -103,7 +103,7 @@ def test_default_threshold(gpu, monkeypatch):
     torch = pytest.importorskip("torch")
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
-    monkeypatch.delenv("MSM_TICA_FOLD_MIN", raising=False)
+    monkeypatch.delenv("MSM_TICA_FOLD", raising=False)
     g = torch.Generator(device="cuda").manual_seed(1)
     X = torch.randn(300000, 256, device="cuda", generator=g)
     m = tICA(n_components=3, lag_time=10).fit([X[:200000]])
@@ -126,7 +126,7 @@ def test_default_threshold(gpu, monkeypatch):
 def test_rejected_input_leaves_the_state_untouched(gpu, monkeypatch, where, dirty):
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
-    monkeypatch.setenv("MSM_TICA_FOLD_MIN", "0")
+    monkeypatch.setenv("MSM_TICA_FOLD", "2")
     F, lag = 256, 9
     good = _data(11, [5000, 700], F)
     bad = _data(12, [4500], F)[0]
@@ -167,11 +167,11 @@ def test_folded_and_plain_launches_add_up(gpu, monkeypatch):
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f32")
     F, lag = 384, 12
     seqs = _data(21, [6000, 2500, 4100, 1500], F, offset=50.0)     # |mean| / sigma up to ~20
-    monkeypatch.setenv("MSM_TICA_FOLD_MIN", "0")
+    monkeypatch.setenv("MSM_TICA_FOLD", "2")
     m = tICA(n_components=4, lag_time=lag, shrinkage=0)
     kinds = []
     for i, s in enumerate(seqs):
-        monkeypatch.setenv("MSM_TICA_FOLD", "1" if i % 2 == 0 else "0")
+        monkeypatch.setenv("MSM_TICA_FOLD", "2" if i % 2 == 0 else "0")
         m.partial_fit(s)
         kinds.append(_folded(m))
     assert kinds == [1, 0, 1, 0]
@@ -198,7 +198,7 @@ def test_image_path_folds_its_column_sums_too(gpu, monkeypatch, mode, F, lag, st
     torch = pytest.importorskip("torch")
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
-    monkeypatch.setenv("MSM_TICA_FOLD_MIN", "0")
+    monkeypatch.setenv("MSM_TICA_FOLD", "2")
     lens = [5000, 4096 + 2 * lag, lag, 2 * lag, 2 * lag + 33, 700]
     seqs = _data(F + lag, lens, F)
     if stored == "bfloat16":
@@ -225,7 +225,7 @@ def test_image_path_folds_its_column_sums_too(gpu, monkeypatch, mode, F, lag, st
     bad = seqs[0].copy()
     bad[1234, 5] = np.nan
     before = m._outer_gram_sum.copy()
-    monkeypatch.setenv("MSM_TICA_FOLD", "1")
+    monkeypatch.setenv("MSM_TICA_FOLD", "2")
     with pytest.raises(ValueError, match="NaN"):
         m.partial_fit(torch.from_numpy(bad).cuda() if stored == "float32" else torch.from_numpy(bad).cuda().to(torch.bfloat16))
     m._is_dirty = True
