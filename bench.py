@@ -592,11 +592,11 @@ def main():
             rec8 = {}
             # the ROW-SHARDED k-centers loop (msm_kcenters_fit_sharded_*, a world of one: its all-gathers are copies), i.e.
             # the code an N = 8 rank runs, not the single-GPU fit
-            os.environ["MSMBUILDER_AMD_FORCE_SHARDED"] = "1"
+            KCenters._force_sharded = True
             step(None, seqs8, X8)
             for _ in range(3):
                 step(rec8, seqs8, X8)
-            os.environ.pop("MSMBUILDER_AMD_FORCE_SHARDED", None)
+            KCenters._force_sharded = False
             rec8.pop("sym", None)
             rec8.pop("folded", None)
             kst8 = (C.c_int64 * 5)()

@@ -61,6 +61,8 @@ class _KCenters(ClusterMixin, TransformerMixin):
     inertia_ : float, sum of distances_
     """
 
+    _force_sharded = False   # measurement hook, see fit()
+
     def __init__(self, n_clusters=8, metric='euclidean', random_state=None):
         self.n_clusters = n_clusters
         self.metric = metric
@@ -73,10 +75,9 @@ class _KCenters(ClusterMixin, TransformerMixin):
             raise ValueError('metric must be one of %s' %
                              ', '.join("'%s'" % s for s in libdistance.VECTOR_METRICS))
         from .. import parallel
-        import os
-        # MSMBUILDER_AMD_FORCE_SHARDED=1: take the row-sharded library loop in a single process too (a world of one; its
-        # all-gathers degenerate to copies) -- what bench.py's strong-scaling model times
-        if parallel.active() or (os.environ.get("MSMBUILDER_AMD_FORCE_SHARDED") == "1" and is_device_array(X)):
+        # _force_sharded (a class attribute bench.py's strong-scaling model sets): take the row-sharded library loop in a
+        # single process too (a world of one; its all-gathers degenerate to copies)
+        if parallel.active() or (self._force_sharded and is_device_array(X)):
             return self._fit_sharded(X, metric)
         n_samples = len(X)
         seed = check_random_state(self.random_state).randint(0, n_samples)

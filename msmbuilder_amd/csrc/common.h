@@ -87,7 +87,7 @@ int sygv_back_device(const double* L, double* Y, int n, int k);    // Y[n x k co
 int syevd_device(double* A, int n, double* D, double* E, int* dinfo);
 // toppairs.hip: own Cholesky and the residual check of the solve, queued on stream(), nothing synchronised
 int potrf_upper_device(double* B, int n, int* dinfo);   // B = U^T U on the row-major upper triangle (== dpotrf 'L', col-major)
-int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res2k);
+int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res);   // res: 2k + k*k doubles
 
 // subspace.hip: k largest eigenpairs of a symmetric matrix with spectrum in [lower, inf) by Chebyshev-filtered subspace
 // iteration (block of 32, Rayleigh-Ritz on the host); synchronises; *converged = 0 -> outputs meaningless, use the fallback

@@ -2106,6 +2106,9 @@ struct KcbState {
     double cen[KCB_JMAX][16];
     long long list[KCB_CAP];
 };
+// (levels below 0.91 were tried in round 4 -- twelve levels down to 0.58: the number of rounds did not move, 19 on the bench's
+//  projection at 10M and at 1.25M rows: what ends a round is the list's capacity, not the threshold's rate of descent -- and
+//  the extra level counters cost 15 % of a fit)
 __device__ __forceinline__ float kcb_level(int l) { return l == 0 ? 1.f : l == 1 ? 0.985f : l == 2 ? 0.97f : l == 3 ? 0.955f : l == 4 ? 0.94f : 0.91f; }
 
 template <int NP>
@@ -2245,6 +2248,83 @@ __global__ __launch_bounds__(1024) void kcb_select_kernel(KscArgs P, KcbState* S
         S->k_done = k0 + J;
         S->rounds += 1;
         S->fallbacks += fell;
+    }
+}
+
+// ---- row-sharded fit: the same rounds with ONE exchange per round -----------------------------------------------------
+// A rank's round record (doubles): [0] rows it listed (more than KCB_CAPR: list unusable), [8] value and [9] GLOBAL row of its
+// per-block-partials argmax (-1: none), [10..25] that row's coordinates, [32 + l] the count of level l, then from [KCB_HDR]
+// on the listed rows as {distance, global row, coordinates[m]}.  The records are all-gathered and every rank runs the same selection on
+// the same numbers: no rank learns anything another does not, so the batches -- and the number of rounds -- agree.
+constexpr int KCB_CAPR = 1024, KCB_HDR = 48, KCB_LEV0 = 32;
+__host__ __device__ constexpr size_t kcb_rec_doubles(long long m) { return (size_t)KCB_HDR + (size_t)KCB_CAPR * (size_t)(2 + m); }
+
+// the records of the first round, made from the one-centre protocol's gathered candidates {value, global row, coordinates}
+__global__ void kcb_boot_records_kernel(const double* __restrict__ cands, int world, long long m, double* __restrict__ recs)
+{
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (r >= world) return;
+    const double* c = cands + (size_t)r * (2 + m);
+    double* o = recs + (size_t)r * kcb_rec_doubles(m);
+    if (tid < KCB_HDR) {
+        double v = 0.0;
+        if (tid == 8) v = c[0];
+        else if (tid == 9) v = c[1];
+        else if (tid >= 10 && tid < 10 + 16) v = tid - 10 < m ? c[2 + tid - 10] : 0.0;
+        o[tid] = v;
+    }
+}
+
+// the shard's record of a round.  (A launch of its own: folding it into the pass kernel -- the last workgroup to arrive packs
+// -- was tried in round 4 and cost 24 us per pass instead of the 7 + 4 us of this launch: the agent-scope release that
+// every one of the pass's ~5,000 workgroups must then make before it counts itself in is an L2 write-back each.)
+template <int NP>
+__global__ __launch_bounds__(DT) void kcb_pack_kernel(KscArgs P, KcbState* S, double* __restrict__ rec)
+{
+    __shared__ double rv[DT];
+    __shared__ long long ri[DT];
+    const int tid = threadIdx.x, m = (int)P.m;
+    if (S->J == 0) return;   // an empty round: nobody reads the record
+    double bv = -1.0;
+    long long bi = -1;
+    for (int k = tid; k < P.nblk; k += DT) {
+        const KcPartial q = P.next[k];
+        if (q.i >= 0 && (bi < 0 || kc_better(q.v, q.i, bv, bi))) {
+            bv = q.v;
+            bi = q.i;
+        }
+    }
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int k = DT / 2; k > 0; k >>= 1) {
+        if (tid < k) {
+            const long long oi = ri[tid + k];
+            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + k], oi, rv[tid], ri[tid]))) {
+                rv[tid] = rv[tid + k];
+                ri[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const long long w = ri[0];
+    const unsigned cnt = S->count;
+    if (tid < KCB_HDR) {
+        double v = 0.0;
+        if (tid == 0) v = (double)cnt;
+        else if (tid > KCB_LEV0 && tid < KCB_LEV0 + KCB_NLEV) v = (double)S->lev[tid - KCB_LEV0];
+        else if (tid == 8) v = w >= 0 ? rv[0] : -1.0;
+        else if (tid == 9) v = w >= 0 ? (double)(P.row_offset + w) : -1.0;
+        else if (tid >= 10 && tid < 26) v = (w >= 0 && tid - 10 < m) ? P.X[w * P.m + (tid - 10)] : 0.0;
+        rec[tid] = v;
+    }
+    const unsigned ne = cnt <= (unsigned)KCB_CAPR ? cnt : 0u;
+    for (unsigned e = tid; e < ne; e += DT) {
+        const long long p = S->list[e];
+        double* o = rec + KCB_HDR + (size_t)e * (2 + m);
+        o[0] = P.dist[p];
+        o[1] = (double)(P.row_offset + p);
+        for (int f = 0; f < m; ++f) o[2 + f] = P.X[p * P.m + f];
     }
 }
 
@@ -2483,80 +2563,6 @@ __global__ __launch_bounds__(DT) void kcenters_batch_pass_kernel(KscArgs P, KcbS
     }
 }
 
-// ---- row-sharded fit: the same rounds with ONE exchange per round -----------------------------------------------------
-// A rank's round record (doubles): [0] rows it listed (more than KCB_CAPR: list unusable), [1..5] level counts, [8] value and
-// [9] GLOBAL row of its per-block-partials argmax (-1: none), [10..25] that row's coordinates, then from [32] on the listed
-// rows as {distance, global row, coordinates[m]}.  The records are all-gathered and every rank runs the same selection on
-// the same numbers: no rank learns anything another does not, so the batches -- and the number of rounds -- agree.
-constexpr int KCB_CAPR = 256, KCB_HDR = 32;
-__host__ __device__ constexpr size_t kcb_rec_doubles(long long m) { return (size_t)KCB_HDR + (size_t)KCB_CAPR * (size_t)(2 + m); }
-
-// the records of the first round, made from the one-centre protocol's gathered candidates {value, global row, coordinates}
-__global__ void kcb_boot_records_kernel(const double* __restrict__ cands, int world, long long m, double* __restrict__ recs)
-{
-    const int r = blockIdx.x, tid = threadIdx.x;
-    if (r >= world) return;
-    const double* c = cands + (size_t)r * (2 + m);
-    double* o = recs + (size_t)r * kcb_rec_doubles(m);
-    if (tid < KCB_HDR) {
-        double v = 0.0;
-        if (tid == 8) v = c[0];
-        else if (tid == 9) v = c[1];
-        else if (tid >= 10 && tid < 10 + 16) v = tid - 10 < m ? c[2 + tid - 10] : 0.0;
-        o[tid] = v;
-    }
-}
-
-template <int NP>
-__global__ __launch_bounds__(DT) void kcb_pack_kernel(KscArgs P, KcbState* S, double* __restrict__ rec)
-{
-    __shared__ double rv[DT];
-    __shared__ long long ri[DT];
-    const int tid = threadIdx.x, m = (int)P.m;
-    if (S->J == 0) return;   // an empty round: nobody reads the record
-    double bv = -1.0;
-    long long bi = -1;
-    for (int k = tid; k < P.nblk; k += DT) {
-        const KcPartial q = P.next[k];
-        if (q.i >= 0 && (bi < 0 || kc_better(q.v, q.i, bv, bi))) {
-            bv = q.v;
-            bi = q.i;
-        }
-    }
-    rv[tid] = bv;
-    ri[tid] = bi;
-    __syncthreads();
-    for (int k = DT / 2; k > 0; k >>= 1) {
-        if (tid < k) {
-            const long long oi = ri[tid + k];
-            if (oi >= 0 && (ri[tid] < 0 || kc_better(rv[tid + k], oi, rv[tid], ri[tid]))) {
-                rv[tid] = rv[tid + k];
-                ri[tid] = oi;
-            }
-        }
-        __syncthreads();
-    }
-    const long long w = ri[0];
-    const unsigned cnt = S->count;
-    if (tid < KCB_HDR) {
-        double v = 0.0;
-        if (tid == 0) v = (double)cnt;
-        else if (tid < KCB_NLEV) v = (double)S->lev[tid];
-        else if (tid == 8) v = w >= 0 ? rv[0] : -1.0;
-        else if (tid == 9) v = w >= 0 ? (double)(P.row_offset + w) : -1.0;
-        else if (tid >= 10 && tid < 26) v = (w >= 0 && tid - 10 < m) ? P.X[w * P.m + (tid - 10)] : 0.0;
-        rec[tid] = v;
-    }
-    const unsigned ne = cnt <= (unsigned)KCB_CAPR ? cnt : 0u;
-    for (unsigned e = tid; e < ne; e += DT) {
-        const long long p = S->list[e];
-        double* o = rec + KCB_HDR + (size_t)e * (2 + m);
-        o[0] = P.dist[p];
-        o[1] = (double)(P.row_offset + p);
-        for (int f = 0; f < m; ++f) o[2 + f] = P.X[p * P.m + f];
-    }
-}
-
 // a rank without rows: nothing listed, no argmax
 __global__ void kcb_empty_record_kernel(double* __restrict__ rec)
 {
@@ -2621,7 +2627,7 @@ __global__ __launch_bounds__(1024) void kcb_select_sharded_kernel(const double* 
         if (c > (unsigned)KCB_CAPR) fits = false;
         else total += c;
 #pragma unroll
-        for (int q = 1; q < KCB_NLEV; ++q) lev[q] += (unsigned)h[q];
+        for (int q = 1; q < KCB_NLEV; ++q) lev[q] += (unsigned)h[KCB_LEV0 + q];
     }
     const float theta = S->theta;
     const bool usable = fits && total > 0 && total <= (unsigned)KCB_CAP && theta > 0.f && theta < 3e38f;

@@ -2067,6 +2067,8 @@ struct msm_tica {
     bool timed = false;
     DevBuf table, table2, staging;
     int img_on = 0, T2 = 0, ntile2 = 0, S_img = 0, img_grid = 0;  // 256-wide tiles per side, H and D tiles of the upper triangle, whole cohorts, workgroups
+    double* solve_pin = nullptr; // pinned host staging of the solve's results (one device-to-host copy per solve)
+    size_t solve_pin_n = 0;
     DevBuf solve;                // device-resident solve: [A (F*F) | B (F*F) | mu F | D F | E F | scal 4 | part 2*nblk | scale F | Y k*F | vals F | ints]
     bool reduced = false;        // solve.A / solve.B hold the reduced matrix and the Cholesky factor of the current state
     size_t packed_len() const { return 2 * (size_t)F * F + 2 * (size_t)F + 2; }
@@ -2775,6 +2777,7 @@ int msm_tica_destroy(msm_tica_t* h)
     if (h->fold) (void)hipFree(h->fold);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->solve_pin) (void)hipHostFree(h->solve_pin);
     delete h;
     return MSM_OK;
 }
@@ -3010,7 +3013,7 @@ namespace {
 struct SolveBufs {
     double *A, *B, *mu, *D, *E, *scal, *part, *scale, *Y, *vals, *trdw;
     double* sswork;               // subspace iteration workspace (subspace.hip)
-    double *lam, *S, *Yk, *res;   // top-k tail (toppairs.hip): eigenvalues [64], tridiagonal vectors / back-transformed vectors [64][F], residuals [128]
+    double *lam, *S, *Yk, *res;   // top-k tail (toppairs.hip): eigenvalues [64], back-transformed vectors [64][F], reduced vectors [64][F], checks [320]
     int* ints;  // [0..1] non-finite flags (OC, S), [2] potrf info, [3] syevd info; [8 ..] sytrd barrier flags + status
     int nblk;
 };
@@ -3019,7 +3022,7 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
 {
     const size_t F = (size_t)h->F, FF = F * F;
     const int nblk = (int)ceil_div((int64_t)FF, 256);
-    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk + 192 + 128 * F + subspace_work_doubles((int)F);
+    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk + 384 + 128 * F + subspace_work_doubles((int)F);
     int rc = h->solve.reserve(nd * sizeof(double) + (8 + F / 16 + 4) * sizeof(int));
     if (rc) return rc;
     double* p = h->solve.as<double>();
@@ -3036,7 +3039,7 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
     b->trdw = b->part + 2 * (size_t)nblk;   // 8F doubles of sytrd exchange records
     b->lam = b->trdw + 8 * F;
     b->res = b->lam + 64;
-    b->S = b->res + 128;
+    b->S = b->res + 320;   // res: 2k + k^2 doubles, k <= 16
     b->Yk = b->S + 64 * F;
     b->sswork = b->Yk + 64 * F;
     b->ints = reinterpret_cast<int*>(b->sswork + subspace_work_doubles((int)F));
@@ -3096,6 +3099,26 @@ int tica_reduce_status(const double scal[4], const int ints[8], double* info)
         return fail(MSM_ERR_INVALID, "The leading minor of order %d of B is not positive definite. The factorization of B "
                     "could not be completed and no eigenvalues or eigenvectors were computed.", ints[2]);
     return MSM_OK;
+}
+
+// the results of a top-k solve gathered into ONE buffer for one device-to-host copy (seven small copies into pageable host
+// arrays cost 20-40 us each): out = [vals k | checks 2k + k^2 | scal 4 | ints 8 | mu n | vecs k n]
+__global__ void tica_solve_emit_kernel(const double* __restrict__ lam, const double* __restrict__ res, const double* __restrict__ scal,
+                                       const int* __restrict__ ints, const double* __restrict__ mu, const double* __restrict__ vecs,
+                                       int n, int k, double* __restrict__ out)
+{
+    const int nres = 2 * k + k * k;
+    const size_t o_res = k, o_scal = o_res + nres, o_ints = o_scal + 4, o_mu = o_ints + 8, o_vec = o_mu + n, total = o_vec + (size_t)k * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        double v;
+        if (e < o_res) v = lam[e];
+        else if (e < o_scal) v = res[e - o_res];
+        else if (e < o_ints) v = scal[e - o_scal];
+        else if (e < o_mu) v = (double)ints[e - o_ints];
+        else if (e < o_vec) v = mu[e - o_mu];
+        else v = vecs[e - o_vec];
+        out[e] = v;
+    }
 }
 
 }  // namespace
@@ -3158,17 +3181,30 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
     // the residual kernel has read Yk; L^-T in place for the k vectors
     MSM_HIP_CHECK(hipMemcpyAsync(b.S, b.Yk, (size_t)k * n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
     if ((rc = sygv_back_device(b.B, b.S, n, (int)k))) return rc;
-    double scal[4], res[128];
-    int ints[8];
-    std::vector<double> yk((size_t)k * n);
-    MSM_HIP_CHECK(hipMemcpyAsync(yk.data(), b.Yk, (size_t)k * n * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(vecs, b.S, (size_t)k * n * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(vals, b.lam, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(res, b.res, 2 * (size_t)k * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(mu, b.mu, n * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(scal, b.scal, sizeof(scal), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(ints, b.ints, sizeof(ints), hipMemcpyDeviceToHost, stream()));
+    // one packed copy of everything the caller gets (b.Y, n^2 doubles, is free at this point)
+    const int nres = 2 * (int)k + (int)k * (int)k;
+    const size_t o_res = (size_t)k, o_scal = o_res + nres, o_ints = o_scal + 4, o_mu = o_ints + 8, o_vec = o_mu + n, total = o_vec + (size_t)k * n;
+    if (h->solve_pin_n < total) {
+        if (h->solve_pin) (void)hipHostFree(h->solve_pin);
+        h->solve_pin = nullptr;
+        h->solve_pin_n = 0;
+        MSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->solve_pin), (17 + 320 + 12 + 17 * (size_t)n) * sizeof(double), hipHostMallocDefault));
+        h->solve_pin_n = 17 + 320 + 12 + 17 * (size_t)n;
+    }
+    hipLaunchKernelGGL(tica_solve_emit_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(), b.lam, b.res, b.scal, b.ints, b.mu,
+                       b.S, n, (int)k, b.Y);
+    MSM_HIP_CHECK(hipGetLastError());
+    MSM_HIP_CHECK(hipMemcpyAsync(h->solve_pin, b.Y, total * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    const double* hp = h->solve_pin;
+    const double* res = hp + o_res;
+    double scal[4];
+    int ints[8];
+    for (int i = 0; i < 4; ++i) scal[i] = hp[o_scal + i];
+    for (int i = 0; i < 8; ++i) ints[i] = (int)hp[o_ints + i];
+    memcpy(vals, hp, (size_t)k * sizeof(double));
+    memcpy(mu, hp + o_mu, (size_t)n * sizeof(double));
+    memcpy(vecs, hp + o_vec, (size_t)k * n * sizeof(double));
     rc = tica_reduce_status(scal, ints, info);
     if (rc) return rc;
     if (info) {
@@ -3176,17 +3212,17 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
         info[9] = (double)outer;      // filtered iterations spent (also when they did not converge)
     }
     // self-check on the reduced matrix: every returned pair must satisfy C y = lambda y to rounding, be normalised, and the
-    // k vectors must be mutually orthogonal (a rank-deficient block would pass the per-pair checks).  A failure
-    // hands the reduced matrix to the caller's LAPACK route instead of returning a wrong pair.
+    // k vectors must be mutually orthogonal (a rank-deficient block would pass the per-pair checks; the Gram
+    // matrix of the vectors comes from the residual kernel).  A failure hands the reduced matrix to the caller's LAPACK
+    // route instead of returning a wrong pair.
     double lmax = 1.0, rmax = 0.0, nmax = 0.0, omax = 0.0;
     for (int j = 0; j < (int)k; ++j) {
         lmax = std::max(lmax, std::fabs(vals[j]));
         rmax = std::max(rmax, res[j]);
         nmax = std::max(nmax, res[k + j]);
         for (int i = 0; i < j; ++i) {
-            double dot = 0.0;
-            for (int c = 0; c < n; ++c) dot += yk[(size_t)i * n + c] * yk[(size_t)j * n + c];
-            omax = std::max(omax, std::fabs(dot));
+            const double dot = res[2 * k + (size_t)j * k + i];
+            omax = std::max(omax, (dot == dot) ? std::fabs(dot) : INFINITY);
         }
     }
     if (info) {

@@ -79,71 +79,70 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict__ B, int n, int j0, int* __restrict__ minidx,
                                                              const double* __restrict__ dsave)
 {
-    // pW: wave-private staging of a 32-row chunk of the panel above
-    // ([wave][A | B][32][33]) and, afterwards, the four waves' partial products
+    // pW: the four waves' partial products ([wave][diagonal block | tile][32][33])
     __shared__ double pW[4][2][CH_NB][CH_NB + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int lane = tid & 63, wave = tid >> 6;
-    const int lx = lane & 7, ly = lane >> 3;   // the lane's 4 x 4 patch of the 32 x 32 product: rows 4 ly.., columns 4 lx..
     const int c0 = j0 + CH_NB * blockIdx.x;
     const bool diag = blockIdx.x == 0;
-    // ---- W = sum_K U[K, J]^T U[K, tile]: the K chunks are dealt out over the four waves (no barrier inside the loop: a
-    // wave stages and multiplies its own chunk), each lane accumulating a 4 x 4 patch of both products
-    double accD[4][4], accT[4][4];
+    // ---- W = sum_K U[K, J]^T U[K, tile] on the fp64 matrix pipe (v_mfma_f64_16x16x4: 16 x 4 times 4 x 16), operands
+    // straight from global memory: lane (r = lane & 15, g = lane >> 4) supplies U[kappa0 + g][j0 + 16 ta + r] as the A operand
+    // of row tile ta and U[kappa0 + g][c0 + 16 tb + r] as the B operand of column tile tb -- 128-byte segments, no LDS.  The
+    // steps of four rows kappa are dealt out over the four waves, eight steps (32 loads per lane) in flight; the diagonal
+    // product re-uses the A operands.  (Round 3 staged 32 x 32 chunks through LDS and multiplied on the VALU: 5 us per
+    // chunk and wave, 20 us of the 44 us the last block row took.)
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    f64x4 aD[2][2], aT[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) accD[a][b] = accT[a][b] = 0.0;
-    const int nchunk = j0 / CH_NB;
-    double pa[16], pb[16];   // a 32 x 32 chunk = 1024 values = 16 per lane
-    auto fetch = [&](int ch) {
-        const int kk = ch * CH_NB;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int s4 = 0; s4 < 16; ++s4) {
-            const int q = lane + 64 * s4, r = q >> 5, c = q & 31;
-            pa[s4] = (j0 + c < n) ? B[(size_t)(kk + r) * n + j0 + c] : 0.0;
-            pb[s4] = (!diag && c0 + c < n) ? B[(size_t)(kk + r) * n + c0 + c] : 0.0;
-        }
-    };
-    if (wave < nchunk) fetch(wave);
-    for (int ch = wave; ch < nchunk; ch += 4) {
+            for (int q = 0; q < 4; ++q) aD[a][b][q] = aT[a][b][q] = 0.0;
+    {
+        const int r16 = lane & 15, g4 = lane >> 4;
+        const int nstep = j0 / 4;   // j0 is a multiple of CH_NB
+        constexpr int UNR = 8;
+        const bool inA0 = j0 + r16 < n, inA1 = j0 + 16 + r16 < n;
+        const bool inB0 = !diag && c0 + r16 < n, inB1 = !diag && c0 + 16 + r16 < n;
+        for (int s0 = wave; s0 < nstep; s0 += 4 * UNR) {
+            double va0[UNR], va1[UNR], vb0[UNR], vb1[UNR];
 #pragma unroll
-        for (int s4 = 0; s4 < 16; ++s4) {
-            const int q = lane + 64 * s4, r = q >> 5, c = q & 31;
-            pW[wave][0][r][c] = pa[s4];
-            pW[wave][1][r][c] = pb[s4];
-        }
-        if (ch + 4 < nchunk) fetch(ch + 4);   // the next chunk's loads fly while this one is multiplied
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-        for (int q = 0; q < CH_NB; ++q) {
-            double av[4], dv[4], bv[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                av[a] = pW[wave][0][q][4 * ly + a];
-                dv[a] = pW[wave][0][q][4 * lx + a];
-                bv[a] = pW[wave][1][q][4 * lx + a];
+            for (int u = 0; u < UNR; ++u) {
+                const int st = s0 + 4 * u;
+                const bool ok = st < nstep;
+                const double* row = B + (size_t)(4 * (ok ? st : 0) + g4) * n;
+                va0[u] = (ok && inA0) ? row[j0 + r16] : 0.0;
+                va1[u] = (ok && inA1) ? row[j0 + 16 + r16] : 0.0;
+                vb0[u] = (ok && inB0) ? row[c0 + r16] : 0.0;
+                vb1[u] = (ok && inB1) ? row[c0 + 16 + r16] : 0.0;
             }
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    accD[a][b] += av[a] * dv[b];
-                    if (!diag) accT[a][b] += av[a] * bv[b];
+            for (int u = 0; u < UNR; ++u) {
+                aD[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va0[u], va0[u], aD[0][0], 0, 0, 0);
+                aD[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va0[u], va1[u], aD[0][1], 0, 0, 0);
+                aD[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1[u], va0[u], aD[1][0], 0, 0, 0);
+                aD[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1[u], va1[u], aD[1][1], 0, 0, 0);
+                if (!diag) {
+                    aT[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va0[u], vb0[u], aT[0][0], 0, 0, 0);
+                    aT[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va0[u], vb1[u], aT[0][1], 0, 0, 0);
+                    aT[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1[u], vb0[u], aT[1][0], 0, 0, 0);
+                    aT[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1[u], vb1[u], aT[1][1], 0, 0, 0);
                 }
+            }
         }
-        __builtin_amdgcn_wave_barrier();
+        // partial products of the four waves -> pW[wave][0 / 1] (C/D layout: column = lane & 15, row = (lane >> 4) + 4 q), then
+        // summed while the blocks are formed
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pW[wave][0][16 * a + g4 + 4 * q][16 * b + r16] = aD[a][b][q];
+                    pW[wave][1][16 * a + g4 + 4 * q][16 * b + r16] = aT[a][b][q];
+                }
     }
-    __syncthreads();
-    // partial products of the four waves -> pW[wave][0 / 1], then summed while the blocks are formed
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            pW[wave][0][4 * ly + a][4 * lx + b] = accD[a][b];
-            pW[wave][1][4 * ly + a][4 * lx + b] = accT[a][b];
-        }
     __syncthreads();
     // ---- right-looking elimination of the diagonal block and of this workgroup's tile with UNSCALED pivot rows: step p
     // subtracts sD[p][r] sD[p][c] / piv_p (and sD[p][r] sT[p][c] / piv_p) from the rows r > p; the rows are scaled by
@@ -165,31 +164,36 @@ __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict_
             eT[a][b] = (!diag && j0 + r < n && c0 + c < n) ? B[(size_t)(j0 + r) * n + c0 + c] - sumT : 0.0;
         }
     double pivsave[2] = {1.0, 1.0};   // the pivots of this thread's two rows (valid in every thread of the row)
+    // (Fully unrolled, branch-free: the step's eight LDS reads are issued together and waited for once.  Round 3's loop
+    //  kept p in a register and branched on r > p / c >= r: five dependent LDS round trips per step, 0.47 us a step --
+    //  15 of the 22 us of a launch.)
+#pragma unroll
     for (int p = 0; p < CH_NB; ++p) {
         const int buf = p & 1;
         if (ty == (p >> 1)) {   // owners of row p: publish it as it stands (all earlier steps applied)
-            const int a = p & 1;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                rowD[buf][2 * tx + b] = eD[a][b];
-                rowT[buf][2 * tx + b] = eT[a][b];
-            }
-            if (tx == (p >> 1)) rinv[buf] = fast_recip(eD[a][p & 1]);   // the thread holding (p, p)
+            rowD[buf][2 * tx] = eD[p & 1][0];
+            rowD[buf][2 * tx + 1] = eD[p & 1][1];
+            rowT[buf][2 * tx] = eT[p & 1][0];
+            rowT[buf][2 * tx + 1] = eT[p & 1][1];
+            if (tx == (p >> 1)) rinv[buf] = fast_recip(eD[p & 1][p & 1]);   // the thread holding (p, p)
         }
         __syncthreads();
-        const double piv_inv = rinv[buf];
+        const double piv_inv = rinv[buf], dpp = rowD[buf][p];
+        const double rD[2] = {rowD[buf][2 * ty], rowD[buf][2 * ty + 1]};
+        const double cD[2] = {rowD[buf][2 * tx], rowD[buf][2 * tx + 1]};
+        const double cT[2] = {rowT[buf][2 * tx], rowT[buf][2 * tx + 1]};
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int r = 2 * ty + a;
-            if (r == p) pivsave[a] = rowD[buf][p];
-            if (r > p) {
-                const double f = rowD[buf][r] * piv_inv;
+            pivsave[a] = (r == p) ? dpp : pivsave[a];
+            const bool act = r > p;   // finished rows keep their values whatever the pivot row holds (select, not 0 * x)
+            const double f = rD[a] * piv_inv;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int c = 2 * tx + b;
-                    if (c >= r) eD[a][b] -= f * rowD[buf][c];
-                    eT[a][b] -= f * rowT[buf][c];
-                }
+            for (int b = 0; b < 2; ++b) {
+                // (entries left of the diagonal are updated too: nothing reads them)
+                const double nd = fma(-f, cD[b], eD[a][b]), nt = fma(-f, cT[b], eT[a][b]);
+                eD[a][b] = act ? nd : eD[a][b];
+                eT[a][b] = act ? nt : eT[a][b];
             }
         }
         // (double-buffered rows: the owners of row p + 1 may publish while others still read row p)
@@ -240,52 +244,71 @@ int potrf_upper_device(double* B, int n, int* dinfo)
 
 constexpr int TRI_MAXN = 1024;   // rows of the reduced matrix the residual kernel stages
 
-// res[j] = max_r |(C y_j)_r - lambda_j y_j[r]|, res[k + j] = | ||y_j||^2 - 1 |   (C symmetric n x n, Y [k][n])
+// res[j] = max_r |(C y_j)_r - lambda_j y_j[r]|, res[k + j] = | ||y_j||^2 - 1 |, res[2k + i k + j] = y_i . y_j   (C symmetric
+// n x n, Y [k][n]; res[0 .. 2k) zeroed by the caller: the maxima are merged with atomicMax on the bits of non-negative
+// doubles).  Grid (ceil(n / 64) + 1, k): workgroup (b, j) forms rows 64 b .. 64 b + 63 of C y_j, the four waves splitting
+// the columns (16 loads in flight per lane: round 3's one-workgroup-per-vector kernel made 128 dependent trips, 48 us);
+// the last workgroup of a column forms row j of the Gram matrix of the vectors (mutual orthogonality).
 __global__ __launch_bounds__(256) void pair_residual_kernel(const double* __restrict__ Cm, int n, const double* __restrict__ Y,
                                                             const double* __restrict__ vals, int k, double* __restrict__ res)
 {
     __shared__ double sy[TRI_MAXN];
-    __shared__ double rm[4], rs[4];
-    const int j = blockIdx.x, tid = threadIdx.x;
+    __shared__ double part[4][64];
+    const int j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = (n + 63) / 64;
     for (int i = tid; i < n; i += 256) sy[i] = Y[(size_t)j * n + i];
     __syncthreads();
-    const double lam = vals[j];
-    double mx = 0.0, ss = 0.0;
-    for (int r = tid; r < n; r += 256) {
-        double acc = 0.0;
-        int c = 0;
-        for (; c + 8 <= n; c += 8) {   // symmetric: column r read as a row, coalesced; eight loads in flight per trip
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = Cm[(size_t)(c + u) * n + r];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u] * sy[c + u];
+    if ((int)blockIdx.x == nb) {
+        // Gram row j: wave w takes the vectors i = w, w + 4, ...
+        for (int i = wave; i < k; i += 4) {
+            double acc = 0.0;
+            for (int c = lane; c < n; c += 64) acc = fma(Y[(size_t)i * n + c], sy[c], acc);
+            acc = wave_sum_f64(acc);
+            if (lane == 0) res[2 * k + (size_t)j * k + i] = acc;
         }
-        for (; c < n; ++c) acc += Cm[(size_t)c * n + r] * sy[c];
-        mx = fmax(mx, fabs(acc - lam * sy[r]));
-        ss += sy[r] * sy[r];
+        return;
     }
-    if (!(mx == mx)) mx = INFINITY;
+    const int r = 64 * blockIdx.x + lane;
+    const int rc = r < n ? r : n - 1;
+    const int q = (n + 3) / 4, c0 = wave * q, c1 = (c0 + q) < n ? (c0 + q) : n;
+    double acc = 0.0;
+    int c = c0;
+    for (; c + 16 <= c1; c += 16) {   // symmetric: column r read as a row, coalesced
+        double v[16];
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        mx = fmax(mx, __shfl_xor(mx, m, 64));
-        ss += __shfl_xor(ss, m, 64);
+        for (int u = 0; u < 16; ++u) v[u] = Cm[(size_t)(c + u) * n + rc];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fma(v[u], sy[c + u], acc);
     }
-    if ((tid & 63) == 0) {
-        rm[tid >> 6] = mx;
-        rs[tid >> 6] = ss;
-    }
+    for (; c < c1; ++c) acc = fma(Cm[(size_t)c * n + rc], sy[c], acc);
+    part[wave][lane] = acc;
     __syncthreads();
-    if (tid == 0) {
-        res[j] = fmax(fmax(rm[0], rm[1]), fmax(rm[2], rm[3]));
-        const double nn = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    if (wave == 0) {
+        const double cy = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        double mx = r < n ? fabs(cy - vals[j] * sy[rc]) : 0.0;
+        if (!(mx == mx)) mx = INFINITY;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(res + j), (unsigned long long)__double_as_longlong(mx));
+    }
+}
+
+// res[k + j] = | y_j . y_j - 1 | from the Gram matrix the kernel above left at res[2k ...]
+__global__ void pair_norms_kernel(int k, double* __restrict__ res)
+{
+    const int j = threadIdx.x;
+    if (j < k) {
+        const double nn = res[2 * k + (size_t)j * k + j];
         res[k + j] = (nn == nn) ? fabs(nn - 1.0) : INFINITY;
     }
 }
 
-int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res2k)
+// res: 2k + k^2 doubles (residual maxima, norm defects, Gram matrix of the vectors)
+int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res)
 {
-    hipLaunchKernelGGL(pair_residual_kernel, dim3(k), dim3(256), 0, stream(), Cm, n, Y, vals, k, res2k);
+    MSM_HIP_CHECK(hipMemsetAsync(res, 0, 2 * (size_t)k * sizeof(double), stream()));
+    hipLaunchKernelGGL(pair_residual_kernel, dim3((unsigned)ceil_div(n, 64) + 1, (unsigned)k), dim3(256), 0, stream(), Cm, n, Y, vals, k, res);
+    hipLaunchKernelGGL(pair_norms_kernel, dim3(1), dim3(64), 0, stream(), k, res);
     MSM_HIP_CHECK(hipGetLastError());
     return MSM_OK;
 }

@@ -24,12 +24,11 @@ for name, Z in (("tICA projection", Y), ("white noise", torch.randn_like(Y))):
 # one rank's share of an 8-GPU run (1.25M rows): the single-process fit against the row-sharded library loop (a world of one)
 Z = Y[:1_250_000].contiguous()
 for name, env in (("single-process fit", None), ("sharded loop, world of one", "1")):
-    if env:
-        os.environ["MSMBUILDER_AMD_FORCE_SHARDED"] = env
+    KCenters._force_sharded = bool(env)
     ts = []
     for _ in range(4):
         torch.cuda.synchronize(); t = time.perf_counter()
         kc = KCenters(n_clusters=200, random_state=0).fit([Z])
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-    os.environ.pop("MSMBUILDER_AMD_FORCE_SHARDED", None)
+    KCenters._force_sharded = False
     print("1.25M x 10 f64, %s: KCenters(200).fit %.2f ms  ids[:4] %s" % (name, 1e3 * min(ts[1:]), kc.cluster_ids_[:4]))

@@ -1,6 +1,7 @@
 """One pass over every leg the bench prints, at moderate sizes, for the PMC passes of scripts/r04_pmc_all.sh (each leg runs
 its kernels a known number of times; the table printed at the end gives the ALGORITHMIC bytes of each leg's dominant
-kernel per launch, to set beside FETCH_SIZE x 2 + WRITE_SIZE)."""
+kernel per launch, to set beside FETCH_SIZE x 2 + WRITE_SIZE).  `legs.py c5`: only BASELINE configs[4]'s width at
+1,000,000 x 2048 bfloat16-stored rows, one fit per bf16 mode (scripts/r04_final.sh c5)."""
 import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,6 +15,16 @@ rows = []
 
 def seqs_of(X, n):
     return list(X.view(n, T, X.shape[1]).unbind(0))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "c5":
+    Xb = (torch.randn(100 * T, 2048, generator=g, device=dev) + 1.0).to(torch.bfloat16)
+    for mode in ("bf16", "bf16x2"):
+        os.environ["MSMBUILDER_AMD_TICA_MODE"] = mode
+        tICA(n_components=10, lag_time=100).fit(seqs_of(Xb, 100))
+    torch.cuda.synchronize()
+    print("ALGORITHMIC bytes per fit: %.4g B (1,000,000 x 2048 bfloat16-stored)" % (Xb.numel() * 2))
+    sys.exit(0)
 
 
 # 1) fp32 sum/difference kernel (the bench's dominant kernel), 2M x 512
