@@ -82,11 +82,12 @@ int comm_allreduce_f64(double* dbuf, size_t n);                     // sum, in p
 int comm_allgather(const void* dsend, void* drecv, size_t bytes);   // drecv[r * bytes ...] = rank r's dsend
 
 // eigsolve.hip: rocSOLVER / rocBLAS building blocks (dlopen'ed at first use) on stream(), nothing synchronised
-int sygv_reduce_device(double* A, double* B, int n, int* dinfo);   // B = L L^T (lower, col-major), A <- L^-1 A L^-T
+int sygv_reduce_device(double* A, double* B, int n, int* dinfo, double* Winv, double* T);   // B = L L^T (lower, col-major), A <- L^-1 A L^-T; Winv, T: optional n x n (own route: Winv <- L^-1)
 int sygv_back_device(const double* L, double* Y, int n, int k);    // Y[n x k col-major] <- L^-T Y
 int syevd_device(double* A, int n, double* D, double* E, int* dinfo);
 // toppairs.hip: own Cholesky and the residual check of the solve, queued on stream(), nothing synchronised
-int potrf_upper_device(double* B, int n, int* dinfo);   // B = U^T U on the row-major upper triangle (== dpotrf 'L', col-major)
+int potrf_upper_device(double* B, int n, int* dinfo, double* Winv);   // B = U^T U on the row-major upper triangle (== dpotrf 'L', col-major); Winv (or null) <- U^-T
+int winv_back_device(const double* W, int n, const double* Y, int k, double* V);   // V (k rows) = W^T Y
 int pair_residual_device(const double* Cm, int n, const double* Y, const double* vals, int k, double* res);   // res: 2k + k*k doubles
 
 // subspace.hip: k largest eigenpairs of a symmetric matrix with spectrum in [lower, inf) by Chebyshev-filtered subspace

@@ -23,6 +23,7 @@ typedef int (*fn_set_stream)(rb_handle, hipStream_t);
 typedef int (*fn_dpotrf)(rb_handle, int, int, double*, int, int*);
 typedef int (*fn_dsyevd)(rb_handle, int, int, int, double*, int, double*, double*, int*);
 typedef int (*fn_dtrsm)(rb_handle, int, int, int, int, int, int, const double*, const double*, int, double*, int);
+typedef int (*fn_dgemm)(rb_handle, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int);
 
 struct Solver {
     void* lib = nullptr;
@@ -31,6 +32,7 @@ struct Solver {
     fn_dpotrf dpotrf = nullptr;
     fn_dsyevd dsyevd = nullptr;
     fn_dtrsm dtrsm = nullptr;
+    fn_dgemm dgemm = nullptr;
     rb_handle handle = nullptr;
     std::string error;
 };
@@ -52,8 +54,9 @@ static Solver& solver()
         s.dpotrf = (fn_dpotrf)dlsym(s.lib, "rocsolver_dpotrf");
         s.dsyevd = (fn_dsyevd)dlsym(s.lib, "rocsolver_dsyevd");
         s.dtrsm = (fn_dtrsm)dlsym(s.lib, "rocblas_dtrsm");
-        if (!s.create || !s.set_stream || !s.dpotrf || !s.dsyevd || !s.dtrsm) {
-            s.error = "rocsolver_dpotrf / rocsolver_dsyevd / rocblas_dtrsm not reachable through librocsolver";
+        s.dgemm = (fn_dgemm)dlsym(s.lib, "rocblas_dgemm");
+        if (!s.create || !s.set_stream || !s.dpotrf || !s.dsyevd || !s.dtrsm || !s.dgemm) {
+            s.error = "rocsolver_dpotrf / rocsolver_dsyevd / rocblas_dtrsm / rocblas_dgemm not reachable through librocsolver";
             return;
         }
         if (s.create(&s.handle) != 0) s.error = "rocblas_create_handle failed";
@@ -74,7 +77,9 @@ __global__ void top_pairs_kernel(const double* __restrict__ Z, const double* __r
 // ---- building blocks shared with tica.hip's device-resident solve (declared in common.h) -----------------------
 // B = L L^T in place (lower, column-major == upper of the row-major symmetric buffer), then A <- L^-1 A L^-T.
 // Nothing is synchronised: *dinfo (device int) receives potrf's info and is read by the caller with its results.
-int sygv_reduce_device(double* A, double* B, int n, int* dinfo)
+// With `Winv` and `T` (n x n scratch each) and n <= 1024 the library's own factorisation also leaves W = U^-T in Winv and the
+// reduction is C = W A W^T by two GEMMs; otherwise two dtrsm against the factor.
+int sygv_reduce_device(double* A, double* B, int n, int* dinfo, double* Winv, double* T)
 {
     Solver& s = solver();
     if (!s.error.empty()) return fail(MSM_ERR_STATE, "device eigensolver unavailable: %s", s.error.c_str());
@@ -84,8 +89,19 @@ int sygv_reduce_device(double* A, double* B, int n, int* dinfo)
     // B = L L^T: the library's own blocked kernel up to n = 1024 (one launch per 32 rows; rocSOLVER's dpotrf is launch-
     // latency bound there: 1.3 ms at n = 512), rocSOLVER beyond.
     const bool own = n <= 1024;
+    if (own && Winv && T) {
+        int rc = potrf_upper_device(B, n, dinfo, Winv);
+        if (rc) return rc;
+        // buffers are row-major; rocBLAS reads them column-major, i.e. transposed: T = (Winv buffer)^T A = W A, then
+        // C = T (Winv buffer) = W A W^T (symmetric, so the result is the same in either reading)
+        const double zero = 0.0;
+        st = s.dgemm(s.handle, 112, 111, n, n, n, &one, Winv, n, A, n, &zero, T, n);
+        if (st == 0) st = s.dgemm(s.handle, 111, 111, n, n, n, &one, T, n, Winv, n, &zero, A, n);
+        if (st != 0) return fail(MSM_ERR_HIP, "rocblas_dgemm failed with rocblas_status %d", st);
+        return MSM_OK;
+    }
     if (own) {
-        int rc = potrf_upper_device(B, n, dinfo);
+        int rc = potrf_upper_device(B, n, dinfo, nullptr);
         if (rc) return rc;
     } else {
         st = s.dpotrf(s.handle, 122, n, B, n, dinfo);

@@ -534,6 +534,7 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     cholqr(X);
     std::vector<double> H(SB * SB), G(SB * SB), w, V;
     double prev_res = INFINITY;
+    int last_deg = degree;
     for (int outer = 0; outer <= max_outer; ++outer) {
         // ---- Rayleigh-Ritz on span(X)
         product(X, nullptr, W, 1.0, 0.0, 0.0);
@@ -574,28 +575,48 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
         }
         // stalled: a filtered iteration that does not gain two orders of magnitude will not get there in time
         if (outer == max_outer || (outer >= 2 && !(rmax < 1e-2 * prev_res))) return MSM_OK;
+        // Degree of the next filter: `degree`, or -- once a filter's gain is known -- what the remaining distance to the
+        // tolerance asks for at that rate per degree (up to 3 x degree): one longer filter instead of two filters with a
+        // Rayleigh-Ritz round trip (two host synchronisations, ~0.2 ms) between them.
+        int deg = degree;
+        if (outer >= 1 && prev_res < INFINITY && rmax < prev_res) {
+            const double tol_abs = tol * std::max(1.0, std::fabs(w[0]));
+            const double rate = std::log(rmax / prev_res) / last_deg;        // < 0, per degree
+            const double need = std::log(0.3 * tol_abs / rmax) / rate;       // degrees still needed, with a margin
+            if (need > degree) deg = (int)std::min(3.0 * degree, std::ceil(need));
+        }
+        last_deg = deg;
         prev_res = rmax;
         // ---- filter: damp [lower, cut], cut = the smallest Ritz value of the block; scaled so that theta_1 stays O(1)
         const double cut = w[SB - 1], top = w[0];
         if (!(cut > lower) || !(top > cut)) return MSM_OK;
         const double e = 0.5 * (cut - lower), cen = 0.5 * (cut + lower);
         const double sigma1 = e / (top - cen);
-        double sigma = sigma1;
-        // Y = (sigma1 / e) (C X - cen X)
-        product(X, nullptr, Y, sigma1 / e, -sigma1 * cen / e, 0.0);
-        double *xp = X, *xc = Y, *xn = Z;
-        for (int i = 2; i <= degree; ++i) {
-            const double sn = 1.0 / (2.0 / sigma1 - sigma);
-            // xn = (2 sn / e) (C xc - cen xc) - sigma sn xp
-            product(xc, xp, xn, 2.0 * sn / e, -2.0 * sn * cen / e, -sigma * sn);
-            double* t = xp;
-            xp = xc;
-            xc = xn;
-            xn = t;
-            sigma = sn;
+        // `deg` degrees in chunks of at most `degree`, a Cholesky QR after each: the block's condition number grows with
+        // the degree of one polynomial (a single filter of degree 30 lost rank at F = 200), and re-orthonormalising costs
+        // 30 us on the device where a Rayleigh-Ritz round trip costs 0.2 ms
+        const int nchunk = (deg + degree - 1) / degree;
+        int left = deg;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int d = (left + (nchunk - ch) - 1) / (nchunk - ch);
+            left -= d;
+            double sigma = sigma1;
+            // Y = (sigma1 / e) (C X - cen X)
+            product(X, nullptr, Y, sigma1 / e, -sigma1 * cen / e, 0.0);
+            double *xp = X, *xc = Y, *xn = Z;
+            for (int i = 2; i <= d; ++i) {
+                const double sn = 1.0 / (2.0 / sigma1 - sigma);
+                // xn = (2 sn / e) (C xc - cen xc) - sigma sn xp
+                product(xc, xp, xn, 2.0 * sn / e, -2.0 * sn * cen / e, -sigma * sn);
+                double* t = xp;
+                xp = xc;
+                xc = xn;
+                xn = t;
+                sigma = sn;
+            }
+            if (xc != X) MSM_HIP_CHECK(hipMemcpyAsync(X, xc, NB * sizeof(double), hipMemcpyDeviceToDevice, stream()));
+            cholqr(X);
         }
-        if (xc != X) MSM_HIP_CHECK(hipMemcpyAsync(X, xc, NB * sizeof(double), hipMemcpyDeviceToDevice, stream()));
-        cholqr(X);
     }
     return MSM_OK;
 }

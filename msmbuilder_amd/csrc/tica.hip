@@ -2058,6 +2058,7 @@ struct msm_tica {
     bool shift_on = true, have_shift = false;
     double* fold = nullptr;     // folded column sums: [S_sym][F] per-cohort sums of the left frames | [FOLD_NB][F] sample partials | [F] zeros
     bool last_folded = false;   // the most recent launch took the folded path
+    bool cg_dirty = false;      // the C/G slabs (`slabs`) hold something since the last reset: only then does the export sum them
     bool slabs_dirty = false;   // slabs_sym hold something since the last reset (a rejected folded launch must be able to undo itself)
     DevBuf snap;                // ... from this copy
     DevBuf foldimg;             // bf16 image path: [nchunks][F] per-chunk sums of the left frames
@@ -2105,6 +2106,7 @@ int tica_zero(msm_tica* h)
     MSM_HIP_CHECK(hipMemsetAsync(h->shsum, 0, 3 * (size_t)h->F * sizeof(double), stream()));
     h->have_shift = false;
     h->slabs_dirty = false;
+    h->cg_dirty = false;
     h->reduced = false;
     h->n_sh = h->nw_sh = 0;
     {
@@ -2586,6 +2588,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         if (rc) return rc;
     }
     if (usesym) h->slabs_dirty = true;
+    else h->cg_dirty = true;
     h->last_folded = fold;
     for (msm_idx_t s = 0; s < n_seq; ++s) {
         const SegInfo g = seg_of(s);
@@ -2601,7 +2604,7 @@ int tica_export_device(msm_tica* h)
 {
     const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
-                       h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
+                       h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->cg_dirty ? h->S : 0);
     hipLaunchKernelGGL(tica_export_cols_kernel, dim3((unsigned)ceil_div(2 * (int64_t)h->F, 64)), dim3(256), 0, stream(), h->colpart, h->base,
                        h->packed, h->F);
     MSM_HIP_CHECK(hipGetLastError());
@@ -3012,6 +3015,7 @@ namespace {
 
 struct SolveBufs {
     double *A, *B, *mu, *D, *E, *scal, *part, *scale, *Y, *vals, *trdw;
+    double *Winv, *T;             // U^-T of the factorisation (n <= 1024: reduction by GEMMs, back-transformation by a thin product), GEMM scratch
     double* sswork;               // subspace iteration workspace (subspace.hip)
     double *lam, *S, *Yk, *res;   // top-k tail (toppairs.hip): eigenvalues [64], back-transformed vectors [64][F], reduced vectors [64][F], checks [320]
     int* ints;  // [0..1] non-finite flags (OC, S), [2] potrf info, [3] syevd info; [8 ..] sytrd barrier flags + status
@@ -3022,7 +3026,7 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
 {
     const size_t F = (size_t)h->F, FF = F * F;
     const int nblk = (int)ceil_div((int64_t)FF, 256);
-    const size_t nd = 3 * FF + 13 * F + 4 + 2 * (size_t)nblk + 384 + 128 * F + subspace_work_doubles((int)F);
+    const size_t nd = 5 * FF + 13 * F + 4 + 2 * (size_t)nblk + 384 + 128 * F + subspace_work_doubles((int)F);
     int rc = h->solve.reserve(nd * sizeof(double) + (8 + F / 16 + 4) * sizeof(int));
     if (rc) return rc;
     double* p = h->solve.as<double>();
@@ -3042,7 +3046,9 @@ int solve_bufs(msm_tica* h, SolveBufs* b)
     b->S = b->res + 320;   // res: 2k + k^2 doubles, k <= 16
     b->Yk = b->S + 64 * F;
     b->sswork = b->Yk + 64 * F;
-    b->ints = reinterpret_cast<int*>(b->sswork + subspace_work_doubles((int)F));
+    b->Winv = b->sswork + subspace_work_doubles((int)F);
+    b->T = b->Winv + FF;
+    b->ints = reinterpret_cast<int*>(b->T + FF);
     b->nblk = nblk;
     return MSM_OK;
 }
@@ -3057,7 +3063,7 @@ int tica_reduce_device(msm_tica* h, double shrinkage, long long n_rblw, const do
     // the packed raw moments (slab sums, un-shifted) stay on the device
     const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
-                       h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->S);
+                       h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->cg_dirty ? h->S : 0);
     hipLaunchKernelGGL(tica_export_cols_kernel, dim3((unsigned)ceil_div(2 * (int64_t)h->F, 64)), dim3(256), 0, stream(), h->colpart, h->base,
                        h->packed, h->F);
     if (h->sym) {
@@ -3077,7 +3083,7 @@ int tica_reduce_device(msm_tica* h, double shrinkage, long long n_rblw, const do
     hipLaunchKernelGGL(tica_rblw_kernel, dim3(1), dim3(256), 0, stream(), b->part, b->nblk, shrinkage, (double)n_rblw, h->F, b->scal);
     hipLaunchKernelGGL(tica_shrink_kernel, dim3((unsigned)b->nblk), dim3(256), 0, stream(), b->B, b->scal, h->F);
     MSM_HIP_CHECK(hipGetLastError());
-    if ((rc = sygv_reduce_device(b->A, b->B, h->F, b->ints + 2))) return rc;
+    if ((rc = sygv_reduce_device(b->A, b->B, h->F, b->ints + 2, b->Winv, b->T))) return rc;
     h->reduced = true;
     return MSM_OK;
 }
@@ -3178,9 +3184,8 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
         return MSM_OK;
     }
     if ((rc = pair_residual_device(b.A, n, b.Yk, b.lam, (int)k, b.res))) return rc;
-    // the residual kernel has read Yk; L^-T in place for the k vectors
-    MSM_HIP_CHECK(hipMemcpyAsync(b.S, b.Yk, (size_t)k * n * sizeof(double), hipMemcpyDeviceToDevice, stream()));
-    if ((rc = sygv_back_device(b.B, b.S, n, (int)k))) return rc;
+    // the vectors of the original problem: S = U^-1 Yk = W^T Yk (n <= 1024 here: W = U^-T was formed with the factor)
+    if ((rc = winv_back_device(b.Winv, n, b.Yk, (int)k, b.S))) return rc;
     // one packed copy of everything the caller gets (b.Y, n^2 doubles, is free at this point)
     const int nres = 2 * (int)k + (int)k * (int)k;
     const size_t o_res = (size_t)k, o_scal = o_res + nres, o_ints = o_scal + 4, o_mu = o_ints + 8, o_vec = o_mu + n, total = o_vec + (size_t)k * n;
@@ -3247,8 +3252,13 @@ int msm_tica_backsolve(msm_tica_t* h, const double* Y, msm_idx_t k, double* V)
     if (rc) return rc;
     const size_t bytes = (size_t)k * h->F * sizeof(double);
     MSM_HIP_CHECK(hipMemcpyAsync(b.Y, Y, bytes, hipMemcpyHostToDevice, stream()));
-    if ((rc = sygv_back_device(b.B, b.Y, h->F, (int)k))) return rc;
-    MSM_HIP_CHECK(hipMemcpyAsync(V, b.Y, bytes, hipMemcpyDeviceToHost, stream()));
+    if (h->F <= 1024 && k <= 64) {
+        if ((rc = winv_back_device(b.Winv, h->F, b.Y, (int)k, b.S))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(V, b.S, bytes, hipMemcpyDeviceToHost, stream()));
+    } else {
+        if ((rc = sygv_back_device(b.B, b.Y, h->F, (int)k))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(V, b.Y, bytes, hipMemcpyDeviceToHost, stream()));
+    }
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
 }

@@ -76,15 +76,25 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// With `Winv` the launch also forms block row J of W = U^-T (lower triangular, row-major): workgroups nu .. nu + J take the
+// tiles (J, I), I <= J, of  W[J, :] = U[J, J]^-T (I[J, :] - sum_{I <= K < J} U[K, J]^T W[K, :])  -- the same product and the same
+// elimination with the identity as right-hand side, in the launches the factorisation makes anyway.  The reduction to
+// standard form is then two GEMMs (C = W A W^T) and the back-transformation of an eigenvector one thin product (W^T y)
+// instead of rocBLAS' dtrsm (two of ~14 launches each for the reduction, one for the vectors: 0.5 ms at n = 512).
 __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict__ B, int n, int j0, int* __restrict__ minidx,
-                                                             const double* __restrict__ dsave)
+                                                             const double* __restrict__ dsave, double* __restrict__ Winv, int nu)
 {
     // pW: the four waves' partial products ([wave][diagonal block | tile][32][33])
     __shared__ double pW[4][2][CH_NB][CH_NB + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int lane = tid & 63, wave = tid >> 6;
-    const int c0 = j0 + CH_NB * blockIdx.x;
+    const bool inv = (int)blockIdx.x >= nu;                    // a tile of U^-T
+    const int ti = inv ? (int)blockIdx.x - nu : 0;             // ... its block column I
+    const int c0 = inv ? CH_NB * ti : j0 + CH_NB * (int)blockIdx.x;
     const bool diag = blockIdx.x == 0;
+    const double* Bsrc = inv ? Winv : B;                       // rows K of the product's right operand
+    double* Bdst = inv ? Winv : B;
+    const int stepB0 = inv ? ti * (CH_NB / 4) : 0;             // W[K, I] = 0 for K < I
     // ---- W = sum_K U[K, J]^T U[K, tile] on the fp64 matrix pipe (v_mfma_f64_16x16x4: 16 x 4 times 4 x 16), operands
     // straight from global memory: lane (r = lane & 15, g = lane >> 4) supplies U[kappa0 + g][j0 + 16 ta + r] as the A operand
     // of row tile ta and U[kappa0 + g][c0 + 16 tb + r] as the B operand of column tile tb -- 128-byte segments, no LDS.  The
@@ -111,11 +121,12 @@ __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict_
             for (int u = 0; u < UNR; ++u) {
                 const int st = s0 + 4 * u;
                 const bool ok = st < nstep;
-                const double* row = B + (size_t)(4 * (ok ? st : 0) + g4) * n;
-                va0[u] = (ok && inA0) ? row[j0 + r16] : 0.0;
-                va1[u] = (ok && inA1) ? row[j0 + 16 + r16] : 0.0;
-                vb0[u] = (ok && inB0) ? row[c0 + r16] : 0.0;
-                vb1[u] = (ok && inB1) ? row[c0 + 16 + r16] : 0.0;
+                const size_t ro = (size_t)(4 * (ok ? st : 0) + g4) * n;
+                const bool okb = ok && st >= stepB0;
+                va0[u] = (ok && inA0) ? B[ro + j0 + r16] : 0.0;
+                va1[u] = (ok && inA1) ? B[ro + j0 + 16 + r16] : 0.0;
+                vb0[u] = (okb && inB0) ? Bsrc[ro + c0 + r16] : 0.0;
+                vb1[u] = (okb && inB1) ? Bsrc[ro + c0 + 16 + r16] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -161,7 +172,9 @@ __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict_
             // rows / columns beyond n: identity, so the factorisation below needs no special cases
             const double orig = !in ? 0.0 : (r == c ? dsave[j0 + r] : B[(size_t)(j0 + (r > c ? r : c)) * n + j0 + (r > c ? c : r)]);
             eD[a][b] = in ? orig - sumD : (r == c ? 1.0 : 0.0);
-            eT[a][b] = (!diag && j0 + r < n && c0 + c < n) ? B[(size_t)(j0 + r) * n + c0 + c] - sumT : 0.0;
+            const bool inT = !diag && j0 + r < n && c0 + c < n;
+            const double rhs = !inT ? 0.0 : inv ? ((c0 == j0 && r == c) ? 1.0 : 0.0) : B[(size_t)(j0 + r) * n + c0 + c];
+            eT[a][b] = inT ? rhs - sumT : 0.0;
         }
     double pivsave[2] = {1.0, 1.0};   // the pivots of this thread's two rows (valid in every thread of the row)
     // (Fully unrolled, branch-free: the step's eight LDS reads are issued together and waited for once.  Round 3's loop
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(256) void potrf_blockrow_kernel(double* __restrict_
             if (diag) {
                 if (c >= r && j0 + c < n) B[(size_t)(j0 + r) * n + j0 + c] = eD[a][b] * ui;
             } else if (c0 + c < n) {
-                B[(size_t)(j0 + r) * n + c0 + c] = eT[a][b] * ui;
+                Bdst[(size_t)(j0 + r) * n + c0 + c] = eT[a][b] * ui;
             }
         }
     }
@@ -226,7 +239,7 @@ __global__ void potrf_info_kernel(const int* __restrict__ minidx, int* __restric
     if (threadIdx.x == 0) *info = *minidx == 0x7fffffff ? 0 : *minidx;
 }
 
-int potrf_upper_device(double* B, int n, int* dinfo)
+int potrf_upper_device(double* B, int n, int* dinfo, double* Winv)
 {
     const int nb = (int)ceil_div(n, CH_NB);
     DevBuf& sv = pool(PS_PAR);   // n doubles + 1 int of scratch; every entry point that reaches here synchronises before it returns
@@ -235,9 +248,43 @@ int potrf_upper_device(double* B, int n, int* dinfo)
     double* dsave = sv.as<double>();
     int* minidx = reinterpret_cast<int*>(dsave + n);
     hipLaunchKernelGGL(potrf_save_diag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(), B, n, dsave, minidx);
+    if (Winv) MSM_HIP_CHECK(hipMemsetAsync(Winv, 0, (size_t)n * n * sizeof(double), stream()));   // the GEMMs read the whole square
     for (int J = 0; J < nb; ++J)
-        hipLaunchKernelGGL(potrf_blockrow_kernel, dim3(nb - J), dim3(256), 0, stream(), B, n, J * CH_NB, minidx, dsave);
+        hipLaunchKernelGGL(potrf_blockrow_kernel, dim3(nb - J + (Winv ? J + 1 : 0)), dim3(256), 0, stream(), B, n, J * CH_NB, minidx, dsave,
+                           Winv, nb - J);
     hipLaunchKernelGGL(potrf_info_kernel, dim3(1), dim3(64), 0, stream(), minidx, dinfo);
+    MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
+// V[v][i] = sum_{j >= i} W[j][i] Y[v][j]: the vectors U^-1 y = W^T y of the original problem (k vectors, rows of Y / V).
+// One thread per component i (coalesced over i for every j), the vector held in LDS, 16 loads in flight.
+__global__ __launch_bounds__(256) void winv_back_kernel(const double* __restrict__ W, int n, const double* __restrict__ Y, double* __restrict__ V)
+{
+    __shared__ double sy[1024];
+    const int v = blockIdx.y, tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    for (int j = tid; j < n; j += 256) sy[j] = Y[(size_t)v * n + j];
+    __syncthreads();
+    if (i >= n) return;
+    const int jb = (blockIdx.x * 256) & ~15;   // uniform start for the workgroup: rows above the diagonal hold zeros
+    double acc = 0.0;
+    int j = jb;
+    for (; j + 16 <= n; j += 16) {
+        double w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = W[(size_t)(j + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fma(w[u], sy[j + u], acc);
+    }
+    for (; j < n; ++j) acc = fma(W[(size_t)j * n + i], sy[j], acc);
+    V[(size_t)v * n + i] = acc;
+}
+
+// V (k rows of n) <- W^T Y, W = U^-T from potrf_upper_device (n <= 1024); V may not alias Y
+int winv_back_device(const double* W, int n, const double* Y, int k, double* V)
+{
+    hipLaunchKernelGGL(winv_back_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream(), W, n, Y, V);
     MSM_HIP_CHECK(hipGetLastError());
     return MSM_OK;
 }
@@ -333,7 +380,7 @@ int msm_potrf(double* B, msm_idx_t n, int* info, int on_device)
     int* dinfo = reinterpret_cast<int*>(buf.as<char>() + nn * sizeof(double));
     if (!on_device) MSM_HIP_CHECK(hipMemcpyAsync(dB, B, nn * sizeof(double), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemsetAsync(dinfo, 0, sizeof(int), stream()));
-    if ((rc = potrf_upper_device(dB, (int)n, dinfo))) return rc;
+    if ((rc = potrf_upper_device(dB, (int)n, dinfo, nullptr))) return rc;
     if (!on_device) MSM_HIP_CHECK(hipMemcpyAsync(B, dB, nn * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(info, dinfo, sizeof(int), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));

@@ -37,9 +37,9 @@ def test_potrf_matches_lapack(gpu, n):
                                       (130, 8, False), (100, 5, False)])
 def test_topk_solve_matches_host_route(gpu, monkeypatch, F, k, flat):
     """The hybrid solve on wide models against the all-host numpy / dsygvx route of the same accumulators: through the
-    subspace iteration where the spectrum has a gap (k <= 16, F >= 128), through LAPACK on the reduced matrix where it has
-    none (`flat`: white-noise features -- the iteration must notice that it stalls and hand over), k is large or the model
-    narrow."""
+    subspace iteration where the spectrum has a gap (k <= 16, F >= 128), through LAPACK on the reduced matrix where k is
+    large or the model narrow; with no gap at all (`flat`: white-noise features) the iteration must either converge to
+    verified pairs or notice that it stalls and hand over."""
     from msmbuilder_amd import tICA
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
     rs = np.random.RandomState(F + k)
@@ -61,9 +61,12 @@ def test_topk_solve_matches_host_route(gpu, monkeypatch, F, k, flat):
     route = out["hybrid"][3]
     if k <= 16 and F >= 128 and not flat:
         assert route[0] == "subspace" and route[2] == 0, route
+    elif flat:
+        # white noise: the iteration either gets there with its longer, chunked filters (verified pairs, status 0) or
+        # notices that it stalls and hands the reduced matrix to LAPACK (status 1) -- the numbers below must hold either way
+        assert (route[0] == "subspace" and route[2] == 0) or (route[0] == "lapack" and route[2] == 1), route
     else:
-        assert route[0] == "lapack", route
-        assert (route[2] == 1) == (flat and k <= 16 and F >= 128), route      # 1: the iteration ran and handed over
+        assert route[0] == "lapack" and route[2] != 1, route
     for name in ("hybrid",):
         np.testing.assert_allclose(out[name][0], out["host"][0], rtol=1e-10)
         V, Vh, S = out[name][1], out["host"][1], out["host"][2]
