@@ -603,10 +603,11 @@ def main():
             _lib.check(_lib.lib().msm_kcenters_last_stats(kst8))
             ph8 = {k: 1e3 * float(np.mean(v)) for k, v in rec8.items() if k != "mfma_ms"}
             step8 = sum(ph8.values())
-            # assumed RCCL latencies over xGMI (not measured here).  The sharded k-centers loop makes one small all-gather per
-            # centre for its first plain passes and then ONE all-gather of a 25 KB round record per ROUND of several centres
+            # ASSUMED RCCL latencies over xGMI -- NOT measured (this leg runs on one GPU).  The sharded k-centers loop makes one
+            # small all-gather per centre for its first plain passes and then ONE all-gather of a 99 KB round record per ROUND
+            # of several centres (round 3: 25 KB records, 40 us assumed, 31 rounds; lists of 1,024 rows now: 21 rounds)
             # (msm_kcenters_last_stats of the sharded fit above: plain passes + rounds = the number of its exchanges)
-            comm_us = {"allreduce_4MB": 150.0, "allgather_per_centre": 25.0, "allgather_per_round_record": 40.0}
+            comm_us = {"allreduce_4MB": 150.0, "allgather_per_centre": 25.0, "allgather_per_round_record": 55.0}
             kc_exchanges = {"one_centre": int(kst8[1]), "rounds": int(kst8[2])}
             comm_ms = (comm_us["allreduce_4MB"] + kc_exchanges["one_centre"] * comm_us["allgather_per_centre"]
                        + kc_exchanges["rounds"] * comm_us["allgather_per_round_record"]) / 1e3
@@ -615,7 +616,8 @@ def main():
                 "what": "one rank's share at N=8 (%d of %d trajectories) run alone on this GPU through the sharded code path "
                         "(msm_kcenters_fit_sharded, screened passes): per-phase ms measured, collectives modelled" % (n8, n_seq),
                 "phases_ms": ph8, "mfma_ms": float(np.mean(rec8["mfma_ms"])), "measured_step_ms": step8,
-                "assumed_comm_us": comm_us, "kcenters_exchanges": kc_exchanges, "modelled_step_ms": step8 + comm_ms,
+                "assumed_comm_us": comm_us, "assumed_comm_us_note": "UNMEASURED assumptions (no multi-GPU node in this run): the "
+                "driver's SCALE run is the measurement", "kcenters_exchanges": kc_exchanges, "modelled_step_ms": step8 + comm_ms,
                 "modelled_speedup_at_8": ms_per_step / (step8 + comm_ms),
                 "serial_fraction_of_n1_step": serial / ms_per_step}
             del X8, seqs8

@@ -93,8 +93,10 @@ int pair_residual_device(const double* Cm, int n, const double* Y, const double*
 // subspace.hip: k largest eigenpairs of a symmetric matrix with spectrum in [lower, inf) by Chebyshev-filtered subspace
 // iteration (block of 32, Rayleigh-Ritz on the host); synchronises; *converged = 0 -> outputs meaningless, use the fallback
 int subspace_topk_device(const double* Cm, int n, int k, double lower, double tol, int degree, int max_outer, double* lam,
-                         double* Yk, double* work, int* converged, int* outer_used);
+                         double* Yk, double* work, double* pin /* subspace_pin_doubles() of pinned host memory */, int* converged,
+                         int* outer_used);
 size_t subspace_work_doubles(int n);
+size_t subspace_pin_doubles();
 
 // A data pointer that was itself LOADED from memory (e.g. out of a descriptor table) is a
 // generic pointer to the compiler, which then emits flat_load: slower, and because FLAT counts on

@@ -2109,6 +2109,15 @@ struct KcbState {
 // (levels below 0.91 were tried in round 4 -- twelve levels down to 0.58: the number of rounds did not move, 19 on the bench's
 //  projection at 10M and at 1.25M rows: what ends a round is the list's capacity, not the threshold's rate of descent -- and
 //  the extra level counters cost 15 % of a fit)
+// the part of KcbState the host initialises (everything before `cen`), as a value on the caller's stack
+struct KcbHead {
+    int k_done, J, rounds, fallbacks;
+    float theta;
+    unsigned count;
+    unsigned lev[KCB_NLEV];
+};
+static_assert(sizeof(KcbHead) <= offsetof(KcbState, cen) && offsetof(KcbHead, lev) == offsetof(KcbState, lev),
+              "KcbHead must mirror the head of KcbState");
 __device__ __forceinline__ float kcb_level(int l) { return l == 0 ? 1.f : l == 1 ? 0.985f : l == 2 ? 0.97f : l == 3 ? 0.955f : l == 4 ? 0.94f : 0.91f; }
 
 template <int NP>
@@ -2869,13 +2878,13 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                 DevBuf& SB = pool(PS_W);
                 if ((rc = SB.reserve(sizeof(KcbState)))) return rc;
                 KcbState* St = SB.as<KcbState>();
-                static KcbState init;   // (18 KiB: not on the stack; only the header is ever written or copied)
+                KcbHead init;
                 init.k_done = (int)it;
                 init.J = init.rounds = init.fallbacks = 0;
                 init.theta = INFINITY;
                 init.count = 0;
                 for (int l = 0; l < KCB_NLEV; ++l) init.lev[l] = 0;
-                MSM_HIP_CHECK(hipMemcpyAsync(St, &init, offsetof(KcbState, cen), hipMemcpyHostToDevice, stream()));
+                MSM_HIP_CHECK(hipMemcpyAsync(St, &init, sizeof(KcbHead), hipMemcpyHostToDevice, stream()));
                 MSM_HIP_CHECK(hipStreamSynchronize(stream()));   // `init` is pageable host memory
                 int rounds = 0, done = (int)it;
                 while (done < (int)K) {
@@ -3231,13 +3240,13 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
             KcbState* St = W.as<KcbState>();
             double* recL = reinterpret_cast<double*>(static_cast<char*>(W.p) + stb);
             double* recsG = comm_active() ? recL + RD : recL;   // a world of one: the gathered records ARE the rank's record
-            static KcbState init;
+            KcbHead init;
             init.k_done = (int)PROBE;
             init.J = init.rounds = init.fallbacks = 0;
             init.theta = INFINITY;
             init.count = 0;
             for (int l = 0; l < KCB_NLEV; ++l) init.lev[l] = 0;
-            MSM_HIP_CHECK(hipMemcpyAsync(St, &init, offsetof(KcbState, cen), hipMemcpyHostToDevice, stream()));
+            MSM_HIP_CHECK(hipMemcpyAsync(St, &init, sizeof(KcbHead), hipMemcpyHostToDevice, stream()));
             MSM_HIP_CHECK(hipStreamSynchronize(stream()));
             hipLaunchKernelGGL(kcb_boot_records_kernel, dim3((unsigned)world), dim3(64), 0, stream(), cands, world, (long long)m, recsG);
             KscArgs S;

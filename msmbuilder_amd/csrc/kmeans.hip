@@ -1763,30 +1763,51 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
                         double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
 {
     if (!h || !offsets || !state6 || !steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run_sharded: null argument");
-    if (n_local < 0 || B < 1 || S < 1 || S > 4096) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: bad shape");
-    const msm_idx_t total = offsets[S];
-    if (offsets[0] != 0 || total < 0 || (total > 0 && (!local_idx || !X))) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: bad offsets");
-    for (msm_idx_t s = 0; s < S; ++s)
-        if (offsets[s + 1] < offsets[s]) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: offsets must not decrease");
-    for (msm_idx_t b = 0; b < total; ++b)
-        if (local_idx[b] < 0 || local_idx[b] >= n_local) return fail(MSM_ERR_INVALID, "mbk: batch index out of range");
-    int rc;
-    const size_t idx_bytes = (size_t)std::max<msm_idx_t>(total, 1) * sizeof(msm_idx_t);
-    const size_t st_bytes = (6 + (size_t)S) * sizeof(double);
-    const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(float);
-    const size_t need = idx_bytes + 64 + out_bytes;
-    if (h->pinned_bytes < need) {
-        if (h->pinned) (void)hipHostFree(h->pinned);
-        h->pinned = nullptr;
-        h->pinned_bytes = 0;
-        MSM_HIP_CHECK(hipHostMalloc((void**)&h->pinned, need, hipHostMallocDefault));
-        h->pinned_bytes = need;
+    // Everything that can fail on ONE rank -- argument checks, allocations -- happens before the first collective, and the
+    // ranks agree on the outcome with one all-reduced flag: a rank that returned early on its own would leave the others
+    // blocked inside the first step's all-reduce.
+    msm_idx_t total = 0;
+    size_t idx_bytes = 0, st_bytes = 0;
+    auto prepare = [&]() -> int {
+        if (n_local < 0 || B < 1 || S < 1 || S > 4096) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: bad shape");
+        total = offsets[S];
+        if (offsets[0] != 0 || total < 0 || (total > 0 && (!local_idx || !X))) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: bad offsets");
+        for (msm_idx_t s = 0; s < S; ++s)
+            if (offsets[s + 1] < offsets[s]) return fail(MSM_ERR_INVALID, "msm_mbk_run_sharded: offsets must not decrease");
+        for (msm_idx_t b = 0; b < total; ++b)
+            if (local_idx[b] < 0 || local_idx[b] >= n_local) return fail(MSM_ERR_INVALID, "mbk: batch index out of range");
+        int rc;
+        idx_bytes = (size_t)std::max<msm_idx_t>(total, 1) * sizeof(msm_idx_t);
+        st_bytes = (6 + (size_t)S) * sizeof(double);
+        const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(float);
+        const size_t need = idx_bytes + 64 + out_bytes;
+        if (h->pinned_bytes < need) {
+            if (h->pinned) (void)hipHostFree(h->pinned);
+            h->pinned = nullptr;
+            h->pinned_bytes = 0;
+            MSM_HIP_CHECK(hipHostMalloc((void**)&h->pinned, need, hipHostMallocDefault));
+            h->pinned_bytes = need;
+        }
+        if (!h->stop) MSM_HIP_CHECK(hipMalloc((void**)&h->stop, 2 * sizeof(int)));
+        if ((rc = h->idx.reserve(idx_bytes))) return rc;
+        if ((rc = h->runbuf.reserve(st_bytes))) return rc;
+        if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
+        if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
+        if (total > 0 && (rc = h->xb.reserve((size_t)total * h->m * sizeof(float)))) return rc;
+        return MSM_OK;
+    };
+    int rc = prepare();
+    if (comm_active()) {
+        const double mine = rc ? 1.0 : 0.0;
+        double failed = 0.0;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->packed, &mine, sizeof(double), hipMemcpyHostToDevice, stream()));
+        const int rca = comm_allreduce_f64(h->packed, 1);
+        if (rca) return rca;
+        MSM_HIP_CHECK(hipMemcpyAsync(&failed, h->packed, sizeof(double), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+        if (!rc && failed > 0.0) return fail(MSM_ERR_STATE, "msm_mbk_run_sharded: %d other rank(s) rejected their arguments or ran out of memory", (int)failed);
     }
-    if (!h->stop) MSM_HIP_CHECK(hipMalloc((void**)&h->stop, 2 * sizeof(int)));
-    if ((rc = h->idx.reserve(idx_bytes))) return rc;
-    if ((rc = h->runbuf.reserve(st_bytes))) return rc;
-    if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
-    if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
+    if (rc) return rc;
     double* st = h->runbuf.as<double>();
     if (total > 0) {
         memcpy(h->pinned, local_idx, (size_t)total * sizeof(msm_idx_t));
@@ -1798,7 +1819,6 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
     MSM_HIP_CHECK(hipMemcpyAsync(st, st0, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, 2 * sizeof(int), stream()));
     if (total > 0) {
-        if ((rc = h->xb.reserve((size_t)total * h->m * sizeof(float)))) return rc;
         hipLaunchKernelGGL(mbk_gather_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
                            (long long)total, (long long)h->m, h->xb.as<float>());
         MSM_HIP_CHECK(hipGetLastError());

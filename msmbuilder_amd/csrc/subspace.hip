@@ -487,7 +487,7 @@ bool small_geigh(std::vector<double>& H, std::vector<double>& G, int m, std::vec
 // *converged (host) = 1 when the k leading residuals reached tol * max(1, |lambda_1|) within max_outer filtered
 // iterations, 0 when the iteration stalled or the block lost rank (outputs are then meaningless).  Synchronises.
 int subspace_topk_device(const double* Cm, int n, int k, double lower, double tol, int degree, int max_outer, double* lam,
-                         double* Yk, double* work, int* converged, int* outer_used)
+                         double* Yk, double* work, double* pin, int* converged, int* outer_used)
 {
     *converged = 0;
     if (outer_used) *outer_used = 0;
@@ -505,9 +505,8 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     double* dtheta = dS + SB * SB;
     double* dres = dtheta + SB;
     int* dflag = reinterpret_cast<int*>(dres + SB);
-    // pinned staging for the small host <-> device transfers of the Rayleigh-Ritz steps
-    static double* pin = nullptr;
-    if (!pin) MSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pin), (4 * SB * SB + 4 * SB) * sizeof(double), hipHostMallocDefault));
+    // pinned staging for the small host <-> device transfers of the Rayleigh-Ritz steps: `pin`, subspace_pin_doubles()
+    // doubles of the CALLER's pinned memory (round 3 kept a function-static buffer: not safe for two handles in two threads)
     double* hGH = pin;                 // 2 SB^2
     double* hS = pin + 2 * SB * SB;    // SB^2
     double* htheta = hS + SB * SB;     // SB
@@ -620,6 +619,8 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     }
     return MSM_OK;
 }
+
+size_t subspace_pin_doubles() { return 4 * (size_t)SB * SB + 4 * SB; }
 
 size_t subspace_work_doubles(int n)
 {

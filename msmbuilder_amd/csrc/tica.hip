@@ -3165,7 +3165,16 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
     // second device route in between -- cooperative tridiagonalisation + multisection + inverse iteration; removed in round
     // 4: two routes, one fallback).
     int conv = 0, outer = 0;
-    if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, 10, 6, b.lam, b.Yk, b.sswork, &conv, &outer))) return rc;
+    // pinned host memory of the handle: [results of the solve | staging of the iteration's Rayleigh-Ritz steps]
+    const size_t pin_res = 17 + 320 + 12 + 17 * (size_t)n, pin_total = pin_res + subspace_pin_doubles();
+    if (h->solve_pin_n < pin_total) {
+        if (h->solve_pin) (void)hipHostFree(h->solve_pin);
+        h->solve_pin = nullptr;
+        h->solve_pin_n = 0;
+        MSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->solve_pin), pin_total * sizeof(double), hipHostMallocDefault));
+        h->solve_pin_n = pin_total;
+    }
+    if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, 10, 6, b.lam, b.Yk, b.sswork, h->solve_pin + pin_res, &conv, &outer))) return rc;
     if (!conv) {
         double scal[4];
         int ints[8];
@@ -3189,13 +3198,7 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
     // one packed copy of everything the caller gets (b.Y, n^2 doubles, is free at this point)
     const int nres = 2 * (int)k + (int)k * (int)k;
     const size_t o_res = (size_t)k, o_scal = o_res + nres, o_ints = o_scal + 4, o_mu = o_ints + 8, o_vec = o_mu + n, total = o_vec + (size_t)k * n;
-    if (h->solve_pin_n < total) {
-        if (h->solve_pin) (void)hipHostFree(h->solve_pin);
-        h->solve_pin = nullptr;
-        h->solve_pin_n = 0;
-        MSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->solve_pin), (17 + 320 + 12 + 17 * (size_t)n) * sizeof(double), hipHostMallocDefault));
-        h->solve_pin_n = 17 + 320 + 12 + 17 * (size_t)n;
-    }
+    if (total > pin_res) return fail(MSM_ERR_STATE, "msm_tica_solve_topk: result staging too small");
     hipLaunchKernelGGL(tica_solve_emit_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(), b.lam, b.res, b.scal, b.ints, b.mu,
                        b.S, n, (int)k, b.Y);
     MSM_HIP_CHECK(hipGetLastError());

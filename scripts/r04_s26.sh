@@ -1,0 +1,7 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r04
+mkdir -p $OUT
+cd $ROOT
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt
+bash scripts/r04_final.sh smoke pmc bench stats c5 all
