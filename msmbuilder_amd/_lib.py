@@ -233,6 +233,60 @@ def is_device_array(x) -> bool:
     return hasattr(x, "data_ptr") and bool(getattr(x, "is_cuda", False))
 
 
+def adjacent_view(sequences):
+    """ONE [total, F] array over a list of 2-D trajectories that lie back to back in one allocation -- what
+    ``X.view(n, T, F).unbind(0)``, ``np.split`` or slices of a joined array give --, or None.  Lets the per-frame
+    operations (`transform`, `predict`) run as one launch over all trajectories instead of one small launch each,
+    without copying anything."""
+    if len(sequences) < 2:
+        return None
+    head = sequences[0]
+    if hasattr(head, "shape") and len(head.shape) == 2 and head.shape[0] == 0:
+        return None   # (keep it simple: the first trajectory anchors the view)
+    try:
+        if is_device_array(head):
+            import torch
+            if head.dim() != 2 or not head.is_contiguous():
+                return None
+            F, total, nxt = head.shape[1], 0, head.data_ptr()
+            base = head.untyped_storage().data_ptr()
+            for s in sequences:
+                if not is_device_array(s) or s.dim() != 2 or s.shape[1] != F or s.dtype != head.dtype or s.device != head.device:
+                    return None
+                if s.shape[0] == 0:
+                    continue   # an empty trajectory occupies nothing (and its pointer need not follow its neighbours)
+                if not s.is_contiguous() or s.untyped_storage().data_ptr() != base or s.data_ptr() != nxt:
+                    return None
+                nxt += s.numel() * s.element_size()
+                total += s.shape[0]
+            return torch.as_strided(head, (total, F), (F, 1))
+        if isinstance(head, np.ndarray):
+            if head.ndim != 2 or not head.flags.c_contiguous or head.base is None:
+                return None
+            root = head.base
+            while getattr(root, "base", None) is not None:
+                root = root.base
+            F, total, nxt = head.shape[1], 0, head.ctypes.data
+            for s in sequences:
+                if not isinstance(s, np.ndarray) or s.ndim != 2 or s.shape[1] != F or s.dtype != head.dtype:
+                    return None
+                if s.shape[0] == 0:
+                    continue
+                if not s.flags.c_contiguous or s.ctypes.data != nxt:
+                    return None
+                r = s.base
+                while getattr(r, "base", None) is not None:
+                    r = r.base
+                if r is not root:
+                    return None
+                nxt += s.nbytes
+                total += s.shape[0]
+            return np.lib.stride_tricks.as_strided(head, shape=(total, F), strides=(F * head.itemsize, head.itemsize), writeable=False)
+    except Exception:
+        return None
+    return None
+
+
 class Arr:
     """(pointer, shape, dtype, on_device) view of a numpy array or torch CUDA tensor."""
     __slots__ = ("ptr", "shape", "dtype", "on_device", "keep")

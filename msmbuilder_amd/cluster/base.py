@@ -3,7 +3,8 @@
 MSMBuilder estimators take a LIST of trajectories; the clustering kernels take one [n, F] array.  This mixin sits
 between the two: it joins the trajectories (``torch.cat`` for device-resident ones, so they never leave HBM;
 ``numpy.concatenate`` for host arrays), lets the wrapped single-array estimator run once, and cuts ``labels_`` back
-into one piece per trajectory with the remembered lengths.  ``predict`` / ``transform`` work trajectory by trajectory.
+into one piece per trajectory with the remembered lengths.  ``predict`` / ``transform`` work trajectory by trajectory (in one launch when the trajectories are views of one
+allocation).
 mdtraj trajectories (RMSD metric) are outside this package's scope.
 """
 import numpy as np
@@ -19,6 +20,10 @@ def _join(sequences):
     if not len(sequences):
         raise TypeError('sequences must be a list of numpy arrays (or torch CUDA tensors)')
     head = sequences[0]
+    from .._lib import adjacent_view
+    joined = adjacent_view(sequences) if isinstance(sequences, (list, tuple)) else None
+    if joined is not None:
+        return joined   # the trajectories already lie back to back in one allocation: no copy
     if isinstance(head, np.ndarray):
         return np.ascontiguousarray(np.concatenate(sequences))
     if is_device_array(head):
@@ -69,6 +74,17 @@ class MultiSequenceClusterMixin(object):
     def predict(self, sequences, y=None):
         """Nearest-centre index for every frame of every trajectory (a list of arrays)."""
         check_iter_of_sequences(sequences, allow_trajectory=self._allow_trajectory)
+        # trajectories that lie back to back in one allocation (views of a joined array / tensor) are labelled in ONE
+        # launch and the labels cut per trajectory: a launch per 10,000-frame trajectory fills a sixth of the GPU
+        from .._lib import adjacent_view
+        joined = adjacent_view(sequences) if isinstance(sequences, (list, tuple)) else None
+        if joined is not None:
+            labels = self.partial_predict(joined)
+            out, start = [], 0
+            for X in sequences:
+                out.append(labels[start:start + len(X)])
+                start += len(X)
+            return out
         return [self.partial_predict(X) for X in sequences]
 
     def fit_predict(self, sequences, y=None):

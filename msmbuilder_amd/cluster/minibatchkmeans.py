@@ -51,6 +51,8 @@ def label_inertia(X, centers):
     ax = X if isinstance(X, Arr) else Arr(X, np.float32)
     centers = np.ascontiguousarray(centers, dtype=np.float32)
     labels = empty_like_placement(ax, (ax.shape[0],), np.int32)
+    if ax.shape[0] == 0:
+        return labels, 0.0   # an empty trajectory: nothing to label (and an empty device tensor has no address)
     al = Arr(labels, np.int32)
     inertia = C.c_double(0.0)
     check(_lib.lib().msm_kmeans_label_f32(ax.vp, ax.shape[0], ax.shape[1], centers.ctypes.data,

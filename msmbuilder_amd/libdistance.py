@@ -85,6 +85,8 @@ def assign_nearest(X, Y, metric, X_indices=None):
             raise ValueError("X and X_indices must live on the same side (host or device)")
         n = idx.shape[0]
     out = empty_like_placement(ax, (n,), np.intp)
+    if n == 0:
+        return out, 0.0   # nothing to assign (assign.hpp's loop does not run; an empty device tensor has no address)
     aout = Arr(out, np.int64)
     inertia = C.c_double(0.0)
     fn = getattr(_lib.lib(), "msm_assign_nearest_" + kind)

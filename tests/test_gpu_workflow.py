@@ -84,3 +84,36 @@ def test_basic_workflow(gpu, oracle, tmp_path, monkeypatch):
     ocounts, omapping = transition_counts([np.asarray(l) for l in kc.labels_], lag_time=1)
     assert np.array_equal(counts, ocounts) and list(mapping.items()) == list(omapping.items())
     assert counts.sum() == sum(len(l) - 1 for l in kc.labels_)
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_transform_and_predict_over_adjacent_views_equal_the_per_trajectory_calls(gpu, where):
+    """Trajectories that are views of ONE allocation (`X.view(n, T, F).unbind(0)`, slices of a joined numpy array) are
+    projected / labelled in one launch (`_lib.adjacent_view`); the per-trajectory results must be the ones separate
+    allocations get, ragged lengths and an empty trajectory included."""
+    import torch
+    from msmbuilder_amd import tICA, KCenters, MiniBatchKMeans
+    rs = np.random.RandomState(5)
+    lens = [700, 1300, 0, 64, 2001]
+    X = (rs.randn(sum(lens), 24) + rs.randn(24)).astype(np.float32)
+    big = torch.from_numpy(X).cuda() if where == "device" else X
+    bounds = np.concatenate(([0], np.cumsum(lens)))
+    views = [big[bounds[i]:bounds[i + 1]] for i in range(len(lens))]
+    copies = [v.clone() if where == "device" else v.copy() for v in views]
+    fit_on = [v for v in views if len(v)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tica = tICA(n_components=3, lag_time=5).fit(fit_on)
+        ya, yb = tica.transform(views), tica.transform(copies)
+    as_np = lambda t: t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+    assert [len(y) for y in ya] == lens
+    for a, b in zip(ya, yb):
+        assert a.shape == b.shape and np.array_equal(as_np(a), as_np(b))
+    for est in (KCenters(n_clusters=12, random_state=0), MiniBatchKMeans(n_clusters=12, random_state=0, n_init=1)):
+        Yv = [y for y in ya]
+        est.fit([y for y in Yv if len(y)])
+        la, lb = est.predict(Yv), est.predict([y.clone() if hasattr(y, "clone") else y.copy() for y in Yv])
+        assert [len(l) for l in la] == lens
+        for a, b in zip(la, lb):
+            assert np.array_equal(as_np(a), as_np(b))
+

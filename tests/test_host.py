@@ -657,3 +657,21 @@ def test_bench_cpu_baseline_runs_on_the_host():
     assert out["tica_fit_best_frames_per_s"] >= max(out["tica_fit_frames_per_s"], out["tica_fit_1thread_frames_per_s"]) * 0.999
     assert out["threadpool_info"] and all(p["num_threads"] == 1 for p in out["threadpool_info_limited"] if p["user_api"] == "blas")
     assert len(used) >= 1 and oracle_model.n_sequences_ == len(used)
+
+
+def test_adjacent_view_only_joins_what_lies_back_to_back():
+    """`_lib.adjacent_view` (one launch for `transform` / `predict` over trajectories that are views of one allocation):
+    joins consecutive C-contiguous slices of one base array, and nothing else."""
+    from msmbuilder_amd._lib import adjacent_view
+    X = np.arange(60, dtype=np.float32).reshape(12, 5)
+    v = adjacent_view([X[:3], X[3:7], X[7:]])
+    assert v is not None and v.shape == (12, 5) and np.array_equal(v, X) and not v.flags.writeable
+    assert adjacent_view([X[:3], X[3:3], X[3:]]).shape == (12, 5)          # an empty trajectory in between
+    assert adjacent_view([X[:3], X[4:7]]) is None                          # a gap
+    assert adjacent_view([X[3:7], X[:3]]) is None                          # out of order
+    assert adjacent_view([X[:3].copy(), X[3:7].copy()]) is None            # separate allocations
+    assert adjacent_view([X]) is None and adjacent_view([]) is None
+    assert adjacent_view([X[:3], X[3:7].astype(np.float64)]) is None       # dtypes differ
+    assert adjacent_view([X[:3], X[3:7, :4]]) is None                      # widths differ / not contiguous
+    assert adjacent_view([X[:3], [[1.0] * 5]]) is None                     # not arrays
+
