@@ -235,6 +235,12 @@ int msm_tica_counts(msm_tica_t* h, msm_idx_t* n_observations, msm_idx_t* n_seque
 int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features,
                      msm_idx_t ld, const double* mean, const double* comps, msm_idx_t k,
                      double* out, int on_device, int check_finite);
+/* The same for a LIST of device-resident trajectories in one launch per block of 16 components (tica.py:329-352 walks the
+ * list): X_ptrs[s] is [n_rows[s], n_features] with row stride n_features, out_ptrs[s] its [n_rows[s], k] float64 output.
+ * Rows must be whole 16-byte vectors at 16-byte aligned addresses; MSM_ERR_INVALID otherwise (project one by one then). */
+int msm_tica_project_batch(const void* const* X_ptrs, double* const* out_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq,
+                           int dtype_bytes, msm_idx_t n_features, const double* mean, const double* comps, msm_idx_t k,
+                           int check_finite);
 
 /* ---- libdistance: exact-arithmetic vector metrics --------------------- */
 /* metric in {"euclidean","sqeuclidean","cityblock","chebyshev","canberra",

@@ -87,6 +87,7 @@ def _declare(lib):
     f("msm_tica_export_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_import_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_project", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, _i64, _p, C.c_int, C.c_int)
+    f("msm_tica_project_batch", C.c_int, C.POINTER(_p), C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _p, _p, _i64, C.c_int)
     f("msm_tica_last_folded", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_allreduce", C.c_int, _p)
     f("msm_tica_counts", C.c_int, _p, _i64p, _i64p)
@@ -246,20 +247,23 @@ def adjacent_view(sequences):
     try:
         if is_device_array(head):
             import torch
-            if head.dim() != 2 or not head.is_contiguous():
+            base = getattr(head, "_base", None)
+            if head.dim() != 2 or not head.is_contiguous() or base is None:
                 return None
-            F, total, nxt = head.shape[1], 0, head.data_ptr()
-            base = head.untyped_storage().data_ptr()
-            for s in sequences:
-                if not is_device_array(s) or s.dim() != 2 or s.shape[1] != F or s.dtype != head.dtype or s.device != head.device:
-                    return None
-                if s.shape[0] == 0:
-                    continue   # an empty trajectory occupies nothing (and its pointer need not follow its neighbours)
-                if not s.is_contiguous() or s.untyped_storage().data_ptr() != base or s.data_ptr() != nxt:
-                    return None
-                nxt += s.numel() * s.element_size()
-                total += s.shape[0]
-            return torch.as_strided(head, (total, F), (F, 1))
+            # (list comprehensions: a thousand trajectories are checked in well under a millisecond)
+            if not all(getattr(s, "_base", None) is base for s in sequences):   # views of ONE tensor: one storage
+                return None
+            F, dt = head.shape[1], head.dtype
+            shapes = [tuple(s.shape) for s in sequences]
+            if any(len(sh) != 2 or sh[1] != F for sh in shapes) or any(s.dtype != dt for s in sequences):
+                return None
+            rows = np.array([sh[0] for sh in shapes], dtype=np.int64)
+            ptrs = np.array([s.data_ptr() for s in sequences], dtype=np.int64)
+            want = ptrs[0] + np.concatenate(([0], np.cumsum(rows[:-1]))) * (F * head.element_size())
+            live = rows > 0   # an empty trajectory occupies nothing (and its pointer need not follow its neighbours)
+            if not np.array_equal(ptrs[live], want[live]) or not all(s.is_contiguous() for s in sequences):
+                return None
+            return torch.as_strided(head, (int(rows.sum()), F), (F, 1))
         if isinstance(head, np.ndarray):
             if head.ndim != 2 or not head.flags.c_contiguous or head.base is None:
                 return None
@@ -285,6 +289,18 @@ def adjacent_view(sequences):
     except Exception:
         return None
     return None
+
+
+def cut_rows(joined, lengths):
+    """Per-trajectory views of an array / tensor indexed like the joined frames (one C++ call for a thousand pieces)."""
+    lengths = [int(n) for n in lengths]
+    if hasattr(joined, "split") and not isinstance(joined, np.ndarray):
+        return list(joined.split(lengths)) if lengths else []
+    out, start = [], 0
+    for n in lengths:
+        out.append(joined[start:start + n])
+        start += n
+    return out
 
 
 class Arr:

@@ -1822,13 +1822,28 @@ __global__ __launch_bounds__(NT) void tica_project_kernel(const TIn* __restrict_
 // ---------------------------------------------------------------------------
 constexpr int PVP = 20;  // LDS pitch of a Vp feature row in doubles (16 comps + 4: lanes of different g hit different banks)
 
+// one 256-row tile of a BATCHED projection (msm_tica_project_batch): the tile's first row, the rows of its trajectory from
+// there on, and where the tile's first output row goes
+struct ProjTile {
+    const void* x;
+    double* out;
+    long long rows;
+};
+
 template <typename TIn>
 __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __restrict__ X, long long n, int F,
                                                                   long long ld, const double* __restrict__ muV,
                                                                   const double* __restrict__ Vp /* [F][16] */, int k,
                                                                   int kbase, int ktot, double* __restrict__ out,
-                                                                  int* flag)
+                                                                  int* flag, const ProjTile* __restrict__ tiles)
 {
+    if (tiles) {   // a list of trajectories: this workgroup's tile stands for the whole array (uniform branch)
+        const ProjTile t = tiles[blockIdx.x];
+        X = static_cast<const TIn*>(t.x);
+        out = t.out;
+        n = t.rows;
+    }
+    const long long blk = tiles ? 0 : (long long)blockIdx.x;
     constexpr int FCH = 128 / (int)sizeof(TIn);  // features per chunk (64 bf16 / 32 f32 / 16 f64)
     constexpr int NT4 = FCH / 4;                 // MFMAs per chunk and row block (16 / 8 / 4)
     constexpr int NV = (FCH + 31) / 32;          // Vp rows a thread stages per chunk
@@ -1836,12 +1851,12 @@ __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __r
     __shared__ double Vs[2][FCH * PVP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const long long row0 = (long long)blockIdx.x * (4 * RB * 16) + wave * (RB * 16);
+    const long long row0 = blk * (4 * RB * 16) + wave * (RB * 16);
     const int nch = (F + FCH - 1) / FCH;
     const unsigned ldb = (unsigned)(ld * sizeof(TIn));
 
     // per-lane byte offsets of this lane's rows (clamped into [0, n)) relative to the tile's first row
-    const long long tile0 = (long long)blockIdx.x * (4 * RB * 16);
+    const long long tile0 = blk * (4 * RB * 16);
     const global_ptr<char> Xg = as_global<char>(X) + (size_t)tile0 * ldb;
     unsigned xo[RB];
 #pragma unroll
@@ -1919,7 +1934,7 @@ __global__ __launch_bounds__(NT, 2) void tica_project_mfma_kernel(const TIn* __r
                 const long long i = row0 + b * 16 + g + 4 * q;
                 const double v = acc[b][q] - mv;
                 if (i < n) {
-                    out[i * ktot + kbase + comp] = v;
+                    ((double __attribute__((address_space(1)))*)(uintptr_t)out)[i * ktot + kbase + comp] = v;   // (global store also when `out` came from the tile table)
                     bad |= !isfinite(v);
                 }
             }
@@ -3393,15 +3408,15 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
             if (dtype_bytes == 2)
                 hipLaunchKernelGGL((tica_project_mfma_kernel<Bf16Raw>), dim3(g2), dim3(NT), 0, stream(), (const Bf16Raw*)Xd,
                                    (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
-                                   outd, dflag);
+                                   outd, dflag, nullptr);
             else if (dtype_bytes == 4)
                 hipLaunchKernelGGL((tica_project_mfma_kernel<float>), dim3(g2), dim3(NT), 0, stream(), (const float*)Xd,
                                    (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
-                                   outd, dflag);
+                                   outd, dflag, nullptr);
             else
                 hipLaunchKernelGGL((tica_project_mfma_kernel<double>), dim3(g2), dim3(NT), 0, stream(), (const double*)Xd,
                                    (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
-                                   outd, dflag);
+                                   outd, dflag, nullptr);
         }
         MSM_HIP_CHECK(hipGetLastError());
         if (!on_device) {
@@ -3447,6 +3462,81 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
     if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // scratch buffers die with this frame
     if (check_finite && f) return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
+    return MSM_OK;
+}
+
+/* msm_tica_project for a LIST of device-resident trajectories in one launch per block of 16 components: X_ptrs[s] is
+ * [n_rows[s], n_features] (row stride n_features), out_ptrs[s] its [n_rows[s], k] float64 output.  Needs 16-byte aligned
+ * rows (n_features a multiple of 16 / dtype_bytes, aligned base pointers); returns MSM_ERR_INVALID otherwise and the
+ * caller projects trajectory by trajectory.  (tica.py:329-352 walks the list; a launch per 10,000-frame trajectory keeps a
+ * sixth of the GPU busy.) */
+int msm_tica_project_batch(const void* const* X_ptrs, double* const* out_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int dtype_bytes,
+                           msm_idx_t n_features, const double* mean, const double* comps, msm_idx_t k, int check_finite)
+{
+    if (!X_ptrs || !out_ptrs || !n_rows || !mean || !comps) return fail(MSM_ERR_INVALID, "msm_tica_project_batch: null pointer");
+    if (dtype_bytes != 2 && dtype_bytes != 4 && dtype_bytes != 8)
+        return fail(MSM_ERR_INVALID, "dtype_bytes must be 2 (bfloat16), 4 or 8");
+    if (n_seq < 0 || n_features < 1 || k < 1) return fail(MSM_ERR_INVALID, "bad shape");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    const int cw = 16 / dtype_bytes;
+    if (n_features % cw != 0 || (size_t)256 * n_features * dtype_bytes >= ((size_t)1 << 32))
+        return fail(MSM_ERR_INVALID, "msm_tica_project_batch: rows must be whole 16-byte vectors");
+    std::vector<ProjTile> tiles;
+    for (msm_idx_t s = 0; s < n_seq; ++s) {
+        if (n_rows[s] < 0) return fail(MSM_ERR_INVALID, "bad shape");
+        if (n_rows[s] == 0) continue;
+        if (!X_ptrs[s] || !out_ptrs[s]) return fail(MSM_ERR_INVALID, "msm_tica_project_batch: null pointer");
+        if (((uintptr_t)X_ptrs[s]) % 16 != 0) return fail(MSM_ERR_INVALID, "msm_tica_project_batch: rows must be 16-byte aligned");
+        for (msm_idx_t r = 0; r < n_rows[s]; r += 256) {
+            ProjTile t;
+            t.x = static_cast<const char*>(X_ptrs[s]) + (size_t)r * n_features * dtype_bytes;
+            t.out = out_ptrs[s] + (size_t)r * k;
+            t.rows = n_rows[s] - r;
+            tiles.push_back(t);
+        }
+    }
+    if (tiles.empty()) return MSM_OK;
+    int rc;
+    DevBuf &dPar = pool(PS_PAR), &dVp = pool(PS_W), &dT = pool(PS_IDX);
+    const msm_idx_t nkb = ceil_div(k, 16);
+    if ((rc = dPar.reserve((size_t)k * sizeof(double) + 16))) return rc;
+    if ((rc = dVp.reserve((size_t)nkb * n_features * 16 * sizeof(double)))) return rc;
+    if ((rc = dT.reserve(tiles.size() * sizeof(ProjTile)))) return rc;
+    std::vector<double> muV((size_t)k), vp((size_t)nkb * n_features * 16, 0.0);
+    for (msm_idx_t c = 0; c < k; ++c) {
+        double sacc = 0.0;
+        for (msm_idx_t f = 0; f < n_features; ++f) {
+            sacc += mean[f] * comps[c * n_features + f];
+            vp[((size_t)(c / 16) * n_features + f) * 16 + (c % 16)] = comps[c * n_features + f];
+        }
+        muV[(size_t)c] = sacc;
+    }
+    double* dmean = dPar.as<double>();
+    int* dflag = reinterpret_cast<int*>(dmean + k);
+    MSM_HIP_CHECK(hipMemcpyAsync(dmean, muV.data(), k * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(dVp.p, vp.data(), vp.size() * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(dT.p, tiles.data(), tiles.size() * sizeof(ProjTile), hipMemcpyHostToDevice, stream()));
+    const ProjTile* dtiles = dT.as<ProjTile>();
+    const unsigned g2 = (unsigned)tiles.size();
+    for (msm_idx_t kb = 0; kb < nkb; ++kb) {
+        const int kk = (int)std::min<msm_idx_t>(16, k - kb * 16);
+        const double* vpk = dVp.as<double>() + (size_t)kb * n_features * 16;
+        if (dtype_bytes == 2)
+            hipLaunchKernelGGL((tica_project_mfma_kernel<Bf16Raw>), dim3(g2), dim3(NT), 0, stream(), (const Bf16Raw*)nullptr, 0LL,
+                               (int)n_features, (long long)n_features, dmean, vpk, kk, (int)(kb * 16), (int)k, (double*)nullptr, dflag, dtiles);
+        else if (dtype_bytes == 4)
+            hipLaunchKernelGGL((tica_project_mfma_kernel<float>), dim3(g2), dim3(NT), 0, stream(), (const float*)nullptr, 0LL,
+                               (int)n_features, (long long)n_features, dmean, vpk, kk, (int)(kb * 16), (int)k, (double*)nullptr, dflag, dtiles);
+        else
+            hipLaunchKernelGGL((tica_project_mfma_kernel<double>), dim3(g2), dim3(NT), 0, stream(), (const double*)nullptr, 0LL,
+                               (int)n_features, (long long)n_features, dmean, vpk, kk, (int)(kb * 16), (int)k, (double*)nullptr, dflag, dtiles);
+    }
+    MSM_HIP_CHECK(hipGetLastError());
+    int f2 = 0;
+    if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f2, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));   // `tiles`, `vp` and `muV` die with this frame
+    if (check_finite && f2) return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
     return MSM_OK;
 }
 

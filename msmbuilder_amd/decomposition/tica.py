@@ -744,12 +744,10 @@ class tICA(BaseEstimator, TransformerMixin):
         # trajectory (a launch per 10,000-frame trajectory keeps a sixth of the GPU busy)
         joined = _lib.adjacent_view(sequences) if isinstance(sequences, (list, tuple)) else None
         if joined is not None:
-            Y = self.transform([joined])[0]
-            out, start = [], 0
-            for X in sequences:
-                out.append(Y[start:start + len(X)])
-                start += len(X)
-            return out
+            return _lib.cut_rows(self.transform([joined])[0], [X.shape[0] for X in sequences])
+        batched = self._transform_device_list(sequences) if isinstance(sequences, (list, tuple)) else None
+        if batched is not None:
+            return batched
         sequences_new = []
         mean, comps = None, None
         L = _lib.lib()
@@ -780,6 +778,43 @@ class tICA(BaseEstimator, TransformerMixin):
                                          mean.ctypes.data, comps.ctypes.data, k, aout.vp, ax.on_device, 1))
             sequences_new.append(out)
         return sequences_new
+
+    def _transform_device_list(self, sequences):
+        """``transform`` of several separately allocated device trajectories in ONE launch per 16 components
+        (``msm_tica_project_batch``: a table of 256-row tiles), the result one [total, k] tensor cut per trajectory; None
+        when the list does not qualify (host arrays, mixed dtypes, rows that are not whole 16-byte vectors) -- the caller
+        then projects trajectory by trajectory."""
+        if len(sequences) < 2 or not all(is_device_array(X) for X in sequences):
+            return None
+        import torch
+        head = sequences[0]
+        if head.dim() != 2 or head.dtype not in (torch.float32, torch.float64, torch.bfloat16):
+            return None
+        F = head.shape[1]
+        nbytes = head.element_size()
+        if (F * nbytes) % 16 != 0:
+            return None
+        for X in sequences:
+            if X.dim() != 2 or X.shape[1] != F or X.dtype != head.dtype or X.device != head.device:
+                return None
+        seqs = [X if X.is_contiguous() else X.contiguous() for X in sequences]
+        if any(X.shape[0] and X.data_ptr() % 16 for X in seqs):
+            return None
+        mean, comps = self._projection()
+        if F != comps.shape[1]:
+            raise ValueError("shapes (%d,%d) and (%d,%d) not aligned" % (head.shape[0], F, comps.shape[1], comps.shape[0]))
+        k = comps.shape[0]
+        _lib.ensure_device(head.device.index)
+        _lib.set_stream(torch.cuda.current_stream(head.device).cuda_stream)
+        lens = [int(X.shape[0]) for X in seqs]
+        Y = torch.empty((sum(lens), k), dtype=torch.float64, device=head.device)
+        outs = _lib.cut_rows(Y, lens)
+        n = len(seqs)
+        xp = (C.c_void_p * n)(*[X.data_ptr() if X.shape[0] else None for X in seqs])
+        op = (C.c_void_p * n)(*[o.data_ptr() if o.shape[0] else None for o in outs])
+        rows = (C.c_int64 * n)(*lens)
+        check(_lib.lib().msm_tica_project_batch(xp, op, rows, n, nbytes, F, mean.ctypes.data, comps.ctypes.data, k, 1))
+        return outs
 
     def partial_transform(self, features):
         """Apply the dimensionality reduction on a single featurized trajectory."""

@@ -117,3 +117,28 @@ def test_transform_and_predict_over_adjacent_views_equal_the_per_trajectory_call
         for a, b in zip(la, lb):
             assert np.array_equal(as_np(a), as_np(b))
 
+
+@pytest.mark.parametrize("dtype,F,k", [("float32", 64, 3), ("float64", 30, 20), ("bfloat16", 40, 5), ("float32", 36, 17)])
+def test_transform_of_separately_allocated_device_trajectories_is_one_batched_launch(gpu, dtype, F, k):
+    """`tICA.transform` on a list of separately allocated device trajectories goes through `msm_tica_project_batch` (a table
+    of 256-row tiles, one launch per 16 components); every trajectory's result must equal `partial_transform` of it alone
+    -- lengths that are not multiples of the tile, one row, an empty trajectory, more than 16 components, bfloat16 rows."""
+    import torch
+    from msmbuilder_amd import tICA
+    rs = np.random.RandomState(F + k)
+    tdt = getattr(torch, dtype)
+    lens = [257, 1, 0, 1024, 300, 255, 2049]
+    seqs = [torch.from_numpy((rs.randn(n, F) + 0.5).astype(np.float32)).cuda().to(tdt) for n in lens]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = tICA(n_components=k, lag_time=3).fit([s.float() for s in seqs if len(s) > 10])
+        ys = m.transform(seqs)
+        one = [m.partial_transform(s) for s in seqs]
+    assert [tuple(y.shape) for y in ys] == [(n, k) for n in lens]
+    for a, b in zip(ys, one):
+        assert a.dtype == torch.float64 and np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    bad = [s.clone() for s in seqs]
+    bad[4][7, 3] = float("nan")
+    with pytest.raises(ValueError, match="NaN"):
+        m.transform(bad)
+
