@@ -94,7 +94,7 @@ int pair_residual_device(const double* Cm, int n, const double* Y, const double*
 // iteration (block of 32, Rayleigh-Ritz on the host); synchronises; *converged = 0 -> outputs meaningless, use the fallback
 int subspace_topk_device(const double* Cm, int n, int k, double lower, double tol, int degree, int max_outer, double* lam,
                          double* Yk, double* work, double* pin /* subspace_pin_doubles() of pinned host memory */, int* converged,
-                         int* outer_used);
+                         int* outer_used, double first_cut /* prior for the first filter, NaN: Rayleigh-Ritz first */, double first_top);
 size_t subspace_work_doubles(int n);
 size_t subspace_pin_doubles();
 

@@ -3189,7 +3189,9 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
         MSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->solve_pin), pin_total * sizeof(double), hipHostMallocDefault));
         h->solve_pin_n = pin_total;
     }
-    if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, 10, 6, b.lam, b.Yk, b.sswork, h->solve_pin + pin_res, &conv, &outer))) return rc;
+    if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, 10, 6, b.lam, b.Yk, b.sswork, h->solve_pin + pin_res, &conv, &outer,
+                                   0.0, 1.0)))   // prior: the reduced tICA matrix has its spectrum in [-1, 1], the noise bulk near 0
+        return rc;
     if (!conv) {
         double scal[4];
         int ints[8];
