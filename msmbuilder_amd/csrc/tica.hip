@@ -1585,23 +1585,31 @@ __global__ void tica_fold_fix_kernel(double* __restrict__ tmp, const double* __r
 //   segments, owned rows, H/D kernel         A|W_a        (its Gram is over owned PAIRS: W = A + B)
 //   segments, the pairs' right rows          B_a (|W_a for the H/D kernel)
 enum { SH_A_a = 1, SH_B_b = 2, SH_W_ab = 4, SH_B_a = 8, SH_W_a = 16 };
-__global__ __launch_bounds__(256) void tica_shift_kernel(const double* __restrict__ part, double* __restrict__ shsum,
+__global__ __launch_bounds__(512) void tica_shift_kernel(const double* __restrict__ part, double* __restrict__ shsum,
                                                          float* __restrict__ r, int F, double inv_n, int set_r, int what)
 {
-    __shared__ double red[2][256];
-    const int tid = threadIdx.x, col = blockIdx.x * 64 + (tid & 63), rl = tid >> 6;
-    double a = 0.0, b = 0.0;
-    if (col < F)
-        for (int k = rl; k < NCB; k += 4) {
-            a += part[(size_t)k * 2 * F + col];
-            b += part[(size_t)k * 2 * F + F + col];
-        }
-    red[0][tid] = a;
-    red[1][tid] = b;
+    // 64 columns per workgroup of 512; thread = (column, half a / b, one of four row lanes) with ONE accumulator and sixteen
+    // partials requested per trip -- the shape tica_export_cols_kernel has.  (Round 3's loop -- four row lanes, `a += ...; b += ...`
+    // under `if (col < F)` -- compiled to pairs of loads each waited for on the spot: 256 dependent round trips per
+    // thread, 84 us per launch; two batched accumulators per thread were paired up again by the scheduler.)
+    __shared__ double red[2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, half = (tid >> 6) & 1, rl = tid >> 7;
+    const int col = blockIdx.x * 64 + lane;
+    const int cc = col < F ? col : F - 1;
+    static_assert(NCB % 64 == 0, "whole groups of 16 per row lane");
+    double acc = 0.0;
+    for (int k0 = rl; k0 < NCB; k0 += 64) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(k0 + 4 * u) * 2 * F + (size_t)half * F + cc];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    red[half][rl][lane] = acc;
     __syncthreads();
-    if (rl == 0 && col < F) {
-        a += red[0][tid + 64] + red[0][tid + 128] + red[0][tid + 192];
-        b += red[1][tid + 64] + red[1][tid + 128] + red[1][tid + 192];
+    if (tid < 64 && col < F) {
+        const double a = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        const double b = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
         if (set_r) r[col] = (float)((a + b) * inv_n);
         if (what & SH_A_a) shsum[col] += a;
         if (what & SH_B_b) shsum[F + col] += b;
@@ -2325,7 +2333,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
                 nw_call += (segs && !usesym) ? n0 + nt : 2 * n0;
             }
             const int what = !segs ? (SH_A_a | SH_B_b | SH_W_ab) : usesym ? (SH_A_a | SH_W_a) : (SH_A_a | SH_W_ab);
-            hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(256), 0, stream(), h->coltmp,
+            hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(512), 0, stream(), h->coltmp,
                                h->shsum, h->shift, h->F, 1.0 / (double)std::max<long long>(1, nmean), set_r, what);
             MSM_HIP_CHECK(hipGetLastError());
             h->have_shift = true;
@@ -2456,7 +2464,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
                 hipLaunchKernelGGL(tica_colsum_kernel<__bf16>, dim3(NCB), dim3(NT), 0, stream(), Q);
             else
                 hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), Q);
-            hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(256), 0, stream(), h->coltmp,
+            hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(512), 0, stream(), h->coltmp,
                                h->shsum, h->shift, h->F, 0.0, 0, usesym ? (SH_B_a | SH_W_a) : SH_B_a);
             MSM_HIP_CHECK(hipGetLastError());
             MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
