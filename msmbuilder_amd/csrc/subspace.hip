@@ -319,6 +319,14 @@ __global__ void ss_emit_kernel(const double* __restrict__ X, int n, int k, doubl
 // Small dense symmetric eigenproblem on the host: Householder tridiagonalisation with accumulated transformations, then
 // QL with implicit shifts (the classical tred2 / tql2 pair).  A (m x m, row-major, destroyed) -> eigenvalues w and
 // eigenvectors as COLUMNS of V, sorted by descending eigenvalue.  ~m^3 flops: microseconds at m = 32.
+// sqrt(a^2 + b^2): the plain form where it cannot over- or underflow (std::hypot's careful scaling costs ~25 ns, and QL
+// calls it once per rotation: a third of the function at m = 32), std::hypot otherwise
+inline double fast_hypot(double a, double b)
+{
+    const double s = a * a + b * b;
+    return (s > 1e-280 && s < 1e280) ? std::sqrt(s) : std::hypot(a, b);
+}
+
 void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vector<double>& V)
 {
     std::vector<double> d(m), e(m);
@@ -376,7 +384,12 @@ void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vect
         a(i, i) = 1.0;
         for (int j = 0; j <= l; ++j) a(j, i) = a(i, j) = 0.0;
     }
-    // QL with implicit shifts on (d, e), rotations accumulated into A (columns = eigenvectors)
+    // QL with implicit shifts on (d, e), rotations accumulated into Zt = A^T (ROWS = eigenvectors: a rotation of two
+    // eigenvectors then runs over two contiguous rows -- as columns of the row-major A it was a stride-m walk, and the
+    // rotations are most of this function's flops: 72 -> ~25 us at m = 32, inside the solve's two host round trips)
+    std::vector<double> Zt((size_t)m * m);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) Zt[(size_t)j * m + i] = a(i, j);
     for (int i = 1; i < m; ++i) e[i - 1] = e[i];
     e[m - 1] = 0.0;
     for (int l = 0; l < m; ++l) {
@@ -389,14 +402,14 @@ void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vect
             if (mm != l) {
                 if (iter++ == 60) break;
                 double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                double r = std::hypot(g, 1.0);
+                double r = fast_hypot(g, 1.0);
                 g = d[mm] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
                 double s2 = 1.0, c = 1.0, p = 0.0;
                 int i;
                 for (i = mm - 1; i >= l; --i) {
                     double f = s2 * e[i];
                     const double bb = c * e[i];
-                    e[i + 1] = (r = std::hypot(f, g));
+                    e[i + 1] = (r = fast_hypot(f, g));
                     if (r == 0.0) {
                         d[i + 1] -= p;
                         e[mm] = 0.0;
@@ -408,10 +421,12 @@ void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vect
                     r = (d[i] - g) * s2 + 2.0 * c * bb;
                     d[i + 1] = g + (p = s2 * r);
                     g = c * r - bb;
+                    double* __restrict__ z0 = &Zt[(size_t)i * m];
+                    double* __restrict__ z1 = &Zt[(size_t)(i + 1) * m];
                     for (int k2 = 0; k2 < m; ++k2) {
-                        f = a(k2, i + 1);
-                        a(k2, i + 1) = s2 * a(k2, i) + c * f;
-                        a(k2, i) = c * a(k2, i) - s2 * f;
+                        const double f1 = z1[k2], f0 = z0[k2];
+                        z1[k2] = s2 * f0 + c * f1;
+                        z0[k2] = c * f0 - s2 * f1;
                     }
                 }
                 if (r == 0.0 && i >= l) continue;
@@ -428,7 +443,7 @@ void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vect
     V.assign((size_t)m * m, 0.0);
     for (int j = 0; j < m; ++j) {
         w[j] = d[order[j]];
-        for (int i = 0; i < m; ++i) V[(size_t)i * m + j] = a(i, order[j]);
+        for (int i = 0; i < m; ++i) V[(size_t)i * m + j] = Zt[(size_t)order[j] * m + i];
     }
 }
 
@@ -451,18 +466,29 @@ bool small_geigh(std::vector<double>& H, std::vector<double>& G, int m, std::vec
     }
     // M = L^-1 H L^-T: forward substitutions on the rows, then on the columns
     std::vector<double> M(H);
-    for (int c = 0; c < m; ++c)          // M <- L^-1 M (column by column)
+    // M <- L^-1 M: row i minus the finished rows above it (contiguous inner loops the compiler vectorises; the dot-product
+    // forms of these substitutions are chains of dependent adds, 4 cycles each).  Twice, with a transposition in between:
+    // (L^-1 H)^T = H L^-T, so the second application gives L^-1 H L^-T.
+    auto forward = [&](std::vector<double>& X) {
         for (int i = 0; i < m; ++i) {
-            double t = M[(size_t)i * m + c];
-            for (int k2 = 0; k2 < i; ++k2) t -= L[(size_t)i * m + k2] * M[(size_t)k2 * m + c];
-            M[(size_t)i * m + c] = t / L[(size_t)i * m + i];
+            double* __restrict__ xi = &X[(size_t)i * m];
+            for (int k2 = 0; k2 < i; ++k2) {
+                const double lik = L[(size_t)i * m + k2];
+                const double* __restrict__ xk = &X[(size_t)k2 * m];
+                for (int c = 0; c < m; ++c) xi[c] -= lik * xk[c];
+            }
+            const double lii = L[(size_t)i * m + i];
+            for (int c = 0; c < m; ++c) xi[c] /= lii;
         }
-    for (int r = 0; r < m; ++r)          // M <- M L^-T (row by row)
-        for (int j = 0; j < m; ++j) {
-            double t = M[(size_t)r * m + j];
-            for (int k2 = 0; k2 < j; ++k2) t -= M[(size_t)r * m + k2] * L[(size_t)j * m + k2];
-            M[(size_t)r * m + j] = t / L[(size_t)j * m + j];
-        }
+    };
+    forward(M);
+    {
+        std::vector<double> T((size_t)m * m);
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) T[(size_t)j * m + i] = M[(size_t)i * m + j];
+        forward(T);
+        M.swap(T);
+    }
     for (int i = 0; i < m; ++i)
         for (int j = i + 1; j < m; ++j) {
             const double t = 0.5 * (M[(size_t)i * m + j] + M[(size_t)j * m + i]);
@@ -470,13 +496,17 @@ bool small_geigh(std::vector<double>& H, std::vector<double>& G, int m, std::vec
         }
     std::vector<double> Sp;
     small_eigh(M, m, w, Sp);
-    S.assign((size_t)m * m, 0.0);
-    for (int c = 0; c < m; ++c)          // S = L^-T S': back substitution per column
-        for (int i = m - 1; i >= 0; --i) {
-            double t = Sp[(size_t)i * m + c];
-            for (int k2 = i + 1; k2 < m; ++k2) t -= L[(size_t)k2 * m + i] * S[(size_t)k2 * m + c];
-            S[(size_t)i * m + c] = t / L[(size_t)i * m + i];
+    S = Sp;
+    for (int i = m - 1; i >= 0; --i) {   // S = L^-T S': back substitution, row i minus the finished rows below it
+        double* __restrict__ si = &S[(size_t)i * m];
+        for (int k2 = i + 1; k2 < m; ++k2) {
+            const double lki = L[(size_t)k2 * m + i];
+            const double* __restrict__ sk = &S[(size_t)k2 * m];
+            for (int c = 0; c < m; ++c) si[c] -= lki * sk[c];
         }
+        const double lii = L[(size_t)i * m + i];
+        for (int c = 0; c < m; ++c) si[c] /= lii;
+    }
     return true;
 }
 
