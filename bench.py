@@ -403,6 +403,20 @@ def main():
     kst = (C.c_int64 * 5)()
     _lib.check(_lib.lib().msm_kcenters_last_stats(kst))
 
+    # N > 1: the latencies of the library's collectives as its loops see them (queued back to back on the library stream),
+    # MEASURED on this run's communicator -- RCCL over xGMI on a node with a GPU per rank -- for the sizes the step uses: the
+    # tICA all-reduce (2 F^2 + 2 F doubles), the k-centers candidate all-gather and the k-centers round record
+    comm_measured = None
+    if world > 1 and ci[2].value != 0:
+        comm_measured = {"transport": comm_kind}
+        rec_bytes = 8 * (48 + 1024 * (2 + args.components))
+        for name, kind, nbytes in (("allreduce_tica_%dKB" % ((2 * F * F + 2 * F) * 8 // 1024), 0, (2 * F * F + 2 * F) * 8),
+                                   ("allgather_per_centre_%dB" % (8 * (2 + args.components)), 1, 8 * (2 + args.components)),
+                                   ("allgather_per_round_record_%dKB" % (rec_bytes // 1024), 1, rec_bytes)):
+            us = C.c_float(0.0)
+            rc_m = _lib.lib().msm_comm_measure(kind, nbytes, 50, C.byref(us))   # every rank takes part
+            comm_measured[name + "_us"] = float(us.value) if rc_m == 0 else None
+
     weak = None
     if world > 1 and args.scaling == "strong" and not args.no_extras:
         # the other reading of "N GPUs", untimed secondary leg: every rank its own full-size shard (weak scaling)
@@ -461,8 +475,8 @@ def main():
                                       args.components, args.lag, args.clusters),
                        "total_frames": total_frames, "frames_per_gpu": frames, "n_features": F, "lag_time": args.lag,
                        "n_components": args.components, "n_clusters": args.clusters,
-                       "parallelism": "whole trajectories dealt over %d rank%s, 1 all-reduce (tICA) + 1 all-gather per ROUND of centres (KCenters: ~35 per fit)"
-                                      % (world, "s" if world > 1 else "")},
+                       "parallelism": "whole trajectories dealt over %d rank%s, 1 all-reduce (tICA) + 1 all-gather per ROUND of centres (KCenters: %d exchanges in this fit)"
+                                      % (world, "s" if world > 1 else "", int(kst[1] + kst[2]))},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": executed, "peak": peak, "unit": "TFLOP/s",
                          "frac": executed / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic": algorithmic, "algorithmic_frac": algorithmic / peak,
@@ -483,6 +497,8 @@ def main():
         }
         if weak is not None:
             out["weak_scaling"] = weak
+        if comm_measured is not None:
+            out["comm_measured_us"] = comm_measured
         fit_s, pred_s = float(np.mean(times["kcenters_fit"])), float(np.mean(times["kcenters_predict"]))
         # bytes the K passes of one fit READ on this rank (msm_kcenters_last_stats): plain passes stream the float64 row +
         # distances_ + labels_, screened passes the bfloat16 copy + the rounded-up distance; the one-off conversion reads

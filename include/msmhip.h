@@ -111,6 +111,9 @@ int msm_comm_destroy(void);
 int msm_comm_info(int* rank, int* world, int* kind); /* kind: 0 none, 1 RCCL, 2 host callback */
 int msm_comm_allreduce_f64(double* dbuf, msm_idx_t n);                    /* device buffer, in place; synchronises */
 int msm_comm_allgather(const void* dsend, void* drecv, msm_idx_t bytes);  /* device buffers; synchronises */
+int msm_comm_measure(int kind, msm_idx_t bytes, int reps, float* us_per_call); /* latency of `reps` queued collectives of `bytes`
+                                      per rank (kind 0: all-reduce of doubles, 1: all-gather), microseconds per call; every
+                                      rank calls it (bench.py reports these instead of assumptions when it runs on N > 1) */
 
 /* ---- tICA second-moment accumulation ---------------------------------- */
 typedef struct msm_tica msm_tica_t;

@@ -100,6 +100,7 @@ def _declare(lib):
     f("msm_comm_info", C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
     f("msm_comm_allreduce_f64", C.c_int, _p, _i64)
     f("msm_comm_allgather", C.c_int, _p, _p, _i64)
+    f("msm_comm_measure", C.c_int, C.c_int, _i64, C.c_int, C.POINTER(C.c_float))
     f("msm_mbk_zero_packed", C.c_int, _p)
     f("msm_mbk_allreduce", C.c_int, _p, _f64p, _p)
     for sfx in ("f32", "f64"):

@@ -316,4 +316,36 @@ int msm_comm_allgather(const void* dsend, void* drecv, msm_idx_t bytes)
     return MSM_OK;
 }
 
+/* Latency of the library's collectives as the k-centers and tICA loops see them: `reps` collectives of `bytes` per rank
+ * queued back to back on the library stream between two events (3 untimed ones first), microseconds per call.
+ * kind 0: in-place all-reduce of bytes / 8 doubles; kind 1: all-gather of `bytes` per rank.  Every rank calls it. */
+int msm_comm_measure(int kind, msm_idx_t bytes, int reps, float* us_per_call)
+{
+    if (!us_per_call || bytes < 8 || reps < 1 || (kind != 0 && kind != 1)) return fail(MSM_ERR_INVALID, "msm_comm_measure: bad argument");
+    if (!comm_active()) return fail(MSM_ERR_STATE, "msm_comm_measure: no communicator");
+    const int W = g_comm.world;
+    char* d = nullptr;
+    MSM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)bytes * (kind == 1 ? (size_t)W + 1 : 1)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = MSM_OK;
+    if (hipMemsetAsync(d, 0, (size_t)bytes * (kind == 1 ? (size_t)W + 1 : 1), stream()) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess)
+        rc = fail(MSM_ERR_HIP, "msm_comm_measure: setup failed");
+    auto once = [&]() -> int {
+        return kind == 0 ? comm_allreduce_f64(reinterpret_cast<double*>(d), (size_t)bytes / 8) : comm_allgather(d, d + bytes, (size_t)bytes);
+    };
+    for (int i = 0; i < 3 && !rc; ++i) rc = once();
+    if (!rc && hipEventRecord(e0, stream()) != hipSuccess) rc = fail(MSM_ERR_HIP, "msm_comm_measure: event");
+    for (int i = 0; i < reps && !rc; ++i) rc = once();
+    if (!rc && (hipEventRecord(e1, stream()) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(MSM_ERR_HIP, "msm_comm_measure: event");
+    float ms = 0.f;
+    if (!rc && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(MSM_ERR_HIP, "msm_comm_measure: event");
+    *us_per_call = 1e3f * ms / (float)reps;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(stream());
+    (void)hipFree(d);
+    return rc;
+}
+
 }  // extern "C"

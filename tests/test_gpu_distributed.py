@@ -302,5 +302,7 @@ def test_bench_world_of_eight_on_the_box(gpu):
     else:
         assert out["comm"] == "host" and out["rccl_ranks"] == 0
     assert out["value"] > 0 and set(out["phases_ms"]) >= {"fit", "allreduce", "solve", "transform", "kcenters_fit", "kcenters_predict"}
+    cm = out["comm_measured_us"]
+    assert cm["transport"] == out["comm"] and all(v is not None and v > 0 for k_, v in cm.items() if k_.endswith("_us"))
     ev = out["top_eigenvalues"] if "top_eigenvalues" in out else None
     assert ev is None or (0.0 < ev[0] < 1.0)
