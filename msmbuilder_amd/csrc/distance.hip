@@ -2109,15 +2109,32 @@ struct KcbState {
 // (levels below 0.91 were tried in round 4 -- twelve levels down to 0.58: the number of rounds did not move, 19 on the bench's
 //  projection at 10M and at 1.25M rows: what ends a round is the list's capacity, not the threshold's rate of descent -- and
 //  the extra level counters cost 15 % of a fit)
-// the part of KcbState the host initialises (everything before `cen`), as a value on the caller's stack
-struct KcbHead {
-    int k_done, J, rounds, fallbacks;
-    float theta;
-    unsigned count;
-    unsigned lev[KCB_NLEV];
-};
-static_assert(sizeof(KcbHead) <= offsetof(KcbState, cen) && offsetof(KcbHead, lev) == offsetof(KcbState, lev),
-              "KcbHead must mirror the head of KcbState");
+// Rounds the host queues before it looks at the progress counter again.  A synchronisation costs 35-50 us of idle GPU, an
+// empty round (all K centres fixed: three early-returning launches) about 14: so the first group aims at the whole fit at
+// a typical 12 centres per round, and the later ones at what is left at the rate seen so far, plus one.  The value depends
+// on nothing but K and the counter, which every rank of a sharded fit holds identically.
+static int kcb_group(int K, int done, int rounds_so_far, int done_at_start)
+{
+    const int left = K - done;
+    if (left <= 0) return 0;
+    int per = 12;
+    if (rounds_so_far > 0) per = std::max(1, (done - done_at_start) / rounds_so_far);
+    const int g = (left + per - 1) / per + (rounds_so_far > 0 ? 1 : 0);
+    return std::min(std::max(g, 1), 24);
+}
+
+// the state before the first round: `k_done` centres fixed by the plain passes, no list yet.  (A launch instead of a copy
+// from the host's stack and the synchronisation that keeps the stack alive: 20-30 us per fit.)
+__global__ void kcb_init_kernel(KcbState* S, int k_done)
+{
+    if (threadIdx.x == 0) {
+        S->k_done = k_done;
+        S->J = S->rounds = S->fallbacks = 0;
+        S->theta = INFINITY;
+        S->count = 0;
+    }
+    if (threadIdx.x < KCB_NLEV) S->lev[threadIdx.x] = 0;
+}
 __device__ __forceinline__ float kcb_level(int l) { return l == 0 ? 1.f : l == 1 ? 0.985f : l == 2 ? 0.97f : l == 3 ? 0.955f : l == 4 ? 0.94f : 0.91f; }
 
 template <int NP>
@@ -2878,17 +2895,12 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                 DevBuf& SB = pool(PS_W);
                 if ((rc = SB.reserve(sizeof(KcbState)))) return rc;
                 KcbState* St = SB.as<KcbState>();
-                KcbHead init;
-                init.k_done = (int)it;
-                init.J = init.rounds = init.fallbacks = 0;
-                init.theta = INFINITY;
-                init.count = 0;
-                for (int l = 0; l < KCB_NLEV; ++l) init.lev[l] = 0;
-                MSM_HIP_CHECK(hipMemcpyAsync(St, &init, sizeof(KcbHead), hipMemcpyHostToDevice, stream()));
-                MSM_HIP_CHECK(hipStreamSynchronize(stream()));   // `init` is pageable host memory
+                hipLaunchKernelGGL(kcb_init_kernel, dim3(1), dim3(64), 0, stream(), St, (int)it);
                 int rounds = 0, done = (int)it;
+                int head4[4] = {(int)it, 0, 0, 0};   // k_done, J, rounds, fallbacks: the head of KcbState
                 while (done < (int)K) {
-                    for (int r = 0; r < 4; ++r, ++rounds) {
+                    const int group = kcb_group((int)K, done, rounds, (int)it);
+                    for (int r = 0; r < group; ++r, ++rounds) {
                         S.prev = part + (size_t)((it + 1 + rounds) & 1) * nblk;   // partials of the last pass that ran
                         S.next = part + (size_t)((it + rounds) & 1) * nblk;
                         switch (np) {
@@ -2899,15 +2911,13 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                         }
                     }
                     MSM_HIP_CHECK(hipGetLastError());
-                    MSM_HIP_CHECK(hipMemcpyAsync(&done, &St->k_done, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                    MSM_HIP_CHECK(hipMemcpyAsync(head4, St, sizeof(head4), hipMemcpyDeviceToHost, stream()));
                     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                    done = head4[0];
                     if (rounds > 4 * (int)K) return fail(MSM_ERR_HIP, "k-centers: the batched passes made no progress");
                 }
-                int rf[2] = {0, 0};
-                MSM_HIP_CHECK(hipMemcpyAsync(rf, &St->rounds, sizeof(rf), hipMemcpyDeviceToHost, stream()));
-                MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-                g_kc_stats.screened_passes = rf[0];   // passes that streamed the copy (the empty rounds of the last group are not counted)
-                g_kc_stats.batch_fallbacks = rf[1];
+                g_kc_stats.screened_passes = head4[2];   // passes that streamed the copy (the empty rounds of the last group are not counted)
+                g_kc_stats.batch_fallbacks = head4[3];
                 it = K;
             }
             for (; it < K; ++it) {
@@ -3240,14 +3250,7 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
             KcbState* St = W.as<KcbState>();
             double* recL = reinterpret_cast<double*>(static_cast<char*>(W.p) + stb);
             double* recsG = comm_active() ? recL + RD : recL;   // a world of one: the gathered records ARE the rank's record
-            KcbHead init;
-            init.k_done = (int)PROBE;
-            init.J = init.rounds = init.fallbacks = 0;
-            init.theta = INFINITY;
-            init.count = 0;
-            for (int l = 0; l < KCB_NLEV; ++l) init.lev[l] = 0;
-            MSM_HIP_CHECK(hipMemcpyAsync(St, &init, sizeof(KcbHead), hipMemcpyHostToDevice, stream()));
-            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+            hipLaunchKernelGGL(kcb_init_kernel, dim3(1), dim3(64), 0, stream(), St, (int)PROBE);
             hipLaunchKernelGGL(kcb_boot_records_kernel, dim3((unsigned)world), dim3(64), 0, stream(), cands, world, (long long)m, recsG);
             KscArgs S;
             memset(&S, 0, sizeof(S));
@@ -3281,8 +3284,10 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
             }
             MSM_HIP_CHECK(hipGetLastError());
             int rounds = 0, done = (int)PROBE;
+            int head4[4] = {(int)PROBE, 0, 0, 0};
             while (done < (int)K) {
-                for (int r = 0; r < 4; ++r, ++rounds) {
+                const int group = kcb_group((int)K, done, rounds, (int)PROBE);
+                for (int r = 0; r < group; ++r, ++rounds) {
                     switch (np) {
 #define MSM_KSC(NP_) case NP_: \
                         hipLaunchKernelGGL((kcb_select_sharded_kernel<NP_>), dim3(1), dim3(1024), 0, stream(), recsG, world, (long long)m, St, (int)K, \
@@ -3299,15 +3304,13 @@ int kcenters_fit_sharded_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K,
                     MSM_HIP_CHECK(hipGetLastError());
                     if ((rc = comm_allgather(recL, recsG, RD * sizeof(double)))) return rc;
                 }
-                MSM_HIP_CHECK(hipMemcpyAsync(&done, &St->k_done, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                MSM_HIP_CHECK(hipMemcpyAsync(head4, St, sizeof(head4), hipMemcpyDeviceToHost, stream()));
                 MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                done = head4[0];
                 if (rounds > 4 * (int)K) return fail(MSM_ERR_HIP, "k-centers: the batched rounds made no progress");
             }
-            int rf[2] = {0, 0};
-            MSM_HIP_CHECK(hipMemcpyAsync(rf, &St->rounds, sizeof(rf), hipMemcpyDeviceToHost, stream()));
-            MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-            g_kc_stats.screened_passes = rf[0];
-            g_kc_stats.batch_fallbacks = rf[1];
+            g_kc_stats.screened_passes = head4[2];
+            g_kc_stats.batch_fallbacks = head4[3];
         }
     }
     if (batched) {
