@@ -235,6 +235,29 @@ def is_device_array(x) -> bool:
     return hasattr(x, "data_ptr") and bool(getattr(x, "is_cuda", False))
 
 
+def adjacent_rows(sequences):
+    """Row counts (int64 array) of a list of 2-D torch CUDA tensors that are contiguous views of ONE tensor lying back to
+    back in its storage, first to last -- or None.  A few list comprehensions: a thousand trajectories are checked in
+    well under a millisecond (a Python loop with six checks per trajectory is 1 us each)."""
+    head = sequences[0]
+    base = getattr(head, "_base", None)
+    if base is None or head.dim() != 2 or not head.is_contiguous():
+        return None
+    if not all(getattr(s, "_base", None) is base for s in sequences):   # views of ONE tensor: one storage, one dtype, one device
+        return None
+    F, dt = head.shape[1], head.dtype
+    shapes = [tuple(s.shape) for s in sequences]
+    if any(len(sh) != 2 or sh[1] != F for sh in shapes) or any(s.dtype != dt for s in sequences):
+        return None
+    rows = np.array([sh[0] for sh in shapes], dtype=np.int64)
+    ptrs = np.array([s.data_ptr() for s in sequences], dtype=np.int64)
+    want = ptrs[0] + np.concatenate(([0], np.cumsum(rows[:-1]))) * (F * head.element_size())
+    live = rows > 0   # an empty trajectory occupies nothing (and its pointer need not follow its neighbours)
+    if not np.array_equal(ptrs[live], want[live]) or not all(s.is_contiguous() for s in sequences):
+        return None
+    return rows
+
+
 def adjacent_view(sequences):
     """ONE [total, F] array over a list of 2-D trajectories that lie back to back in one allocation -- what
     ``X.view(n, T, F).unbind(0)``, ``np.split`` or slices of a joined array give --, or None.  Lets the per-frame
@@ -248,23 +271,10 @@ def adjacent_view(sequences):
     try:
         if is_device_array(head):
             import torch
-            base = getattr(head, "_base", None)
-            if head.dim() != 2 or not head.is_contiguous() or base is None:
+            rows = adjacent_rows(sequences)
+            if rows is None:
                 return None
-            # (list comprehensions: a thousand trajectories are checked in well under a millisecond)
-            if not all(getattr(s, "_base", None) is base for s in sequences):   # views of ONE tensor: one storage
-                return None
-            F, dt = head.shape[1], head.dtype
-            shapes = [tuple(s.shape) for s in sequences]
-            if any(len(sh) != 2 or sh[1] != F for sh in shapes) or any(s.dtype != dt for s in sequences):
-                return None
-            rows = np.array([sh[0] for sh in shapes], dtype=np.int64)
-            ptrs = np.array([s.data_ptr() for s in sequences], dtype=np.int64)
-            want = ptrs[0] + np.concatenate(([0], np.cumsum(rows[:-1]))) * (F * head.element_size())
-            live = rows > 0   # an empty trajectory occupies nothing (and its pointer need not follow its neighbours)
-            if not np.array_equal(ptrs[live], want[live]) or not all(s.is_contiguous() for s in sequences):
-                return None
-            return torch.as_strided(head, (int(rows.sum()), F), (F, 1))
+            return torch.as_strided(head, (int(rows.sum()), head.shape[1]), (head.shape[1], 1))
         if isinstance(head, np.ndarray):
             if head.ndim != 2 or not head.flags.c_contiguous or head.base is None:
                 return None
