@@ -330,6 +330,7 @@ inline double fast_hypot(double a, double b)
 void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vector<double>& V)
 {
     std::vector<double> d(m), e(m);
+    if (m > 64) return;   // (the accumulation below keeps a 64-entry row on the stack; callers pass the 32 x 32 Ritz problem)
     auto a = [&](int i, int j) -> double& { return A[(size_t)i * m + j]; };
     for (int i = m - 1; i > 0; --i) {
         const int l = i - 1;
@@ -348,20 +349,33 @@ void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vect
                 e[i] = scale * g;
                 h -= f * g;
                 a(i, l) = f - g;
+                // The active block [0..l] x [0..l] is kept FULL (both triangles), so that p = A u / h is a contiguous
+                // row-times-vector product (four accumulators: a chain of dependent adds is 4 cycles per term) and the
+                // rank-2 update A -= u q^T + q u^T runs over whole rows (vectorisable).  The textbook form touches the lower
+                // triangle only and walks columns of the row-major matrix for half of its terms.
+                const double* __restrict__ ui = &A[(size_t)i * m];
                 f = 0.0;
                 for (int j = 0; j <= l; ++j) {
-                    a(j, i) = a(i, j) / h;
-                    g = 0.0;
-                    for (int k2 = 0; k2 <= j; ++k2) g += a(j, k2) * a(i, k2);
-                    for (int k2 = j + 1; k2 <= l; ++k2) g += a(k2, j) * a(i, k2);
-                    e[j] = g / h;
-                    f += e[j] * a(i, j);
+                    const double* __restrict__ aj = &A[(size_t)j * m];
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    int k2 = 0;
+                    for (; k2 + 4 <= l + 1; k2 += 4) {
+                        s0 += aj[k2] * ui[k2];
+                        s1 += aj[k2 + 1] * ui[k2 + 1];
+                        s2 += aj[k2 + 2] * ui[k2 + 2];
+                        s3 += aj[k2 + 3] * ui[k2 + 3];
+                    }
+                    for (; k2 <= l; ++k2) s0 += aj[k2] * ui[k2];
+                    e[j] = ((s0 + s1) + (s2 + s3)) / h;
+                    f += e[j] * ui[j];
                 }
+                for (int j = 0; j <= l; ++j) a(j, i) = ui[j] / h;   // u / h, kept in column i for the accumulation below
                 const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) e[j] -= hh * ui[j];
                 for (int j = 0; j <= l; ++j) {
-                    f = a(i, j);
-                    e[j] = g = e[j] - hh * f;
-                    for (int k2 = 0; k2 <= j; ++k2) a(j, k2) -= f * e[k2] + g * a(i, k2);
+                    const double fj = ui[j], gj = e[j];
+                    double* __restrict__ aj = &A[(size_t)j * m];
+                    for (int k2 = 0; k2 <= l; ++k2) aj[k2] -= fj * e[k2] + gj * ui[k2];
                 }
             }
         } else {
@@ -374,10 +388,19 @@ void small_eigh(std::vector<double>& A, int m, std::vector<double>& w, std::vect
     for (int i = 0; i < m; ++i) {
         const int l = i - 1;
         if (d[i] != 0.0) {
-            for (int j = 0; j <= l; ++j) {
-                double g = 0.0;
-                for (int k2 = 0; k2 <= l; ++k2) g += a(i, k2) * a(k2, j);
-                for (int k2 = 0; k2 <= l; ++k2) a(k2, j) -= g * a(k2, i);
+            // Q <- Q - (Q u / h)(u^T Q) on the block [0..l]: g = u^T Q accumulated row by row, then a rank-1 update row
+            // by row (the same sums in the same order as the column-wise textbook loops, over contiguous memory)
+            double gv[64];
+            for (int j = 0; j <= l; ++j) gv[j] = 0.0;
+            for (int k2 = 0; k2 <= l; ++k2) {
+                const double uk = a(i, k2);
+                const double* __restrict__ qk = &A[(size_t)k2 * m];
+                for (int j = 0; j <= l; ++j) gv[j] += uk * qk[j];
+            }
+            for (int k2 = 0; k2 <= l; ++k2) {
+                const double c = a(k2, i);
+                double* __restrict__ qk = &A[(size_t)k2 * m];
+                for (int j = 0; j <= l; ++j) qk[j] -= gv[j] * c;
             }
         }
         d[i] = a(i, i);
