@@ -118,7 +118,8 @@ def test_transform_and_predict_over_adjacent_views_equal_the_per_trajectory_call
             assert np.array_equal(as_np(a), as_np(b))
 
 
-@pytest.mark.parametrize("dtype,F,k", [("float32", 64, 3), ("float64", 30, 20), ("bfloat16", 40, 5), ("float32", 36, 17)])
+@pytest.mark.parametrize("dtype,F,k", [("float32", 64, 3), ("float64", 30, 20), ("bfloat16", 40, 5), ("float32", 36, 17),
+                                       ("float32", 30, 4)])   # (30 float32 features: rows are no whole 16-byte vectors -- one by one)
 def test_transform_of_separately_allocated_device_trajectories_is_one_batched_launch(gpu, dtype, F, k):
     """`tICA.transform` on a list of separately allocated device trajectories goes through `msm_tica_project_batch` (a table
     of 256-row tiles, one launch per 16 components); every trajectory's result must equal `partial_transform` of it alone
