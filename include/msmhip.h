@@ -290,6 +290,14 @@ int msm_kcenters_fit_f32(const float* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_c
 int msm_kcenters_fit_f64(const double* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters,
                          const char* metric, msm_idx_t seed_index, msm_idx_t* ids,
                          msm_idx_t* labels, double* distances, double* inertia, int on_device);
+/* the same fit, also returning the chosen rows themselves: centers[n_clusters][m] (HOST memory) = X[ids]
+ * (kcenters.py:98 cluster_centers_), in the fit's final synchronisation */
+int msm_kcenters_fit2_f32(const float* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters, const char* metric,
+                          msm_idx_t seed_index, msm_idx_t* ids, msm_idx_t* labels, double* distances, double* inertia,
+                          int on_device, float* centers);
+int msm_kcenters_fit2_f64(const double* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters, const char* metric,
+                          msm_idx_t seed_index, msm_idx_t* ids, msm_idx_t* labels, double* distances, double* inertia,
+                          int on_device, double* centers);
 
 /* One externally driven k-centers pass for row-sharded data (one process per GPU): the centre's
  * coordinates y (host, m values; it may live on another rank) are supplied, distances_/labels_

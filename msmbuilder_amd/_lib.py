@@ -136,6 +136,8 @@ def _declare(lib):
           _f64p, C.c_int)
         f("msm_kcenters_fit_" + sfx, C.c_int, _p, _i64, _i64, _i64, C.c_char_p, _i64, _p, _p, _p, _f64p,
           C.c_int)
+        f("msm_kcenters_fit2_" + sfx, C.c_int, _p, _i64, _i64, _i64, C.c_char_p, _i64, _p, _p, _p, _f64p,
+          C.c_int, _p)
     for sfx in ("f32", "f64"):
         f("msm_kcenters_pass_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, C.c_char_p, _p, _p, _f64p, _i64p, _p, C.c_int)
         f("msm_kcenters_pass_dev_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, C.c_char_p, _p, _p, _i64, _p)

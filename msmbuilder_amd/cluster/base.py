@@ -20,6 +20,11 @@ def _join(sequences):
     if not len(sequences):
         raise TypeError('sequences must be a list of numpy arrays (or torch CUDA tensors)')
     head = sequences[0]
+    if len(sequences) == 1:   # one trajectory: itself (torch.cat / np.concatenate of one piece is a full copy: 0.3 ms per 0.8 GB)
+        if isinstance(head, np.ndarray):
+            return np.ascontiguousarray(head)
+        if is_device_array(head):
+            return head.contiguous()
     from .._lib import adjacent_view
     joined = adjacent_view(sequences) if isinstance(sequences, (list, tuple)) else None
     if joined is not None:

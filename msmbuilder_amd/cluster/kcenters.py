@@ -91,13 +91,17 @@ class _KCenters(ClusterMixin, TransformerMixin):
         distances = empty_like_placement(ax, (n_samples,), np.float64)
         al, ad = Arr(labels, np.int64), Arr(distances, np.float64)
         inertia = C.c_double(0.0)
-        fn = getattr(_lib.lib(), "msm_kcenters_fit_" + kind)
+        # cluster_centers_ (kcenters.py:98: the chosen rows) comes back with the ids as a HOST array, like the reference's
+        # attribute: gathering it afterwards with torch indexing was three more round trips, and `predict` needs it on
+        # the host anyway
+        centers = np.empty((K, ax.shape[1]), dtype=ax.dtype)
+        fn = getattr(_lib.lib(), "msm_kcenters_fit2_" + kind)
         check(fn(ax.vp, n_samples, ax.shape[1], K, metric.encode(), int(seed), ids.ctypes.data,
-                 al.vp, ad.vp, C.byref(inertia), ax.on_device))
+                 al.vp, ad.vp, C.byref(inertia), ax.on_device, centers.ctypes.data))
         self.labels_ = labels
         self.distances_ = distances
-        self.cluster_ids_ = [int(i) for i in ids]
-        self.cluster_centers_ = ax.keep[self.cluster_ids_]
+        self.cluster_ids_ = ids.tolist()
+        self.cluster_centers_ = centers
         # np.sum(distances_) as in kcenters.py:101 on the host; on the device the kernel's
         # fp64 tree sum of the same values
         self.inertia_ = np.sum(distances) if not ax.on_device else float(inertia.value)

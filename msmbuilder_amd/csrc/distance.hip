@@ -2785,11 +2785,21 @@ static KscBufs& ksc_bufs()
     return b;
 }
 
+// out[k][:] = X[ids[k]][:] -- the chosen rows themselves (cluster_centers_), gathered on the device so that they travel
+// with the ids in the fit's one final synchronisation (torch indexing with a Python list is three round trips)
+template <typename T>
+__global__ void kc_gather_centres_kernel(const T* __restrict__ X, long long m, const msm_idx_t* __restrict__ ids, T* __restrict__ out)
+{
+    const msm_idx_t row = ids[blockIdx.x];
+    for (long long f = threadIdx.x; f < m; f += blockDim.x) out[(size_t)blockIdx.x * m + f] = X[(size_t)row * m + f];
+}
+
 template <typename T>
 int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char* metric,
                   msm_idx_t seed, msm_idx_t* ids, msm_idx_t* labels, double* distances,
-                  double* inertia, int on_device)
+                  double* inertia, int on_device, T* centers_out = nullptr)
 {
+    const msm_idx_t m_rows = m;   // the caller's row length (the fit may run on a zero-padded copy)
     const int mid = metric_id(metric);
     if (mid < 0) return fail(MSM_ERR_METRIC, "unknown metric '%s'", metric ? metric : "(null)");
     if (!X || !ids || !labels || !distances) return fail(MSM_ERR_INVALID, "kcenters_fit: null pointer");
@@ -2942,6 +2952,14 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
     hipLaunchKernelGGL(sum_partial_kernel, dim3(nblk), dim3(DT), 0, stream(), P.dist, (long long)n, dSum.as<double>());
     MSM_HIP_CHECK(hipGetLastError());
     MSM_HIP_CHECK(hipMemcpyAsync(ids, P.ids, (size_t)K * sizeof(msm_idx_t), hipMemcpyDeviceToHost, stream()));
+    if (centers_out) {
+        DevBuf& dCen = pool(PS_Y);
+        if ((rc = dCen.reserve((size_t)K * m_rows * sizeof(T)))) return rc;
+        const T* Xsrc = on_device ? X : static_cast<const T*>(dX.p);
+        hipLaunchKernelGGL((kc_gather_centres_kernel<T>), dim3((unsigned)K), dim3(64), 0, stream(), Xsrc, (long long)m_rows, P.ids, dCen.as<T>());
+        MSM_HIP_CHECK(hipGetLastError());
+        MSM_HIP_CHECK(hipMemcpyAsync(centers_out, dCen.p, (size_t)K * m_rows * sizeof(T), hipMemcpyDeviceToHost, stream()));
+    }
     if (!on_device) {
         MSM_HIP_CHECK(hipMemcpyAsync(labels, P.labels, (size_t)n * sizeof(msm_idx_t), hipMemcpyDeviceToHost, stream()));
         MSM_HIP_CHECK(hipMemcpyAsync(distances, P.dist, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream()));
@@ -3585,6 +3603,19 @@ int msm_kcenters_fit_f64(const double* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_
                          msm_idx_t* labels, double* distances, double* inertia, int on_device)
 {
     return kcenters_impl<double>(X, n, m, n_clusters, metric, seed_index, ids, labels, distances, inertia, on_device);
+}
+
+/* the same fit, also returning the chosen rows: centers[n_clusters][m] (HOST) = X[ids] (kcenters.py:98 cluster_centers_) */
+int msm_kcenters_fit2_f32(const float* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters, const char* metric, msm_idx_t seed_index,
+                          msm_idx_t* ids, msm_idx_t* labels, double* distances, double* inertia, int on_device, float* centers)
+{
+    return kcenters_impl<float>(X, n, m, n_clusters, metric, seed_index, ids, labels, distances, inertia, on_device, centers);
+}
+
+int msm_kcenters_fit2_f64(const double* X, msm_idx_t n, msm_idx_t m, msm_idx_t n_clusters, const char* metric, msm_idx_t seed_index,
+                          msm_idx_t* ids, msm_idx_t* labels, double* distances, double* inertia, int on_device, double* centers)
+{
+    return kcenters_impl<double>(X, n, m, n_clusters, metric, seed_index, ids, labels, distances, inertia, on_device, centers);
 }
 
 }  // extern "C"
