@@ -154,14 +154,21 @@ int msm_tica_nonfinite(msm_tica_t* h, int* flag); /* synchronises; sticky until 
  * X[:-tau].T @ X[tau:] is not kept. */
 int msm_tica_lagged_symmetrised(msm_tica_t* h, int* flag);
 /* HIP-event duration (ms) of the most recent MFMA accumulation launch of this handle,
- * measured on the stream it ran on (bench.py's roofline leg); synchronises on it.  bf16 modes: the whole
- * pack-and-multiply pipeline (the packing of super-chunk k + 1 overlaps the MFMA kernel of super-chunk k). */
+ * measured on the stream it ran on (bench.py's roofline leg); synchronises on it.  bf16 modes: the whole pipeline --
+ * float32 rows: pack, then multiply, super-chunk after super-chunk in turn on one stream (sequential: overlapping them
+ * was measured slower); with MSM_TICA_IMG_FUSED=1 on bfloat16-stored rows: the step-record kernel + the fused kernel. */
 int msm_tica_last_kernel_ms(msm_tica_t* h, float* ms);
 /* 1 when the most recent accumulation launch had no column-sum pass over X of its own: the sum/difference kernel's
  * staging lanes summed the left frames (float32 input, whole trajectories of >= 2 lag frames, n_features % 128 == 0, at
  * least MSM_TICA_FOLD_MIN = 2^26 elements; MSM_TICA_FOLD=0 disables).  The sums (tica.py:418-419) and the finite check
  * (utils/validation.py:68-74; a rejected launch is undone) are the same either way. */
 int msm_tica_last_folded(msm_tica_t* h, int* flag);
+/* 1 when the most recent accumulation launch of a bf16 / bf16x2 handle ran the FUSED kernel (round 5; opt-in,
+ * MSM_TICA_IMG_FUSED=1): bfloat16-stored rows, n_features % 256 == 0, ld % 8 == 0, 16-byte aligned trajectories -- the MFMA
+ * kernel's load role stages the raw rows in LDS and forms the pair frames itself, no packed image is written
+ * (tica.py:402-422 in one streamed pass + a column-sum pass).  Bit-identical accumulators to the packed-image pipeline on such
+ * input, half its fabric traffic, no image ring -- and measured slower, hence not the default. */
+int msm_tica_last_img_fused(msm_tica_t* h, int* flag);
 /* profiling: {shader-clock start, end, 100 MHz wall-clock start, end} of workgroup 0 of that launch */
 int msm_tica_debug_clocks(msm_tica_t* h, long long* out4);
 /* profiling builds (csrc built with -DMSM_TICA_PROFILE) only: out64[8 + 8*slot + i] = shader cycles wave 0 of

@@ -1349,8 +1349,18 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const bool ok = inF && (gi * 8 + e) < nv;
-                const float ya = ok ? a[e][q] - r[q] : 0.f, yb = ok ? b[e][q] - r[q] : 0.f;
-                const float u = ya + yb, d = ya - yb;
+                float u, d;
+                if (P.dtype_bytes == 2) {
+                    // bfloat16 rows: a + b and a - b are exact in fp32 (8-bit significands), so ONE rounding each -- and the
+                    // arithmetic of the fused kernel (tica_img_dev.h), which this path must match bit for bit
+                    u = ok ? (a[e][q] + b[e][q]) - 2.f * r[q] : 0.f;
+                    d = ok ? a[e][q] - b[e][q] : 0.f;
+                } else {
+                    // float32 rows: x - r first (exact by Sterbenz when |mean| >> std, the case the shift exists for)
+                    const float ya = ok ? a[e][q] - r[q] : 0.f, yb = ok ? b[e][q] - r[q] : 0.f;
+                    u = ya + yb;
+                    d = ya - yb;
+                }
                 const __bf16 u1 = (__bf16)u, d1 = (__bf16)d;
                 uh[e] = u1;
                 dh[e] = d1;
@@ -1383,6 +1393,28 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
 }
 
 // (ImgMfmaArgs and the MFMA kernels of the image path: tica_img_dev.h)
+
+// Round 5, fused kernel (tica_img_dev.h): the K-step records {row of the step's first pair, valid pairs} from the chunk table.
+// A chunk's pairs are padded to whole 32-pair steps exactly as tica_img_kernel padded the image (g0 = the chunk's first
+// 8-pair group); bf16x2 splits a 32-pair step into two 16-pair steps (the second may hold no pair: nvalid 0).
+__global__ void tica_img_steps_kernel(const TicaChunk* __restrict__ chunks, long long ld, int lag, int x2, ImgStep* __restrict__ steps)
+{
+    const TicaChunk ch = chunks[blockIdx.x];
+    long long nv = ch.len - lag - ch.row0;
+    if (nv > ch.n) nv = ch.n;
+    if (nv < 0) nv = 0;
+    const long long n32 = (nv + 31) / 32, first = ch.g0 / 4;
+    for (long long j = threadIdx.x; j < n32; j += blockDim.x) {
+        const char* base = (const char*)ch.base + (size_t)(ch.row0 + j * 32) * (size_t)ld * 2;
+        const int n = (int)(nv - j * 32 < 32 ? nv - j * 32 : 32);
+        if (!x2) {
+            steps[first + j] = ImgStep{base, n, 0};
+        } else {
+            steps[2 * (first + j)] = ImgStep{base, n < 16 ? n : 16, 0};
+            steps[2 * (first + j) + 1] = n > 16 ? ImgStep{base + (size_t)16 * (size_t)ld * 2, n - 16, 0} : ImgStep{base, 0, 0};
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // Column sums s0 / stau (tica.py:418-419) + the finite check of
@@ -2085,6 +2117,8 @@ struct msm_tica {
     bool slabs_dirty = false;   // slabs_sym hold something since the last reset (a rejected folded launch must be able to undo itself)
     DevBuf snap;                // ... from this copy
     DevBuf foldimg;             // bf16 image path: [nchunks][F] per-chunk sums of the left frames
+    DevBuf imgsteps;            // fused bf16 kernel: the launch's K-step records (tica_img_steps_kernel)
+    int last_fused = 0;         // the last accumulate ran the fused kernel (msm_tica_last_img_fused)
     long long n_sh = 0, nw_sh = 0;  // shifted pairs, and the total weight of their Gram terms (2 n_sh for whole trajectories)
     long long n_obs = 0, n_seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the most recent MFMA launch (bf16 image path: the whole pack + multiply pipeline)
@@ -2179,6 +2213,17 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
     const bool bfmode = (h->mode == MSM_TICA_BF16 || h->mode == MSM_TICA_BF16X2);
     const bool useimg = bfmode && h->img_on && (dtype_bytes == 4 || dtype_bytes == 2);  // packed bf16 image + 256 x 256 tiles
+    // Round 5, MSM_TICA_IMG_FUSED=1 (read per launch): bfloat16-STORED rows of whole 256-feature panels skip the image -- the MFMA
+    // kernel's load role stages the raw rows in LDS and forms the packets itself (tica_img_fused_kernel; its slabs equal the
+    // packed-image pipeline's bit for bit).  Half the fabric traffic and no ring, but NOT faster (1M x 2048: 13.9 ms + a
+    // column-sum pass against 12.3 ms; DESIGN 3.2c has the measurements), so the packed image stays the default.
+    bool usefused = false;
+    if (useimg && dtype_bytes == 2 && h->F % 256 == 0 && ld % 8 == 0) {
+        const char* fe = getenv("MSM_TICA_IMG_FUSED");
+        usefused = fe && atoi(fe) == 1;
+        for (msm_idx_t s = 0; s < n_seq && usefused; ++s)
+            if (((uintptr_t)ptrs[s]) & 15) usefused = false;   // 16-byte LDS-direct row pieces
+    }
     // (a bf16 mode whose 256-wide tiles do not fit one resident round -- beyond 3,840 features -- runs the fp32 C/G kernel:
     //  the mode is an accuracy floor, not a promise of the bf16 pipe; bfloat16-stored rows there take the fp64 kernel)
     const bool use32 = dtype_bytes == 4 && (h->mode == MSM_TICA_F32 || (bfmode && !useimg));
@@ -2190,7 +2235,10 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
-    if (useimg && kc > 2048) kc = 2048;   // a chunk = one workgroup column of the packing pre-pass: finer chunks, more of them in flight
+    // a chunk = one workgroup column of the packing pre-pass: finer chunks, more of them in flight (round 5, measured at 1M x 2048
+    // bfloat16-stored, pack + multiply: 2048 -> 12.7 ms, 1024 -> 12.3, 512 -> 11.9, 256 -> 11.6; 1024 keeps the per-chunk
+    // column sums of a 6.25M-frame fit at 100 MB)
+    if (useimg && kc > 1024) kc = 1024;
     if (kc < bk) kc = bk;
     if (kc == KCMAX && total < 16LL * KCMAX * S && !useimg) {
         // Few chunks per cohort (one rank's share of a strong-scaled fit: 1.25M frames = 7.35 chunks of 4096 per cohort, the
@@ -2307,7 +2355,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // left frames, a column-sum pass over the first and last `lag` rows of every trajectory supplies what separates the
     // right frames' sums from the left frames' (and checks those rows), and the finite check is made on the sums afterwards.
     bool fold = false;
-    if (usesym && !segs && h->fold && (useimg || h->F % TM == 0)) {   // (bf16 image path: the pre-pass sums while it packs)
+    if (usesym && !segs && h->fold && !usefused && (useimg || h->F % TM == 0)) {   // (bf16 image path: the pre-pass sums while it packs; the fused kernel has no pre-pass: column-sum pass)
         // MSM_TICA_FOLD, read per launch (A/B switch of the tests): 0 = never, 2 = whatever the size; default: launches of
         // at least 2^26 elements (frames x features)
         const char* fe = getenv("MSM_TICA_FOLD");
@@ -2473,7 +2521,39 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // 2) the MFMA pass
     MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned), stream()));
     if (!useimg && h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));   // (image path: recorded below, around the whole pipeline)
-    if (useimg) {
+    h->last_fused = 0;
+    if (usefused && img_groups > 0 && img_groups / 2 < 0x7fffffffLL) {
+        // ONE launch over every K-step of the call: step records from the chunk table, then the fused kernel
+        const bool x2 = h->mode == MSM_TICA_BF16X2;
+        const long long nsteps = x2 ? img_groups / 2 : img_groups / 4;
+        int rc = h->imgsteps.reserve((size_t)nsteps * sizeof(ImgStep));
+        if (rc) return rc;
+        if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
+        hipLaunchKernelGGL(tica_img_steps_kernel, dim3((unsigned)P.nchunks), dim3(64), 0, stream(), P.chunks, (long long)ld, h->lag, x2 ? 1 : 0,
+                           h->imgsteps.as<ImgStep>());
+        MSM_HIP_CHECK(hipGetLastError());
+        ImgFusedArgs FA;
+        memset(&FA, 0, sizeof(FA));
+        FA.steps = h->imgsteps.as<ImgStep>();
+        FA.shift = P.shift;
+        FA.row_bytes = (long long)ld * 2;
+        FA.lag_bytes = (long long)h->lag * (long long)ld * 2;
+        FA.nsteps = (int)nsteps;
+        FA.T = h->T;
+        FA.T2 = h->T2;
+        FA.ntiles_sym = h->ntiles_sym;
+        FA.ntile2 = h->ntile2;
+        FA.S = h->S_img;
+        FA.main_steps = img_main_steps(nsteps, h->img_grid, h->ntile2);
+        FA.kflush_steps = std::max(1, x2 ? P.kflush / 16 : 8 * P.kflush / 32);   // (the image path's merge interval)
+        FA.slabs = h->slabs_sym;
+        if (x2)
+            hipLaunchKernelGGL((tica_img_fused_kernel<true>), dim3((unsigned)h->img_grid), dim3(IMG_NT), IMG_FUSED_LDS, stream(), FA);
+        else
+            hipLaunchKernelGGL((tica_img_fused_kernel<false>), dim3((unsigned)h->img_grid), dim3(IMG_NT), IMG_FUSED_LDS, stream(), FA);
+        MSM_HIP_CHECK(hipGetLastError());
+        h->last_fused = 1;
+    } else if (useimg) {
         // The image is produced and consumed in SUPER-CHUNKS through a ring that the library owns (runtime.hip, img_ring):
         // tica_img_kernel packs as many chunks as the ring holds, tica_img_pp_kernel multiplies them, and so on, all on
         // stream().  Round 3 packed the WHOLE input into a per-handle image first (2x - 4x the input bytes of scratch,
@@ -2744,6 +2824,10 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_LDS));
             MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<true, IMG_LAG>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_fused_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_FUSED_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_fused_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_FUSED_LDS));
             if (!img_ring()) { delete h; return MSM_ERR_HIP; }   // the process's image ring exists before any fit is timed
             h->img_on = 1;
             h->img_grid = std::max(num_cus(), h->ntile2);   // one workgroup per CU: whole cohorts + a remainder cohort (tica_img_dev.h)
@@ -2946,6 +3030,13 @@ int msm_tica_last_folded(msm_tica_t* h, int* flag)
 {
     if (!h || !flag) return fail(MSM_ERR_STATE, "null argument");
     *flag = h->last_folded ? 1 : 0;
+    return MSM_OK;
+}
+
+int msm_tica_last_img_fused(msm_tica_t* h, int* flag)
+{
+    if (!h || !flag) return fail(MSM_ERR_INVALID, "msm_tica_last_img_fused: null argument");
+    *flag = h->last_fused;
     return MSM_OK;
 }
 

@@ -19,6 +19,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace msm {
@@ -297,5 +299,374 @@ __global__ __launch_bounds__(IMG_NT, 1) void tica_img_pp_kernel(ImgMfmaArgs P)
             img_pp_segment<X2, LAG, WRAP, ABL>(P, smem, unit, S, S * P.main_steps, (int)P.nsteps);
     }
 }
+
+
+// =====================================================================================================================
+// Round 5: the FUSED kernel -- bfloat16-stored trajectories, no image.
+//
+// The two-kernel path writes the pair frames u = x_t + x_{t+tau} - 2 r and d = x_t - x_{t+tau} as a packed image (2x the
+// bfloat16 input) and reads it back 1.8x through the L2 fabric: 7.9x the algorithmic bytes per fit, with the packing pass
+// serialised in front of the multiply (profiles/r04_pmc_config5.txt).  Here the load role of the ping-pong kernel reads
+// the RAW rows x_t, x_{t+tau} (8-byte loads: four bfloat16 features of one pair per lane, a wave-instruction = one
+// 512-byte row segment of a 256-feature panel), forms u (H units) or d (D units) in fp32, rounds to bf16
+// (bf16x2: hi, or mid = bf16(v - hi)) and writes the four 16-byte packets of its 4 features x 8 pairs straight into the
+// slot ring.  The 8 x 4 transpose costs nothing: a packet is the eight pairs of ONE feature, which the lane already
+// holds in eight registers.  No image, no second kernel, no ring in HBM; the lag, the trajectory edges and the shift are
+// handled once per (unit, element) in the load role, beside the partner wave's MFMAs.
+//
+//   * Packet placement.  A lane owns features 4 l .. 4 l + 3 of its panel; writing packet q of every lane at its natural
+//     position (4 l + q) 16 would put the 8 lanes of a ds_write_b128 group on 2 of the 8 bank groups (4-way conflict).
+//     The slot therefore holds each 32-feature block PERMUTED: feature 4 c + q sits at position 8 q + c, so 8 consecutive
+//     lanes write 128 contiguous bytes.  The fragment reads are unchanged (position-linear, conflict-free); the MFMA
+//     tile's row / column p of a block is feature beta(p) = 4 (p & 7) + (p >> 3), and only the slab merge (img_flush,
+//     PERM) needs to know.  Every accumulator still adds the same products in the same order as the image path's, so the
+//     slabs are bit-identical to the two-kernel path's on the same bfloat16 input (tests/test_gpu_configs.py).
+//   * Steps.  K-step s of the launch is described by a 16-byte record {row of pair 0, valid pairs} built on the device
+//     from the chunk table (tica.hip, tica_img_steps_kernel): trajectories are padded to whole 32-pair steps exactly as
+//     the image was; invalid pairs of a trajectory's last step read a zero row and subtract no shift, i.e. give the
+//     zero packets the image held.
+//   * Ring: D = 2 steps ahead, NS = 3 slots (96 KiB).  The raw rows of step s + 3 are in registers (16 x 8 bytes per
+//     lane) while step s is multiplied: one full step (two phases) to land, waited for by the compiler's own vmcnt.
+//       phase 2n    : waves 0-3  MFMA(s)   | waves 4-7  fragments(s),     convert panel A of step s + 2, load A raw of s + 3
+//       phase 2n + 1: waves 4-7  MFMA(s)   | waves 0-3  fragments(s + 1), convert panel B of step s + 2, load B raw of s + 3
+//     A(t) is written in phase 2 (t - 2), B(t) in 2 (t - 2) + 1; first read in phase 2 t - 1 (RAW: two barriers between);
+//     the slot of step t is last read in phase 2 t and rewritten from phase 2 (t + 1) (WAR: one barrier between).
+// =====================================================================================================================
+struct ImgStep {
+    const void* rowa;   // x_t row of the step's first pair (trajectory-relative, bfloat16)
+    int nvalid;         // pairs of this step that exist (0 .. pairs per step); the rest are zero packets
+    int pad;
+};
+
+struct ImgFusedArgs {
+    const ImgStep* steps;   // [nsteps]
+    const float* shift;     // [F] reference row r, or nullptr
+    long long row_bytes;    // ld * 2
+    long long lag_bytes;    // lag * ld * 2
+    int nsteps;
+    int T, T2, ntiles_sym, ntile2, S, kflush_steps, main_steps;
+    double* slabs;
+};
+
+typedef unsigned img_u32x2 __attribute__((ext_vector_type(2)));
+
+// img_flush for the permuted slot layout: tile position p of a 32-block is feature beta(p) = 4 (p & 7) + (p >> 3)
+__device__ __forceinline__ void img_flush_perm(img_f32x16 (&acc)[2][4], double* slabs, int ntiles_sym, int T, int cohort, int which, int I, int J,
+                                               int wr, int wc, int kl, int cl)
+{
+    const int ti = 2 * I + (wr >> 1), tj = 2 * J + wc;
+    if (ti <= tj && tj < T) {
+        const int st = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+        double* slab = slabs + ((size_t)cohort * ntiles_sym + st) * (2 * IMG_TM * IMG_TM) + (size_t)which * (IMG_TM * IMG_TM);
+        // accumulator r of block (bi, bj): position row (r & 3) + 8 (r >> 2) + 4 kl -> feature 4 (r & 3) + 16 kl + (r >> 2)
+        unsigned toff = (unsigned)(((wr & 1) * 64 + 16 * kl) * IMG_TM + 4 * (cl & 7) + (cl >> 3));
+        asm volatile("" : "+v"(toff));
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {   // eight words at a time: the merge must not push the loop's registers out
+                    double old[8];
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * h + r8;
+                        old[r8] = (slab + (bi * 32 + 4 * (r & 3) + (r >> 2)) * IMG_TM + bj * 32)[toff];
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * h + r8;
+                        (slab + (bi * 32 + 4 * (r & 3) + (r >> 2)) * IMG_TM + bj * 32)[toff] = old[r8] + (double)acc[bi][bj][r];
+                    }
+                }
+    }
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+}
+
+template <bool X2, int WHICH, int ABL>
+__device__ __forceinline__ void img_fused_segment(const ImgFusedArgs& P, char* smem, int I, int J, int cohort, int s0, int s1)
+{
+    constexpr int D = 2, NS = 3;
+    constexpr int PS = X2 ? 16 : 32;                              // pairs per K-step
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wi = wave & 3;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kl = lane >> 5, cl = lane & 31;
+
+    img_f32x16 acc[2][4];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+    if (s1 <= s0) return;   // uniform over the workgroup
+    // LDS: [8 waves][x_t rows | x_{t+tau} rows][8 rows][512 bytes] raw staging, then the packet ring [3][A, B][4][256].  (Staging
+    // FIRST: the LDS-DMA destination is M0-addressed; the ring is only ever touched by ds_read / ds_write.)
+    char* const rawbuf = smem + (unsigned)wave * 8192u;
+    char* const ring = smem + 65536u;
+
+    // ---- the load role: packet row `wi` of ONE panel per step (waves 4-7: panel A = columns I; waves 0-3: panel B = columns J)
+    const int mypanel = grp == 1 ? 0 : 1;
+    const int kr = X2 ? (wi & 1) : wi;                            // 8-pair group of the step this wave converts
+    const bool midrow = X2 && wi >= 2;                            // bf16x2: packet rows 2-3 hold mid = bf16(v - hi)
+    const int col0 = (mypanel == 0 ? I : J) * 256;
+    float r2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (WHICH == 0 && P.shift) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r2[q] = 2.f * P.shift[col0 + 4 * lane + q];
+    }
+    // feature 4 c + q of a 32-block sits at position 8 q + c: lane l = 8 block + c writes packet q at (32 block + 8 q + c) 16
+    const unsigned wr_off = (unsigned)(mypanel * 16384 + wi * 4096 + ((lane >> 3) * 32 + (lane & 7)) * 16);
+    const unsigned long long krb = (unsigned long long)(kr * 8) * (unsigned long long)P.row_bytes;   // this wave's first pair row inside a step
+
+    // ---- raw rows: global -> LDS directly (global_load_lds, 16 bytes per lane: lanes 0-31 one 512-byte panel row, lanes 32-63 the
+    //      next) into the wave's PRIVATE staging area, read back as ds_read_b64 one step later.  Only the issuing wave reads its
+    //      staging area: its own vmcnt(0) orders the data, no barrier is involved.  Measured (scripts/micro/img_fused.hip,
+    //      profiles/r05_img_fused_micro.txt): loads that RETURN TO REGISTERS cost the CU's texture path ~24 (8-byte) / ~28
+    //      (16-byte) cycles per wave-instruction, serialised per CU -- 128 / 64 of them per step made the step 3.4x / 2.4x its
+    //      MFMA time whether the input was cache-resident or not; LDS-direct pieces are cheaper and need no registers.
+    unsigned voffD[4];   // piece i of an operand: rows 2 i (lanes 0-31) and 2 i + 1 (lanes 32-63) of the wave's group
+#pragma unroll
+    for (int i = 0; i < 4; ++i)   // (- 1024 i: the instruction's immediate offset, which places piece i in LDS, advances the GLOBAL address too)
+        voffD[i] = (unsigned)(col0 * 2 + (lane & 31) * 16) + (unsigned)(2 * i + (lane >> 5)) * (unsigned)P.row_bytes - (unsigned)(1024 * i);
+    int nv_raw = PS;                       // valid pairs of the STAGED step (set when its pieces were issued)
+    int nv_next = PS;                      // ... of the step being issued
+    unsigned long long base_a = 0;         // its x_t rows (scalar)
+    auto dma_record = [&](int step) {      // the step's record through the CONSTANT address space: uniform address -> s_load
+        const int sc = step < s1 ? step : s1 - 1;                 // beyond the share: a harmless re-load, converted into a dead slot
+        typedef const __attribute__((address_space(4))) ImgStep* step_cptr;
+        const step_cptr dp = (step_cptr)(uintptr_t)(P.steps + sc);
+        base_a = (unsigned long long)(uintptr_t)dp->rowa;
+        nv_next = dp->nvalid;
+    };
+#define IMG_FU_PIECE(I_)                                                                                                       \
+    do {                                                                                                                       \
+        if (!(ABL & 1)) {                                                                                                      \
+            unsigned off_ = voffD[I_];                                                                                         \
+            asm volatile("" : "+v"(off_)); /* keeps the zero-extension in this block: SGPR base + 32-bit VGPR offset form */    \
+            const unsigned long long ba_ = base_a + krb, bb_ = ba_ + (unsigned long long)P.lag_bytes;                          \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((global_ptr<char>)ba_ + off_),    \
+                                             (__attribute__((address_space(3))) void*)rawbuf, 16, (I_) * 1024, 0);             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((global_ptr<char>)bb_ + off_),    \
+                                             (__attribute__((address_space(3))) void*)(rawbuf + 4096), 16, (I_) * 1024, 0);    \
+        }                                                                                                                      \
+    } while (0)
+    auto dma_generic = [&]() {             // any step: a padding pair re-reads the step's last valid pair (its packet entries are zeroed)
+        if (ABL & 1) return;
+        const int last = nv_next > 0 ? nv_next - 1 : 0;   // (bf16x2: the second 16-pair step of a padded 32-pair step may hold no pair at all)
+        const unsigned coloff = (unsigned)(col0 * 2 + (lane & 31) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = kr * 8 + 2 * i + (lane >> 5);
+            const int pe = p < last ? p : last;
+            const global_ptr<char> ga = (global_ptr<char>)(base_a + (unsigned long long)(unsigned)pe * (unsigned long long)P.row_bytes) + coloff;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                             (__attribute__((address_space(3))) void*)(rawbuf + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (size_t)P.lag_bytes),
+                                             (__attribute__((address_space(3))) void*)(rawbuf + 4096 + i * 1024), 16, 0, 0);
+        }
+    };
+    img_u32x2 ra[8], rb[8];
+    auto read_staged = [&]() {   // the wave's staged rows -> registers (ds_read_b64 of 512-byte rows: conflict-free)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of one step ago (the loop has no other VMEM)
+        if (ABL & 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ra[e] = img_u32x2{0x3f803f80u, 0x3f803f80u}; rb[e] = img_u32x2{0x3f003f00u, 0x3f003f00u}; }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ra[e] = *reinterpret_cast<const img_u32x2*>(rawbuf + e * 512 + lane * 8);
+            rb[e] = *reinterpret_cast<const img_u32x2*>(rawbuf + 4096 + e * 512 + lane * 8);
+        }
+    };
+    // packet q of the lane's four features: 8 pairs x (unpack a, unpack b, u or d, round) -> one ds_write_b128
+    auto convert_q = [&](char* dst, int q, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if (ABL & 16) return;
+        bf16x8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned wa = q < 2 ? ra[e].x : ra[e].y, wb = q < 2 ? rb[e].x : rb[e].y;
+            const float a = (q & 1) ? __uint_as_float(wa & 0xffff0000u) : __uint_as_float(wa << 16);
+            const float b = (q & 1) ? __uint_as_float(wb & 0xffff0000u) : __uint_as_float(wb << 16);
+            float v = WHICH == 0 ? (a + b) - r2[q] : a - b;
+            if (TAIL && !(kr * 8 + e < nv_raw)) v = 0.f;   // (uniform) a padding pair: the zero packet entries the image held
+            const __bf16 hi = (__bf16)v;
+            pk[e] = midrow ? (__bf16)(v - (float)hi) : hi;
+        }
+        *reinterpret_cast<bf16x8*>(dst + q * 128) = pk;
+    };
+#define IMG_FU_LDS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    // One load phase's raw-row work: the staged step (valid pairs nv_raw) -> packets of ring slot `slot`; the pieces of `next`
+    // issued BETWEEN the packets, so that the texture path works while the VALU converts (issued in one burst at the end of
+    // the phase -- the first version -- the eight pieces sat on the phase's critical path: 14.4 ms per 1M x 2048).
+    auto convert_and_issue = [&](int slot, int next) {
+        read_staged();
+        dma_record(next);
+        IMG_FU_LDS_DONE();                             // the staged rows are in registers (and the record in SGPRs) before new pieces land
+        __builtin_amdgcn_sched_barrier(0);
+        char* dst = ring + (unsigned)slot * IMG_SLOT + wr_off;
+        if (__builtin_expect(nv_raw >= PS && nv_next >= PS, 1)) {   // (uniform) every pair of both steps exists
+            IMG_FU_PIECE(0);
+            __builtin_amdgcn_sched_barrier(0);
+            convert_q(dst, 0, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            IMG_FU_PIECE(1);
+            __builtin_amdgcn_sched_barrier(0);
+            convert_q(dst, 1, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            IMG_FU_PIECE(2);
+            __builtin_amdgcn_sched_barrier(0);
+            convert_q(dst, 2, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            IMG_FU_PIECE(3);
+            __builtin_amdgcn_sched_barrier(0);
+            convert_q(dst, 3, std::false_type{});
+        } else {                                       // a trajectory's last step on either side
+            dma_generic();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) convert_q(dst, q, std::true_type{});
+            asm volatile("" ::: "memory");             // keeps the two bodies apart (if-converted, every element pays a v_cndmask)
+        }
+        nv_raw = nv_next;
+    };
+    // ---- fragments and MFMAs: tica_img_pp_kernel's, on positions.  Only fragment set 0 is read in the load phase; set 1 is read
+    //      by the multiplying wave itself, ahead of its first MFMA (the first eight MFMAs, 256 cycles, cover the reads): 24
+    //      registers fewer live beside the raw rows and their packets -- without it the kernel spilled.
+    const unsigned fragA = (unsigned)((kl * 256 + wr * 64 + cl) * 16);
+    const unsigned fragB = (unsigned)(16384 + (kl * 256 + wc * 128 + cl) * 16);
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
+    auto frags_set = [&](int slot, int set) {
+        if (ABL & 2) return;
+        const char* base = ring + (unsigned)slot * IMG_SLOT;
+        constexpr int k0 = X2 ? 2 : 0, k1 = X2 ? 0 : 2;
+        if (set == 0) {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) fa0[bi] = *reinterpret_cast<const bf16x8*>(base + fragA + (k0 * 256 + bi * 32) * 16);
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) fb0[bj] = *reinterpret_cast<const bf16x8*>(base + fragB + (k0 * 256 + bj * 32) * 16);
+        } else {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) fa1[bi] = *reinterpret_cast<const bf16x8*>(base + fragA + (k1 * 256 + bi * 32) * 16);
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) fb1[bj] = *reinterpret_cast<const bf16x8*>(base + fragB + (k1 * 256 + bj * 32) * 16);
+        }
+    };
+    auto mfmas = [&](int slot) {
+        frags_set(slot, 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+                acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
+        if (X2) {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 4; ++bj) {
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb0[bj], acc[bi][bj], 0, 0, 0);
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+                acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[bi], fb1[bj], acc[bi][bj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define IMG_FU_BARRIER() do { if (!(ABL & 4)) __builtin_amdgcn_s_barrier(); } while (0)
+
+    // ---- prologue: every wave stages and converts its rows of steps s0, s0 + 1 into slots 0, 1 and stages those of s0 + 2
+    dma_record(s0);
+    dma_generic();
+    nv_raw = nv_next;
+    convert_and_issue(0, s0 + 1);
+    convert_and_issue(1, s0 + 2);
+    IMG_FU_LDS_DONE();
+    IMG_FU_BARRIER();
+
+    int slot = 0, slot_ld = D;
+    int steps_acc = 0;
+    if (grp == 0) {
+        frags_set(0, 0);
+        for (int s = s0; s < s1; ++s) {
+            const int slot1 = slot + 1 == NS ? 0 : slot + 1;
+            mfmas(slot);                               // phase 2n
+            IMG_FU_BARRIER();
+            if (++steps_acc >= P.kflush_steps || s + 1 == s1) {   // (the merge BEFORE the next fragments are read: fewer registers live across it)
+                steps_acc = 0;
+                img_flush_perm(acc, P.slabs, P.ntiles_sym, P.T, cohort, WHICH, I, J, wr, wc, kl, cl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < s1) frags_set(slot1, 0);       // phase 2n + 1
+            __builtin_amdgcn_sched_barrier(0);
+            convert_and_issue(slot_ld, s + D + 1);     //   panel B of step s + 2 (staged one step ago); stage step s + 3
+            IMG_FU_LDS_DONE();
+            IMG_FU_BARRIER();
+            slot = slot1;
+            slot_ld = slot_ld + 1 == NS ? 0 : slot_ld + 1;
+        }
+    } else {
+        for (int s = s0; s < s1; ++s) {
+            frags_set(slot, 0);                        // phase 2n
+            __builtin_amdgcn_sched_barrier(0);
+            convert_and_issue(slot_ld, s + D + 1);     //   panel A of step s + 2
+            IMG_FU_LDS_DONE();
+            IMG_FU_BARRIER();
+            mfmas(slot);                               // phase 2n + 1
+            IMG_FU_BARRIER();
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            slot_ld = slot_ld + 1 == NS ? 0 : slot_ld + 1;
+            if (++steps_acc >= P.kflush_steps || s + 1 == s1) {
+                steps_acc = 0;
+                img_flush_perm(acc, P.slabs, P.ntiles_sym, P.T, cohort, WHICH, I, J, wr, wc, kl, cl);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail pieces: nothing may still be writing LDS ...
+    IMG_FU_BARRIER();                                  // ... or reading the ring when the next segment's prologue refills it (or at exit)
+#undef IMG_FU_BARRIER
+#undef IMG_FU_LDS_DONE
+#undef IMG_FU_PIECE
+}
+
+template <bool X2, int ABL>
+__device__ __forceinline__ void img_fused_unit(const ImgFusedArgs& P, char* smem, int unit, int cohort, int s0, int s1)
+{
+    int which, I, J;
+    img_decode_unit(unit, P.T2, which, I, J);
+    if (which == 0) img_fused_segment<X2, 0, ABL>(P, smem, I, J, cohort, s0, s1);
+    else img_fused_segment<X2, 1, ABL>(P, smem, I, J, cohort, s0, s1);
+}
+
+// work split: tica_img_pp_kernel's (whole cohorts + a remainder cohort)
+template <bool X2, int ABL = 0>   // ABL (micro-benchmark): 1 no global loads, 2 no fragment reads, 4 no barriers, 16 no conversion
+__global__ __launch_bounds__(IMG_NT, 1) void tica_img_fused_kernel(ImgFusedArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [8 waves][x_t | x_{t+tau}][8 rows][512 bytes], then [3][A, B][4][256] packets
+    const int U = P.ntile2, G = (int)gridDim.x;
+    const int S = G / U, R = G - S * U;
+    const int p = img_xcd_linear_id();
+    if (p < S * U) {
+        const int cohort = p / U;
+        const int s1 = (R == 0 && cohort == S - 1) ? P.nsteps : (cohort + 1) * P.main_steps;
+        img_fused_unit<X2, ABL>(P, smem, p - cohort * U, cohort, cohort * P.main_steps, s1);
+    } else {
+        const int r = p - S * U;
+        for (int unit = r; unit < U; unit += R) img_fused_unit<X2, ABL>(P, smem, unit, S, S * P.main_steps, P.nsteps);
+    }
+}
+constexpr size_t IMG_FUSED_LDS = 8 * 8192 + (size_t)3 * IMG_SLOT;   // 64 KiB of raw staging + 96 KiB of packet ring = all 160 KiB of the CU
 
 }  // namespace msm

@@ -189,6 +189,43 @@ def test_config5_bf16_image_path_vs_oracle(gpu, monkeypatch, mode, rtol, ctol, F
     np.testing.assert_allclose(mb.covariance_, ob.covariance_, rtol=0, atol=ctol * np.abs(ob.covariance_).max())
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x2"])
+@pytest.mark.parametrize("F,lag", [(2048, 100), (512, 7), (256, 33)])
+def test_config5_fused_kernel_bit_identical_to_image_path(gpu, monkeypatch, mode, F, lag):
+    """Round 5: with MSM_TICA_IMG_FUSED=1 bfloat16-stored rows of whole 256-feature panels run the FUSED kernel (no packed
+    image; the MFMA kernel's load role forms u = x_t + x_{t+tau} - 2 r and d = x_t - x_{t+tau} from the raw rows).  Its
+    accumulators must equal the packed-image pipeline's bit for bit: same products, same order, same roundings.  Ragged
+    trajectories: lengths that leave 1, 12, 17 and 31 pairs in the last K-step, one of lag + 1 rows, one too short."""
+    import ctypes as C
+    import torch
+    from msmbuilder_amd import tICA, _lib
+    g = torch.Generator(device="cuda").manual_seed(F + lag)
+    lens = [3 * 32 + lag + 1, 40 * 32 + lag + 12, 2000 + lag + 17, 1500 * 2 + lag + 31 - 8, lag + 1, lag, 4096 + lag]
+    base = 3.0 * torch.randn(F, generator=g, device="cuda")
+    seqs = [(base + torch.randn(n, F, generator=g, device="cuda").cumsum(0) * 0.05
+             + torch.randn(n, F, generator=g, device="cuda")).to(torch.bfloat16) for n in lens]
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    monkeypatch.setenv("MSM_TICA_FOLD", "0")      # both paths take the same column-sum pass: every exported word comparable
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MSM_TICA_IMG_FUSED", fused)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=3, lag_time=lag).fit(seqs)
+            # a second call on the same handle: partial_fit on top of existing slabs (the shift row is already set)
+            m.partial_fit(seqs[1])
+        flag = C.c_int(-1)
+        _lib.check(_lib.lib().msm_tica_last_img_fused(m._handle, C.byref(flag)))
+        assert flag.value == int(fused)
+        m._pull()
+        out[fused] = [np.array(getattr(m, a)) for a in ("_outer_0_to_T_lagged", "_outer_gram_sum", "_sum_0_to_TminusTau",
+                                                         "_sum_tau_to_T")] + [np.asarray(m.eigenvalues_)]
+        assert (m.n_observations_, m.n_sequences_) == (sum(n for n in lens if n > lag) + lens[1], 7)
+        assert np.abs(out[fused][0]).max() > 0 and np.isfinite(out[fused][1]).all()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+
+
 def test_config5_per_gpu_share_6250000_x_2048_bf16_stored(gpu, monkeypatch):
     """BASELINE configs[4] at the size ONE of its 8 GPUs holds: 6,250,000 x 2048, bfloat16-STORED (25.6 GB), lag 100,
     through the bf16 image path in both of its modes.  Reference: an independent float64 contraction of the stored values
