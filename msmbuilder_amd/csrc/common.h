@@ -95,10 +95,6 @@ int pair_residual_device(const double* Cm, int n, const double* Y, const double*
 int subspace_topk_device(const double* Cm, int n, int k, double lower, double tol, int degree, int max_outer, double* lam,
                          double* Yk, double* work, double* pin /* subspace_pin_doubles() of pinned host memory */, int* converged,
                          int* outer_used, double first_cut /* prior for the first filter, NaN: Rayleigh-Ritz first */, double first_top);
-// ... queued: nothing synchronised, nothing copied; *dstate (device, or null when the route does not apply) = four ints
-// {done, converged, Rayleigh-Ritz rounds, -} the caller reads back with its results; lam / Yk are valid when converged
-int subspace_topk_queued(const double* Cm, int n, int k, double lower, double tol, int degree, int rounds, double* lam, double* Yk,
-                         double* work, double first_cut, double first_top, const void** dstate);
 size_t subspace_work_doubles(int n);
 size_t subspace_pin_doubles();
 

@@ -35,21 +35,10 @@ constexpr int SS_RT = 4;      // rows of the product per workgroup
 // once, then each wave multiplies a quarter of the panel's columns (lane = a 1 x 2 patch of the 4 x 32 block: one
 // broadcast read of C and one 16-byte read of X per two multiply-adds) and the four partial blocks are summed.
 constexpr int SS_PANEL = 512;
-// Queued (device-driven) iteration: `dcoef` (or null) points at {alpha, beta, gamma} in device memory -- the Chebyshev
-// recurrence of a filter whose bounds the DEVICE chose (ss_residual_kernel's decision) -- and `dstop` (or null) at the
-// iteration's done flag: a set flag makes the launch a no-op, so that a converged block is not filtered away by the launches
-// that were queued behind the decision.
 __global__ __launch_bounds__(SS_NT) void ss_product_kernel(const double* __restrict__ Cm, int n, const double* __restrict__ X,
-                                                           const double* P, double* out, double alpha, double beta, double gamma,
-                                                           const double* __restrict__ dcoef, const int* __restrict__ dstop)
+                                                           const double* P, double* out, double alpha, double beta, double gamma)
 {
     extern __shared__ double ssm[];
-    if (dstop && *dstop) return;
-    if (dcoef) {
-        alpha = dcoef[0];
-        beta = dcoef[1];
-        gamma = dcoef[2];
-    }
     double* sx = ssm;                              // [SS_PANEL][SB]
     double* sc = sx + SS_PANEL * SB;               // [SS_RT][SS_PANEL + 2]
     double* sp = sc + SS_RT * (SS_PANEL + 2);      // [4][SS_RT][SB] partial blocks
@@ -123,10 +112,9 @@ constexpr size_t SS_PRODUCT_LDS = ((size_t)SS_PANEL * SB + (size_t)SS_RT * (SS_P
 // part[blockIdx][i][j] = sum over this block's rows of A[r][i] B[r][j]   (A, B: n x SB)
 constexpr int SG_ROWS = 64;
 __global__ __launch_bounds__(SS_NT) void ss_gram_kernel(const double* __restrict__ A, const double* __restrict__ B, int n,
-                                                        double* __restrict__ part, const int* __restrict__ dstop)
+                                                        double* __restrict__ part)
 {
     __shared__ double sa[SG_ROWS][SB + 1], sb[SG_ROWS][SB + 1];
-    if (dstop && *dstop) return;
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * SG_ROWS;
     for (int q = tid; q < SG_ROWS * SB; q += SS_NT) {
@@ -150,10 +138,8 @@ __global__ __launch_bounds__(SS_NT) void ss_gram_kernel(const double* __restrict
 }
 
 // G = sum of the partial Gram matrices (deterministic order); out[0 .. SB*SB) = G (used for H = X^T W)
-__global__ __launch_bounds__(SS_NT) void ss_gram_sum_kernel(const double* __restrict__ part, int nparts, double* __restrict__ G,
-                                                            const int* __restrict__ dstop)
+__global__ __launch_bounds__(SS_NT) void ss_gram_sum_kernel(const double* __restrict__ part, int nparts, double* __restrict__ G)
 {
-    if (dstop && *dstop) return;
     const double* mine = part + (size_t)blockIdx.x * nparts * SB * SB;   // block 0: part -> G, block 1: part2 -> H (adjacent)
     const int tid = threadIdx.x;
     double acc[SB * SB / SS_NT] = {0.0, 0.0, 0.0, 0.0};
@@ -177,12 +163,11 @@ __global__ __launch_bounds__(SS_NT) void ss_gram_sum_kernel(const double* __rest
 // 32 x 32 matrix redundantly (no exchange) and handles SS_NT rows, one row per thread in registers.
 // *flag is set when G is not numerically positive definite (the block has lost rank): the caller gives up on the method.
 __global__ __launch_bounds__(SS_NT) void ss_cholqr_kernel(const double* __restrict__ part, int nparts, double* X, int n,
-                                                          int* __restrict__ flag, const int* __restrict__ dstop)
+                                                          int* __restrict__ flag)
 {
     __shared__ double sg[SB][SB + 1];
     __shared__ double sinv[SB];
     const int tid = threadIdx.x;
-    if (dstop && *dstop) return;
     {
         double acc[SB * SB / SS_NT] = {0.0, 0.0, 0.0, 0.0};
         for (int p0 = 0; p0 < nparts; p0 += 4) {   // 16 loads in flight per trip
@@ -249,12 +234,10 @@ __global__ __launch_bounds__(SS_NT) void ss_cholqr_kernel(const double* __restri
 }
 
 // X <- X S, W <- W S   (S: SB x SB row-major, columns = Ritz vectors in the wanted order)
-__global__ __launch_bounds__(SS_NT) void ss_rotate_kernel(double* X, double* W, int n, const double* __restrict__ S,
-                                                          const int* __restrict__ dstop)
+__global__ __launch_bounds__(SS_NT) void ss_rotate_kernel(double* X, double* W, int n, const double* __restrict__ S)
 {
     __shared__ double ss[SB][SB + 1];
     const int tid = threadIdx.x;
-    if (dstop && *dstop) return;
     for (int q = tid; q < SB * SB; q += SS_NT) ss[q >> 5][q & (SB - 1)] = S[q];
     __syncthreads();
     const int r = blockIdx.x * (SS_NT / SB) + (tid >> 5), j = tid & (SB - 1);
@@ -280,30 +263,12 @@ __global__ __launch_bounds__(SS_NT) void ss_rotate_kernel(double* X, double* W, 
     }
 }
 
-// State of a queued iteration (device memory, written by ss_state_init_kernel / ss_rr_kernel / ss_residual_kernel, read back
-// ONCE by the host with the solve's results).
-constexpr int SS_MAXDEG = 16;
-struct SsState {
-    int done;        // set when the iteration has decided (either way): every launch queued behind it is a no-op
-    int converged;   // the k leading residuals reached the tolerance
-    int outer;       // Rayleigh-Ritz rounds run
-    int pad;
-    double prev_res; // largest of the k leading residuals at the previous round
-    double rmax;     // ... at the last round
-    double coef[SS_MAXDEG][4];   // the next filter's recurrence: {alpha, beta, gamma} per product
-};
-
-// res[j] = || W[:, j] - theta[j] X[:, j] ||_2; with `st` (queued iteration) thread 0 then DECIDES what the host's loop decided
-// between its round trips: converged (k leading residuals <= tol max(1, |theta_0|)), stalled / out of rounds / degenerate
-// bounds (done, not converged: the caller's fallback takes over), or the recurrence of the next filter of `degree` products
-// damping [lower, theta_31] (Zhou & Saad's scaled three-term form, subspace_topk_device's run_filter).
+// res[j] = || W[:, j] - theta[j] X[:, j] ||_2
 __global__ __launch_bounds__(SS_NT) void ss_residual_kernel(const double* __restrict__ X, const double* __restrict__ W, int n,
-                                                            const double* __restrict__ theta, double* __restrict__ res,
-                                                            SsState* st, int k, double tol, double lower, int degree, int last_round)
+                                                            const double* __restrict__ theta, double* __restrict__ res)
 {
     __shared__ double red[SS_NT / SB][SB];
     const int tid = threadIdx.x, j = tid & (SB - 1), part = tid >> 5;
-    if (st && st->done) return;
     const double th = theta[j];
     double s = 0.0;
     for (int r = part; r < n; r += 8 * (SS_NT / SB)) {   // 16 loads in flight per trip
@@ -326,262 +291,6 @@ __global__ __launch_bounds__(SS_NT) void ss_residual_kernel(const double* __rest
         double t = 0.0;
         for (int p = 0; p < SS_NT / SB; ++p) t += red[p][j];
         res[j] = sqrt(t);
-        red[0][j] = sqrt(t);
-    }
-    if (!st) return;
-    __syncthreads();
-    if (tid == 0) {
-        double rmax = 0.0;
-        bool finite = true;
-        for (int jj = 0; jj < k; ++jj) {
-            const double r = red[0][jj];
-            if (!(r == r)) finite = false;
-            rmax = r > rmax ? r : rmax;
-        }
-        const double top = theta[0], cut = theta[SB - 1];
-        const int outer = st->outer;          // rounds completed BEFORE this one
-        st->outer = outer + 1;
-        st->rmax = rmax;
-        const double scale = fabs(top) > 1.0 ? fabs(top) : 1.0;
-        if (!finite) {
-            st->done = 1;
-        } else if (rmax <= tol * scale) {
-            st->converged = 1;
-            st->done = 1;
-        } else if (last_round || (outer >= 2 && !(rmax < 1e-2 * st->prev_res)) || !(cut > lower) || !(top > cut)) {
-            st->done = 1;                     // stalled, out of rounds, or no usable filter bounds: the caller's fallback decides
-        } else {
-            const double e = 0.5 * (cut - lower), cen = 0.5 * (cut + lower);
-            const double sigma1 = e / (top - cen);
-            double sigma = sigma1;
-            st->coef[0][0] = sigma1 / e;
-            st->coef[0][1] = -sigma1 * cen / e;
-            st->coef[0][2] = 0.0;
-            for (int i = 2; i <= degree; ++i) {
-                const double sn = 1.0 / (2.0 / sigma1 - sigma);
-                st->coef[i - 1][0] = 2.0 * sn / e;
-                st->coef[i - 1][1] = -2.0 * sn * cen / e;
-                st->coef[i - 1][2] = -sigma * sn;
-                sigma = sn;
-            }
-        }
-        st->prev_res = rmax;
-    }
-}
-
-__global__ void ss_state_init_kernel(SsState* st)
-{
-    if (threadIdx.x == 0) {
-        st->done = 0;
-        st->converged = 0;
-        st->outer = 0;
-        st->pad = 0;
-        st->prev_res = 1.0;   // the residual scale of a random block: what the first measured residual is compared with
-        st->rmax = 0.0;
-    }
-}
-
-// dst <- src unless the iteration has decided (the filter's last product may have landed in a scratch block)
-__global__ void ss_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, size_t nelem, const int* __restrict__ dstop)
-{
-    if (dstop && *dstop) return;
-    const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (q < nelem) dst[q] = src[q];
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Rayleigh-Ritz on the DEVICE (round 5): the 32 x 32 generalized problem H s = theta G s that the host solved between two
-// copies and two stream synchronisations (small_geigh: ~0.13 ms of GPU idle per round).  One workgroup:
-//   G = R^T R (upper Cholesky in LDS), M = R^-T H R^-1 (two sweeps of row substitutions), the symmetric eigenproblem of M by
-//   ONE-SIDED Jacobi (Hestenes) on the shifted matrix B = M + shift I > 0 -- column rotations only, 16 disjoint pairs per
-//   round each owned by 16 lanes of one wavefront (dot products by DPP-free shuffles, no barrier inside a pair; one barrier
-//   per round because the tournament re-pairs the columns) -- theta_j = v_j^T M v_j, descending order, S = R^-1 V.
-// The pairs that come out of the iteration are verified against the reduced matrix by the caller (pair_residual_device),
-// so a failure here can only cost the fallback's time.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SS_NT) void ss_rr_kernel(const double* __restrict__ GH, double* __restrict__ S, double* __restrict__ theta,
-                                                      const int* __restrict__ qrflag, SsState* st)
-{
-    __shared__ double sg[SB][SB + 1];      // G -> R (upper)
-    __shared__ double sm[SB][SB + 1];      // H -> M
-    __shared__ double sw[SB][SB + 1];      // columns of W = B V, stored [column][row]
-    __shared__ double sv[SB][SB + 1];      // columns of V, stored [column][row]
-    __shared__ double sinv[SB], sth[SB];
-    __shared__ int sord[SB], srot, sbad;
-    const int tid = threadIdx.x;
-    if (st->done) return;
-    if (tid == 0) sbad = (*qrflag) ? 1 : 0;   // rank loss in a Cholesky QR (or non-finite data)
-    for (int q = tid; q < SB * SB; q += SS_NT) {
-        const int i = q >> 5, j = q & (SB - 1);
-        sg[i][j] = 0.5 * (GH[i * SB + j] + GH[j * SB + i]);
-        sm[i][j] = 0.5 * (GH[SB * SB + i * SB + j] + GH[SB * SB + j * SB + i]);
-    }
-    __syncthreads();
-    {
-        double bad = 0.0;
-        for (int q = tid; q < SB * SB; q += SS_NT) {
-            const int i = q >> 5, j = q & (SB - 1);
-            if (!(fabs(sg[i][j]) < 1e300) || !(fabs(sm[i][j]) < 1e300)) bad = 1.0;
-        }
-        if (bad != 0.0) sbad = 1;
-    }
-    __syncthreads();
-    // ---- G = R^T R: ss_cholqr_kernel's loop (unscaled pivot rows, one barrier per step)
-    {
-        const int i = tid >> 3, j0 = (tid & 7) * 4;
-        for (int p = 0; p < SB - 1; ++p) {
-            const double piv = sg[p][p];
-            if (i > p) {
-                const double f = sg[p][i] / piv;
-#pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4)
-                    if (j0 + b4 >= i) sg[i][j0 + b4] -= f * sg[p][j0 + b4];
-            }
-            __syncthreads();
-        }
-        if (tid < SB) {
-            const double piv = sg[tid][tid];
-            if (!(piv > 0.0)) sbad = 1;
-            sinv[tid] = 1.0 / sqrt(piv);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b4 = 0; b4 < 4; ++b4)
-            if (j0 + b4 > i) sg[i][j0 + b4] *= sinv[i];   // R[p][c] = g[p][c] / sqrt(piv_p); 1 / R[p][p] = sinv[p]
-        __syncthreads();
-    }
-    if (sbad) {
-        if (tid == 0) st->done = 1;    // not converged: the caller's fallback takes over
-        return;
-    }
-    // ---- M = R^-T H R^-1: rows of H times R^-1 (thread = a row, ss_cholqr_kernel's substitution), transpose, again
-    for (int pass = 0; pass < 2; ++pass) {
-        if (tid < SB) {
-            double x[SB];
-#pragma unroll
-            for (int jj = 0; jj < SB; ++jj) x[jj] = sm[tid][jj];
-#pragma unroll
-            for (int jj = 0; jj < SB; ++jj) {
-                double t = x[jj];
-#pragma unroll
-                for (int i2 = 0; i2 < jj; ++i2) t -= x[i2] * sg[i2][jj];
-                x[jj] = t * sinv[jj];
-            }
-#pragma unroll
-            for (int jj = 0; jj < SB; ++jj) sw[jj][tid] = x[jj];   // transposed
-        }
-        __syncthreads();
-        for (int q = tid; q < SB * SB; q += SS_NT) sm[q >> 5][q & (SB - 1)] = sw[q >> 5][q & (SB - 1)];
-        __syncthreads();
-    }
-    // symmetrise M; shift = 1 + the largest absolute row sum (Gershgorin): B = M + shift I has its spectrum in [1, 2 shift]
-    for (int q = tid; q < SB * SB; q += SS_NT) {
-        const int i = q >> 5, j = q & (SB - 1);
-        if (i < j) {
-            const double t = 0.5 * (sm[i][j] + sm[j][i]);
-            sm[i][j] = sm[j][i] = t;
-        }
-    }
-    __syncthreads();
-    if (tid < SB) {
-        double rs = 0.0;
-        for (int jj = 0; jj < SB; ++jj) rs += fabs(sm[tid][jj]);
-        sth[tid] = rs;
-    }
-    __syncthreads();
-    double shift = 0.0;
-    for (int jj = 0; jj < SB; ++jj) shift = sth[jj] > shift ? sth[jj] : shift;
-    shift += 1.0;
-    __syncthreads();
-    for (int q = tid; q < SB * SB; q += SS_NT) {
-        const int c = q >> 5, r = q & (SB - 1);
-        sw[c][r] = sm[r][c] + (r == c ? shift : 0.0);
-        sv[c][r] = r == c ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    // ---- one-sided Jacobi: pair g = tid / 16 of the round, its 16 lanes hold rows 2 l, 2 l + 1 of the pair's two columns
-    {
-        const int g = tid >> 4, l = tid & 15;
-        for (int sweep = 0; sweep < 14; ++sweep) {
-            if (tid == 0) srot = 0;
-            __syncthreads();
-            for (int round = 0; round < SB - 1; ++round) {
-                // round-robin tournament on 32 players: player 31 fixed, the others rotate
-                int p, qc;
-                if (g == 0) {
-                    p = SB - 1;
-                    qc = round;
-                } else {
-                    p = (round + g) % (SB - 1);
-                    qc = (round + (SB - 1) - g) % (SB - 1);
-                }
-                double wp0 = sw[p][2 * l], wp1 = sw[p][2 * l + 1], wq0 = sw[qc][2 * l], wq1 = sw[qc][2 * l + 1];
-                double al = wp0 * wp0 + wp1 * wp1, be = wq0 * wq0 + wq1 * wq1, ga = wp0 * wq0 + wp1 * wq1;
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    al += __shfl_xor(al, m, 16);
-                    be += __shfl_xor(be, m, 16);
-                    ga += __shfl_xor(ga, m, 16);
-                }
-                if (fabs(ga) > 2e-14 * sqrt(al * be)) {   // (uniform over the pair's 16 lanes; the dot product of 32 terms carries ~1e-15 of rounding noise:
-                                                          //  a threshold at that level never lets a sweep come out clean -- 30 sweeps, 208 us, measured)
-                    const double zeta = (be - al) / (2.0 * ga);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                    sw[p][2 * l] = c * wp0 - sn * wq0;
-                    sw[p][2 * l + 1] = c * wp1 - sn * wq1;
-                    sw[qc][2 * l] = sn * wp0 + c * wq0;
-                    sw[qc][2 * l + 1] = sn * wp1 + c * wq1;
-                    const double vp0 = sv[p][2 * l], vp1 = sv[p][2 * l + 1], vq0 = sv[qc][2 * l], vq1 = sv[qc][2 * l + 1];
-                    sv[p][2 * l] = c * vp0 - sn * vq0;
-                    sv[p][2 * l + 1] = c * vp1 - sn * vq1;
-                    sv[qc][2 * l] = sn * vp0 + c * vq0;
-                    sv[qc][2 * l + 1] = sn * vp1 + c * vq1;
-                    if (l == 0) srot = 1;
-                }
-                __syncthreads();
-            }
-            if (!srot) break;          // (uniform: read after the round's barrier)
-            __syncthreads();
-        }
-    }
-    // ---- theta_j = v_j^T M v_j (V is orthogonal to rounding); descending order
-    if (tid < SB) {
-        double acc = 0.0;
-        for (int r = 0; r < SB; ++r) {
-            double mv = 0.0;
-            for (int c2 = 0; c2 < SB; ++c2) mv += sm[r][c2] * sv[tid][c2];
-            acc += sv[tid][r] * mv;
-        }
-        sth[tid] = acc;
-    }
-    __syncthreads();
-    if (tid < SB) {
-        int rank = 0;
-        const double mine = sth[tid];
-        for (int jj = 0; jj < SB; ++jj) {
-            const double o = sth[jj];
-            if (o > mine || (o == mine && jj < tid)) ++rank;
-        }
-        sord[rank] = tid;
-    }
-    __syncthreads();
-    // ---- S = R^-1 V (back substitution per column, thread = wanted column), theta
-    if (tid < SB) {
-        const int src = sord[tid];
-        double x[SB];
-#pragma unroll
-        for (int r = 0; r < SB; ++r) x[r] = sv[src][r];
-#pragma unroll
-        for (int r = SB - 1; r >= 0; --r) {
-            double t = x[r];
-#pragma unroll
-            for (int c2 = r + 1; c2 < SB; ++c2) t -= sg[r][c2] * x[c2];
-            x[r] = t * sinv[r];
-        }
-#pragma unroll
-        for (int r = 0; r < SB; ++r) S[r * SB + tid] = x[r];
-        theta[tid] = sth[src];
     }
 }
 
@@ -864,13 +573,13 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     }
     const dim3 gprod((unsigned)ceil_div(n, SS_RT)), gqr((unsigned)ceil_div(n, SS_NT)), grot((unsigned)ceil_div(n, SS_NT / SB));
     auto product = [&](const double* Xin, const double* P, double* out, double a, double b, double c) {
-        hipLaunchKernelGGL(ss_product_kernel, gprod, dim3(SS_NT), SS_PRODUCT_LDS, stream(), Cm, n, Xin, P, out, a, b, c, (const double*)nullptr, (const int*)nullptr);
+        hipLaunchKernelGGL(ss_product_kernel, gprod, dim3(SS_NT), SS_PRODUCT_LDS, stream(), Cm, n, Xin, P, out, a, b, c);
     };
     // one round of Cholesky QR: orthonormal to ~ cond(X)^2 eps, which the Rayleigh-Ritz step below absorbs by solving
     // the small GENERALIZED problem H s = theta G s with G = X^T X
     auto cholqr = [&](double* Q) {
-        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), Q, Q, n, part, (const int*)nullptr);
-        hipLaunchKernelGGL(ss_cholqr_kernel, gqr, dim3(SS_NT), 0, stream(), part, nparts, Q, n, dflag, (const int*)nullptr);
+        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), Q, Q, n, part);
+        hipLaunchKernelGGL(ss_cholqr_kernel, gqr, dim3(SS_NT), 0, stream(), part, nparts, Q, n, dflag);
     };
     MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
     hipLaunchKernelGGL(ss_init_kernel, dim3((unsigned)ceil_div(NB, 256)), dim3(256), 0, stream(), X, n);
@@ -920,9 +629,9 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     for (int outer = 0; outer <= max_outer; ++outer) {
         // ---- Rayleigh-Ritz on span(X)
         product(X, nullptr, W, 1.0, 0.0, 0.0);
-        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, X, n, part, (const int*)nullptr);
-        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, W, n, part2, (const int*)nullptr);
-        hipLaunchKernelGGL(ss_gram_sum_kernel, dim3(2), dim3(SS_NT), 0, stream(), part, nparts, GH, (const int*)nullptr);
+        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, X, n, part);
+        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, W, n, part2);
+        hipLaunchKernelGGL(ss_gram_sum_kernel, dim3(2), dim3(SS_NT), 0, stream(), part, nparts, GH);
         MSM_HIP_CHECK(hipGetLastError());
         MSM_HIP_CHECK(hipMemcpyAsync(hGH, GH, 2 * SB * SB * sizeof(double), hipMemcpyDeviceToHost, stream()));
         MSM_HIP_CHECK(hipMemcpyAsync(hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
@@ -939,8 +648,8 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
         memcpy(hS, V.data(), SB * SB * sizeof(double));
         memcpy(htheta, w.data(), SB * sizeof(double));
         MSM_HIP_CHECK(hipMemcpyAsync(dS, hS, (SB * SB + SB) * sizeof(double), hipMemcpyHostToDevice, stream()));   // S and theta are adjacent
-        hipLaunchKernelGGL(ss_rotate_kernel, grot, dim3(SS_NT), 0, stream(), X, W, n, dS, (const int*)nullptr);
-        hipLaunchKernelGGL(ss_residual_kernel, dim3(1), dim3(SS_NT), 0, stream(), X, W, n, dtheta, dres, (SsState*)nullptr, 0, 0.0, 0.0, 0, 0);
+        hipLaunchKernelGGL(ss_rotate_kernel, grot, dim3(SS_NT), 0, stream(), X, W, n, dS);
+        hipLaunchKernelGGL(ss_residual_kernel, dim3(1), dim3(SS_NT), 0, stream(), X, W, n, dtheta, dres);
         MSM_HIP_CHECK(hipGetLastError());
         MSM_HIP_CHECK(hipMemcpyAsync(hres, dres, SB * sizeof(double), hipMemcpyDeviceToHost, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
@@ -977,108 +686,11 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     return MSM_OK;
 }
 
-// The same iteration QUEUED (round 5): no host synchronisation, no copy.  The Rayleigh-Ritz problems are solved by
-// ss_rr_kernel, the decisions (converged / stalled / next filter's bounds) are taken by ss_residual_kernel's last thread and
-// every later launch checks the iteration's `done` flag: a fixed schedule -- the prior filter, then `rounds` x (Rayleigh-Ritz,
-// filter of `degree` products), a last Rayleigh-Ritz -- of which the launches behind the decision are no-ops.  lam / Yk are
-// emitted unconditionally and are meaningful only when the state read back by the caller (*dstate: SsState, {done, converged,
-// outer, -} as four ints at its head) says converged; otherwise the caller runs subspace_topk_device (adaptive degrees, more
-// rounds) or its own fallback.  Needs first_cut / first_top (the prior for the first filter).
-int subspace_topk_queued(const double* Cm, int n, int k, double lower, double tol, int degree, int rounds, double* lam, double* Yk,
-                         double* work, double first_cut, double first_top, const void** dstate)
-{
-    if (dstate) *dstate = nullptr;
-    if (n < 2 * SB || k < 1 || k > SB / 2 || degree < 2 || degree > SS_MAXDEG || !(first_cut > lower) || !(first_top > first_cut))
-        return MSM_OK;   // not this route's case: *dstate stays null
-    const size_t NB = (size_t)n * SB;
-    double* X = work;
-    double* Y = X + NB;
-    double* Z = Y + NB;
-    double* W = Z + NB;
-    const int nparts = (int)ceil_div(n, SG_ROWS);
-    double* part = W + NB;
-    double* part2 = part + (size_t)nparts * SB * SB;
-    double* GH = part2 + (size_t)nparts * SB * SB;
-    double* dS = GH + 2 * SB * SB;
-    double* dtheta = dS + SB * SB;
-    double* dres = dtheta + SB;
-    int* dflag = reinterpret_cast<int*>(dres + SB);
-    SsState* st = reinterpret_cast<SsState*>(dres + SB + 8);
-    const int* stop = &st->done;
-    static bool attr = false;
-    if (!attr) {
-        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_product_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)SS_PRODUCT_LDS));
-        attr = true;
-    }
-    const dim3 gprod((unsigned)ceil_div(n, SS_RT)), gqr((unsigned)ceil_div(n, SS_NT)), grot((unsigned)ceil_div(n, SS_NT / SB));
-    MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
-    hipLaunchKernelGGL(ss_state_init_kernel, dim3(1), dim3(64), 0, stream(), st);
-    hipLaunchKernelGGL(ss_init_kernel, dim3((unsigned)ceil_div(NB, 256)), dim3(256), 0, stream(), X, n);
-    auto cholqr = [&](const int* guard) {
-        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, X, n, part, guard);
-        hipLaunchKernelGGL(ss_cholqr_kernel, gqr, dim3(SS_NT), 0, stream(), part, nparts, X, n, dflag, guard);
-    };
-    cholqr(nullptr);
-    // a filter of `degree` products: host-known recurrence (the prior) or the device's (st->coef), then one Cholesky QR
-    auto run_filter = [&](bool device_coef, double cut, double top) {
-        const double e = 0.5 * (cut - lower), cen = 0.5 * (cut + lower);
-        const double sigma1 = device_coef ? 0.0 : e / (top - cen);
-        double sigma = sigma1;
-        const int* guard = device_coef ? stop : nullptr;
-        double *xp = X, *xc = Y, *xn = Z;
-        for (int i = 1; i <= degree; ++i) {
-            double a = 0.0, b = 0.0, c = 0.0;
-            if (!device_coef) {
-                if (i == 1) {
-                    a = sigma1 / e;
-                    b = -sigma1 * cen / e;
-                } else {
-                    const double sn = 1.0 / (2.0 / sigma1 - sigma);
-                    a = 2.0 * sn / e;
-                    b = -2.0 * sn * cen / e;
-                    c = -sigma * sn;
-                    sigma = sn;
-                }
-            }
-            const double* coef = device_coef ? &st->coef[i - 1][0] : nullptr;
-            if (i == 1) {
-                hipLaunchKernelGGL(ss_product_kernel, gprod, dim3(SS_NT), SS_PRODUCT_LDS, stream(), Cm, n, X, (const double*)nullptr, Y, a, b, c, coef, guard);
-            } else {
-                hipLaunchKernelGGL(ss_product_kernel, gprod, dim3(SS_NT), SS_PRODUCT_LDS, stream(), Cm, n, xc, (const double*)xp, xn, a, b, c, coef, guard);
-                double* t = xp;
-                xp = xc;
-                xc = xn;
-                xn = t;
-            }
-        }
-        if (xc != X) hipLaunchKernelGGL(ss_copy_kernel, dim3((unsigned)ceil_div(NB, 256)), dim3(256), 0, stream(), X, (const double*)xc, NB, guard);
-        cholqr(guard);
-    };
-    run_filter(false, first_cut, first_top);
-    for (int r = 0; r <= rounds; ++r) {
-        hipLaunchKernelGGL(ss_product_kernel, gprod, dim3(SS_NT), SS_PRODUCT_LDS, stream(), Cm, n, X, (const double*)nullptr, W, 1.0, 0.0, 0.0,
-                           (const double*)nullptr, stop);
-        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, X, n, part, stop);
-        hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, W, n, part2, stop);
-        hipLaunchKernelGGL(ss_gram_sum_kernel, dim3(2), dim3(SS_NT), 0, stream(), part, nparts, GH, stop);
-        hipLaunchKernelGGL(ss_rr_kernel, dim3(1), dim3(SS_NT), 0, stream(), GH, dS, dtheta, dflag, st);
-        hipLaunchKernelGGL(ss_rotate_kernel, grot, dim3(SS_NT), 0, stream(), X, W, n, dS, stop);
-        hipLaunchKernelGGL(ss_residual_kernel, dim3(1), dim3(SS_NT), 0, stream(), X, W, n, dtheta, dres, st, k, tol, lower, degree, r == rounds ? 1 : 0);
-        if (r < rounds) run_filter(true, 0.0, 0.0);
-    }
-    MSM_HIP_CHECK(hipMemcpyAsync(lam, dtheta, k * sizeof(double), hipMemcpyDeviceToDevice, stream()));
-    hipLaunchKernelGGL(ss_emit_kernel, dim3((unsigned)ceil_div((size_t)n * k, 256)), dim3(256), 0, stream(), X, n, k, Yk);
-    MSM_HIP_CHECK(hipGetLastError());
-    if (dstate) *dstate = st;
-    return MSM_OK;
-}
-
 size_t subspace_pin_doubles() { return 4 * (size_t)SB * SB + 4 * SB; }
 
 size_t subspace_work_doubles(int n)
 {
-    return 4 * (size_t)n * SB + (2 * (size_t)ceil_div(n, SG_ROWS) + 3) * SB * SB + 4 * SB + 8 + (sizeof(SsState) + 7) / 8 + 8;
+    return 4 * (size_t)n * SB + (2 * (size_t)ceil_div(n, SG_ROWS) + 3) * SB * SB + 4 * SB + 8;
 }
 
 }  // namespace msm

@@ -3337,25 +3337,13 @@ int msm_tica_solve_topk(msm_tica_t* h, double shrinkage, msm_idx_t n_rblw, const
         MSM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->solve_pin), pin_total * sizeof(double), hipHostMallocDefault));
         h->solve_pin_n = pin_total;
     }
-    // Round 5: the iteration QUEUED first (Rayleigh-Ritz and every decision on the device, subspace.hip): finalise -> Cholesky
-    // -> reduction -> iteration -> residual check -> back-transformation is then ONE chain of launches with one packed copy
-    // and one synchronisation at its end.  Its state word says whether the fixed schedule (prior filter, then up to two rounds of Rayleigh-Ritz + filter, a last
-    // Rayleigh-Ritz) converged;
-    // if not, the host-driven iteration below (adaptive degrees, 6 rounds) runs on the same reduced matrix as before.
-    const void* dstate = nullptr;
-    {
-        static const bool queued_on = [] { const char* e = getenv("MSM_SOLVE_QUEUED"); return !(e && atoi(e) == 0); }();   // A/B switch of the tests
-        if (queued_on && (rc = subspace_topk_queued(b.A, n, (int)k, -1.02, 5e-12, 10, 2, b.lam, b.Yk, b.sswork, 0.0, 1.0, &dstate))) return rc;
-    }
-    bool queued = dstate != nullptr;
-retry_host_driven:
-    if (!queued) {
-        if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, 10, 6, b.lam, b.Yk, b.sswork, h->solve_pin + pin_res, &conv, &outer,
-                                       0.0, 1.0)))   // prior: the reduced tICA matrix has its spectrum in [-1, 1], the noise bulk near 0
-            return rc;
-    } else {
-        conv = 1;   // provisionally: the state word comes back with the results
-    }
+    // (Round 5 built the iteration QUEUED -- the 32 x 32 Rayleigh-Ritz problems by one-sided Jacobi in one workgroup, every decision
+    //  on the device, one synchronisation per solve -- and removed it again: a Jacobi round is a chain of shuffles, square roots
+    //  and divisions, ~0.5 us of latency, 31 rounds a sweep, and the kernel took 0.2 ms per Rayleigh-Ritz round against ~0.13 ms
+    //  for the two copies, two synchronisations and 25 us of host arithmetic it replaced: solve 1.26 ms against 1.08 ms.  DESIGN 3.9.)
+    if ((rc = subspace_topk_device(b.A, n, (int)k, -1.02, 5e-12, 10, 6, b.lam, b.Yk, b.sswork, h->solve_pin + pin_res, &conv, &outer,
+                                   0.0, 1.0)))   // prior: the reduced tICA matrix has its spectrum in [-1, 1], the noise bulk near 0
+        return rc;
     if (!conv) {
         double scal[4];
         int ints[8];
@@ -3384,16 +3372,7 @@ retry_host_driven:
                        b.S, n, (int)k, b.Y);
     MSM_HIP_CHECK(hipGetLastError());
     MSM_HIP_CHECK(hipMemcpyAsync(h->solve_pin, b.Y, total * sizeof(double), hipMemcpyDeviceToHost, stream()));
-    int* qstate = reinterpret_cast<int*>(h->solve_pin + pin_res);   // (the host-driven iteration's staging: free on this route)
-    if (queued) MSM_HIP_CHECK(hipMemcpyAsync(qstate, dstate, 4 * sizeof(int), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    if (queued) {
-        outer = qstate[2];
-        if (!qstate[1]) {   // the fixed schedule did not converge (or lost rank): the adaptive host-driven iteration decides
-            queued = false;
-            goto retry_host_driven;
-        }
-    }
     const double* hp = h->solve_pin;
     const double* res = hp + o_res;
     double scal[4];
@@ -3406,8 +3385,8 @@ retry_host_driven:
     rc = tica_reduce_status(scal, ints, info);
     if (rc) return rc;
     if (info) {
-        info[8] = queued ? 2.0 : 1.0; // the pairs came from the subspace iteration (2: the queued, device-driven schedule)
-        info[9] = (double)outer;      // filtered iterations / Rayleigh-Ritz rounds spent (also when they did not converge)
+        info[8] = 1.0;                // the pairs came from the subspace iteration
+        info[9] = (double)outer;      // filtered iterations spent (also when they did not converge)
     }
     // self-check on the reduced matrix: every returned pair must satisfy C y = lambda y to rounding, be normalised, and the
     // k vectors must be mutually orthogonal (a rank-deficient block would pass the per-pair checks; the Gram

@@ -362,8 +362,7 @@ class tICA(BaseEstimator, TransformerMixin):
                 run(L.msm_tica_solve_topk(self._handle, shrink, int(self.n_observations_),
                                           None if scale_p is None else scale_p.ctypes.data, k, vals.ctypes.data, V.ctypes.data,
                                           Cs.ctypes.data, mu.ctypes.data, info.ctypes.data, C.byref(status)))
-                self._solve_route = ("subspace" if status.value == 0 else "lapack", int(info[9]), status.value,
-                                     "queued" if info[8] == 2.0 else "host-driven")
+                self._solve_route = ("subspace" if status.value == 0 else "lapack", int(info[9]), status.value)
                 if status.value == 0:
                     done = True
                 else:

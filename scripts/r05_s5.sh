@@ -2,12 +2,7 @@
 O=gpurun_out/r05_s5
 mkdir -p $O
 cd /root/repo
-( timeout 600 python -m pytest tests/test_gpu_toppairs.py -x -q ) > $O/pytest_toppairs.txt 2>&1
-echo "rc=$?" >> $O/pytest_toppairs.txt
-( timeout 300 python scripts/solvetime.py 512 10 ) > $O/solvetime_queued.txt 2>&1
-( MSM_SOLVE_QUEUED=0 timeout 300 python scripts/solvetime.py 512 10 ) > $O/solvetime_hostdriven.txt 2>&1
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/trace -o tr -- python /root/repo/scripts/solvetime.py 512 10 > /root/repo/$O/trace.log 2>&1
-cd /root/repo
-f=$(find $O/trace -name "*kernel_stats.csv" | head -1); head -40 $f > $O/solve_kernel_stats.csv; rm -rf $O/trace
-tail -6 $O/pytest_toppairs.txt; head -6 $O/solvetime_queued.txt; head -6 $O/solvetime_hostdriven.txt; cut -c1-150 $O/solve_kernel_stats.csv | head -30
+( timeout 900 python -m pytest tests/test_gpu_toppairs.py tests/test_gpu_tica.py tests/test_gpu_tica_fold.py tests/test_gpu_tica_seams.py tests/test_gpu_workflow.py tests/test_gpu_tica_uncentred.py -x -q ) > $O/pytest_tica.txt 2>&1
+echo "rc=$?" >> $O/pytest_tica.txt
+( timeout 600 python bench.py --steps 5 --warmup 2 --no-extras --no-mbk --no-cpu-baseline ) > $O/bench_short.txt 2>&1
+tail -3 $O/pytest_tica.txt; tail -1 $O/bench_short.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['phases_ms'], d['roofline']['kernel_ms'])"

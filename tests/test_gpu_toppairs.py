@@ -80,40 +80,3 @@ def test_topk_solve_matches_host_route(gpu, monkeypatch, F, k, flat):
                 sg = np.sign(V[:, j].dot(S).dot(Vh[:, j]))
                 np.testing.assert_allclose(V[:, j] * sg, Vh[:, j], rtol=0, atol=1e-8 * np.abs(Vh[:, j]).max() / min(lo, hi, 1.0))
 
-
-def _queued_fit(F, k, seed):
-    import torch
-    from msmbuilder_amd import tICA
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    n = 60000
-    z = torch.cumsum(torch.randn(n, 12, generator=g, device="cuda", dtype=torch.float64), 0) * 0.02
-    X = torch.tanh(z - z.mean(0)) @ torch.randn(12, F, generator=g, device="cuda", dtype=torch.float64) \
-        + 0.4 * torch.randn(n, F, generator=g, device="cuda", dtype=torch.float64) + torch.randn(F, generator=g, device="cuda", dtype=torch.float64)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        return tICA(n_components=k, lag_time=20).fit([X[:35000], X[35000:]])
-
-
-@pytest.mark.parametrize("F,k", [(512, 10), (256, 4), (128, 1), (1000, 6), (640, 7)])
-def test_queued_iteration_matches_host_driven(gpu, monkeypatch, F, k):
-    """Round 5: the subspace iteration with its Rayleigh-Ritz problems and decisions on the DEVICE (ss_rr_kernel: Cholesky +
-    one-sided Jacobi on the 32 x 32 problem; one synchronisation per solve) against the host-driven iteration
-    (small_geigh between two copies per round; MSM_SOLVE_QUEUED=0 in a subprocess would be the A/B -- here: the LAPACK route
-    on the same accumulators, which both are verified against): eigenvalues rtol 1e-10, B-orthonormal vectors, and the
-    route taken must be the queued one."""
-    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
-    monkeypatch.setenv("MSMBUILDER_AMD_DEVICE_SOLVE", "hybrid")
-    m = _queued_fit(F, k, F + k)
-    ev, V = m.eigenvalues_.copy(), m.eigenvectors_.copy()
-    route = m._solve_route
-    assert route[0] == "subspace" and route[2] == 0 and route[3] == "queued", route
-    monkeypatch.setenv("MSMBUILDER_AMD_DEVICE_SOLVE", "0")
-    m._is_dirty = True
-    evh, Vh, S = m.eigenvalues_.copy(), m.eigenvectors_.copy(), m.covariance_.copy()
-    np.testing.assert_allclose(ev, evh, rtol=1e-10)
-    np.testing.assert_allclose(V.T.dot(S).dot(V), np.eye(k), rtol=0, atol=1e-9)
-    for j in range(k):
-        gap = min(abs(evh[j] - evh[i]) for i in range(k) if i != j) if k > 1 else 1.0
-        if gap > 1e-4:
-            sg = np.sign(V[:, j].dot(S).dot(Vh[:, j]))
-            np.testing.assert_allclose(V[:, j] * sg, Vh[:, j], rtol=0, atol=1e-8 * np.abs(Vh[:, j]).max() / min(gap, 1.0))
