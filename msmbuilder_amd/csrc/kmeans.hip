@@ -38,6 +38,8 @@ struct KmArgs {
     // centre-split launch (small batches): blockIdx.y owns centre tiles [y*jspan, (y+1)*jspan) and
     // writes its (min value, index) candidates to pv/pi [gridDim.y][n]; a reduce kernel finishes
     long long jspan;        // 0 = all centres in one workgroup
+    int xcd_ns;             // > 0 (kmeans_label_v4_kernel, large n): a 1-D grid of ceil(rowblocks / 8) x 8 x xcd_ns workgroups in
+                            // which the xcd_ns centre splits of a row block are CONSECUTIVE workgroups of one XCD (see the kernel)
     float* pv;
     int* pi;
     const int* stop;        // optional device flag: non-zero -> the launch does nothing (msm_mbk_run: steps queued
@@ -438,7 +440,7 @@ __device__ __forceinline__ void km4_argmin(f32x16 (&acc)[2][2], float (&best)[2]
 // centre halves; writes labels (or the split launch's candidates)
 __device__ __forceinline__ void km_finish_rows(const float (&best)[2][16], const int (&bidx)[2][16], const KmArgs& P,
                                                float* redv, int* redi, long long row0, int tid, int wr, int wc,
-                                               int kl, int cl)
+                                               int kl, int cl, int split)
 {
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
@@ -470,8 +472,8 @@ __device__ __forceinline__ void km_finish_rows(const float (&best)[2][16], const
             const bool second = (v1 < v0 || (v1 == v0 && i1 < i0));
             int lab = second ? i1 : i0;
             if (P.jspan) {
-                P.pv[(long long)blockIdx.y * P.n + i] = second ? v1 : v0;
-                P.pi[(long long)blockIdx.y * P.n + i] = lab;
+                P.pv[(long long)split * P.n + i] = second ? v1 : v0;
+                P.pi[(long long)split * P.n + i] = lab;
             } else {
                 if (lab == 0x7fffffff) lab = 0;  // all-NaN row: sklearn's argmin returns 0
                 P.labels[i] = lab;
@@ -515,7 +517,20 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
     float* Cs = Xs + 2 * KR * KP4;                  // [2][KCT * KP4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, kl = lane >> 5, cl = lane & 31;
-    const long long row0 = (long long)blockIdx.x * KR;
+    // Round 5 (P.xcd_ns): a workgroup that walks ALL centre tiles streams its 128 rows once per tile, and with 64 workgroups
+    // per XCD those 8 x 256 KB re-reads never hit the 4 MB L2 (1M x 512, K = 1000: 16 GB fetched per pass for 2 GB of rows).
+    // Instead one workgroup per (row block, centre tile), numbered so that the tiles of a row block are consecutive
+    // workgroups of ONE XCD (workgroup b runs on XCD b % 8): they run side by side, the row block is fetched once and
+    // served to the other tiles from that XCD's L2; the per-tile candidates are merged by the inertia / reduce kernel.
+    long long rb = blockIdx.x;
+    int split = (int)blockIdx.y;
+    if (P.xcd_ns) {
+        const unsigned b = blockIdx.x, q = b >> 3;
+        split = (int)(q % (unsigned)P.xcd_ns);
+        rb = (long long)(q / (unsigned)P.xcd_ns) * 8 + (b & 7);
+        if (rb * KR >= P.n) return;   // (the grid is rounded up to whole groups of 8 row blocks)
+    }
+    const long long row0 = rb * KR;
     const int m = (int)P.m;
     const int nk = (m + KBK - 1) / KBK;
     const unsigned ldb = (unsigned)m * 4u;
@@ -550,7 +565,7 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
     }
     const global_ptr<char> Cg = as_global<char>(P.C);
 
-    const long long jbeg = P.jspan ? (long long)blockIdx.y * P.jspan : 0;
+    const long long jbeg = P.jspan ? (long long)split * P.jspan : 0;
     const long long jend = P.jspan ? (jbeg + P.jspan < P.K ? jbeg + P.jspan : P.K) : P.K;
     const long long total = ((jend - jbeg + KCT - 1) / KCT) * nk;
 
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 #undef KM4_ADVANCE
 #undef KM4_ADDR
 #undef KM4_TILE_OFFS
-    km_finish_rows(best, bidx, P, Xs, reinterpret_cast<int*>(Cs), row0, tid, wr, wc, kl, cl);
+    km_finish_rows(best, bidx, P, Xs, reinterpret_cast<int*>(Cs), row0, tid, wr, wc, kl, cl, split);
 }
 
 // per-row ||x - c_label||^2 (fp32 difference, fp64 accumulate), one wave per row;
@@ -1331,17 +1346,63 @@ static int km_launch_label(const KmArgs& P, dim3 grid)
     return MSM_OK;
 }
 
+// Large batches of wide rows (the final labelling pass of BASELINE configs[3]: 1.25M x 512 per rank, K = 1000): one workgroup
+// per (row block, centre tile), the tiles of a row block side by side on one XCD, so that the rows are fetched ONCE
+// (kmeans_label_v4_kernel, P.xcd_ns); a workgroup takes TWO tiles, the second pass over its rows being an L2 hit.  Returns the
+// number of centre splits to use (0: not this case).
+// MSM_LABEL_XCD=0: the A/B switch of the tests (read per call; labels are identical either way).
+static int km_xcd_splits(const KmArgs& P)
+{
+    const char* xe = getenv("MSM_LABEL_XCD");
+    // centre tiles per workgroup (0 = off).  Measured at 1.25M x 512, K = 1000 (profiles/r05_label_wide.txt; fetched + written
+    // bytes per pass, kernel time): all 8 tiles in one workgroup 21.3 GB, 10.5 ms; 1 tile 3.4 GB, 11.8 ms (the pipeline fill and
+    // the argmin epilogue are paid per 16 K-steps); 2 tiles 5.3 GB = 2.1x the rows, 10.6 ms; 4 tiles 11.2 GB, 10.4 ms.
+    const int tiles_per = xe ? atoi(xe) : 2;
+    if (tiles_per <= 0) return 0;
+    const long long rowblocks = ceil_div(P.n, KR), ctiles = ceil_div(P.K, KCT);
+    const bool v4ok = P.m >= 4 && (P.m & 3) == 0 && (((uintptr_t)P.X | (uintptr_t)P.C) & 15) == 0 && P.m < (1 << 22) && !P.rows;
+    if (!v4ok || ctiles < 2 || ctiles > 16 || rowblocks < 512 || P.m < 64 || ceil_div(rowblocks, 8) * 8 * ctiles >= 0x7fffffffLL) return 0;
+    const int ns = (int)ceil_div(ctiles, tiles_per);
+    return ns > 1 ? ns : 0;
+}
+// ... the launch: candidates of every split into pv / pi ([nsplit][n] each); the caller merges them (reduce or inertia kernel)
+static int km_launch_label_xcd(KmArgs& P, int nsplit, float* pv, int* pi)
+{
+    P.jspan = ceil_div(ceil_div(P.K, KCT), nsplit) * KCT;
+    P.xcd_ns = nsplit;
+    P.pv = pv;
+    P.pi = pi;
+    const int rc = km_launch_label(P, dim3((unsigned)(ceil_div(ceil_div(P.n, KR), 8) * 8 * nsplit)));
+    P.xcd_ns = 0;
+    P.jspan = 0;
+    return rc;
+}
+
 static int km_label_and_inertia(KmArgs& P, double* inertia)
 {
     const unsigned grid = (unsigned)ceil_div(P.n, KR);
-    { int rc0 = km_launch_label(P, dim3(grid)); if (rc0) return rc0; }
+    int nsplit = km_xcd_splits(P);
+    if (nsplit > 1) {
+        DevBuf &dPv = pool(PS_W), &dPi = pool(PS_S);
+        int rc0;
+        if ((rc0 = dPv.reserve((size_t)nsplit * P.n * sizeof(float)))) return rc0;
+        if ((rc0 = dPi.reserve((size_t)nsplit * P.n * sizeof(int)))) return rc0;
+        if ((rc0 = km_launch_label_xcd(P, nsplit, dPv.as<float>(), dPi.as<int>()))) return rc0;
+        if (!inertia)
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(P.n, 256)), dim3(256), 0, stream(), P.pv, P.pi, P.n, nsplit,
+                               P.labels, P.stop);
+    } else {
+        nsplit = 1;
+        int rc0 = km_launch_label(P, dim3(grid));
+        if (rc0) return rc0;
+    }
     MSM_HIP_CHECK(hipGetLastError());
     if (inertia) {
         const int nb = (int)std::min<long long>(ceil_div(P.n, 4), 1024);
         DevBuf& dPart = pool(PS_PART);
         int rc = dPart.reserve((size_t)nb * sizeof(double));
         if (rc) return rc;
-        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, dPart.as<double>(), 1);
+        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, dPart.as<double>(), nsplit);   // (merges the splits' candidates)
         MSM_HIP_CHECK(hipGetLastError());
         std::vector<double> h((size_t)nb);
         MSM_HIP_CHECK(hipMemcpyAsync(h.data(), dPart.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, stream()));
@@ -1487,8 +1548,17 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
     if (rowblocks < 256 && ctiles > 1) {  // small batch: split the centres over workgroups to fill the chip
         nsplit = (int)std::min<long long>(ctiles, std::max<long long>(1, 512 / rowblocks));
     }
+    const int xs = nsplit == 1 ? km_xcd_splits(P) : 0;   // large batches of wide rows: see km_xcd_splits
     int rc;
-    if (nsplit > 1) {
+    if (xs > 1) {
+        nsplit = xs;
+        if ((rc = h->pv.reserve((size_t)nsplit * n * sizeof(float)))) return rc;
+        if ((rc = h->pi.reserve((size_t)nsplit * n * sizeof(int)))) return rc;
+        if ((rc = km_launch_label_xcd(P, nsplit, h->pv.as<float>(), h->pi.as<int>()))) return rc;
+        if (!inertia_dev_partial)
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
+                               P.pv, P.pi, n, nsplit, labels_d, P.stop);
+    } else if (nsplit > 1) {
         const long long tiles_per = ceil_div(ctiles, nsplit);
         nsplit = (int)ceil_div(ctiles, tiles_per);
         if ((rc = h->pv.reserve((size_t)nsplit * n * sizeof(float)))) return rc;

@@ -47,6 +47,31 @@ def test_label_ties_lowest_index(gpu):
     assert np.all(lab == 150) and inertia == 0.0
 
 
+def test_label_xcd_split_identical(gpu, monkeypatch):
+    """Round 5: large batches of wide rows are labelled by one workgroup per (row block, centre tile) with the tiles of a row
+    block side by side on one XCD (the rows are fetched once, not once per tile); labels and inertia must be what the
+    all-tiles-per-workgroup launch gives (MSM_LABEL_XCD=0), including rows beyond the last whole group of 8 row blocks."""
+    import torch
+    from msmbuilder_amd.cluster.minibatchkmeans import label_inertia
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for n, m, K in ((70_001, 256, 300), (66_000, 64, 2048), (65_536 + 129, 512, 1000)):
+        Cn = torch.randn(K, m, generator=g, device="cuda") * 1.5
+        X = Cn[torch.randint(0, K, (n,), generator=g, device="cuda")] + torch.randn(n, m, generator=g, device="cuda")
+        X[5] = Cn[7]                    # an exact hit
+        X[n - 1] = 0.5 * (Cn[3] + Cn[4])  # a near tie
+        Ch = Cn.cpu().numpy()
+        monkeypatch.setenv("MSM_LABEL_XCD", "0")
+        l0, i0 = label_inertia(X, Ch)
+        for tiles_per in (None, "1", "3"):          # the default (two tiles per workgroup), one, an uneven split
+            if tiles_per is None:
+                monkeypatch.delenv("MSM_LABEL_XCD")
+            else:
+                monkeypatch.setenv("MSM_LABEL_XCD", tiles_per)
+            l1, i1 = label_inertia(X, Ch)
+            assert torch.equal(l0, l1) and int(l1[5]) == 7
+            assert abs(i0 - i1) <= 1e-12 * abs(i0)
+
+
 def test_minibatch_golden_sklearn(gpu, golden_dir):
     from msmbuilder_amd import MiniBatchKMeans
     g = np.load(os.path.join(golden_dir, "mbkm_golden.npz"))
