@@ -600,44 +600,57 @@ def main():
                           "top_eigenvalues": [float(x) for x in ev64[:3]]}
             del m64
             os.environ["MSMBUILDER_AMD_TICA_MODE"] = args.mode
-            # --- strong-scaling model: what ONE rank of an 8-GPU run of this problem executes (1/8 of the trajectories),
-            # measured on this GPU without the collectives
-            n8 = max(1, n_seq // 8)
-            X8 = X[: n8 * T]
-            seqs8 = seqs[:n8]
-            rec8 = {}
-            # the ROW-SHARDED k-centers loop (msm_kcenters_fit_sharded_*, a world of one: its all-gathers are copies), i.e.
-            # the code an N = 8 rank runs, not the single-GPU fit
-            KCenters._force_sharded = True
-            step(None, seqs8, X8)
-            step(None, seqs8, X8)
-            for _ in range(7):   # (12 ms each; the phases' MEDIANS go into the model: a share's sub-millisecond phases move with any hiccup)
-                step(rec8, seqs8, X8)
-            KCenters._force_sharded = False
-            rec8.pop("sym", None)
-            rec8.pop("folded", None)
-            kst8 = (C.c_int64 * 5)()
-            _lib.check(_lib.lib().msm_kcenters_last_stats(kst8))
-            ph8 = {k: 1e3 * float(np.median(v)) for k, v in rec8.items() if k != "mfma_ms"}
-            step8 = sum(ph8.values())
+            # --- strong-scaling model: what ONE rank of an N-GPU run of this problem executes (1/N of the trajectories), for
+            # N = 2, 4, 8, measured on this GPU without the collectives.  NO hardware curve exists for this repo: the driver's
+            # SCALE run is the measurement, this is a model (measured phases + ASSUMED collective latencies, labelled so).
             # ASSUMED RCCL latencies over xGMI -- NOT measured (this leg runs on one GPU).  The sharded k-centers loop makes one
             # small all-gather per centre for its first plain passes and then ONE all-gather of a 99 KB round record per ROUND
-            # of several centres (round 3: 25 KB records, 40 us assumed, 31 rounds; lists of 1,024 rows now: 21 rounds)
-            # (msm_kcenters_last_stats of the sharded fit above: plain passes + rounds = the number of its exchanges)
+            # of several centres (msm_kcenters_last_stats of the sharded fit: plain passes + rounds = the number of its exchanges)
             comm_us = {"allreduce_4MB": 150.0, "allgather_per_centre": 25.0, "allgather_per_round_record": 55.0}
-            kc_exchanges = {"one_centre": int(kst8[1]), "rounds": int(kst8[2])}
-            comm_ms = (comm_us["allreduce_4MB"] + kc_exchanges["one_centre"] * comm_us["allgather_per_centre"]
-                       + kc_exchanges["rounds"] * comm_us["allgather_per_round_record"]) / 1e3
-            serial = ph8.get("solve", 0.0) + comm_ms
+            ladder = {}
+            for nshare in (2, 4, 8):
+                nN = max(1, n_seq // nshare)
+                XN = X[: nN * T]
+                seqsN = seqs[:nN]
+                recN = {}
+                # the ROW-SHARDED k-centers loop (msm_kcenters_fit_sharded_*, a world of one: its all-gathers are copies), i.e.
+                # the code an N-rank run executes, not the single-GPU fit
+                KCenters._force_sharded = True
+                try:
+                    step(None, seqsN, XN)
+                    step(None, seqsN, XN)
+                    for _ in range(7):   # (the phases' MEDIANS go into the model: a share's sub-millisecond phases move with any hiccup)
+                        step(recN, seqsN, XN)
+                finally:
+                    KCenters._force_sharded = False
+                recN.pop("sym", None)
+                recN.pop("folded", None)
+                kstN = (C.c_int64 * 5)()
+                _lib.check(_lib.lib().msm_kcenters_last_stats(kstN))
+                phN = {k: 1e3 * float(np.median(v)) for k, v in recN.items() if k != "mfma_ms"}
+                stepN = sum(phN.values())
+                kc_exchanges = {"one_centre": int(kstN[1]), "rounds": int(kstN[2])}
+                comm_ms = (comm_us["allreduce_4MB"] + kc_exchanges["one_centre"] * comm_us["allgather_per_centre"]
+                           + kc_exchanges["rounds"] * comm_us["allgather_per_round_record"]) / 1e3
+                ladder[nshare] = {"trajectories": nN, "phases_ms": phN, "mfma_ms": float(np.median(recN["mfma_ms"])),
+                                  "measured_step_ms": stepN, "kcenters_exchanges": kc_exchanges, "assumed_comm_ms": comm_ms,
+                                  "modelled_step_ms": stepN + comm_ms, "modelled_speedup": ms_per_step / (stepN + comm_ms),
+                                  "serial_fraction_of_n1_step": (phN.get("solve", 0.0) + comm_ms) / ms_per_step}
+                del XN, seqsN
+            l8 = ladder[8]
             out["strong_scaling_model"] = {
-                "what": "one rank's share at N=8 (%d of %d trajectories) run alone on this GPU through the sharded code path "
-                        "(msm_kcenters_fit_sharded, screened passes): per-phase ms measured (medians of 7 steps), collectives modelled" % (n8, n_seq),
-                "phases_ms": ph8, "mfma_ms": float(np.median(rec8["mfma_ms"])), "measured_step_ms": step8,
-                "assumed_comm_us": comm_us, "assumed_comm_us_note": "UNMEASURED assumptions (no multi-GPU node in this run): the "
-                "driver's SCALE run is the measurement", "kcenters_exchanges": kc_exchanges, "modelled_step_ms": step8 + comm_ms,
-                "modelled_speedup_at_8": ms_per_step / (step8 + comm_ms),
-                "serial_fraction_of_n1_step": serial / ms_per_step}
-            del X8, seqs8
+                "what": "one rank's share at N = 2, 4, 8 (1/N of the %d trajectories) run alone on this GPU through the sharded code "
+                        "path (msm_kcenters_fit_sharded, screened passes): per-phase ms measured (medians of 7 steps), collectives "
+                        "MODELLED with assumed latencies" % n_seq,
+                "hardware_curve": "none: no run of this repository with N > 1 RCCL ranks on N GPUs exists; the driver's SCALE run is the measurement",
+                "assumed_comm_us": comm_us, "assumed_comm_us_note": "UNMEASURED assumptions (no multi-GPU node in this run)",
+                "ladder": {str(k): v for k, v in ladder.items()},
+                # (the N = 8 row under the keys earlier rounds printed)
+                "phases_ms": l8["phases_ms"], "mfma_ms": l8["mfma_ms"], "measured_step_ms": l8["measured_step_ms"],
+                "kcenters_exchanges": l8["kcenters_exchanges"], "modelled_step_ms": l8["modelled_step_ms"],
+                "modelled_speedup_at_8": l8["modelled_speedup"], "modelled_speedup_at_4": ladder[4]["modelled_speedup"],
+                "modelled_speedup_at_2": ladder[2]["modelled_speedup"],
+                "serial_fraction_of_n1_step": l8["serial_fraction_of_n1_step"]}
         del X, seqs
         if extras:
             torch.cuda.empty_cache()
@@ -685,6 +698,43 @@ def main():
                                      "assign_pair_elements_per_s": 280_000 * 200 * 171 / tP,
                                      "inertia": float(kcC.inertia_)}
             del XC, seqsC, kcC, labC
+            # --- BASELINE configs[3]'s WIDE clusterer: the final labelling pass of MiniBatchKMeans(k=1000) on one rank's share of
+            # the 8-GPU run, 1,250,000 x 512 fp32 ("final labelling pass dominates at large N"):
+            # kmeans_label_v4_kernel + kmeans_inertia_kernel through msm_kmeans_label_f32, HIP events around the call
+            from msmbuilder_amd.cluster.minibatchkmeans import label_inertia
+            gL = torch.Generator(device=dev).manual_seed(1000)
+            CL = torch.randn(1000, 512, generator=gL, device=dev) * 2
+            XL = CL[torch.randint(0, 1000, (1_250_000,), generator=gL, device=dev)] + torch.randn(1_250_000, 512, generator=gL, device=dev)
+            CLh = CL.cpu().numpy()
+            label_inertia(XL, CLh)
+            label_inertia(XL, CLh)
+            tl = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                labL, inL = label_inertia(XL, CLh)
+                e1.record()
+                torch.cuda.synchronize()
+                tl.append(e0.elapsed_time(e1))
+            msL = float(min(tl))
+            exL = 2.0 * 1_250_000 * 1024 * 512        # executed: 8 centre tiles of 128 x 512 features per row
+            trafficL = None
+            try:
+                trafficL = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["kmeans_label_v4_kernel"]
+            except Exception:
+                pass
+            out["config4_label_wide"] = {
+                "workload": "1,250,000 x 512 fp32 (one rank's share of BASELINE configs[3] over 8 GPUs), K = 1000: labels + inertia "
+                            "(kmeans_label_v4_kernel: one workgroup per row block x 2 centre tiles, grouped per XCD; kmeans_inertia_kernel "
+                            "merges the splits' candidates; the 2 MB of centres uploaded inside the call)",
+                "label_plus_inertia_ms": msL, "rows_per_s": 1_250_000 / msL * 1e3,
+                "executed_TFLOPs_whole_call": exL / msL / 1e9, "frac_of_fp32_mfma_peak_whole_call": exL / msL / 1e9 / PEAK_TFLOPS["f32"],
+                "algorithmic_bytes": 1_250_000 * 512 * 4,
+                "traffic": trafficL, "inertia_per_row": inL / 1_250_000,
+                "note": "the MFMA kernel alone (rocprofv3 kernel trace, profiles/r05_label_wide.txt): 10.6 ms = 0.79 of the fp32 MFMA peak, "
+                        "5.3 GB fetched + written per pass = 2.1 x the rows (all 8 tiles per workgroup: 21.3 GB)"}
+            del XL, CL, labL
+            torch.cuda.empty_cache()
             # --- BASELINE configs[4] width: F = 2048, fp32 vs bf16x2 vs bf16 MFMA
             n5 = 100
             X5 = synth(torch, n5, T, 2048, 7, dev)

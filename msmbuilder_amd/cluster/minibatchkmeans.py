@@ -391,6 +391,8 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         ax = Arr(X, np.float32)
         if len(ax.shape) != 2:
             raise ValueError("Expected 2D array")
+        # indices drawn ahead by an earlier fit that ended in an exception belong to ITS data and ITS generator: never reuse them
+        self.__dict__.pop("_prefetched", None)
         from ..parallel import RowShard
         shard = RowShard(ax.shape[0])  # single process: the whole array
         n_samples, n_features = shard.n_total, ax.shape[1]
@@ -472,8 +474,10 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                 if converged:
                     break
         finally:
+            # leave the generator where scikit-learn does -- also when a step raised (the tuple used to survive an
+            # exception, with the caller's RandomState advanced past the prefetch)
+            self._drop_prefetch(random_state)
             centers = self._mbk_close()
-        self._drop_prefetch(random_state)   # leave the generator where scikit-learn does
 
         self.cluster_centers_ = centers
         self.n_steps_ = i + 1

@@ -22,6 +22,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <atomic>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -38,6 +39,7 @@ typedef void* nccl_comm;
 typedef int (*fn_get_uid)(nccl_uid*);
 typedef int (*fn_init_rank)(nccl_comm*, int, nccl_uid, int);
 typedef int (*fn_destroy)(nccl_comm);
+typedef int (*fn_abort)(nccl_comm);
 typedef const char* (*fn_errstr)(int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
@@ -48,6 +50,7 @@ struct Rccl {
     fn_get_uid get_uid = nullptr;
     fn_init_rank init_rank = nullptr;
     fn_destroy destroy = nullptr;
+    fn_abort abort = nullptr;      // ncclCommAbort (optional: older builds): frees a communicator whose collectives will never complete
     fn_errstr errstr = nullptr;
     fn_allreduce allreduce = nullptr;
     fn_allgather allgather = nullptr;
@@ -71,6 +74,7 @@ Rccl& rccl()
         r.get_uid = (fn_get_uid)dlsym(r.lib, "ncclGetUniqueId");
         r.init_rank = (fn_init_rank)dlsym(r.lib, "ncclCommInitRank");
         r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
+        r.abort = (fn_abort)dlsym(r.lib, "ncclCommAbort");
         r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
         r.allreduce = (fn_allreduce)dlsym(r.lib, "ncclAllReduce");
         r.allgather = (fn_allgather)dlsym(r.lib, "ncclAllGather");
@@ -86,6 +90,7 @@ struct Comm {
     msm_host_collective_fn cb = nullptr;
     void* pinned = nullptr;  // host-callback staging
     size_t pinned_cap = 0;
+    bool wedged = false;     // a collective of this communicator never completed and could not be aborted: never wait for its stream
 };
 Comm g_comm;
 
@@ -200,20 +205,37 @@ int msm_comm_init_rccl(const char* id128, int rank, int world)
     int dev = 0;
     MSM_HIP_CHECK(hipGetDevice(&dev));
     typedef std::pair<int, nccl_comm> InitResult;
-    auto prom = std::make_shared<std::promise<InitResult>>();
-    std::future<InitResult> fut = prom->get_future();
+    struct Join {
+        std::promise<InitResult> prom;
+        std::atomic<int> state{0};   // 0 waiting, 1 the caller gave up (a communicator that still arrives belongs to the helper), 2 delivered
+    };
+    auto join = std::make_shared<Join>();
+    std::future<InitResult> fut = join->prom.get_future();
     const fn_init_rank init = r.init_rank;
-    std::thread([prom, init, dev, world, id, rank] {
+    const fn_abort abort_fn = r.abort;
+    const fn_destroy destroy_fn = r.destroy;
+    std::thread([join, init, abort_fn, destroy_fn, dev, world, id, rank] {
         (void)hipSetDevice(dev);
         nccl_comm c = nullptr;
         const int st = init(&c, world, id, rank);
-        prom->set_value(InitResult(st, c));
+        int expect = 0;
+        if (join->state.compare_exchange_strong(expect, 2)) {
+            join->prom.set_value(InitResult(st, c));
+        } else if (st == 0 && c) {
+            // the caller timed out and has moved on to the host transport: nobody will ever use or free this communicator
+            if (abort_fn) (void)abort_fn(c);
+            else (void)destroy_fn(c);
+        }
     }).detach();
     const char* te = getenv("MSM_COMM_TIMEOUT_S");
     const int tmo = te && atoi(te) > 0 ? atoi(te) : 180;
-    if (fut.wait_for(std::chrono::seconds(tmo)) != std::future_status::ready)
-        return fail(MSM_ERR_STATE, "ncclCommInitRank timed out after %d s on rank %d of %d (device %d): not every rank joined", tmo, rank,
-                    world, dev);
+    if (fut.wait_for(std::chrono::seconds(tmo)) != std::future_status::ready) {
+        int expect = 0;
+        if (join->state.compare_exchange_strong(expect, 1))
+            return fail(MSM_ERR_STATE, "ncclCommInitRank timed out after %d s on rank %d of %d (device %d): not every rank joined", tmo, rank,
+                        world, dev);
+        // (the helper delivered between the wait and the exchange: take the result)
+    }
     const InitResult res = fut.get();
     const int st = res.first;
     nccl_comm c = res.second;
@@ -239,8 +261,13 @@ int msm_comm_init_host(msm_host_collective_fn fn, int rank, int world)
 int msm_comm_destroy(void)
 {
     if (g_comm.kind == 1 && g_comm.comm) {
-        (void)hipStreamSynchronize(stream());
-        (void)rccl().destroy(g_comm.comm);
+        if (g_comm.wedged) {
+            // its stream will never drain: no synchronisation, abort where the library has it, otherwise leaked on purpose
+            if (rccl().abort) (void)rccl().abort(g_comm.comm);
+        } else {
+            (void)hipStreamSynchronize(stream());
+            (void)rccl().destroy(g_comm.comm);
+        }
     }
     if (g_comm.pinned) (void)hipHostFree(g_comm.pinned);
     g_comm = Comm();
@@ -279,8 +306,29 @@ int msm_comm_selftest(int timeout_s)
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(tmo)) break;
             usleep(200);
         }
-        if (q == hipErrorNotReady)   // the stream is wedged: the buffer and the event are leaked on purpose
-            return fail(MSM_ERR_STATE, "rank %d of %d: the communicator's first collectives did not complete within %d s", me, W, tmo);
+        if (q == hipErrorNotReady) {
+            // A collective that will never complete sits on the library's stream, and everything queued behind it -- the
+            // host transport the caller falls back to included -- would wait for it.  ncclCommAbort makes the communicator's
+            // kernels exit; the stream is then given a bounded time to drain.  The buffer and the event are leaked on purpose
+            // when it does not (the caller is told that the stream is unusable).
+            bool drained = false;
+            if (g_comm.kind == 1 && g_comm.comm && rccl().abort) {
+                (void)rccl().abort(g_comm.comm);
+                g_comm.comm = nullptr;
+                g_comm.kind = 0;
+                const auto t1 = std::chrono::steady_clock::now();
+                while ((q = hipEventQuery(ev)) == hipErrorNotReady && std::chrono::steady_clock::now() - t1 < std::chrono::seconds(20)) usleep(1000);
+                drained = q != hipErrorNotReady;
+            }
+            if (drained) {
+                (void)hipEventDestroy(ev);
+                (void)hipFree(d);
+            } else {
+                g_comm.wedged = true;
+            }
+            return fail(MSM_ERR_STATE, "rank %d of %d: the communicator's first collectives did not complete within %d s (%s)", me, W, tmo,
+                        drained ? "communicator aborted, the stream drained" : "the library's stream is still blocked: give the library a new stream");
+        }
         (void)hipEventDestroy(ev);
         if (q != hipSuccess) rc = fail(MSM_ERR_HIP, "rank %d of %d: collective self-test: %s", me, W, hipGetErrorString(q));
     }

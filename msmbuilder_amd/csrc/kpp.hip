@@ -13,8 +13,17 @@
 // this replaces used a float32 sgemm).  The cumulative sums are float64 like `stable_cumsum`'s, formed blockwise instead
 // of sequentially; the potentials are float64 sums (scikit-learn: a float32 dot).  A draw can therefore fall into the
 // neighbouring row only when it lands within ~1e-15 of a bin edge, and the arg-min over the candidates can differ only
-// between potentials that agree to ~1e-7: the seeds are scikit-learn's (tests/test_gpu_kmeans.py compares them with
-// `sklearn.cluster.kmeans_plusplus` at the bench's sizes).
+// between potentials that agree to ~1e-7.  What that means against scikit-learn itself: its current potential is a FLOAT32
+// sum whose value depends on the summation order of its BLAS / numpy build, and `rand_vals = uniform * current_pot` moves
+// with it -- on samples of a few thousand rows the draws land in the same bins and the seeds are scikit-learn's row for row
+// (tests/golden/mbkm_golden.npz: 20,000 x 10, K = 200, captured from scikit-learn 1.7.2; test_kmeans_plusplus_matches_sklearn),
+// on the bench's 196,608-row seeding sample they are the seeds of the float64 restatement the tests keep beside it and differ
+// from the installed scikit-learn's in some rounds (tests/test_gpu_kmeans.py::test_device_kmeans_plusplus_large_sample
+// bounds the potential within 5 %).  INTEGRATION.md section 2 states this where an integrator reads it.
+//
+// Shapes (round 5): candidate rows that do not fit the 60 KB staging tile (L x F x 4 bytes: e.g. K >= 403 at
+// F > 1875) are gathered into a device buffer and read through the L2 instead; seeding samples beyond 7.3M rows keep the
+// block prefix of the draw in device memory instead of LDS.  Both used to be refused.
 #include "common.h"
 
 #include <algorithm>
@@ -43,6 +52,8 @@ struct KppArgs {
     double* pot;         // [1] current potential (float32-rounded like scikit-learn's)
     float* centers;      // [K][F]
     long long* ids;      // [K]
+    float* cglob;        // [L][F] the round's candidate rows when they do not fit the LDS tile (else null)
+    double* bpre;        // [nb] prefix of the block totals when nb doubles do not fit LDS (else null)
 };
 
 // `closest` of round r = the winning candidate's row of the previous round's buffer
@@ -83,7 +94,8 @@ __global__ __launch_bounds__(KPP_NT) void kpp_scan_kernel(KppArgs P, int round)
 // 2) the round's candidates: searchsorted(cumsum(closest), u * pot), side = 'left', clipped to n - 1
 __global__ __launch_bounds__(KPP_NT) void kpp_pick_kernel(KppArgs P, int round, int nb)
 {
-    extern __shared__ double pre[];   // [nb] inclusive prefix of the block totals
+    extern __shared__ double pre_lds[];   // [nb] inclusive prefix of the block totals (or P.bpre: seeding samples beyond 7.3M rows)
+    double* pre = P.bpre ? P.bpre : pre_lds;
     const int tid = threadIdx.x;
     // sequential prefix by chunks: thread t owns blocks [t * per, (t + 1) * per)
     const int per = (nb + KPP_NT - 1) / KPP_NT;
@@ -136,15 +148,18 @@ __global__ __launch_bounds__(KPP_NT) void kpp_pick_kernel(KppArgs P, int round, 
 template <bool FIRST>
 __global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgs P, int round, long long first)
 {
-    extern __shared__ float cs[];   // [L][F] candidate rows
+    extern __shared__ float cs_lds[];   // [L][F] candidate rows (or P.cglob, gathered by kpp_gather_kernel: wide rows)
     __shared__ double cc[KPP_LMAX];
     __shared__ double red[KPP_LMAX][KPP_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = FIRST ? 1 : P.L, F = P.F;
-    for (int e = tid; e < L * F; e += KPP_NT) {
-        const int j = e / F, f = e - j * F;
-        const long long row = FIRST ? first : P.cand[j];
-        cs[e] = P.X[(size_t)row * F + f];
+    const float* cs = P.cglob ? P.cglob : cs_lds;
+    if (!P.cglob) {
+        for (int e = tid; e < L * F; e += KPP_NT) {
+            const int j = e / F, f = e - j * F;
+            const long long row = FIRST ? first : P.cand[j];
+            cs_lds[e] = P.X[(size_t)row * F + f];
+        }
     }
     __syncthreads();
     if (tid < L) {
@@ -197,6 +212,14 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgs P, int round, 
     if (tid < L) P.ppart[(size_t)blockIdx.x * P.L + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
+// 3') wide rows: the round's candidate rows into one device buffer (read by every block of kpp_dist_kernel through the L2)
+__global__ __launch_bounds__(KPP_NT) void kpp_gather_kernel(KppArgs P, int L, long long first)
+{
+    const int j = blockIdx.x;
+    const long long row = L == 1 ? first : P.cand[j];
+    for (int f = threadIdx.x; f < P.F; f += KPP_NT) P.cglob[(size_t)j * P.F + f] = P.X[(size_t)row * P.F + f];
+}
+
 // 4) potentials -> the winner (first minimum), the new centre, the new current potential
 __global__ __launch_bounds__(KPP_NT) void kpp_best_kernel(KppArgs P, int round, int nb, long long first)
 {
@@ -246,10 +269,11 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     if (!X || !centers || !ids || (K > 1 && !u)) return fail(MSM_ERR_INVALID, "kmeans_plusplus: null pointer");
     if (n < 1 || F < 1 || K < 1 || K > n || first < 0 || first >= n) return fail(MSM_ERR_INVALID, "kmeans_plusplus: bad shape");
     if (L < 1 || L > KPP_LMAX) return fail(MSM_ERR_INVALID, "kmeans_plusplus: 1 <= candidates per round <= %d", KPP_LMAX);
-    if ((size_t)L * F * sizeof(float) > 60000) return fail(MSM_ERR_INVALID, "kmeans_plusplus: %lld features x %d candidates exceed the staging tile", (long long)F, L);
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    if (ceil_div(n, KPP_RPB) > 0x7fffffffLL) return fail(MSM_ERR_INVALID, "kmeans_plusplus: too many rows");
     const int nb = (int)ceil_div(n, KPP_RPB);
-    if (nb > 7168) return fail(MSM_ERR_INVALID, "kmeans_plusplus: %lld rows exceed the seeding sample this kernel takes (7.3M)", (long long)n);
+    const bool wide = (size_t)L * F * sizeof(float) > 60000;   // candidate rows beyond the LDS staging tile: through a device buffer
+    const bool longpre = nb > 7168;                            // block prefix beyond LDS: in device memory
     DevBuf &dX = pool(PS_X), &dW = pool(PS_W), &dO = pool(PS_OUT);
     int rc;
     const float* Xd = X;
@@ -265,7 +289,7 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     const size_t o_dbuf = take(2 * (size_t)L * n * sizeof(float)), o_cuml = take((size_t)n * sizeof(double)),
                  o_bsum = take((size_t)nb * sizeof(double)), o_pp = take((size_t)nb * L * sizeof(double)),
                  o_u = take(std::max<size_t>(nu, 1) * sizeof(double)), o_pot = take(sizeof(double)), o_cand = take(L * sizeof(long long)),
-                 o_best = take(sizeof(int));
+                 o_best = take(sizeof(int)), o_cg = take(wide ? (size_t)L * F * sizeof(float) : 0), o_bpre = take(longpre ? (size_t)nb * sizeof(double) : 0);
     if ((rc = dW.reserve(off))) return rc;
     if ((rc = dO.reserve((size_t)K * F * sizeof(float) + (size_t)K * sizeof(long long)))) return rc;
     char* w = dW.as<char>();
@@ -284,14 +308,18 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     P.best = reinterpret_cast<int*>(w + o_best);
     P.centers = dO.as<float>();
     P.ids = reinterpret_cast<long long*>(dO.as<char>() + (size_t)K * F * sizeof(float));
+    P.cglob = wide ? reinterpret_cast<float*>(w + o_cg) : nullptr;
+    P.bpre = longpre ? reinterpret_cast<double*>(w + o_bpre) : nullptr;
     if (nu) MSM_HIP_CHECK(hipMemcpyAsync(w + o_u, u, nu * sizeof(double), hipMemcpyHostToDevice, stream()));
-    const size_t lds_c = (size_t)L * F * sizeof(float);
+    const size_t lds_c = wide ? 0 : (size_t)L * F * sizeof(float), lds_pre = longpre ? 0 : (size_t)nb * sizeof(double);
     // round 0: distances to the first centre = `closest`, its potential
+    if (wide) hipLaunchKernelGGL(kpp_gather_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, 1, (long long)first);
     hipLaunchKernelGGL(kpp_dist_kernel<true>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
     hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, 0, nb, (long long)first);
     for (int r = 1; r < (int)K; ++r) {
         hipLaunchKernelGGL(kpp_scan_kernel, dim3(nb), dim3(KPP_NT), 0, stream(), P, r);
-        hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(KPP_NT), (size_t)nb * sizeof(double), stream(), P, r, nb);
+        hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(KPP_NT), lds_pre, stream(), P, r, nb);
+        if (wide) hipLaunchKernelGGL(kpp_gather_kernel, dim3((unsigned)L), dim3(KPP_NT), 0, stream(), P, L, (long long)first);
         hipLaunchKernelGGL(kpp_dist_kernel<false>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
         hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, r, nb, (long long)first);
     }

@@ -18,7 +18,6 @@ This container is built around the native reader of csrc/npyio.hip rather than a
 import ctypes as C
 import os
 import re
-import tempfile
 
 import numpy as np
 
@@ -117,14 +116,23 @@ class NumpyDirDataset(object):
             x = x.detach().cpu().numpy()
         name = self._file(i)
         self._say('writing', name)
-        fd, tmp = tempfile.mkstemp(suffix='.part', dir=self.path)
+        # a private temporary file next to the target, created with mode 0666 so that the KERNEL applies the umask (np.save,
+        # what the reference uses at dataset.py:323, gets the same mode; reading the umask with os.umask(0) would open a window
+        # in which another thread's files are created world-writable), then an atomic rename
+        tmp = None
+        for attempt in range(100):
+            cand = os.path.join(self.path, '.%s.%d.%d.part' % (os.path.basename(name), os.getpid(), attempt))
+            try:
+                fd = os.open(cand, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o666)
+            except FileExistsError:
+                continue
+            tmp = cand
+            break
+        if tmp is None:
+            raise IOError('could not create a temporary file in %s' % self.path)
         try:
             with os.fdopen(fd, 'wb') as f:
                 np.lib.format.write_array(f, np.asanyarray(x), allow_pickle=False)
-            # mkstemp creates 0600 files; np.save (what the reference uses, dataset.py:323) honours the umask
-            umask = os.umask(0)
-            os.umask(umask)
-            os.chmod(tmp, 0o666 & ~umask)
             os.replace(tmp, name)
         except BaseException:
             if os.path.exists(tmp):

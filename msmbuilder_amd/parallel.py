@@ -80,6 +80,7 @@ def init_from_env(backend=None):
 _lib_comm_kind = None      # None | "rccl" | "host"
 _comm_failures = []        # ranks whose RCCL join / self-test failed when the communicator was last built (then: host transport)
 _host_cb_keepalive = None
+_fresh_stream = None         # the stream this thread was moved to after an un-abortable RCCL collective blocked the old one
 _lib_comm_key = None       # (backend, world, rank, default group identity) the communicator belongs to
 _atexit_registered = False
 
@@ -184,6 +185,14 @@ def library_comm():
                     if rc:
                         warnings.warn("libmsmhip RCCL communicator, rank %d of %d: %s" % (r, w, err))
                     L.msm_comm_destroy()
+                    if rc and "new stream" in err:
+                        # a collective that could not be aborted still blocks the stream the library was on: everything
+                        # queued behind it (the host transport included) would wait for ever -- move this thread, and with
+                        # it the library, to a fresh stream
+                        global _fresh_stream
+                        _fresh_stream = torch.cuda.Stream()
+                        torch.cuda.set_stream(_fresh_stream)
+                        _lib.set_stream(_fresh_stream.cuda_stream)
         if kind is None and want == "rccl":
             raise RuntimeError("libmsmhip could not create its RCCL communicator (failed ranks: %s): %s"
                                % ([f["rank"] for f in _comm_failures], _lib.last_error()))

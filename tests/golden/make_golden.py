@@ -252,6 +252,44 @@ def main():
     print("mbkm_golden.npz: sklearn", sklearn.__version__, "inertia", g["inertia"], "steps", g["n_steps"])
 
 
+def kpp_golden():
+    """Round 5: k-means++ seeds of a MID-SIZE sample captured from scikit-learn itself, so that "the device
+    seeding is scikit-learn's, row for row" is a test with no live scikit-learn behind it: 6,000 x 10 float32, K = 200,
+    RandomState(7).  Appended to mbkm_golden.npz (its other arrays are left as they are).  Why 6,000: scikit-learn's current
+    potential is a float32 sum whose rounding depends on the summation order of its build, and every inverse-CDF draw is
+    scaled by it -- against the float64 restatement (oracle/kpp_oracle.py, = the device kernel) its picks agreed on every
+    sample tried up to 6,000 rows and departed on one of three 8,000-row samples and on most samples from 20,000 rows
+    (scan below, printed)."""
+    import sklearn
+    from sklearn.cluster import kmeans_plusplus as sk_kpp
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.kpp_oracle import kmeans_plusplus_f64
+
+    def sample(n, seed):
+        rs = np.random.RandomState(seed)
+        return (rs.randn(n, 10) * np.linspace(3, 0.3, 10)).astype(np.float32)
+    path = os.path.join(HERE, "mbkm_golden.npz")
+    g = dict(np.load(path, allow_pickle=False))
+    X = sample(6000, 5)
+    centers, ids = sk_kpp(X, 200, random_state=np.random.RandomState(7))
+    g["kpp_n"], g["kpp_data_seed"], g["kpp_k"], g["kpp_stream_seed"] = np.int64(6000), np.int64(5), np.int64(200), np.int64(7)
+    g["kpp_ids"] = np.asarray(ids, dtype=np.int64)
+    g["kpp_centers"] = np.asarray(centers, dtype=np.float32)
+    g["kpp_sklearn_version"] = np.array(sklearn.__version__)
+    scan = []
+    for seed in (5, 6, 7):
+        for n in (3072, 6000, 8000, 15000, 20000, 50000):
+            Xs = sample(n, seed)
+            _, a = sk_kpp(Xs, 200, random_state=np.random.RandomState(7))
+            _, b = kmeans_plusplus_f64(Xs, 200, np.random.RandomState(7))
+            same = np.asarray(a) == np.asarray(b)
+            scan.append((seed, n, int(same.sum())))
+            print("kpp scan: data seed %d, %6d rows: %3d of 200 picks equal scikit-learn's" % scan[-1])
+    g["kpp_scan_seed_rows_equal"] = np.asarray(scan, dtype=np.int64)
+    np.savez_compressed(path, **g)
+    print("mbkm_golden.npz: + k-means++ seeds of 6000 x 10, K = 200 from scikit-learn", sklearn.__version__)
+
+
 def transition_golden():
     """msmbuilder.msm._transition_counts itself (msm/core.py:487-596), loaded by file path with a stub
     for the compiled _ratematrix extension and the numpy aliases (np.int / np.float) it still uses."""
@@ -324,6 +362,9 @@ def transition_golden():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "transition":
         transition_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "kpp":
+        kpp_golden()
     else:
         main()
         transition_golden()
+        kpp_golden()

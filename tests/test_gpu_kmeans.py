@@ -225,6 +225,37 @@ def test_device_kmeans_plusplus_draws_scikit_learns_seeds(gpu, n, F, k):
     np.testing.assert_array_equal(kpp_oracle(X, k, np.random.RandomState(7)), ref)   # ... and so does the oracle restatement
 
 
+def test_device_kmeans_plusplus_matches_sklearn_golden(gpu, golden_dir):
+    """Round 5: scikit-learn 1.7.2's OWN seeds of a mid-size sample (6,000 x 10, K = 200), captured in tests/golden (no live
+    scikit-learn behind this test): the device seeding picks the same 200 rows.  (Why not larger: see the scan stored beside
+    the seeds -- from 8,000 rows scikit-learn's float32 potential sum starts to move draws across bin edges.)"""
+    import torch
+    from msmbuilder_amd.cluster.minibatchkmeans import kmeans_plusplus
+    g = np.load(os.path.join(golden_dir, "mbkm_golden.npz"))
+    n, k = int(g["kpp_n"]), int(g["kpp_k"])
+    rs = np.random.RandomState(int(g["kpp_data_seed"]))
+    X = (rs.randn(n, 10) * np.linspace(3, 0.3, 10)).astype(np.float32)
+    for rows in (X, torch.from_numpy(X).cuda()):
+        mine = kmeans_plusplus(rows, k, np.random.RandomState(int(g["kpp_stream_seed"])))
+        np.testing.assert_array_equal(mine, g["kpp_centers"])
+        np.testing.assert_array_equal(mine, X[g["kpp_ids"]])
+
+
+@pytest.mark.parametrize("n,F,k", [(2000, 2048, 500), (1500, 4000, 30)])
+def test_device_kmeans_plusplus_wide_rows(gpu, n, F, k):
+    """candidate rows beyond the 60 KB LDS staging tile (K >= 403 gives 8 candidates per round: F > 1875) used to
+    be refused -- MiniBatchKMeans(n_clusters=500) on 2,048-feature data raised.  They now go through a device buffer; the
+    picks must still be scikit-learn's (small sample: its float32 sums are order-independent here)."""
+    sk = pytest.importorskip("sklearn.cluster")
+    import torch
+    from msmbuilder_amd.cluster.minibatchkmeans import kmeans_plusplus
+    rs = np.random.RandomState(n + k)
+    X = (rs.randn(n, F) * rs.uniform(0.5, 3, F)).astype(np.float32)
+    ref, _ = sk.kmeans_plusplus(X, k, random_state=np.random.RandomState(7))
+    mine = kmeans_plusplus(torch.from_numpy(X).cuda(), k, np.random.RandomState(7))
+    np.testing.assert_array_equal(mine, ref)
+
+
 def test_device_kmeans_plusplus_large_sample(gpu):
     """The bench's large-batch init sample, 3 x 65,536 rows, K = 1000.  scikit-learn sums its potentials in float32 over
     the 196,608 rows (a BLAS dot: ~1e-5 relative, order-dependent), and every inverse-CDF draw is scaled by that sum -- a

@@ -251,6 +251,22 @@ def test_ctypes_prototypes_match_the_header():
     assert checked >= 50
 
 
+def test_kmeans_plusplus_oracle_matches_sklearn_golden(golden_dir):
+    """The float64 restatement of k-means++ (oracle/kpp_oracle.py: what the device kernel computes) against scikit-learn
+    1.7.2's captured seeds of 6,000 x 10, K = 200 (tests/golden/make_golden.py kpp), and the stored scan of where the two
+    stop agreeing: every sample up to 6,000 rows agrees, none of the three 20,000-row samples with data seeds 5 / 6 does."""
+    from oracle.kpp_oracle import kmeans_plusplus_f64
+    g = np.load(os.path.join(golden_dir, "mbkm_golden.npz"))
+    n, k = int(g["kpp_n"]), int(g["kpp_k"])
+    rs = np.random.RandomState(int(g["kpp_data_seed"]))
+    X = (rs.randn(n, 10) * np.linspace(3, 0.3, 10)).astype(np.float32)
+    mine, ids = kmeans_plusplus_f64(X, k, np.random.RandomState(int(g["kpp_stream_seed"])))
+    np.testing.assert_array_equal(np.asarray(ids), g["kpp_ids"])
+    np.testing.assert_array_equal(mine, g["kpp_centers"])
+    scan = g["kpp_scan_seed_rows_equal"]
+    assert all(e == 200 for s_, n_, e in scan if n_ <= 6000) and any(e < 200 for s_, n_, e in scan if n_ >= 8000)
+
+
 @pytest.mark.parametrize("n,F,k", [(500, 8, 10), (3072, 64, 50), (1000, 3, 25)])
 def test_kmeans_plusplus_oracle_draws_scikit_learns_seeds(n, F, k):
     """oracle/kpp_oracle.py (the numpy restatement the device seeding is checked against on the GPU tier) walks
