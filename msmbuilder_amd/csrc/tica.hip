@@ -1279,6 +1279,8 @@ struct ImgArgs {
 // thread -> 4 consecutive features (one 16-byte load per row for float32, 8 bytes for bfloat16) x the 8 pairs of one group:
 // 16 row loads in flight, an 8 x 4 transpose in registers, four 16-byte packets per image written back to back (a wave
 // writes 4 KiB contiguous).  A workgroup handles one K-step (4 groups) of a 256-feature block per iteration.
+// (nontemporal stores of the image were tried here: no change, 11.6 -> 11.6 ms per 1M x 2048 fit)
+#define IMG_PACK_STORE(PTR, V) (*(PTR) = (V))
 template <bool X2>
 __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
 {
@@ -1298,6 +1300,7 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
     const global_ptr<char> base = as_global<char>(ch.base);
     const int fc = f0 < P.F ? f0 : (P.F >= 4 ? P.F - 4 : 0);  // clamped column of the vector loads
     double cs[4] = {0.0, 0.0, 0.0, 0.0};   // P.colA: fp64 sums of the left frames this thread loads (its four features)
+    __shared__ bf16x8 img_stage[4][X2 ? 4 : 2][256];   // per wave: the packets of its group, one tile per image
     for (long long st = 0; st < nsteps; ++st) {
         const long long gi = st * 4 + gq;
         float a[8][4], b[8][4];
@@ -1369,14 +1372,35 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
                     dm[e] = (__bf16)(d - (float)d1);
                 }
             }
-            const size_t o = (size_t)(ch.g0 - P.g_off + gi) * (size_t)P.Fp + (size_t)(f0 + q);
-            P.u_hi[o] = uh;
-            P.d_hi[o] = dh;
+            // Round 5: the lane's four packets (64 contiguous bytes per image) go through an LDS staging tile and leave as
+            // 1 KiB-contiguous wave stores.  Stored straight from the lane, a store instruction wrote 16 bytes of every 64
+            // (lane stride 64 B): four partial passes over each cache line.  XOR swizzle: conflict-free both ways.
+            const int sl = 4 * fq + q;
+            img_stage[gq][0][sl ^ ((sl >> 3) & 7)] = uh;
+            img_stage[gq][1][sl ^ ((sl >> 3) & 7)] = dh;
             if (X2) {
-                P.u_mid[o] = um;
-                P.d_mid[o] = dm;
+                img_stage[gq][2][sl ^ ((sl >> 3) & 7)] = um;
+                img_stage[gq][3][sl ^ ((sl >> 3) & 7)] = dm;
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a wave's LDS operations complete in order: its own packets are all there)
+        __builtin_amdgcn_wave_barrier();
+        {
+            const size_t o0 = (size_t)(ch.g0 - P.g_off + gi) * (size_t)P.Fp + (size_t)blockIdx.y * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sr = 64 * i + fq;
+                const int sp = sr ^ ((sr >> 3) & 7);
+                IMG_PACK_STORE(P.u_hi + o0 + sr, img_stage[gq][0][sp]);
+                IMG_PACK_STORE(P.d_hi + o0 + sr, img_stage[gq][1][sp]);
+                if (X2) {
+                    IMG_PACK_STORE(P.u_mid + o0 + sr, img_stage[gq][2][sp]);
+                    IMG_PACK_STORE(P.d_mid + o0 + sr, img_stage[gq][3][sp]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is read out before the next step's packets overwrite it
+        __builtin_amdgcn_wave_barrier();
     }
     if (P.colA) {   // the four groups of a feature quad -> one sum per (chunk, feature): plain stores, one writer each
         __shared__ double red[4][64][4];
