@@ -708,6 +708,18 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(4))) pk_sub4(flo
 // [0, P.n_main) round-robin as before, plus R = gridDim.x - P.S * P.ntiles workgroups that round 3 left idle (104 of 512 at
 // 2,048 features): a REMAINDER cohort that takes the chunks [P.n_main, P.nchunks) in ceil(ntiles / R) rounds of R tiles
 // (slab / column-sum row P.S).  The host picks n_main so that every workgroup is busy for the same time.
+// ROLE SPLIT (round 5; built, measured, removed -- git history: "role-split fp32 sum/difference kernel"):
+// eight waves per workgroup on a 128 x 128 tile of H OR of D, waves 0-3 issuing only fragment reads and MFMAs (64 x 64 each),
+// waves 4-7 only staging (loads one half-step ahead in registers, shift, weights, packed adds, LDS writes), one barrier per
+// half-step, two workgroups per CU.  Correct (the fp32 test files pass on it, eigenvalues equal to 1e-10) and SLOWER:
+// 62.5 ms against 49.8 ms at 10M x 512 (0.67 against 0.84 of the fp32 MFMA peak; profiles/r05_role_split_f32_ab.txt).
+// The 256 x 128 tile of H AND D that VERDICT names cannot exist: 4 MFMA waves x (64 x 128) x 2 matrices = 256 accumulators
+// per lane, and a kernel's register allocation is uniform over its waves, so the stagers would be charged 256 + too -- one
+// workgroup per CU; and 256-wide tiles waste a fifth of their products on F = 512's triangle (10 tiles of 128 do not pair up
+// into dominoes without two singles).  With H and D in separate workgroups each reads the raw rows itself (2x the L2 -> CU
+// bytes and 2x the staging arithmetic of this kernel, where one staged pair of panels feeds both matrices), the MFMA wave of a
+// workgroup is alone on its SIMD with its barrier and LDS latencies, and what the interleaved kernel loses to its in-stream
+// staging (matrix pipe busy 0.87) is less than that.  The item is closed.
 template <bool PARTIAL, bool FOLD, bool REM = false>
 __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 {
@@ -1019,267 +1031,6 @@ __global__ __launch_bounds__(NT, 2) void tica_sym_f32_kernel(TicaArgs P)
 #undef MSM_F2
 #undef MSM_SYM_UD
 #undef MSM_SYM_COLADD
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the ROLE-SPLIT sum/difference kernel.  The kernel above interleaves its staging -- 8 loads, ~30
-// packed adds, 8 LDS writes per half-step -- into the MFMA stream of the same wave (matrix pipe busy 0.87).  Here a
-// workgroup is 8 waves on ONE 128 x 128 tile of ONE matrix (H = sum u u^T or D = sum d d^T: a "unit"; H and D of a tile are
-// adjacent workgroups, so their raw rows meet in the XCD's L2):
-//   * waves 0-3 issue nothing but fragment reads and MFMAs (64 x 64 outputs each, 64 accumulators);
-//   * waves 4-7 stage: 8 global_load_dwordx4 per lane one half-step ahead in registers, x - r, the row weight / column
-//     mask, u or d with packed adds, 4 ds_write_b128 into the other LDS buffer -- ONE code path for interior and edge
-//     half-steps (rows clamped, weights 0 or 1): the stagers have ~10x the issue slots they need;
-//   * one workgroup barrier per half-step of 16 frames; two workgroups per CU, so a SIMD hosts two MFMA waves (one per
-//     workgroup) that cover each other's barrier and LDS latencies, and two stagers.
-// A 256 x 128 tile of H AND D per workgroup (the shape VERDICT names) does not exist on this register file: 4 MFMA waves
-// x (64 x 128) x 2 matrices = 256 accumulators per lane, and a kernel's VGPR allocation is uniform over its waves, so the
-// stagers would get 256 + registers too -- one workgroup per CU at most, and the 256-wide tile wastes a fifth of its
-// products on F = 512's triangle (10 tiles of 128 do not pair up into dominoes without leaving two singles).
-// Slabs, export, un-shift, folded column sums: the layout and meaning of the kernel above (the unit (I, I, H) of a cohort sums
-// the left frames of column block I), so the two kernels are interchangeable per launch (MSM_TICA_RS).
-// ---------------------------------------------------------------------------------------------------------------------
-#ifndef MSM_TICA_RS_DEFAULT
-#define MSM_TICA_RS_DEFAULT 0
-#endif
-constexpr int RS_NT = 512;
-constexpr int RS_HK = 16;                                   // frames per half-step
-constexpr int RS_PLANE = RS_HK * TM;                        // floats per plane
-constexpr size_t LDSRS = (size_t)(2 * 2 * RS_PLANE + 2 * TM) * sizeof(float);   // two buffers x [I columns, J columns] + the shift rows: 33 KiB
-
-// The two roles are two code paths with the SAME barrier sequence (per round: 2, then per chunk 2 + its half-steps, then -- FOLD --
-// 3); they share nothing but LDS.  Kept apart so that the stagers do not carry the 64 accumulators through their registers.
-struct RsUnit {
-    int cohort, which, I, J;
-    bool rem;
-    int units;
-};
-
-template <bool FOLD>
-__device__ __forceinline__ void rs_mfma_role(const TicaArgs& P, float* lds, const RsUnit& U, double* slab, int wave, int lane)
-{
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    const int tid = threadIdx.x;
-    const int wr = (wave >> 1) & 1, wc = wave & 1, kl = lane >> 5, cl = lane & 31;
-    // a lane's two row blocks are the ADJACENT columns 2 l, 2 l + 1 (permuted tile, undone at the slab merge as in tica_sym_f32_kernel)
-    const int fa = kl * TM + wr * 64 + 2 * cl, fb = RS_PLANE + kl * TM + wc * 64 + 2 * cl;   // floats inside a buffer
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-        for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
-    __syncthreads();
-    __syncthreads();
-    int rows_acc = 0;
-    const long long c_end = U.rem ? P.nchunks : P.n_main, c_step = U.rem ? 1 : P.S;
-    for (long long c = U.rem ? P.n_main : U.cohort; c < c_end; c += c_step) {
-        const TicaChunk ch = get_chunk(P, c);
-        const int nh = 2 * ((ch.n + BK32 - 1) / BK32);
-        __syncthreads();
-        __syncthreads();
-        for (int h = 0; h < nh; ++h) {
-            // groups of two k-pairs (8 MFMAs, 512 cycles of the pipe): the NEXT group's fragments are read before this group's
-            // MFMAs are issued (left to itself the compiler sinks each read to just in front of its first use and waits)
-            const float* B = lds + (h & 1) * 2 * RS_PLANE;
-            f2v pu0 = *reinterpret_cast<const f2v*>(B + fa), qu0 = *reinterpret_cast<const f2v*>(B + fb);
-            f2v pu1 = *reinterpret_cast<const f2v*>(B + 2 * TM + fa), qu1 = *reinterpret_cast<const f2v*>(B + 2 * TM + fb);
-#pragma unroll
-            for (int g = 0; g < RS_HK / 4; ++g) {
-                f2v npu0 = pu0, nqu0 = qu0, npu1 = pu1, nqu1 = qu1;
-                if (g + 1 < RS_HK / 4) {
-                    npu0 = *reinterpret_cast<const f2v*>(B + (2 * g + 2) * 2 * TM + fa);
-                    nqu0 = *reinterpret_cast<const f2v*>(B + (2 * g + 2) * 2 * TM + fb);
-                    npu1 = *reinterpret_cast<const f2v*>(B + (2 * g + 3) * 2 * TM + fa);
-                    nqu1 = *reinterpret_cast<const f2v*>(B + (2 * g + 3) * 2 * TM + fb);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu0.x, qu0.x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu0.x, qu0.y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu0.y, qu0.x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu0.y, qu0.y, acc[1][1], 0, 0, 0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu1.x, qu1.x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu1.x, qu1.y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu1.y, qu1.x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pu1.y, qu1.y, acc[1][1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                pu0 = npu0; qu0 = nqu0; pu1 = npu1; qu1 = nqu1;
-            }
-            __syncthreads();                                  // buffer (h + 1) & 1 is complete, buffer h & 1 is free
-        }
-        if (P.cosync && !U.rem && tid == 0) __hip_atomic_fetch_add(P.cosync + U.cohort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rows_acc += ch.n;
-        if (rows_acc + P.kc > P.kflush || c + c_step >= c_end) {
-            rows_acc = 0;
-            // accumulator register r of block (bi, bj), lane (kl, cl) = tile row wr*64 + 2*rho + bi with rho = (r & 3) + 8 (r >> 2) + 4 kl,
-            // tile column wc*64 + 2*cl + bj: the two bj of a lane are adjacent doubles
-            unsigned toff = (unsigned)((wr * 64 + 8 * kl) * TM + wc * 64 + 2 * cl);
-            asm volatile("" : "+v"(toff));
-#pragma unroll
-            for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {   // eight rows at a time
-                    double2 old[8];
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = 8 * hh + r8;
-                        old[r8] = *reinterpret_cast<const double2*>(slab + (2 * ((r & 3) + 8 * (r >> 2)) + bi) * TM + toff);
-                    }
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = 8 * hh + r8;
-                        double2* q = reinterpret_cast<double2*>(slab + (2 * ((r & 3) + 8 * (r >> 2)) + bi) * TM + toff);
-                        *q = make_double2(old[r8].x + (double)acc[bi][0][r], old[r8].y + (double)acc[bi][1][r]);
-                        acc[bi][0][r] = acc[bi][1][r] = 0.f;
-                    }
-                }
-        }
-    }
-    if (FOLD) {
-        __syncthreads();
-        __syncthreads();
-        const int I0 = U.I * TM;
-        if (U.I == U.J && U.which == 0 && tid < TM) {   // column tid of the block = element tid & 3 of the stager lanes (srow, tid >> 2), srow = 0 .. 7
-            const double* csl = reinterpret_cast<const double*>(lds);
-            double a = 0.0;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a += csl[(tid & 3) * 256 + r * 32 + (tid >> 2)];
-            P.colA[(size_t)U.cohort * P.F + I0 + tid] = a;
-        }
-        __syncthreads();
-    }
-}
-
-template <bool FOLD>
-__device__ __forceinline__ void rs_stager_role(const TicaArgs& P, float* lds, const RsUnit& U)
-{
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    float* rs = lds + 2 * 2 * RS_PLANE;                       // [2][128] reference row r of the I and J columns
-    const int tid = threadIdx.x, lt = tid & 255;
-    const int I0 = U.I * TM, J0 = U.J * TM;
-    const int which = U.which;
-    // lane -> rows srow, srow + 8 of a half-step, columns scol .. scol + 3 of the I block and of the J block
-    const int srow = lt >> 5, scol = (lt & 31) * 4;
-    const unsigned ca = 4u * (unsigned)(I0 + scol < P.F ? I0 + scol : P.F - 4), cb = 4u * (unsigned)(J0 + scol < P.F ? J0 + scol : P.F - 4);
-    const f4v ma = {I0 + scol + 0 < P.F ? 1.f : 0.f, I0 + scol + 1 < P.F ? 1.f : 0.f, I0 + scol + 2 < P.F ? 1.f : 0.f, I0 + scol + 3 < P.F ? 1.f : 0.f};
-    const f4v mb = {J0 + scol + 0 < P.F ? 1.f : 0.f, J0 + scol + 1 < P.F ? 1.f : 0.f, J0 + scol + 2 < P.F ? 1.f : 0.f, J0 + scol + 3 < P.F ? 1.f : 0.f};
-    double cs0 = 0.0, cs1 = 0.0, cs2 = 0.0, cs3 = 0.0;       // FOLD: fp64 sums of this lane's four I columns of the left frames
-    const bool sums = FOLD && U.I == U.J && which == 0;       // (uniform) the unit that owns column block I's sums in this cohort
-    __syncthreads();                                          // (a previous round's readers are done with the shift rows)
-    if (lt < 64) {
-        const int col = (lt < 32 ? I0 : J0) + (lt & 31) * 4;
-        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.shift) rv = *reinterpret_cast<const float4*>(P.shift + (col < P.F ? col : P.F - 4));
-        *reinterpret_cast<float4*>(rs + lt * 4) = rv;
-    }
-    __syncthreads();
-    const f4v rx = *reinterpret_cast<const f4v*>(rs + scol), ry = *reinterpret_cast<const f4v*>(rs + TM + scol);
-    int chunks_done = 0;
-    const long long c_end = U.rem ? P.nchunks : P.n_main, c_step = U.rem ? 1 : P.S;
-    for (long long c = U.rem ? P.n_main : U.cohort; c < c_end; c += c_step) {
-        const TicaChunk ch = get_chunk(P, c);
-        const int nh = 2 * ((ch.n + BK32 - 1) / BK32);        // half-steps (a chunk is walked in whole 32-frame steps, like the kernel above)
-        ChunkCtx cx = make_ctx(P, ch);
-        set_lag(cx, P.lag, sizeof(float), P.ld);
-        float4 xa[2], xb[2], ya[2], yb[2];                    // the raw rows of the half-step being prepared
-        float sc[2] = {0.f, 0.f};
-        auto load_rows = [&](int k0) {                        // rows k0 + srow, k0 + srow + 8: clamped into the trajectory, weight = pair exists
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kr = k0 + srow + 8 * j;
-                const unsigned ra = (unsigned)(kr < cx.nmax ? kr : cx.nmax) * cx.ldb;
-                const unsigned rb = (unsigned)(kr < cx.nmaxB ? kr : cx.nmaxB) * cx.ldb;
-                xa[j] = load16_global<char>(cx.base + (ra + ca));
-                xb[j] = load16_global<char>(cx.baseB + (rb + ca));
-                ya[j] = load16_global<char>(cx.base + (ra + cb));
-                yb[j] = load16_global<char>(cx.baseB + (rb + cb));
-                sc[j] = (kr < cx.hi) ? 1.f : 0.f;
-            }
-        };
-        auto convert_store = [&](int buf) {                   // (x_t, x_{t+tau}) -> u or d of the shifted frames, into buffer `buf`
-            float* dst = lds + buf * 2 * RS_PLANE + srow * TM + scol;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (sums && sc[j] != 0.f) {
-                    cs0 += (double)xa[j].x;
-                    cs1 += (double)xa[j].y;
-                    cs2 += (double)xa[j].z;
-                    cs3 += (double)xa[j].w;
-                }
-                const f4v wa = ma * sc[j], wb = mb * sc[j];
-                const f4v ax = pk_sub4(*reinterpret_cast<const f4v*>(&xa[j]), rx) * wa, bx = pk_sub4(*reinterpret_cast<const f4v*>(&xb[j]), rx) * wa;
-                const f4v ay = pk_sub4(*reinterpret_cast<const f4v*>(&ya[j]), ry) * wb, by = pk_sub4(*reinterpret_cast<const f4v*>(&yb[j]), ry) * wb;
-                const f4v vx = which ? pk_sub4(ax, bx) : ax + bx, vy = which ? pk_sub4(ay, by) : ay + by;
-                *reinterpret_cast<f4v*>(dst + j * 8 * TM) = vx;
-                *reinterpret_cast<f4v*>(dst + RS_PLANE + j * 8 * TM) = vy;
-            }
-        };
-        __syncthreads();                                      // every wave is done with both buffers (previous chunk)
-        if (P.cosync && !U.rem && chunks_done > 0 && tid == 256) {   // cohort pacing (see the kernel above): bounded wait
-            const unsigned target = (unsigned)U.units * (unsigned)chunks_done;
-            const long long t0 = clock64();
-            while (__hip_atomic_load(P.cosync + U.cohort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (clock64() - t0 > 200000) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        load_rows(0);
-        convert_store(0);
-        if (nh > 1) load_rows(RS_HK);
-        __syncthreads();
-        for (int h = 0; h < nh; ++h) {
-            if (h + 1 < nh) {
-                convert_store((h & 1) ^ 1);                   // half-step h + 1 (its rows were loaded one half-step ago)
-                if (h + 2 < nh) load_rows((h + 2) * RS_HK);
-            }
-            __syncthreads();                                  // buffer (h + 1) & 1 is complete, buffer h & 1 is free
-        }
-        ++chunks_done;
-    }
-    if (FOLD) {
-        __syncthreads();                                      // the panels are free
-        double* csl = reinterpret_cast<double*>(lds);         // [4 elements][256 stager lanes]
-        csl[0 * 256 + lt] = cs0;
-        csl[1 * 256 + lt] = cs1;
-        csl[2 * 256 + lt] = cs2;
-        csl[3 * 256 + lt] = cs3;
-        __syncthreads();
-        __syncthreads();
-    }
-}
-
-template <bool FOLD>
-__global__ __launch_bounds__(RS_NT, 4) void tica_symrs_f32_kernel(TicaArgs P)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* lds = reinterpret_cast<float*>(smem);             // [2 buffers][I plane, J plane][16 frames][128 columns], then [2][128] shift rows
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int units = 2 * P.ntiles;
-    const int p = xcd_linear_id();
-    const bool rem = p >= P.S * units;                        // a workgroup of the remainder cohort (uniform)
-    const int remR = (int)gridDim.x - P.S * units;
-    for (int round = 0; round < (rem ? (units + remR - 1) / remR : 1); ++round) {
-        RsUnit U;
-        U.rem = rem;
-        U.units = units;
-        U.cohort = rem ? P.S : p / units;
-        const int unit = rem ? p - P.S * units + round * remR : p % units;
-        if (rem && unit >= units) break;
-        U.which = unit & 1;                                   // H and D of a tile: adjacent workgroups
-        const int tile = unit >> 1;
-        int I = 0, uu = tile;
-        while (uu >= P.T - I) {
-            uu -= P.T - I;
-            ++I;
-        }
-        U.I = I;
-        U.J = I + uu;
-        double* slab = P.slabs + ((size_t)U.cohort * P.ntiles + tile) * (2 * TM * TM) + (size_t)U.which * (TM * TM);
-        if (wave >= 4) rs_stager_role<FOLD>(P, lds, U);       // (wave-uniform: a scalar branch)
-        else rs_mfma_role<FOLD>(P, lds, U, slab, wave, tid & 63);
-    }
-}
 
 // packed C and G contributions of the symmetric kernel's slabs: G += (H + D) / 2 and "C" += (H - D) / 4
 // (a symmetric matrix whose symmetrisation (C + C^T) / 2 is the lagged moment's).  One thread per element of an UPPER tile
@@ -2384,7 +2135,6 @@ struct msm_tica {
     int S32 = 0, S64 = 0, S = 0, G = 0;  // cohorts per kernel flavour; S = max (slab count), G = S * ntiles
     int sym = 0, ntiles_sym = 0, S_sym = 0;                // symmetric fp32 kernel: upper tiles, slab / column-sum ROWS (cohorts, + 1 with a remainder cohort)
     int sym_cohorts = 0, sym_grid = 0;                     // ... whole cohorts, workgroups of a launch (sym_grid > sym_cohorts * ntiles_sym: remainder cohort)
-    int rs_on = 0, rs_cohorts = 0, rs_grid = 0;            // role-split sum/difference kernel (round 5): whole cohorts of 2 ntiles_sym units, workgroups of a launch
     double* slabs_sym = nullptr;                           // [S_sym * ntiles_sym][2][TM*TM]: H and D blocks
     double* slabs = nullptr;    // [G][TM*TM]
     double* base = nullptr;     // packed [2FF+2F] imported state
@@ -2522,17 +2272,9 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     const bool use32 = dtype_bytes == 4 && (h->mode == MSM_TICA_F32 || (bfmode && !useimg));
     const int bk = (use32 || useimg) ? BK32 : BK64;
     const bool usesym = (use32 && h->mode == MSM_TICA_F32 && h->sym && aligned) || useimg;  // pair semantics: sum/difference slabs (H/D kernel: 16-byte aligned rows only)
-    // Round 5: the role-split sum/difference kernel (tica_symrs_f32_kernel: 8 waves per 128 x 128 tile of H OR of D, four that
-    // only multiply and four that only stage).  MSM_TICA_RS, read per launch: the A/B switch of the tests and of the bench.
-    bool users = false;
-    if (usesym && !useimg && h->rs_on) {
-        const char* re = getenv("MSM_TICA_RS");
-        users = re ? atoi(re) != 0 : MSM_TICA_RS_DEFAULT != 0;
-    }
-    const int rs_units = 2 * h->ntiles_sym;
-    const int S = useimg ? h->S_img : users ? h->rs_cohorts : usesym ? h->sym_cohorts : use32 ? h->S32 : h->S64;  // one resident round
-    const bool symrem = users ? h->rs_grid > S * rs_units : (usesym && !useimg && h->sym_grid > S * h->ntiles_sym);   // ... + a remainder cohort
-    const int G = users ? h->rs_grid : symrem ? h->sym_grid : S * (usesym ? h->ntiles_sym : h->ntiles);
+    const int S = useimg ? h->S_img : usesym ? h->sym_cohorts : use32 ? h->S32 : h->S64;  // one resident round
+    const bool symrem = usesym && !useimg && h->sym_grid > S * h->ntiles_sym;              // ... + a remainder cohort
+    const int G = symrem ? h->sym_grid : S * (usesym ? h->ntiles_sym : h->ntiles);
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
@@ -2681,8 +2423,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     if (symrem) {
         // chunks of the remainder cohort: its R workgroups walk them once per round, the whole cohorts share the others
         // S ways -- equal time when n_rem x rounds = n_main / S
-        const int upc = users ? rs_units : h->ntiles_sym;   // workgroups per cohort
-        const int R = G - S * upc, rounds = (int)ceil_div(upc, R);
+        const int R = G - S * h->ntiles_sym, rounds = (int)ceil_div(h->ntiles_sym, R);
         const long long n_rem = (P.nchunks + ((long long)S * rounds + 1) / 2) / ((long long)S * rounds + 1);
         P.n_main = P.nchunks - n_rem;
     }
@@ -2976,11 +2717,6 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             MSM_HIP_CHECK(hipGetLastError());
             c0 = c1;
         }
-    } else if (users) {
-        if (fold)
-            hipLaunchKernelGGL((tica_symrs_f32_kernel<true>), dim3(G), dim3(RS_NT), LDSRS, stream(), P);
-        else
-            hipLaunchKernelGGL((tica_symrs_f32_kernel<false>), dim3(G), dim3(RS_NT), LDSRS, stream(), P);
     } else if (usesym) {
         if (symrem) {
             if (fold)
@@ -3162,20 +2898,6 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
             const bool rem = h->sym && R * 16 >= slots && 3 * R >= h->ntiles_sym;
             h->sym_grid = rem ? slots : h->sym_cohorts * h->ntiles_sym;
             h->S_sym = h->sym_cohorts + (rem ? 1 : 0);
-            if (h->sym) {
-                // the role-split kernel: 512-thread workgroups, 33 KiB of LDS, <= 128 registers: two per CU
-                int o1 = 0, o2 = 0;
-                MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, tica_symrs_f32_kernel<true>, RS_NT, LDSRS));
-                MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, tica_symrs_f32_kernel<false>, RS_NT, LDSRS));
-                const int rs_slots = std::min(std::min(o1, o2), 2) * num_cus();
-                const int units = 2 * h->ntiles_sym;
-                h->rs_cohorts = rs_slots / units;
-                if (h->rs_cohorts >= 1) {
-                    h->rs_on = 1;
-                    h->rs_grid = rs_slots > h->rs_cohorts * units ? rs_slots : h->rs_cohorts * units;   // the left-over slots: a remainder cohort, always
-                    h->S_sym = std::max(h->S_sym, h->rs_cohorts + (h->rs_grid > h->rs_cohorts * units ? 1 : 0));   // slab / column-sum rows for either kernel
-                }
-            }
         }
     }
     {
