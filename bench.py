@@ -455,10 +455,12 @@ def main():
         try:
             import hashlib
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
-            sha = hashlib.sha256(open(os.path.join(ROOT, "msmbuilder_amd", "csrc", "tica.hip"), "rb").read()).hexdigest()[:16]
+            # (the kernel's source: csrc/tica_sym_dev.h since round 5's split of tica.hip by kernel family, + the staging helpers it uses)
+            sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "msmbuilder_amd", "csrc", f), "rb").read()
+                                          for f in ("tica_common_dev.h", "tica_cg_dev.h", "tica_sym_dev.h"))).hexdigest()[:16]
             if tj["workload"].startswith("%dx%d " % (frames, F)) and tj.get("tica_hip_sha16") == sha:
                 traffic = tj["bytes_per_launch"]
-                traffic_source = "rocprofv3 PMC passes of this kernel source (tica.hip sha16 %s), separate run: %s" % (sha, tj["source"])
+                traffic_source = "rocprofv3 PMC passes of this kernel source (tica_{common,cg,sym}_dev.h sha16 %s), separate run: %s" % (sha, tj["source"])
             else:
                 traffic_source = "null: profiles/traffic.json (%s) was taken on another kernel source or workload" % tj.get("source", "?")
         except Exception:
