@@ -32,6 +32,8 @@ stats() {  # $1 tag, rest: command
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$tag -o t -- "$@" > $OUT/${tag}_log.txt 2>&1 < /dev/null
   f=$(find $OUT/tmp_$tag -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $OUT/${tag}_kernel_stats.csv && head -14 "$f" | cut -c1-180
+  t=$(find $OUT/tmp_$tag -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && [ "$tag" = "bench" ] && python $ROOT/scripts/timeline.py "$t" > $OUT/r05_step_timeline.txt 2>&1 && tail -1 $OUT/r05_step_timeline.txt
   rm -rf $OUT/tmp_$tag
 }
 pmc() {  # $1 tag, $2 counters, rest: command
