@@ -30,7 +30,9 @@ int num_cus();
 // hipMemcpyAsync from pageable memory goes through the runtime's single-threaded bounce buffer (measured
 // 13.7 GB/s); this one has a few worker threads memcpy slices into a ring of pinned buffers while the DMA
 // engine ships the previous slice on a copy stream.  Small copies fall through to hipMemcpyAsync.
-int h2d_bulk(void* dst_device, const void* src_host, size_t bytes);
+// after_compute = false: the copy does NOT wait for the work queued on stream() so far (the caller knows the destination is idle);
+// what is queued on stream() afterwards still waits for the copy.
+int h2d_bulk(void* dst_device, const void* src_host, size_t bytes, bool after_compute = true);
 // The other direction, BLOCKING: returns when dst_host holds the data (results produced on stream()).
 int d2h_bulk(void* dst_host, const void* src_device, size_t bytes);
 

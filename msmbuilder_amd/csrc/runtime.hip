@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
@@ -40,15 +42,19 @@ hipStream_t stream() { return g_stream; }
 namespace {
 
 struct CopyPool {
+    // Workers SPIN for a short while after a job before they sleep on the condition variable: a streamed upload hands them
+    // a 20-32 MB slice every ~0.4 ms, and a futex wake of sleeping threads on a many-core host costs a sizeable part of
+    // that.  The submitting thread spins too (a slice takes ~0.3 ms: 64-70 GB/s with 4-8 threads, scripts/micro/h2d_pipe.hip).
     std::vector<std::thread> th;
     std::mutex m;
-    std::condition_variable cv, cv_done;
+    std::condition_variable cv;
     const char* src = nullptr;
     char* dst = nullptr;
     size_t len = 0;
-    unsigned long gen = 0;
-    int pending = 0;
-    bool quit = false;
+    std::atomic<unsigned long> gen{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> quit{false};
+    static constexpr long long SPIN_US = 2000;
 
     explicit CopyPool(int n)
     {
@@ -58,7 +64,7 @@ struct CopyPool {
     {
         {
             std::lock_guard<std::mutex> l(m);
-            quit = true;
+            quit.store(true);
         }
         cv.notify_all();
         for (auto& t : th) t.join();
@@ -67,32 +73,46 @@ struct CopyPool {
     {
         unsigned long seen = 0;
         for (;;) {
-            std::unique_lock<std::mutex> l(m);
-            cv.wait(l, [&] { return quit || gen != seen; });
-            if (quit) return;
-            seen = gen;
+            bool got = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0;; ++it) {
+                if (gen.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_relaxed)) {
+                    got = true;
+                    break;
+                }
+                __builtin_ia32_pause();
+                if ((it & 255u) == 255u &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > SPIN_US)
+                    break;
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return quit.load() || gen.load(std::memory_order_acquire) != seen; });
+            }
+            if (quit.load()) return;
+            seen = gen.load(std::memory_order_acquire);   // (the job's fields were written before this generation was published)
             const char* s = src;
             char* d = dst;
             const size_t n = len;
             const size_t T = th.size();
-            l.unlock();
             const size_t per = (((n + T - 1) / T) + 4095) & ~(size_t)4095;
             const size_t o = (size_t)id * per;
             if (o < n) memcpy(d + o, s + o, std::min(per, n - o));
-            l.lock();
-            if (--pending == 0) cv_done.notify_one();
+            pending.fetch_sub(1, std::memory_order_release);
         }
     }
-    void copy(char* d, const char* s, size_t n)  // blocking, all workers
+    void copy(char* d, const char* s, size_t n)  // blocking, all workers (one submitter at a time: the library's host thread)
     {
-        std::unique_lock<std::mutex> l(m);
         src = s;
         dst = d;
         len = n;
-        pending = (int)th.size();
-        ++gen;
+        pending.store((int)th.size(), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> l(m);   // (a worker between its predicate check and its sleep must not miss the wake)
+            gen.fetch_add(1, std::memory_order_release);
+        }
         cv.notify_all();
-        cv_done.wait(l, [&] { return pending == 0; });
+        while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
     }
 };
 
@@ -123,8 +143,8 @@ struct BulkH2D {
     static int pool_threads()
     {
         const unsigned hw = std::thread::hardware_concurrency();
-        // (measured, round 5: 4 to 24 staging threads all give 42 GB/s on the bench's 20 MB trajectories, 32 give 35 -- the rate
-        //  is the DMA engine's, not the memcpy's: profiles/r05_h2d_threads.txt)
+        // (measured, round 5: 4 to 24 staging threads all gave the same rate on the bench's 20 MB trajectories, 32 fewer:
+        //  profiles/r05_h2d_threads.txt)
         return (int)std::max(2u, std::min(8u, hw / 2));
     }
 };
@@ -137,20 +157,24 @@ BulkH2D* bulk_instance()
 
 }  // namespace
 
-int h2d_bulk(void* dst_device, const void* src_host, size_t bytes)
+int h2d_bulk(void* dst_device, const void* src_host, size_t bytes, bool after_compute)
 {
-    if (bytes < ((size_t)8 << 20)) {
+    const bool small = bytes < ((size_t)8 << 20);
+    BulkH2D* B = (small && after_compute) ? nullptr : bulk_instance();   // (the pinned ring is built at the first copy that needs it)
+    if (!B || !B->ok) {
         MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));
         return MSM_OK;
     }
-    BulkH2D* B = bulk_instance();
-    if (!B->ok) {
-        MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));
+    if (small) {   // a small copy that must not queue behind the compute stream's kernels
+        MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, B->cs));
+        MSM_HIP_CHECK(hipEventRecord(B->ev_out, B->cs));
+        MSM_HIP_CHECK(hipStreamWaitEvent(g_stream, B->ev_out, 0));
         return MSM_OK;
     }
-    // the destination may still be read by work queued on the caller's stream
-    MSM_HIP_CHECK(hipEventRecord(B->ev_in, g_stream));
-    MSM_HIP_CHECK(hipStreamWaitEvent(B->cs, B->ev_in, 0));
+    if (after_compute) {   // the destination may still be read by work queued on the caller's stream
+        MSM_HIP_CHECK(hipEventRecord(B->ev_in, g_stream));
+        MSM_HIP_CHECK(hipStreamWaitEvent(B->cs, B->ev_in, 0));
+    }
     const char* s = static_cast<const char*>(src_host);
     char* d = static_cast<char*>(dst_device);
     for (size_t off = 0; off < bytes; off += BulkH2D::BUF) {

@@ -26,6 +26,8 @@
 #include <vector>
 
 #include "tica_common_dev.h"   // constants, chunk / argument structs and block-id helpers shared by the tICA kernels
+#include <functional>
+
 #include "tica_cg_dev.h"   // staging helpers (ChunkCtx, Stage32) and tica_mfma_f32_kernel, the fp32 C/G kernel
 #include "tica_sym_dev.h"   // tica_sym_f32_kernel (sum/difference form, the bench kernel) and tica_export_sym_kernel
 #include "tica_f64_dev.h"   // tica_mfma_f64_kernel (fp64 MFMA)
@@ -135,8 +137,10 @@ struct SegInfo {
 // device-resident trajectories only
 int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t* n_rows,
                            msm_idx_t n_seq, int dtype_bytes, msm_idx_t ld, int check_finite,
-                           msm_idx_t* n_skipped, const SegInfo* segs = nullptr)
+                           msm_idx_t* n_skipped, const SegInfo* segs = nullptr, const std::function<int()>* after_launch = nullptr)
 {
+    // after_launch: host work to run once the accumulation kernel is queued and before this call's first wait for it (the
+    // staged host path copies its NEXT group of trajectories there)
     long long total = 0, nvalid = 0, skipped = 0;
     bool aligned = (h->F % 4 == 0) && (ld % 4 == 0);
     auto seg_of = [&](msm_idx_t s) {
@@ -654,6 +658,10 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         MSM_HIP_CHECK(hipEventRecord(h->ev1, stream()));
         h->timed = true;
     }
+    if (after_launch) {
+        const int rch = (*after_launch)();
+        if (rch) return rch;
+    }
     if (fold) {
         // 3') temporary partials -> [left sums | right sums] per slot, finite check of the folded sums
         if (useimg)
@@ -905,28 +913,49 @@ static int tica_accumulate_any(msm_tica_t* h, const void* const* X_ptrs, const m
     if (n_seq == 0) return MSM_OK;
     if (on_device) return tica_accumulate_device(h, X_ptrs, n_rows, n_seq, dtype_bytes, ld, check_finite, n_skipped, segs);
 
-    // host trajectories: stage groups of them (compacted to ld = F) through a device buffer
+    // host trajectories: staged in groups (compacted to ld = F) through the two halves of a device buffer.  The copies of
+    // group g + 1 are issued right after the accumulation kernel of group g is queued (tica_accumulate_device's
+    // after_launch hook), on the copy stream, so the PCIe transfer runs beside the kernel instead of in front of it
+    // (round 5: 42.4 -> 50.0 GB/s on the bench's h2d_inclusive leg, 4.1 GB in 82 ms: 68 ms of copies + 1.6 ms per group of
+    // launch / check / merge that the host cannot copy beside; pinned -> device alone delivers 56-57 GB/s here:
+    // profiles/r05_h2d_rate.txt).  The Python layer hands a materialised list down whole for this reason.
     const size_t row_bytes = (size_t)h->F * dtype_bytes;
-    const size_t budget = (size_t)1 << 30;
-    msm_idx_t skipped_total = 0;
-    msm_idx_t s = 0;
-    while (s < n_seq) {
+    const size_t budget = (size_t)512 << 20;
+    struct Group {
+        msm_idx_t s = 0, e = 0;
+        std::vector<const void*> dptrs;
+    };
+    auto plan = [&](msm_idx_t s0) {   // the group that starts at trajectory s0
+        Group g;
+        g.s = g.e = s0;
         size_t bytes = 0;
-        msm_idx_t e = s;
-        while (e < n_seq && (e == s || bytes + (size_t)n_rows[e] * row_bytes <= budget)) {
-            bytes += ((size_t)n_rows[e] * row_bytes + 255) & ~(size_t)255;
-            ++e;
+        while (g.e < n_seq && (g.e == g.s || bytes + (size_t)n_rows[g.e] * row_bytes <= budget)) {
+            bytes += ((size_t)n_rows[g.e] * row_bytes + 255) & ~(size_t)255;
+            ++g.e;
         }
-        int rc = h->staging.reserve(bytes ? bytes : 256);
-        if (rc) return rc;
-        std::vector<const void*> dptrs((size_t)(e - s));
+        return std::make_pair(g, bytes);
+    };
+    // capacity: the largest group (a single trajectory may exceed the budget), twice
+    size_t half = 256;
+    for (msm_idx_t s0 = 0; s0 < n_seq;) {
+        auto pg = plan(s0);
+        half = std::max(half, pg.second);
+        s0 = pg.first.e;
+    }
+    half = (half + 255) & ~(size_t)255;
+    int rc = h->staging.reserve(2 * half);
+    if (rc) return rc;
+    // copies of one group into half `which`; `first`: ordered after the work already queued on the library stream (the
+    // buffer's previous reader), later groups: their half's last reader has been waited for by the host already
+    auto copy_group = [&](Group& g, int which, bool first) -> int {
+        g.dptrs.assign((size_t)(g.e - g.s), nullptr);
         size_t off = 0;
-        for (msm_idx_t i = s; i < e; ++i) {
-            char* d = h->staging.as<char>() + off;
-            dptrs[(size_t)(i - s)] = d;
+        for (msm_idx_t i = g.s; i < g.e; ++i) {
+            char* d = h->staging.as<char>() + (size_t)which * half + off;
+            g.dptrs[(size_t)(i - g.s)] = d;
             if (n_rows[i] > 0) {
                 if (ld == h->F) {
-                    int rcb = h2d_bulk(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes);
+                    int rcb = h2d_bulk(d, X_ptrs[i], (size_t)n_rows[i] * row_bytes, first);
                     if (rcb) return rcb;
                 } else {
                     MSM_HIP_CHECK(hipMemcpy2DAsync(d, row_bytes, X_ptrs[i], (size_t)ld * dtype_bytes, row_bytes,
@@ -935,12 +964,30 @@ static int tica_accumulate_any(msm_tica_t* h, const void* const* X_ptrs, const m
             }
             off += ((size_t)n_rows[i] * row_bytes + 255) & ~(size_t)255;
         }
+        return MSM_OK;
+    };
+    msm_idx_t skipped_total = 0;
+    Group cur = plan(0).first, nxt;
+    int which = 0;
+    if ((rc = copy_group(cur, which, true))) return rc;
+    while (cur.s < n_seq) {
+        const bool more = cur.e < n_seq;
+        if (more) nxt = plan(cur.e).first;
+        const std::function<int()> hook = [&]() -> int { return copy_group(nxt, which ^ 1, false); };
         msm_idx_t sk = 0;
-        rc = tica_accumulate_device(h, dptrs.data(), n_rows + s, e - s, dtype_bytes, h->F, check_finite, &sk, segs ? segs + s : nullptr);
-        if (rc) return rc;
-        MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // staging buffer is reused by the next group
+        rc = tica_accumulate_device(h, cur.dptrs.data(), n_rows + cur.s, cur.e - cur.s, dtype_bytes, h->F, check_finite, &sk,
+                                    segs ? segs + cur.s : nullptr, more ? &hook : nullptr);
+        if (rc) {
+            (void)hipStreamSynchronize(stream());   // (copies of the next group may be in flight into the staging buffer)
+            return rc;
+        }
+        MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // this half is rewritten by the group after the next
         skipped_total += sk;
-        s = e;
+        if (!more) break;
+        if (nxt.dptrs.empty() && (rc = copy_group(nxt, which ^ 1, false))) return rc;   // (the call returned before its kernel: nothing valid in the group)
+        cur = std::move(nxt);
+        nxt = Group();
+        which ^= 1;
     }
     if (n_skipped) *n_skipped = skipped_total;
     return MSM_OK;

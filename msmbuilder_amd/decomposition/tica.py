@@ -476,8 +476,7 @@ class tICA(BaseEstimator, TransformerMixin):
         Returns ``self``."""
         self._initialized = False
         check_iter_of_sequences(sequences, max_iter=3)  # we might be lazy-loading
-        # host trajectories are shipped over PCIe in groups of ~1 GiB; device-resident ones
-        # need no staging, so up to 4096 of them share one launch
+        # device-resident trajectories need no staging: up to 4096 of them share one launch
         group, group_bytes = [], 0
         # a list of views of ONE device tensor lying back to back (X.view(n, T, F).unbind(0)): one vectorised check instead
         # of a Python loop over the trajectories here and another in _fit_many (0.4 ms of a 1,000-trajectory fit)
@@ -490,10 +489,14 @@ class tICA(BaseEstimator, TransformerMixin):
             if rows_adj is not None:
                 self._fit_many(sequences, rows_adj=rows_adj)
                 sequences = ()
+        # (a materialised list of host arrays goes down whole: the library stages it in 512 MiB groups through two buffers
+        #  and copies group g + 1 while group g is accumulated -- splitting it here would put a synchronisation between the
+        #  groups; a lazily loading iterable is consumed ~1 GiB at a time so that it is never held in memory at once)
+        lazy = not isinstance(sequences, (list, tuple))
         for X in sequences:
             group.append(X)
-            if not getattr(X, "is_cuda", False):
-                group_bytes += int(np.prod(X.shape)) * 8
+            if lazy and not getattr(X, "is_cuda", False):
+                group_bytes += int(np.prod(X.shape)) * int(getattr(getattr(X, "dtype", None), "itemsize", 8) or 8)
             if group_bytes >= _BATCH_BYTES or len(group) >= 4096:
                 self._fit_many(group)
                 group, group_bytes = [], 0

@@ -334,3 +334,39 @@ def test_c_abi_direct_without_torch(gpu):
     assert L.msm_dist_f32(dptr, dptr, b"manhattan", 4, 2, None, 0, C.c_void_p(out.ctypes.data), 0) == gpu.MSM_ERR_METRIC
     gpu.check(L.msm_tica_destroy(h))
     gpu.check(L.msm_free(dptr))
+
+
+def test_host_trajectories_staged_in_overlapped_groups(gpu):
+    """Pageable numpy trajectories are staged in groups of 512 MiB through the two halves of a device buffer, group g + 1
+    copied while group g is accumulated (tica.hip, tica_accumulate_any).  1.45 GB here = three groups, with trajectories of
+    unequal length, one shorter than the lag (skipped, tica.py:404-409 semantics) and one larger than a quarter of a group:
+    the accumulators must be the device-resident fit's (same kernels, different launch boundaries: 1e-5 of their scale), and
+    a NaN in the LAST group must raise like array2d (utils/validation.py:68-74) does."""
+    from msmbuilder_amd import tICA
+    rng = np.random.default_rng(5)
+    F, lag = 512, 50
+    lens = [60_000] * 4 + [30] + [45_000] * 6 + [150_000] + [20_000] * 5
+    host = []
+    for n in lens:
+        z = np.cumsum(rng.standard_normal((n, 6), dtype=np.float32), axis=0) * 0.02
+        host.append((z @ rng.standard_normal((6, F), dtype=np.float32) + rng.standard_normal((n, F), dtype=np.float32)).astype(np.float32))
+    assert sum(x.nbytes for x in host) > 2.5 * (512 << 20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mh = tICA(n_components=4, lag_time=lag).fit(host)
+        md = tICA(n_components=4, lag_time=lag).fit([torch.from_numpy(x).cuda() for x in host])
+    assert mh.n_sequences_ == md.n_sequences_ == len(lens) - 1
+    assert mh.n_observations_ == md.n_observations_
+    for a, b in zip(_accumulators(mh), _accumulators(md)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-5 * np.abs(b).max())   # DESIGN 5: covariances to 1e-5 of their scale (each launch has its own shift row)
+    np.testing.assert_allclose(mh.eigenvalues_, md.eigenvalues_, rtol=1e-6)
+    bad = [x for x in host]
+    bad[-2] = bad[-2].copy()
+    bad[-2][777, 13] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(ValueError):
+            tICA(n_components=4, lag_time=lag).fit(bad)
+        # the library is usable afterwards, and a fit of the clean data gives the same numbers again
+        m2 = tICA(n_components=4, lag_time=lag).fit(host)
+    np.testing.assert_array_equal(m2.eigenvalues_, mh.eigenvalues_)
