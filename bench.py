@@ -727,14 +727,15 @@ def main():
                 pass
             out["config4_label_wide"] = {
                 "workload": "1,250,000 x 512 fp32 (one rank's share of BASELINE configs[3] over 8 GPUs), K = 1000: labels + inertia "
-                            "(kmeans_label_v4_kernel: one workgroup per row block x 2 centre tiles, grouped per XCD; kmeans_inertia_kernel "
+                            "(kmeans_label_v4_kernel: one workgroup per row block x 4 centre tiles, grouped per XCD; kmeans_inertia_kernel "
                             "merges the splits' candidates; the 2 MB of centres uploaded inside the call)",
                 "label_plus_inertia_ms": msL, "rows_per_s": 1_250_000 / msL * 1e3,
                 "executed_TFLOPs_whole_call": exL / msL / 1e9, "frac_of_fp32_mfma_peak_whole_call": exL / msL / 1e9 / PEAK_TFLOPS["f32"],
                 "algorithmic_bytes": 1_250_000 * 512 * 4,
                 "traffic": trafficL, "inertia_per_row": inL / 1_250_000,
-                "note": "the MFMA kernel alone (rocprofv3 kernel trace, profiles/r05_label_wide.txt): 10.6 ms = 0.79 of the fp32 MFMA peak, "
-                        "5.3 GB fetched + written per pass = 2.1 x the rows (all 8 tiles per workgroup: 21.3 GB)"}
+                "note": "the MFMA kernel alone (rocprofv3 kernel trace, profiles/r05_label_wide.txt, last session): 10.07 ms = 0.85 of the "
+                        "fp32 MFMA peak, 11.5 GB fetched + written per pass = 4.5 x the rows (all 8 tiles per workgroup: 21.8 GB, 9.9 ms; "
+                        "2 tiles: 5.4 GB, 10.6 ms); kmeans_inertia_kernel 0.58 ms"}
             del XL, CL, labL
             torch.cuda.empty_cache()
             # --- BASELINE configs[4] width: F = 2048, fp32 vs bf16x2 vs bf16 MFMA

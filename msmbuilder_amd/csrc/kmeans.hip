@@ -732,20 +732,22 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 // per-block fp64 partial sums for the inertia.
 // nsplit > 1 (centre-split labelling of a small batch): the row's label is first picked from the splits' candidates
 // (lowest value, then lowest index -- what kmeans_label_reduce_kernel does as a launch of its own) and written out.
+// Round 5: two rows per wave in flight and 16-byte loads when the rows allow it (m % 4 == 0, 16-byte aligned bases) -- one row
+// at a time with 4-byte loads and three dependent round trips per row (candidates -> centre row -> sum) ran at 1.7 TB/s
+// (1.5 ms per 1.25M x 512 pass beside a 10.4 ms labelling kernel; profiles/r05_label_wide.txt).
 __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* __restrict__ partial, int nsplit)
 {
     if (P.stop && *P.stop) return;  // uniform
     __shared__ double red[KNT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double tot = 0.0;
-    for (long long i = (long long)blockIdx.x * 4 + wave; i < P.n; i += (long long)gridDim.x * 4) {
-        const long long r = P.rows ? P.rows[i] : i;
-        const float* x = P.X + r * P.m;
-        int lab;
-        if (nsplit > 1) {  // uniform over the wave
-            // lane q fetches split q's candidate (one round trip, not nsplit of them), then a butterfly: lowest (value, index)
-            float bv = INFINITY;
-            int bi = 0x7fffffff;
+    const bool vec4 = (P.m & 3) == 0 && ((((uintptr_t)P.X) | ((uintptr_t)P.C)) & 15) == 0;
+    const long long m4 = P.m >> 2;
+    // the row's label: from the splits' candidates (lane q fetches split q's: one round trip, then a butterfly for the lowest
+    // (value, index)) or as the labelling kernel wrote it
+    auto cand_load = [&](long long i, float& bv, int& bi) {
+        bv = INFINITY;
+        bi = 0x7fffffff;
+        if (nsplit > 1) {
             for (int q0 = 0; q0 < nsplit; q0 += 64) {
                 const int q = q0 + lane;
                 const int qc = q < nsplit ? q : nsplit - 1;
@@ -756,30 +758,68 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
                     bi = ix;
                 }
             }
-#pragma unroll
-            for (int msk = 32; msk > 0; msk >>= 1) {
-                const float ov = __shfl_xor(bv, msk, 64);
-                const int oi = __shfl_xor(bi, msk, 64);
-                if (ov < bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                }
-            }
-            if (bi == 0x7fffffff) bi = 0;  // all-NaN row: sklearn's argmin returns 0
-            lab = bi;
-            if (lane == 0) P.labels[i] = bi;
         } else {
-            lab = P.labels[i];
+            bi = P.labels[i];
         }
-        const float* c = P.C + (long long)lab * P.m;
-        double s = 0.0;
-        for (long long k = lane; k < P.m; k += 64) {
-            const float d = x[k] - c[k];
-            s += (double)d * (double)d;
-        }
+    };
+    auto cand_finish = [&](long long i, bool live, float bv, int bi) -> int {
+        if (nsplit <= 1) return bi;
 #pragma unroll
-        for (int msk = 32; msk > 0; msk >>= 1) s += __shfl_xor(s, msk, 64);
-        tot += s;
+        for (int msk = 32; msk > 0; msk >>= 1) {
+            const float ov = __shfl_xor(bv, msk, 64);
+            const int oi = __shfl_xor(bi, msk, 64);
+            if (ov < bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (bi == 0x7fffffff) bi = 0;  // all-NaN row: sklearn's argmin returns 0
+        if (live && lane == 0) P.labels[i] = bi;
+        return bi;
+    };
+    auto row_sum = [&](const float* x, const float* c) -> double {
+        double s = 0.0;
+        if (vec4) {
+            const float4* x4 = reinterpret_cast<const float4*>(x);
+            const float4* c4 = reinterpret_cast<const float4*>(c);
+            for (long long k = lane; k < m4; k += 64) {
+                const float4 a = x4[k], b = c4[k];
+                const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+                s += (double)d0 * (double)d0;
+                s += (double)d1 * (double)d1;
+                s += (double)d2 * (double)d2;
+                s += (double)d3 * (double)d3;
+            }
+        } else {
+            for (long long k = lane; k < P.m; k += 64) {
+                const float d = x[k] - c[k];
+                s += (double)d * (double)d;
+            }
+        }
+        return s;
+    };
+    double tot = 0.0;
+    const long long stride = (long long)gridDim.x * 4;
+    for (long long i0 = (long long)blockIdx.x * 4 + wave; i0 < P.n; i0 += 2 * stride) {
+        const long long i1 = i0 + stride;
+        const bool has1 = i1 < P.n;
+        const long long i1c = has1 ? i1 : i0;
+        float v0, v1;
+        int b0, b1;
+        cand_load(i0, v0, b0);
+        cand_load(i1c, v1, b1);
+        const int lab0 = cand_finish(i0, true, v0, b0), lab1 = cand_finish(i1c, has1, v1, b1);
+        const long long r0 = P.rows ? P.rows[i0] : i0, r1 = P.rows ? P.rows[i1c] : i1c;
+        double s0 = row_sum(P.X + r0 * P.m, P.C + (long long)lab0 * P.m);
+        double s1 = row_sum(P.X + r1 * P.m, P.C + (long long)lab1 * P.m);
+        if (!has1) s1 = 0.0;
+#pragma unroll
+        for (int msk = 32; msk > 0; msk >>= 1) {
+            s0 += __shfl_xor(s0, msk, 64);
+            s1 += __shfl_xor(s1, msk, 64);
+        }
+        tot += s0;
+        tot += s1;
     }
     if (lane == 0) red[wave] = tot;
     __syncthreads();
@@ -1307,14 +1347,28 @@ static int km_prepare(const float* centers, msm_idx_t K, msm_idx_t m, DevBuf& dC
     int rc = dC.reserve(((size_t)K * m + (size_t)K) * sizeof(float));
     if (rc) return rc;
     std::vector<float> cn((size_t)K);
-    for (msm_idx_t j = 0; j < K; ++j) {
+    // (eight centres side by side: every centre's sum keeps its sequential order, the eight dependent chains overlap --
+    //  one chain of 512 fp64 adds per centre was 0.6 ms of a K = 1000 x 512 call)
+    msm_idx_t j = 0;
+    for (; j + 8 <= K; j += 8) {
+        double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float* c0 = centers + j * m;
+        for (msm_idx_t f = 0; f < m; ++f)
+            for (int q = 0; q < 8; ++q) s8[q] += (double)c0[q * m + f] * (double)c0[q * m + f];
+        for (int q = 0; q < 8; ++q) cn[(size_t)(j + q)] = (float)s8[q];
+    }
+    for (; j < K; ++j) {
         double s = 0.0;
         for (msm_idx_t f = 0; f < m; ++f) s += (double)centers[j * m + f] * (double)centers[j * m + f];
         cn[(size_t)j] = (float)s;
     }
     *dCent = dC.as<float>();
     *dNorm = *dCent + (size_t)K * m;
-    MSM_HIP_CHECK(hipMemcpyAsync(*dCent, centers, (size_t)K * m * sizeof(float), hipMemcpyHostToDevice, stream()));
+    // (2 MB of centres from pageable memory: 0.32 ms through hipMemcpyAsync's own staging, 0.1 ms through the library's pinned ring)
+    {
+        const int rcu = h2d_bulk(*dCent, centers, (size_t)K * m * sizeof(float));
+        if (rcu) return rcu;
+    }
     MSM_HIP_CHECK(hipMemcpyAsync(*dNorm, cn.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // `cn` is a stack-frame vector
     return MSM_OK;
@@ -1348,16 +1402,23 @@ static int km_launch_label(const KmArgs& P, dim3 grid)
 
 // Large batches of wide rows (the final labelling pass of BASELINE configs[3]: 1.25M x 512 per rank, K = 1000): one workgroup
 // per (row block, centre tile), the tiles of a row block side by side on one XCD, so that the rows are fetched ONCE
-// (kmeans_label_v4_kernel, P.xcd_ns); a workgroup takes TWO tiles, the second pass over its rows being an L2 hit.  Returns the
+// (kmeans_label_v4_kernel, P.xcd_ns); a workgroup takes FOUR tiles, the later passes over its rows being L2 hits.  Returns the
 // number of centre splits to use (0: not this case).
 // MSM_LABEL_XCD=0: the A/B switch of the tests (read per call; labels are identical either way).
 static int km_xcd_splits(const KmArgs& P)
 {
     const char* xe = getenv("MSM_LABEL_XCD");
-    // centre tiles per workgroup (0 = off).  Measured at 1.25M x 512, K = 1000 (profiles/r05_label_wide.txt; fetched + written
-    // bytes per pass, kernel time): all 8 tiles in one workgroup 21.3 GB, 10.5 ms; 1 tile 3.4 GB, 11.8 ms (the pipeline fill and
-    // the argmin epilogue are paid per 16 K-steps); 2 tiles 5.3 GB = 2.1x the rows, 10.6 ms; 4 tiles 11.2 GB, 10.4 ms.
-    const int tiles_per = xe ? atoi(xe) : 2;
+    // centre tiles per workgroup (0 = off: one workgroup walks all tiles).  Measured at 1.25M x 512, K = 1000
+    // (profiles/r05_label_wide.txt: fetched + written bytes per pass | kernel | label + inertia call, last session):
+    //   all 8 tiles  21.3 GB = 8.3x the rows |  9.9 ms | 10.6 ms
+    //   4 tiles      11.2 GB = 4.4x          | 10.1 ms | 10.9 ms      <- default
+    //   2 tiles       5.3 GB = 2.1x          | 10.6 ms | 11.4 ms
+    //   1 tile        3.4 GB                 | 11.8 ms | 12.7 ms
+    // The kernel is MFMA-bound: the re-reads of the all-tiles form come out of the Infinity Cache and cost no time, while
+    // every split pays the pipeline fill and the argmin epilogue once more per row block and adds a candidate merge to
+    // the inertia pass.  Four tiles halve the traffic for 2-3 % of the call; two tiles (the first default of the round)
+    // cost 7 %.
+    const int tiles_per = xe ? atoi(xe) : 4;
     if (tiles_per <= 0) return 0;
     const long long rowblocks = ceil_div(P.n, KR), ctiles = ceil_div(P.K, KCT);
     const bool v4ok = P.m >= 4 && (P.m & 3) == 0 && (((uintptr_t)P.X | (uintptr_t)P.C) & 15) == 0 && P.m < (1 << 22) && !P.rows;
@@ -1398,7 +1459,7 @@ static int km_label_and_inertia(KmArgs& P, double* inertia)
     }
     MSM_HIP_CHECK(hipGetLastError());
     if (inertia) {
-        const int nb = (int)std::min<long long>(ceil_div(P.n, 4), 1024);
+        const int nb = (int)std::min<long long>(ceil_div(P.n, 8), 2048);   // (two rows per wave and pass)
         DevBuf& dPart = pool(PS_PART);
         int rc = dPart.reserve((size_t)nb * sizeof(double));
         if (rc) return rc;

@@ -159,7 +159,7 @@ BulkH2D* bulk_instance()
 
 int h2d_bulk(void* dst_device, const void* src_host, size_t bytes, bool after_compute)
 {
-    const bool small = bytes < ((size_t)8 << 20);
+    const bool small = bytes < ((size_t)1 << 20);   // (1 MB: below it the runtime's own staging of a pageable copy costs less than a slice hand-off)
     BulkH2D* B = (small && after_compute) ? nullptr : bulk_instance();   // (the pinned ring is built at the first copy that needs it)
     if (!B || !B->ok) {
         MSM_HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g_stream));

@@ -62,7 +62,7 @@ def test_label_xcd_split_identical(gpu, monkeypatch):
         Ch = Cn.cpu().numpy()
         monkeypatch.setenv("MSM_LABEL_XCD", "0")
         l0, i0 = label_inertia(X, Ch)
-        for tiles_per in (None, "1", "3"):          # the default (two tiles per workgroup), one, an uneven split
+        for tiles_per in (None, "1", "2", "3"):     # the default (four tiles per workgroup), one, two, an uneven split
             if tiles_per is None:
                 monkeypatch.delenv("MSM_LABEL_XCD")
             else:
