@@ -14,7 +14,8 @@
 // The spectrum of the reduced tICA matrix lies in [-1, 1] (|u^T C_sym u| <= u^T Sigma u by Cauchy-Schwarz; shrinkage only
 // adds to Sigma), which gives the filter its lower bound.  Nothing here is trusted: the caller verifies the returned pairs
 // against the reduced matrix (pair_residual_device) and falls back to the tridiagonalisation when the iteration stalls --
-// a flat spectrum, or a matrix that is not a tICA matrix -- so the method can only cost time, never accuracy.
+// a matrix that is not a tICA matrix -- so the method can only cost time, never accuracy.  When n_components reaches
+// into the flat part of the spectrum the damped interval is narrowed to the noise bulk ("hard" mode, in the loop below).
 #include "common.h"
 
 #include <algorithm>
@@ -591,10 +592,11 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     // `degree`, a Cholesky QR after each -- the block's condition number grows with the degree of one polynomial (a single
     // filter of degree 30 lost rank at F = 200), and re-orthonormalising costs 30 us on the device where a Rayleigh-Ritz
     // round trip costs 0.2 ms
-    auto run_filter = [&](double cut, double top, int deg) {
-        const double e = 0.5 * (cut - lower), cen = 0.5 * (cut + lower);
+    double lo = lower;   // lower end of the damped interval: the caller's bound, tightened in "hard" mode (below)
+    auto run_filter = [&](double cut, double top, int deg, int chunk) {
+        const double e = 0.5 * (cut - lo), cen = 0.5 * (cut + lo);
         const double sigma1 = e / (top - cen);
-        const int nchunk = (deg + degree - 1) / degree;
+        const int nchunk = (deg + chunk - 1) / chunk;
         int left = deg;
         for (int ch = 0; ch < nchunk; ++ch) {
             const int d = (left + (nchunk - ch) - 1) / (nchunk - ch);
@@ -622,11 +624,13 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
     // reduced matrix has its spectrum in [-1, 1], noise near 0): one round trip (0.25 ms) less per solve.
     int filters = 0;
     if (first_cut > lower && first_top > first_cut) {
-        run_filter(first_cut, first_top, degree);
+        run_filter(first_cut, first_top, degree, degree);
         filters = 1;
         prev_res = 1.0;   // the residual scale of a random block (the spectrum's width): lets the first measured residual size the next filter
     }
-    for (int outer = 0; outer <= max_outer; ++outer) {
+    bool hard = false, hard_adjusted = false;
+    int hard_outer = 0;
+    for (int outer = 0; outer <= max_outer + 12; ++outer) {
         // ---- Rayleigh-Ritz on span(X)
         product(X, nullptr, W, 1.0, 0.0, 0.0);
         hipLaunchKernelGGL(ss_gram_kernel, dim3(nparts), dim3(SS_NT), 0, stream(), X, X, n, part);
@@ -664,14 +668,83 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
             *converged = 1;
             return MSM_OK;
         }
-        // stalled: a filtered iteration that does not gain two orders of magnitude will not get there in time
-        if (outer == max_outer || (outer >= 2 && !(rmax < 1e-2 * prev_res))) return MSM_OK;
+        const double tol_abs = tol * std::max(1.0, std::fabs(w[0]));
+        // ---- "hard" mode (round 5).  When n_components reaches into the flat part of the spectrum (fewer slow processes than
+        // components: the k-th eigenvalue sits at the edge of the noise bulk, percents of the bulk's width above the block's
+        // last Ritz value) a filter that damps [-1, cut] gains next to nothing per degree -- the wanted gap is measured
+        // against the whole interval -- and the iteration used to give up after three rounds: LAPACK on the host, 7.6 ms at
+        // n = 512 and 24 ms at n = 1,024 against 1-2 ms (scripts/solveprobe.py).  The bulk, however, is narrow: with the
+        // damped interval shrunk to [just below the bulk, cut] the same gap is a sizeable fraction of the interval and a
+        // few dozen degrees suffice.  The lower end is not known, so it is GUESSED (the noise bulk of a reduced tICA matrix
+        // is roughly symmetric about 0) and MAINTAINED: a Ritz value always lies above lambda_min, and directions below
+        // the guessed bound are amplified by the filter and show up as Ritz values near it -- the bound then moves below
+        // them, and the next filter damps them again.  The slow processes above the bulk are amplified (2 x)^degree times
+        // more than the wanted edge, x = their distance in half-widths of the narrow interval (~30): the filter is cut into
+        // chunks of a few degrees, a Cholesky QR after each, so that no chunk stretches the block by more than ~1e7.
+        // Nothing else changes: same convergence test on the ORIGINAL matrix, same verification by the caller, and when
+        // this stalls too the reduced matrix still goes to LAPACK.  Measured (scripts/solveprobe.py, k = 10 with 2 or 6
+        // slow processes): the solve 7.6 -> 3.1 ms at n = 512, 24 -> 4.9 ms at n = 1,024, two or three hard rounds of
+        // 40-64 degrees; the rate per degree is ~0.22 where acosh of the Ritz gap says 0.6 (the 33rd eigenvalue sits right
+        // under the block) -- a restart-free recurrence or deflating the converged pairs changes the number of
+        // re-orthonormalisations, not that rate (both tried).
+        if (!hard) {
+            const double cut0 = w[SB - 1], wk = w[k - 1];
+            bool slow = false;
+            if (cut0 > lo && wk > cut0) {
+                const double gap0 = (wk - cut0) / (cut0 - lo);
+                slow = std::acosh(1.0 + 2.0 * gap0) * (3.0 * degree) < std::log(1e3);   // a maximal easy filter would not gain 1e3
+            }
+            const bool stalled = outer >= 2 && !(rmax < 1e-2 * prev_res);
+            if ((slow || stalled) && n < 256) return MSM_OK;   // (LAPACK on so small a matrix beats a hundred filter degrees: 0.6 ms at n = 128)
+            if (slow || stalled) {
+                hard = true;
+                const double guess = cut0 > 0.0 ? -1.6 * cut0 : cut0 - 3.0 * (wk - cut0);
+                lo = std::max(lower, guess);
+                hard_adjusted = true;
+            } else if (outer >= max_outer) {
+                return MSM_OK;
+            }
+        }
+        if (hard) {
+            if (++hard_outer > 12) return MSM_OK;
+            const double wk = w[k - 1], wmin = w[SB - 1];
+            double mid = 0.5 * (lo + wk);
+            if (wmin < mid) {   // directions from below the bound have entered the block: move the bound below them
+                lo = std::max(lower, wmin - 0.25 * (wk - wmin));
+                mid = 0.5 * (lo + wk);
+                hard_adjusted = true;
+            }
+            if (!hard_adjusted && hard_outer >= 2 && !(rmax < 0.2 * prev_res)) return MSM_OK;   // stalled for good
+            hard_adjusted = false;
+            int ngood = 0;
+            double cut = wk;
+            for (int j = 0; j < SB; ++j)
+                if (w[j] > mid) {
+                    ++ngood;
+                    cut = std::min(cut, w[j]);
+                }
+            const double top = w[0];
+            if (ngood < k + 2 || !(cut > lo) || !(wk > cut) || !(top > cut)) return MSM_OK;
+            const double e = 0.5 * (cut - lo), cen = 0.5 * (cut + lo);
+            const double rate = std::acosh(1.0 + 2.0 * (wk - cut) / (cut - lo));                 // per degree, for the k-th pair
+            // degrees still needed: at the rate the last hard filter was measured to deliver, else at 0.6 of the theoretical one
+            // (the Ritz values that define cut and the gap are themselves still converging)
+            double per_degree = 0.6 * rate;
+            if (hard_outer >= 2 && rmax < prev_res) per_degree = std::min(rate, std::log(prev_res / rmax) / last_deg);
+            const double need = std::log(std::max(rmax, tol_abs) / (0.3 * tol_abs)) / std::max(per_degree, 1e-3);
+            const int deg = (int)std::min(64.0, std::max((double)degree, std::ceil(need)));
+            const double xtop = (top - cen) / e;
+            const int chunk = (int)std::min((double)degree, std::max(2.0, std::floor(std::log(1e7) / std::log(2.0 * std::max(xtop, 1.0) + 1.0))));
+            last_deg = deg;
+            prev_res = rmax;
+            run_filter(cut, top, deg, chunk);
+            continue;
+        }
         // Degree of the next filter: `degree`, or -- once a filter's gain is known -- what the remaining distance to the
         // tolerance asks for at that rate per degree (up to 3 x degree): one longer filter instead of two filters with a
         // Rayleigh-Ritz round trip (two host synchronisations, ~0.2 ms) between them.
         int deg = degree;
         if ((outer >= 1 || filters) && prev_res < INFINITY && rmax < prev_res) {
-            const double tol_abs = tol * std::max(1.0, std::fabs(w[0]));
             const double rate = std::log(rmax / prev_res) / last_deg;        // < 0, per degree
             const double need = std::log(0.3 * tol_abs / rmax) / rate;       // degrees still needed, with a margin
             if (need > degree) deg = (int)std::min(3.0 * degree, std::ceil(need));
@@ -680,8 +753,8 @@ int subspace_topk_device(const double* Cm, int n, int k, double lower, double to
         prev_res = rmax;
         // ---- filter: damp [lower, cut], cut = the smallest Ritz value of the block; scaled so that theta_1 stays O(1)
         const double cut = w[SB - 1], top = w[0];
-        if (!(cut > lower) || !(top > cut)) return MSM_OK;
-        run_filter(cut, top, deg);
+        if (!(cut > lo) || !(top > cut)) return MSM_OK;
+        run_filter(cut, top, deg, degree);
     }
     return MSM_OK;
 }

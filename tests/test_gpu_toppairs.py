@@ -80,3 +80,51 @@ def test_topk_solve_matches_host_route(gpu, monkeypatch, F, k, flat):
                 sg = np.sign(V[:, j].dot(S).dot(Vh[:, j]))
                 np.testing.assert_allclose(V[:, j] * sg, Vh[:, j], rtol=0, atol=1e-8 * np.abs(Vh[:, j]).max() / min(lo, hi, 1.0))
 
+
+
+@pytest.mark.parametrize("F,n_slow,neg", [(256, 3, False), (512, 6, False), (512, 2, True), (1024, 2, False)])
+def test_topk_solve_components_reaching_into_the_noise_bulk(gpu, monkeypatch, F, n_slow, neg):
+    """Fewer slow processes than components: eigenvalues n_slow + 1 .. k sit at the upper edge of the noise bulk, a few
+    percent of the bulk's width apart.  The subspace iteration narrows its damped interval to the bulk (hard mode,
+    csrc/subspace.hip) instead of handing over to LAPACK; `neg` adds an oscillating feature whose autocorrelation at the lag
+    is about -0.9, i.e. an eigenvalue far BELOW the bulk that the guessed lower bound misses and the iteration has to
+    find.  Whatever route is taken, the numbers must be the host route's (reference: tica.py:188-194, dsygvx)."""
+    from msmbuilder_amd import tICA
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "f64")
+    rs = np.random.RandomState(F + n_slow)
+    n, lag, k = 12000, 5, 10
+    ts = np.logspace(np.log10(30.0), np.log10(600.0), n_slow)
+    a = np.exp(-1.0 / ts)
+    z = np.zeros((n, n_slow))
+    e = rs.randn(n, n_slow) * np.sqrt(1 - a * a)
+    for t in range(1, n):
+        z[t] = a * z[t - 1] + e[t]
+    X = z.dot(rs.randn(n_slow, F) / np.sqrt(n_slow)) + 0.5 * rs.randn(n, F) + rs.randn(F)
+    if neg:
+        X[:, 7] += 3.0 * np.cos(np.pi * 0.95 / lag * np.arange(n) + 0.3)
+    seqs = [X[:7000], X[7000:]]
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, env in (("host", "0"), ("hybrid", "hybrid")):
+            monkeypatch.setenv("MSMBUILDER_AMD_DEVICE_SOLVE", env)
+            m = tICA(n_components=k, lag_time=lag).fit(seqs)
+            out[name] = (m.eigenvalues_.copy(), m.eigenvectors_.copy(), m.covariance_.copy(), getattr(m, "_solve_route", None))
+    ev = out["host"][0]
+    assert ev[n_slow - 1] > 2 * ev[n_slow] > 0, ev            # the construction: n_slow processes, then the bulk's edge
+    route = out["hybrid"][3]
+    assert route[0] == "subspace" and route[2] == 0, route   # no LAPACK hand-over for these
+    np.testing.assert_allclose(out["hybrid"][0], ev, rtol=0, atol=2e-11)
+    V, Vh, S = out["hybrid"][1], out["host"][1], out["host"][2]
+    np.testing.assert_allclose(V.T.dot(S).dot(V), np.eye(k), rtol=0, atol=1e-9)
+    gaps = np.abs(np.diff(ev))
+    for j in range(k):
+        lo_ = gaps[j - 1] if j > 0 else np.inf
+        hi_ = gaps[j] if j < k - 1 else np.inf
+        g = min(lo_, hi_, 1.0)
+        if g > 1e-4:
+            sg = np.sign(V[:, j].dot(S).dot(Vh[:, j]))
+            np.testing.assert_allclose(V[:, j] * sg, Vh[:, j], rtol=0, atol=1e-8 * np.abs(Vh[:, j]).max() / g)
+    # the span of all k vectors (near-degenerate pairs included): projectors agree in the Sigma inner product
+    P = V.T.dot(S).dot(Vh)
+    np.testing.assert_allclose(P.dot(P.T), np.eye(k), rtol=0, atol=1e-6)
