@@ -212,6 +212,104 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgs P, int round, 
     if (tid < L) P.ppart[(size_t)blockIdx.x * P.L + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
+// 3w) the same for rows of 32 features and more: ONE WAVE per row, lanes over the features (16-byte loads when the rows allow
+// it), 32 rows per workgroup.  kpp_dist_kernel gives a row to a THREAD: its loads are strided by the row length and a
+// seeding sample of 3 x batch_size rows is a grid of a few dozen workgroups -- 1.1 ms per round on 24,576 x 512 (50 MB), a
+// MiniBatchKMeans(k=1000) fit of 1M x 512 spent 1.1 of its 1.28 s there (scripts/clusterprobe.py).  Same float64 formula;
+// the features are summed lane-strided and by a butterfly instead of front to back (scikit-learn's order is its BLAS's).
+constexpr int KPP_WROWS = 32;   // rows per workgroup (8 per wave)
+template <bool FIRST>
+__global__ __launch_bounds__(KPP_NT) void kpp_dist_wide_kernel(KppArgs P, int round, long long first)
+{
+    extern __shared__ __attribute__((aligned(16))) float cs_lds_w[];   // [L][F] candidate rows (or P.cglob)
+    __shared__ double cc[KPP_LMAX];
+    __shared__ double red[KPP_LMAX][KPP_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = FIRST ? 1 : P.L, F = P.F;
+    const float* cs = P.cglob ? P.cglob : cs_lds_w;
+    if (!P.cglob) {
+        for (int e = tid; e < L * F; e += KPP_NT) {
+            const int j = e / F, f = e - j * F;
+            const long long row = FIRST ? first : P.cand[j];
+            cs_lds_w[e] = P.X[(size_t)row * F + f];
+        }
+    }
+    __syncthreads();
+    for (int j = wave; j < L; j += KPP_NT / 64) {
+        double s = 0.0;
+        for (int f = lane; f < F; f += 64) s = fma((double)cs[j * F + f], (double)cs[j * F + f], s);
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) cc[j] = s;
+    }
+    __syncthreads();
+    const float* closest = FIRST ? nullptr : kpp_closest(P, round);
+    float* out = P.dbuf + (size_t)(round & 1) * P.L * (size_t)P.n;
+    const bool vec4 = (F & 3) == 0 && ((((uintptr_t)P.X) | ((uintptr_t)cs)) & 15) == 0;
+    double pot[KPP_LMAX];
+#pragma unroll
+    for (int j = 0; j < KPP_LMAX; ++j) pot[j] = 0.0;
+    for (int q = 0; q < KPP_WROWS / (KPP_NT / 64); ++q) {
+        const long long i = (long long)blockIdx.x * KPP_WROWS + q * (KPP_NT / 64) + wave;   // uniform over the wave
+        if (i >= P.n) break;
+        const float* x = P.X + (size_t)i * F;
+        double xx = 0.0, dot[KPP_LMAX];
+#pragma unroll
+        for (int j = 0; j < KPP_LMAX; ++j) dot[j] = 0.0;
+        if (vec4) {
+            for (int f4 = lane; f4 < (F >> 2); f4 += 64) {
+                const float4 xv = reinterpret_cast<const float4*>(x)[f4];
+                const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w;
+                xx = fma(x0, x0, xx);
+                xx = fma(x1, x1, xx);
+                xx = fma(x2, x2, xx);
+                xx = fma(x3, x3, xx);
+#pragma unroll
+                for (int j = 0; j < KPP_LMAX; ++j)
+                    if (j < L) {
+                        const float4 cv = reinterpret_cast<const float4*>(cs + (size_t)j * F)[f4];
+                        dot[j] = fma(x0, (double)cv.x, dot[j]);
+                        dot[j] = fma(x1, (double)cv.y, dot[j]);
+                        dot[j] = fma(x2, (double)cv.z, dot[j]);
+                        dot[j] = fma(x3, (double)cv.w, dot[j]);
+                    }
+            }
+        } else {
+            for (int f = lane; f < F; f += 64) {
+                const double xv = (double)x[f];
+                xx = fma(xv, xv, xx);
+#pragma unroll
+                for (int j = 0; j < KPP_LMAX; ++j)
+                    if (j < L) dot[j] = fma(xv, (double)cs[(size_t)j * F + f], dot[j]);
+            }
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) xx += __shfl_xor(xx, m, 64);
+        const float cl = FIRST ? INFINITY : closest[i];
+#pragma unroll
+        for (int j = 0; j < KPP_LMAX; ++j)
+            if (j < L) {
+                double dj = dot[j];
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) dj += __shfl_xor(dj, m, 64);
+                double d = -2.0 * dj;   // scikit-learn's order of the three terms (kpp_dist_kernel)
+                d += cc[j];
+                d += xx;
+                float df = (float)(d > 0.0 ? d : 0.0);
+                df = df < cl ? df : cl;
+                if (lane == 0) {
+                    out[(size_t)j * P.n + i] = df;
+                    pot[j] += (double)df;
+                }
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < KPP_LMAX; ++j)
+        if (j < L && lane == 0) red[j][wave] = pot[j];
+    __syncthreads();
+    if (tid < L) P.ppart[(size_t)blockIdx.x * P.L + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
 // 3') wide rows: the round's candidate rows into one device buffer (read by every block of kpp_dist_kernel through the L2)
 __global__ __launch_bounds__(KPP_NT) void kpp_gather_kernel(KppArgs P, int L, long long first)
 {
@@ -272,6 +370,8 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     if (ceil_div(n, KPP_RPB) > 0x7fffffffLL) return fail(MSM_ERR_INVALID, "kmeans_plusplus: too many rows");
     const int nb = (int)ceil_div(n, KPP_RPB);
+    const bool wrows = F >= 32 && ceil_div(n, KPP_WROWS) <= 0x7fffffffLL;   // a wave per row (kpp_dist_wide_kernel)
+    const int nbd = wrows ? (int)ceil_div(n, KPP_WROWS) : nb;                // workgroups (= potential partials) of the distance kernel
     const bool wide = (size_t)L * F * sizeof(float) > 60000;   // candidate rows beyond the LDS staging tile: through a device buffer
     const bool longpre = nb > 7168;                            // block prefix beyond LDS: in device memory
     DevBuf &dX = pool(PS_X), &dW = pool(PS_W), &dO = pool(PS_OUT);
@@ -287,7 +387,7 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_dbuf = take(2 * (size_t)L * n * sizeof(float)), o_cuml = take((size_t)n * sizeof(double)),
-                 o_bsum = take((size_t)nb * sizeof(double)), o_pp = take((size_t)nb * L * sizeof(double)),
+                 o_bsum = take((size_t)nb * sizeof(double)), o_pp = take((size_t)nbd * L * sizeof(double)),
                  o_u = take(std::max<size_t>(nu, 1) * sizeof(double)), o_pot = take(sizeof(double)), o_cand = take(L * sizeof(long long)),
                  o_best = take(sizeof(int)), o_cg = take(wide ? (size_t)L * F * sizeof(float) : 0), o_bpre = take(longpre ? (size_t)nb * sizeof(double) : 0);
     if ((rc = dW.reserve(off))) return rc;
@@ -314,14 +414,16 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     const size_t lds_c = wide ? 0 : (size_t)L * F * sizeof(float), lds_pre = longpre ? 0 : (size_t)nb * sizeof(double);
     // round 0: distances to the first centre = `closest`, its potential
     if (wide) hipLaunchKernelGGL(kpp_gather_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, 1, (long long)first);
-    hipLaunchKernelGGL(kpp_dist_kernel<true>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
-    hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, 0, nb, (long long)first);
+    if (wrows) hipLaunchKernelGGL(kpp_dist_wide_kernel<true>, dim3(nbd), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
+    else hipLaunchKernelGGL(kpp_dist_kernel<true>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
+    hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, 0, nbd, (long long)first);
     for (int r = 1; r < (int)K; ++r) {
         hipLaunchKernelGGL(kpp_scan_kernel, dim3(nb), dim3(KPP_NT), 0, stream(), P, r);
         hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(KPP_NT), lds_pre, stream(), P, r, nb);
         if (wide) hipLaunchKernelGGL(kpp_gather_kernel, dim3((unsigned)L), dim3(KPP_NT), 0, stream(), P, L, (long long)first);
-        hipLaunchKernelGGL(kpp_dist_kernel<false>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
-        hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, r, nb, (long long)first);
+        if (wrows) hipLaunchKernelGGL(kpp_dist_wide_kernel<false>, dim3(nbd), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
+        else hipLaunchKernelGGL(kpp_dist_kernel<false>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
+        hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, r, nbd, (long long)first);
     }
     MSM_HIP_CHECK(hipGetLastError());
     MSM_HIP_CHECK(hipMemcpyAsync(centers, P.centers, (size_t)K * F * sizeof(float), hipMemcpyDeviceToHost, stream()));

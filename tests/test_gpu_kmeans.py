@@ -202,7 +202,8 @@ def test_small_batch_step_kernels_equal_general_kernels(gpu, K, F, B):
         assert abs(float(b[4]) - float(g[4])) <= 1e-5 * abs(float(g[4]))
 
 
-@pytest.mark.parametrize("n,F,k", [(500, 8, 10), (3072, 64, 50), (1000, 3, 25), (3072, 512, 200), (1, 4, 1), (7, 2, 7)])
+@pytest.mark.parametrize("n,F,k", [(500, 8, 10), (3072, 64, 50), (1000, 3, 25), (3072, 512, 200), (1, 4, 1), (7, 2, 7),
+                                   (3072, 70, 100), (2500, 33, 40), (8192, 512, 300), (40, 32, 40)])   # from 32 features: a wave per row (kpp_dist_wide_kernel)
 def test_device_kmeans_plusplus_draws_scikit_learns_seeds(gpu, n, F, k):
     """The device seeding (msm_kmeans_plusplus_f32: scikit-learn's float64-upcast distance arithmetic, the caller's
     RandomState stream) against `sklearn.cluster.kmeans_plusplus` ITSELF, live: the same rows are chosen and the generator
