@@ -251,6 +251,13 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
 int msm_tica_project_batch(const void* const* X_ptrs, double* const* out_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq,
                            int dtype_bytes, msm_idx_t n_features, const double* mean, const double* comps, msm_idx_t k,
                            int check_finite);
+/* The same for a LIST of HOST trajectories of float32 / float64 rows (dtype_bytes 4 / 8, row stride n_features): `out`
+ * (host) is ONE [sum of n_rows][k] float64 array, trajectory after trajectory.  Staged over PCIe in groups through two
+ * device buffers, group g + 1 copied while group g is projected, one copy back at the end (tica.py:329-352 walks the
+ * list of numpy arrays one by one). */
+int msm_tica_project_host_list(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int dtype_bytes,
+                               msm_idx_t n_features, const double* mean, const double* comps, msm_idx_t k, double* out,
+                               int check_finite);
 
 /* ---- libdistance: exact-arithmetic vector metrics --------------------- */
 /* metric in {"euclidean","sqeuclidean","cityblock","chebyshev","canberra",

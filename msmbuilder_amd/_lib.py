@@ -88,6 +88,7 @@ def _declare(lib):
     f("msm_tica_import_packed", C.c_int, _p, _p, C.c_int)
     f("msm_tica_project", C.c_int, _p, C.c_int, _i64, _i64, _i64, _p, _p, _i64, _p, C.c_int, C.c_int)
     f("msm_tica_project_batch", C.c_int, C.POINTER(_p), C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _p, _p, _i64, C.c_int)
+    f("msm_tica_project_host_list", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _p, _p, _i64, _p, C.c_int)
     f("msm_tica_last_folded", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_last_img_fused", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_allreduce", C.c_int, _p)

@@ -1489,90 +1489,78 @@ int msm_tica_export_sums(msm_tica_t* h, double* s0, double* stau)
 
 extern "C" {
 
-int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features,
-                     msm_idx_t ld, const double* mean, const double* comps, msm_idx_t k,
-                     double* out, int on_device, int check_finite)
+// ---- projection: parameters on the device (once per call) and the launches for one device-resident matrix
+struct ProjParams {
+    double* dmean = nullptr;    // mean @ comps^T (k values)
+    double* dcomps = nullptr;   // [k][F]
+    double* dVp = nullptr;      // [ceil(k / 16)][F][16] panels of the fp64-MFMA path
+    int* dflag = nullptr;       // non-finite input seen
+    std::vector<double> muV, vp;   // host sources of the uploads: alive until the caller has synchronised
+};
+
+static int proj_upload(ProjParams& Q, const double* mean, const double* comps, msm_idx_t k, msm_idx_t n_features)
 {
-    if (!X || !mean || !comps || !out) return fail(MSM_ERR_INVALID, "msm_tica_project: null pointer");
-    if (dtype_bytes != 2 && dtype_bytes != 4 && dtype_bytes != 8)
-        return fail(MSM_ERR_INVALID, "dtype_bytes must be 2 (bfloat16), 4 or 8");
-    if (n_rows < 0 || n_features < 1 || k < 1 || ld < n_features) return fail(MSM_ERR_INVALID, "bad shape");
-    if (n_rows == 0) return MSM_OK;
-    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
-    DevBuf &dX = pool(PS_X), &dOut = pool(PS_OUT), &dPar = pool(PS_PAR);
+    DevBuf &dPar = pool(PS_PAR), &dVp = pool(PS_W);
     int rc;
     const size_t par_n = (size_t)k + (size_t)k * n_features;
+    const msm_idx_t nkb = ceil_div(k, 16);
     if ((rc = dPar.reserve(par_n * sizeof(double) + 16))) return rc;
-    std::vector<double> muV((size_t)k);
+    if ((rc = dVp.reserve((size_t)nkb * n_features * 16 * sizeof(double)))) return rc;
+    Q.muV.assign((size_t)k, 0.0);
     for (msm_idx_t c = 0; c < k; ++c) {
         double sacc = 0.0;
         for (msm_idx_t f = 0; f < n_features; ++f) sacc += mean[f] * comps[c * n_features + f];
-        muV[(size_t)c] = sacc;
+        Q.muV[(size_t)c] = sacc;
     }
-    double* dmean = dPar.as<double>();  // holds mean @ comps^T (k values)
-    double* dcomps = dmean + k;
-    int* dflag = reinterpret_cast<int*>(dcomps + (size_t)k * n_features);
-    MSM_HIP_CHECK(hipMemcpyAsync(dmean, muV.data(), k * sizeof(double), hipMemcpyHostToDevice, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(dcomps, comps, (size_t)k * n_features * sizeof(double), hipMemcpyHostToDevice, stream()));
-    MSM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), stream()));
-    const void* Xd = X;
-    double* outd = out;
-    msm_idx_t ldd = ld;
-    if (!on_device) {
-        if ((rc = dX.reserve((size_t)n_rows * n_features * dtype_bytes))) return rc;
-        if ((rc = dOut.reserve((size_t)n_rows * k * sizeof(double)))) return rc;
-        if (ld == n_features) {
-            if ((rc = h2d_bulk(dX.p, X, (size_t)n_rows * n_features * dtype_bytes))) return rc;
-        } else {
-            MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, (size_t)n_features * dtype_bytes, X, (size_t)ld * dtype_bytes,
-                                           (size_t)n_features * dtype_bytes, (size_t)n_rows, hipMemcpyHostToDevice, stream()));
-        }
-        Xd = dX.p;
-        outd = dOut.as<double>();
-        ldd = n_features;
-    }
+    Q.vp.assign((size_t)nkb * n_features * 16, 0.0);   // components in blocks of 16, panel Vp[F][16] (feature-major, zero padded)
+    for (msm_idx_t c = 0; c < k; ++c)
+        for (msm_idx_t f = 0; f < n_features; ++f)
+            Q.vp[((size_t)(c / 16) * n_features + f) * 16 + (c % 16)] = comps[c * n_features + f];
+    Q.dmean = dPar.as<double>();
+    Q.dcomps = Q.dmean + k;
+    Q.dflag = reinterpret_cast<int*>(Q.dcomps + (size_t)k * n_features);
+    Q.dVp = dVp.as<double>();
+    MSM_HIP_CHECK(hipMemcpyAsync(Q.dmean, Q.muV.data(), k * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(Q.dcomps, comps, (size_t)k * n_features * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(Q.dVp, Q.vp.data(), Q.vp.size() * sizeof(double), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemsetAsync(Q.dflag, 0, sizeof(int), stream()));
+    return MSM_OK;
+}
+
+// out[n_rows][k] (device) = (X - mean) comps^T for the device-resident X[n_rows][ldd]; queued on stream(), nothing synchronised
+static int proj_launch(const ProjParams& Q, const void* Xd, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features, msm_idx_t ldd,
+                       msm_idx_t k, double* outd)
+{
     const unsigned grid = (unsigned)ceil_div(n_rows, 128);
     const int cw = 16 / dtype_bytes;
     const int vec = (((uintptr_t)Xd) % 16 == 0) && (ldd % cw == 0) && (n_features % cw == 0);
     if (vec && (size_t)256 * ldd * dtype_bytes < ((size_t)1 << 32)) {
-        // fp64-MFMA path: components in blocks of 16, panel Vp[F][16] (feature-major, zero padded)
-        DevBuf& dVp = pool(PS_W);
+        // fp64-MFMA path
         const msm_idx_t nkb = ceil_div(k, 16);
-        if ((rc = dVp.reserve((size_t)nkb * n_features * 16 * sizeof(double)))) return rc;
-        std::vector<double> vp((size_t)nkb * n_features * 16, 0.0);
-        for (msm_idx_t c = 0; c < k; ++c)
-            for (msm_idx_t f = 0; f < n_features; ++f)
-                vp[((size_t)(c / 16) * n_features + f) * 16 + (c % 16)] = comps[c * n_features + f];
-        MSM_HIP_CHECK(hipMemcpyAsync(dVp.p, vp.data(), vp.size() * sizeof(double), hipMemcpyHostToDevice, stream()));
         const unsigned g2 = (unsigned)ceil_div(n_rows, 256);
         for (msm_idx_t kb = 0; kb < nkb; ++kb) {
             const int kk = (int)std::min<msm_idx_t>(16, k - kb * 16);
-            const double* vpk = dVp.as<double>() + (size_t)kb * n_features * 16;
+            const double* vpk = Q.dVp + (size_t)kb * n_features * 16;
             if (dtype_bytes == 2)
                 hipLaunchKernelGGL((tica_project_mfma_kernel<Bf16Raw>), dim3(g2), dim3(NT), 0, stream(), (const Bf16Raw*)Xd,
-                                   (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
-                                   outd, dflag, nullptr);
+                                   (long long)n_rows, (int)n_features, (long long)ldd, Q.dmean, vpk, kk, (int)(kb * 16), (int)k,
+                                   outd, Q.dflag, nullptr);
             else if (dtype_bytes == 4)
                 hipLaunchKernelGGL((tica_project_mfma_kernel<float>), dim3(g2), dim3(NT), 0, stream(), (const float*)Xd,
-                                   (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
-                                   outd, dflag, nullptr);
+                                   (long long)n_rows, (int)n_features, (long long)ldd, Q.dmean, vpk, kk, (int)(kb * 16), (int)k,
+                                   outd, Q.dflag, nullptr);
             else
                 hipLaunchKernelGGL((tica_project_mfma_kernel<double>), dim3(g2), dim3(NT), 0, stream(), (const double*)Xd,
-                                   (long long)n_rows, (int)n_features, (long long)ldd, dmean, vpk, kk, (int)(kb * 16), (int)k,
-                                   outd, dflag, nullptr);
+                                   (long long)n_rows, (int)n_features, (long long)ldd, Q.dmean, vpk, kk, (int)(kb * 16), (int)k,
+                                   outd, Q.dflag, nullptr);
         }
         MSM_HIP_CHECK(hipGetLastError());
-        if (!on_device) {
-            int rcd = d2h_bulk(out, outd, (size_t)n_rows * k * sizeof(double));
-            if (rcd) return rcd;
-        }
-        int f2 = 0;
-        if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f2, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
-        MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // `vp` and the scratch buffers die with this frame
-        if (check_finite && f2) return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
         return MSM_OK;
     }
     const int npw = (int)std::min<msm_idx_t>(8, ceil_div(k, 4));  // components per wave
+    double* dmean = Q.dmean;
+    double* dcomps = Q.dcomps;
+    int* dflag = Q.dflag;
 #define MSM_PROJ(TT, NN)                                                                              \
     hipLaunchKernelGGL((tica_project_kernel<TT, NN>), dim3(grid), dim3(NT), 0, stream(), (const TT*)Xd, \
                        (long long)n_rows, (int)n_features, (long long)ldd, dmean, dcomps, (int)k, outd, dflag, vec)
@@ -1597,15 +1585,141 @@ int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t
 #undef MSM_PROJ_T
 #undef MSM_PROJ
     MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
+int msm_tica_project(const void* X, int dtype_bytes, msm_idx_t n_rows, msm_idx_t n_features,
+                     msm_idx_t ld, const double* mean, const double* comps, msm_idx_t k,
+                     double* out, int on_device, int check_finite)
+{
+    if (!X || !mean || !comps || !out) return fail(MSM_ERR_INVALID, "msm_tica_project: null pointer");
+    if (dtype_bytes != 2 && dtype_bytes != 4 && dtype_bytes != 8)
+        return fail(MSM_ERR_INVALID, "dtype_bytes must be 2 (bfloat16), 4 or 8");
+    if (n_rows < 0 || n_features < 1 || k < 1 || ld < n_features) return fail(MSM_ERR_INVALID, "bad shape");
+    if (n_rows == 0) return MSM_OK;
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    DevBuf &dX = pool(PS_X), &dOut = pool(PS_OUT);
+    int rc;
+    ProjParams Q;
+    if ((rc = proj_upload(Q, mean, comps, k, n_features))) return rc;
+    const void* Xd = X;
+    double* outd = out;
+    msm_idx_t ldd = ld;
+    if (!on_device) {
+        if ((rc = dX.reserve((size_t)n_rows * n_features * dtype_bytes))) return rc;
+        if ((rc = dOut.reserve((size_t)n_rows * k * sizeof(double)))) return rc;
+        if (ld == n_features) {
+            if ((rc = h2d_bulk(dX.p, X, (size_t)n_rows * n_features * dtype_bytes))) return rc;
+        } else {
+            MSM_HIP_CHECK(hipMemcpy2DAsync(dX.p, (size_t)n_features * dtype_bytes, X, (size_t)ld * dtype_bytes,
+                                           (size_t)n_features * dtype_bytes, (size_t)n_rows, hipMemcpyHostToDevice, stream()));
+        }
+        Xd = dX.p;
+        outd = dOut.as<double>();
+        ldd = n_features;
+    }
+    if ((rc = proj_launch(Q, Xd, dtype_bytes, n_rows, n_features, ldd, k, outd))) return rc;
     if (!on_device) {
         int rcd = d2h_bulk(out, outd, (size_t)n_rows * k * sizeof(double));
         if (rcd) return rcd;
     }
     int f = 0;
-    if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f, dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // scratch buffers die with this frame
+    if (check_finite) MSM_HIP_CHECK(hipMemcpyAsync(&f, Q.dflag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // the uploads' host sources and the scratch buffers die with this frame
     if (check_finite && f) return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
     return MSM_OK;
+}
+
+/* msm_tica_project for a LIST of HOST trajectories (contiguous rows of n_features values): out (host) is ONE
+ * [sum of n_rows][k] float64 array, trajectory after trajectory.  The rows are staged in groups of 512 MiB through the two
+ * halves of a device buffer -- group g + 1 is copied while group g is projected (one launch per group: the projection is
+ * row by row) --, the result stays on the device until ONE copy at the end.  A call per trajectory (msm_tica_project) is
+ * copy, kernel, copy back, synchronise: 27 GB/s on 100 x (10,000 x 512 f32) against the link's 56 (scripts/apiprobe.py). */
+int msm_tica_project_host_list(const void* const* X_ptrs, const msm_idx_t* n_rows, msm_idx_t n_seq, int dtype_bytes,
+                               msm_idx_t n_features, const double* mean, const double* comps, msm_idx_t k, double* out,
+                               int check_finite)
+{
+    if (!X_ptrs || !n_rows || !mean || !comps || !out) return fail(MSM_ERR_INVALID, "msm_tica_project_host_list: null pointer");
+    if (dtype_bytes != 4 && dtype_bytes != 8) return fail(MSM_ERR_INVALID, "dtype_bytes must be 4 or 8");
+    if (n_seq < 0 || n_features < 1 || k < 1) return fail(MSM_ERR_INVALID, "bad shape");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    size_t total = 0;
+    for (msm_idx_t s = 0; s < n_seq; ++s) {
+        if (n_rows[s] < 0 || (n_rows[s] > 0 && !X_ptrs[s])) return fail(MSM_ERR_INVALID, "bad sequence %lld", (long long)s);
+        total += (size_t)n_rows[s];
+    }
+    if (total == 0) return MSM_OK;
+    const size_t row_bytes = (size_t)n_features * dtype_bytes;
+    const size_t budget = (size_t)512 << 20;
+    // groups of whole trajectories, rows packed back to back (a trajectory larger than the budget is a group of its own)
+    std::vector<msm_idx_t> gend;
+    size_t half = 0;
+    {
+        size_t bytes = 0;
+        for (msm_idx_t s = 0; s < n_seq; ++s) {
+            const size_t b = (size_t)n_rows[s] * row_bytes;
+            if (bytes > 0 && bytes + b > budget) {
+                gend.push_back(s);
+                half = std::max(half, bytes);
+                bytes = 0;
+            }
+            bytes += b;
+        }
+        gend.push_back(n_seq);
+        half = std::max(half, bytes);
+    }
+    half = (half + 255) & ~(size_t)255;
+    DevBuf &dX = pool(PS_X), &dOut = pool(PS_OUT);
+    int rc;
+    if ((rc = dX.reserve(2 * half))) return rc;
+    if ((rc = dOut.reserve(total * k * sizeof(double)))) return rc;
+    ProjParams Q;
+    if ((rc = proj_upload(Q, mean, comps, k, n_features))) return rc;
+    hipEvent_t evk[2] = {nullptr, nullptr};   // the projection of the group that last used a half has finished
+    for (auto& e : evk) MSM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto cleanup = [&](int code) {
+        (void)hipStreamSynchronize(stream());
+        for (auto& e : evk)
+            if (e) (void)hipEventDestroy(e);
+        return code;
+    };
+    auto copy_group = [&](size_t g, bool first) -> int {
+        char* d = dX.as<char>() + (g & 1) * half;
+        for (msm_idx_t s = g ? gend[g - 1] : 0; s < gend[g]; ++s) {
+            const size_t b = (size_t)n_rows[s] * row_bytes;
+            if (b) {
+                const int rcb = h2d_bulk(d, X_ptrs[s], b, first);
+                if (rcb) return rcb;
+            }
+            d += b;
+        }
+        return MSM_OK;
+    };
+    if ((rc = copy_group(0, true))) return cleanup(rc);
+    size_t row0 = 0;
+    for (size_t g = 0; g < gend.size(); ++g) {
+        size_t rows = 0;
+        for (msm_idx_t s = g ? gend[g - 1] : 0; s < gend[g]; ++s) rows += (size_t)n_rows[s];
+        if (rows) {
+            rc = proj_launch(Q, dX.as<char>() + (g & 1) * half, dtype_bytes, (msm_idx_t)rows, n_features, n_features, k,
+                             dOut.as<double>() + row0 * k);
+            if (rc) return cleanup(rc);
+        }
+        if (hipEventRecord(evk[g & 1], stream()) != hipSuccess) return cleanup(fail(MSM_ERR_HIP, "hipEventRecord failed"));
+        row0 += rows;
+        if (g + 1 < gend.size()) {
+            // the other half was last read by the projection of group g - 1 (queued before this one)
+            if (g >= 1 && hipEventSynchronize(evk[(g + 1) & 1]) != hipSuccess) return cleanup(fail(MSM_ERR_HIP, "hipEventSynchronize failed"));
+            if ((rc = copy_group(g + 1, false))) return cleanup(rc);
+        }
+    }
+    if ((rc = d2h_bulk(out, dOut.p, total * k * sizeof(double)))) return cleanup(rc);
+    int f = 0;
+    if (check_finite && hipMemcpyAsync(&f, Q.dflag, sizeof(int), hipMemcpyDeviceToHost, stream()) != hipSuccess)
+        return cleanup(fail(MSM_ERR_HIP, "hipMemcpyAsync failed"));
+    rc = cleanup(MSM_OK);
+    if (check_finite && f) return fail(MSM_ERR_NONFINITE, "Input contains NaN, infinity or a value too large");
+    return rc;
 }
 
 /* msm_tica_project for a LIST of device-resident trajectories in one launch per block of 16 components: X_ptrs[s] is

@@ -783,6 +783,9 @@ class tICA(BaseEstimator, TransformerMixin):
         batched = self._transform_device_list(sequences) if isinstance(sequences, (list, tuple)) else None
         if batched is not None:
             return batched
+        batched = self._transform_host_list(sequences) if isinstance(sequences, (list, tuple)) else None
+        if batched is not None:
+            return batched
         sequences_new = []
         mean, comps = None, None
         L = _lib.lib()
@@ -813,6 +816,35 @@ class tICA(BaseEstimator, TransformerMixin):
                                          mean.ctypes.data, comps.ctypes.data, k, aout.vp, ax.on_device, 1))
             sequences_new.append(out)
         return sequences_new
+
+    def _transform_host_list(self, sequences):
+        """``transform`` of several HOST trajectories (C-contiguous float32 or float64 numpy arrays of the model's width) in one
+        library call: staged over PCIe in overlapped groups, one [total, k] result cut per trajectory
+        (``msm_tica_project_host_list``); None when the list does not qualify -- the caller then goes trajectory by
+        trajectory (copy, kernel, copy back and a synchronisation each: half the link's rate)."""
+        if len(sequences) < 2:
+            return None
+        head = sequences[0]
+        if not isinstance(head, np.ndarray) or head.ndim != 2 or head.dtype not in (np.float32, np.float64):
+            return None
+        F = head.shape[1]
+        for X in sequences:
+            if (not isinstance(X, np.ndarray) or X.ndim != 2 or X.shape[1] != F or X.dtype != head.dtype
+                    or not X.flags.c_contiguous):
+                return None
+        mean, comps = self._projection()
+        if F != comps.shape[1]:
+            raise ValueError("shapes (%d,%d) and (%d,%d) not aligned" % (head.shape[0], F, comps.shape[1], comps.shape[0]))
+        k = comps.shape[0]
+        n = len(sequences)
+        lens = [int(X.shape[0]) for X in sequences]
+        Y = np.empty((sum(lens), k), dtype=np.float64)
+        _lib.ensure_device()
+        xp = (C.c_void_p * n)(*[X.ctypes.data if X.shape[0] else None for X in sequences])
+        rows = (C.c_int64 * n)(*lens)
+        check(_lib.lib().msm_tica_project_host_list(xp, rows, n, head.dtype.itemsize, F, mean.ctypes.data, comps.ctypes.data, k,
+                                                    Y.ctypes.data, 1))
+        return _lib.cut_rows(Y, lens)
 
     def _transform_device_list(self, sequences):
         """``transform`` of several separately allocated device trajectories in ONE launch per 16 components

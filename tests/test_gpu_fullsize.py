@@ -370,3 +370,32 @@ def test_host_trajectories_staged_in_overlapped_groups(gpu):
         # the library is usable afterwards, and a fit of the clean data gives the same numbers again
         m2 = tICA(n_components=4, lag_time=lag).fit(host)
     np.testing.assert_array_equal(m2.eigenvalues_, mh.eigenvalues_)
+
+
+def test_transform_of_host_trajectories_in_overlapped_groups(gpu):
+    """tICA.transform on a list of numpy trajectories goes down in ONE call (msm_tica_project_host_list: groups of 512 MiB
+    through two device buffers, the copy of group g + 1 beside the projection of group g, one copy back): every row must be
+    what the per-trajectory path (partial_transform: tica.py:356-377) returns, bit for bit -- ragged lengths, an empty
+    trajectory, three groups, float64 rows, a width that is no multiple of 4, and a NaN raises like array2d."""
+    from msmbuilder_amd import tICA
+    rng = np.random.default_rng(11)
+    for F, dtype, lens in ((512, np.float32, [60_000, 1, 45_000, 0, 150_000, 20_000, 33_333, 90_000, 70_000, 41_000, 52_000, 66_000]),
+                           (171, np.float32, [5_000, 12_345, 7]), (64, np.float64, [30_000, 2_000])):
+        host = [rng.standard_normal((n, F)).astype(dtype) + np.linspace(-1, 1, F, dtype=dtype) for n in lens]
+        if F == 512:
+            assert sum(x.nbytes for x in host) > 2.2 * (512 << 20)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=7, lag_time=3, kinetic_mapping=(F == 171)).fit([x for x in host if len(x) > 3])
+            Y = m.transform(host)
+            assert len(Y) == len(host)
+            for x, y in zip(host, Y):
+                assert y.shape == (len(x), 7) and y.dtype == np.float64
+                if len(x):
+                    np.testing.assert_array_equal(y, m.partial_transform(x))
+            bad = list(host)
+            bad[-1] = bad[-1].copy()
+            bad[-1][-1, 5] = np.inf
+            with pytest.raises(ValueError):
+                m.transform(bad)
+            np.testing.assert_array_equal(m.transform(host)[0], Y[0])     # usable afterwards
