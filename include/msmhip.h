@@ -76,6 +76,10 @@ int msm_free(void* dptr);
 int msm_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int msm_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int msm_memcpy_d2d(void* dst, const void* src, size_t bytes);
+/* n host buffers back to back into one device buffer (dst must hold their sum), staged through the library's pinned ring
+ * with no synchronisation between them; returns when the data is on the device.  What tICA.fit_transform uses to upload a
+ * list of host trajectories ONCE for both passes. */
+int msm_upload_list(void* dst, const void* const* src, const msm_idx_t* nbytes, msm_idx_t n);
 /* out[i, :] = X[rows[i], :]  (X device or host per on_device; rows/out follow it) */
 int msm_gather_rows(const void* X, int elem_size, msm_idx_t n_features, const msm_idx_t* rows,
                     msm_idx_t n_rows, void* out, int on_device);

@@ -62,6 +62,7 @@ def _declare(lib):
     f("msm_memcpy_h2d", C.c_int, _p, _p, C.c_size_t)
     f("msm_memcpy_d2h", C.c_int, _p, _p, C.c_size_t)
     f("msm_memcpy_d2d", C.c_int, _p, _p, C.c_size_t)
+    f("msm_upload_list", C.c_int, _p, C.POINTER(_p), _i64p, _i64)
     f("msm_gather_rows", C.c_int, _p, C.c_int, _i64, _p, _i64, _p, C.c_int)
     f("msm_event_create", C.c_int, C.POINTER(_p))
     f("msm_event_record", C.c_int, _p)

@@ -383,14 +383,33 @@ int msm_free(void* dptr)
 
 int msm_memcpy_h2d(void* dst, const void* src, size_t bytes)
 {
-    MSM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
+    if (!dst || !src) return fail(MSM_ERR_INVALID, "msm_memcpy_h2d: null pointer");
+    const int rc = h2d_bulk(dst, src, bytes);   // (large copies through the pinned ring: 50+ GB/s against ~10 from pageable memory)
+    if (rc) return rc;
     MSM_HIP_CHECK(hipStreamSynchronize(g_stream));
     return MSM_OK;
 }
 
 int msm_memcpy_d2h(void* dst, const void* src, size_t bytes)
 {
-    MSM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+    if (!dst || !src) return fail(MSM_ERR_INVALID, "msm_memcpy_d2h: null pointer");
+    return d2h_bulk(dst, src, bytes);   // blocking
+}
+
+/* n host buffers (src[i], nbytes[i]) back to back into ONE device buffer, staged through the pinned ring without a
+ * synchronisation between them; returns when the data is on the device. */
+int msm_upload_list(void* dst, const void* const* src, const msm_idx_t* nbytes, msm_idx_t n)
+{
+    if (!dst || (n > 0 && (!src || !nbytes)) || n < 0) return fail(MSM_ERR_INVALID, "msm_upload_list: bad argument");
+    char* d = static_cast<char*>(dst);
+    for (msm_idx_t i = 0; i < n; ++i) {
+        if (nbytes[i] < 0 || (nbytes[i] > 0 && !src[i])) return fail(MSM_ERR_INVALID, "msm_upload_list: bad buffer %lld", (long long)i);
+        if (nbytes[i] > 0) {
+            const int rc = h2d_bulk(d, src[i], (size_t)nbytes[i], i == 0);
+            if (rc) return rc;
+        }
+        d += nbytes[i];
+    }
     MSM_HIP_CHECK(hipStreamSynchronize(g_stream));
     return MSM_OK;
 }

@@ -889,9 +889,59 @@ class tICA(BaseEstimator, TransformerMixin):
         return self.transform(sequences)[0]
 
     def fit_transform(self, sequences, y=None):
-        """Fit the model with X and apply the dimensionality reduction on X."""
-        self.fit(sequences)
-        return self.transform(sequences)
+        """Fit the model with X and apply the dimensionality reduction on X.  A list of host (numpy) trajectories that fits
+        into a quarter of the free device memory crosses PCIe ONCE: it is uploaded back to back into one device buffer
+        (``msm_upload_list``), fitted and projected there, and the projection comes back as one array cut per trajectory
+        -- ``fit`` followed by ``transform`` on host arrays would upload every frame twice."""
+        staged = self._stage_host_list(sequences)
+        if staged is None:
+            self.fit(sequences)
+            return self.transform(sequences)
+        Xd, lens = staged
+        views = _lib.cut_rows(Xd, lens)
+        self.fit(views)
+        Yd = self.transform([Xd])[0]                     # [total, k] float64 on the device
+        Y = np.empty(tuple(Yd.shape), dtype=np.float64)
+        if Y.size:
+            check(_lib.lib().msm_memcpy_d2h(Y.ctypes.data, C.c_void_p(Yd.data_ptr()), Y.nbytes))
+        return _lib.cut_rows(Y, lens)
+
+    @staticmethod
+    def _stage_host_list(sequences):
+        """(device tensor [total, F], row counts) holding a list of C-contiguous float32 / float64 numpy trajectories of one
+        width back to back, or None when the list does not qualify (other types, mixed dtypes / widths, torch without a
+        device, more bytes than a quarter of the free device memory)."""
+        if not isinstance(sequences, (list, tuple)) or len(sequences) < 1:
+            return None
+        head = sequences[0]
+        if not isinstance(head, np.ndarray) or head.ndim != 2 or head.dtype not in (np.float32, np.float64):
+            return None
+        F = head.shape[1]
+        for X in sequences:
+            if (not isinstance(X, np.ndarray) or X.ndim != 2 or X.shape[1] != F or X.dtype != head.dtype
+                    or not X.flags.c_contiguous):
+                return None
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return None
+            _lib.ensure_device()
+            dev = torch.device("cuda", int(_lib._initialized_device or 0))   # the library's device (LOCAL_RANK-aware)
+            free_bytes = torch.cuda.mem_get_info(dev)[0]
+        except Exception:
+            return None
+        lens = [int(X.shape[0]) for X in sequences]
+        total = sum(lens)
+        nbytes = total * F * head.dtype.itemsize
+        if total == 0 or nbytes > free_bytes // 4:
+            return None
+        Xd = torch.empty((total, F), dtype=torch.float32 if head.dtype == np.float32 else torch.float64, device=dev)
+        n = len(sequences)
+        src = (C.c_void_p * n)(*[X.ctypes.data if X.shape[0] else None for X in sequences])
+        nb = (C.c_int64 * n)(*[int(X.nbytes) for X in sequences])
+        _lib.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        check(_lib.lib().msm_upload_list(C.c_void_p(Xd.data_ptr()), src, nb, n))
+        return Xd, lens
 
     # ---------------------------------------------------------------------- score
     def score(self, sequences, y=None):

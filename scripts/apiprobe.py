@@ -43,3 +43,6 @@ timeit("libdistance.pdist 20000 x 64 f32 euclidean (200M pairs -> 1.6 GB host)",
 timeit("libdistance.assign_nearest 20000 x 64 vs 5000 centres", lambda: libdistance.assign_nearest(A, B, "euclidean"))
 timeit("libdistance.dist 20000 x 64 row 7", lambda: libdistance.dist(A, A[7], "euclidean"))
 timeit("libdistance.sumdist 20000 x 64, 100000 pairs", lambda: libdistance.sumdist(A, "euclidean", np.random.RandomState(3).randint(0, 20000, (100000, 2)).astype(np.int64)), reps=2)
+hostL = [np.random.RandomState(i).randn(10000, 512).astype(np.float32) for i in range(100)]
+timeit("tICA.fit_transform on 100 host trajectories (2 GB)", lambda: tICA(n_components=10, lag_time=50).fit_transform(hostL))
+timeit("tICA.fit + transform on the same (two passes over PCIe)", lambda: (lambda mm: mm.transform(hostL))(tICA(n_components=10, lag_time=50).fit(hostL)))

@@ -399,3 +399,39 @@ def test_transform_of_host_trajectories_in_overlapped_groups(gpu):
             with pytest.raises(ValueError):
                 m.transform(bad)
             np.testing.assert_array_equal(m.transform(host)[0], Y[0])     # usable afterwards
+
+
+def test_fit_transform_of_host_trajectories_uploads_once(gpu):
+    """tICA.fit_transform on numpy trajectories stages the list on the device once (msm_upload_list) and runs fit and
+    transform there: the result must be exactly what fit + transform of the same rows as device tensors give, numpy arrays
+    per trajectory like the reference's mixin (base.py fit_transform), close to the two-pass host route, and a NaN raises."""
+    from msmbuilder_amd import tICA
+    rng = np.random.default_rng(3)
+    F, lag = 256, 7
+    lens = [20_000, 3, 15_001, 40_000, 9_999]
+    host = []
+    for n in lens:
+        z = np.cumsum(rng.standard_normal((n, 5)), axis=0) * 0.05
+        host.append((np.tanh(z) @ rng.standard_normal((5, F)) + 0.5 * rng.standard_normal((n, F))).astype(np.float32))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m1 = tICA(n_components=4, lag_time=lag)
+        Y1 = m1.fit_transform(host)
+        dev = [torch.from_numpy(x).cuda() for x in host]
+        m2 = tICA(n_components=4, lag_time=lag).fit(dev)
+        Y2 = [y.cpu().numpy() for y in m2.transform(dev)]
+        m3 = tICA(n_components=4, lag_time=lag).fit(host)
+        Y3 = m3.transform(host)
+    assert m1.n_sequences_ == m2.n_sequences_ == len(lens) - 1
+    assert all(isinstance(y, np.ndarray) and y.dtype == np.float64 and y.shape == (n, 4) for y, n in zip(Y1, lens))
+    np.testing.assert_array_equal(m1.eigenvalues_, m2.eigenvalues_)
+    for a, b, c in zip(Y1, Y2, Y3):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, c, rtol=0, atol=2e-4 * max(1.0, np.abs(c).max()))
+    bad = list(host)
+    bad[0] = bad[0].copy()
+    bad[0][11, 2] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(ValueError):
+            tICA(n_components=4, lag_time=lag).fit_transform(bad)
