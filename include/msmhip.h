@@ -368,19 +368,28 @@ int msm_kcenters_fit_sharded_f64(const double* X, msm_idx_t n_local, msm_idx_t m
  * and the updates are not counted: a lower bound on the traffic). */
 int msm_kcenters_last_stats(msm_idx_t* out5);
 
-/* ---- k-means labelling / mini-batch step (fp32, GEMM form on MFMA) ---- */
+/* ---- k-means labelling / mini-batch step (GEMM form on MFMA) ----
+ * Element type: scikit-learn (the arithmetic behind msmbuilder.cluster.MiniBatchKMeans, cluster/__init__.py:67-69) works
+ * in the type of X -- float32 rows give float32 centres / counts, everything else is float64 -- and the reference
+ * pipeline feeds it the float64 output of tICA.transform (decomposition/tica.py:329-352).  Both types are built:
+ * `_f32` entry points on v_mfma_f32_32x32x2_f32, `_f64` entry points on v_mfma_f64_16x16x4_f64 (round 6). */
 /* labels[i] = argmin_j ||X[i]-C[j]||^2 computed as ||c||^2 - 2 x.c (+||x||^2 for the
- * inertia), fp32 like scikit-learn's _labels_inertia; centers host [K, m].
- * labels int32 (sklearn's dtype) follow on_device; *inertia fp64 sum of fp32 terms. */
+ * inertia), in the rows' own type like scikit-learn's _labels_inertia; centers host [K, m].
+ * labels int32 (sklearn's dtype) follow on_device; *inertia fp64 sum of per-row terms. */
 int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* centers,
                          msm_idx_t K, int32_t* labels, double* inertia, int on_device);
+int msm_kmeans_label_f64(const double* X, msm_idx_t n, msm_idx_t m, const double* centers,
+                         msm_idx_t K, int32_t* labels, double* inertia, int on_device);
 /* k-means++ seeds (scikit-learn `_kmeans_plusplus`, sklearn/cluster/_kmeans.py:163-259; reached from
- * msmbuilder/cluster/__init__.py:67-69) of the n x F float32 rows X (host or device per on_device): centre 0 = row
+ * msmbuilder/cluster/__init__.py:67-69) of the n x F rows X (host or device per on_device): centre 0 = row
  * `first`, then K - 1 rounds of L candidates drawn by inverse-CDF sampling of the current squared distances with the
  * uniforms u[(K - 1) * L] (host float64 in [0, 1): the caller's RandomState stream), the candidate of lowest potential
- * wins.  Distances in scikit-learn's float64-upcast arithmetic.  centers[K * F] float32 and ids[K] (rows of X): host. */
+ * wins.  float32 rows: distances in scikit-learn's float64-upcast arithmetic rounded to float32; float64 rows: float64
+ * throughout.  centers[K * F] (the rows' type) and ids[K] (rows of X): host. */
 int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t K, msm_idx_t first, const double* u, int L,
                             float* centers, msm_idx_t* ids, int on_device);
+int msm_kmeans_plusplus_f64(const double* X, msm_idx_t n, msm_idx_t F, msm_idx_t K, msm_idx_t first, const double* u, int L,
+                            double* centers, msm_idx_t* ids, int on_device);
 /* One MiniBatchKMeans step on the rows X[batch_idx[b]] (batch_idx host int64, length B):
  * label, then per-centre streaming mean c <- (c*w + sum x)/(w + n) with cumulative
  * counts (sklearn _k_means_minibatch.pyx:59-109, unit sample weights).  centers
@@ -391,9 +400,15 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
                      msm_idx_t B, float* centers, float* counts, msm_idx_t K,
                      double* batch_inertia, double* batch_sums, double* batch_counts,
                      int apply_update, int on_device);
+int msm_mbk_step_f64(const double* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* batch_idx,
+                     msm_idx_t B, double* centers, double* counts, msm_idx_t K,
+                     double* batch_inertia, double* batch_sums, double* batch_counts,
+                     int apply_update, int on_device);
 
 /* Device-resident MiniBatchKMeans state (centres [K, m], cumulative counts [K] and ||c||^2 stay in
  * HBM for the whole fit).  A step ships the batch indices in and [inertia | counts] out.
+ * The handle has an element type: msm_mbk_create -> float32, msm_mbk_create_f64 -> float64 (msm_mbk_is_f64 tells); every
+ * `void*` below (X, centers, counts, counts_out) is an array of THAT type.
  *   msm_mbk_step(apply_update = 1): label the batch rows X[batch_idx[b]], streaming-mean update,
  *       *batch_inertia (before the update) and counts_out (host, K; nullable) after it.
  *   apply_update = 0 (multi-GPU): label + fp64 batch sums only; msm_mbk_export_packed() hands out
@@ -403,12 +418,14 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
  *       (scikit-learn's starved-centre reassignment, decided on the host with its RNG). */
 typedef struct msm_mbk msm_mbk_t;
 int msm_mbk_create(msm_mbk_t** h, msm_idx_t n_clusters, msm_idx_t n_features);
+int msm_mbk_create_f64(msm_mbk_t** h, msm_idx_t n_clusters, msm_idx_t n_features);
+int msm_mbk_is_f64(msm_mbk_t* h);
 int msm_mbk_destroy(msm_mbk_t* h);
-int msm_mbk_set(msm_mbk_t* h, const float* centers, const float* counts);
-int msm_mbk_set_counts(msm_mbk_t* h, const float* counts);
-int msm_mbk_get(msm_mbk_t* h, float* centers, float* counts);
-int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
-                 double* batch_inertia, float* counts_out, int apply_update, int on_device);
+int msm_mbk_set(msm_mbk_t* h, const void* centers, const void* counts);
+int msm_mbk_set_counts(msm_mbk_t* h, const void* counts);
+int msm_mbk_get(msm_mbk_t* h, void* centers, void* counts);
+int msm_mbk_step(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
+                 double* batch_inertia, void* counts_out, int apply_update, int on_device);
 /* S consecutive plain steps (label + streaming-mean update, as msm_mbk_step with apply_update = 1) on device-resident X
  * with ONE host synchronisation: batch_idx is [S][B] (host), and sklearn's _mini_batch_convergence (_kmeans.py:1963-2027,
  * the tol == 0 / verbose == 0 branch) runs on the device after every step -- state6 = {ewa_inertia, ewa_inertia_min,
@@ -416,35 +433,35 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
  * = None.  Steps queued behind the one at which the criterion fires are not executed: *steps_done <= S says how many were,
  * inertias[0 .. steps_done) are their batch inertias, *converged the criterion.  first_step = index of the run's first
  * step in the fit (step 0 is excluded from the moving average, as in sklearn). */
-int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+int msm_mbk_run(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
                 msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
-                msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
+                msm_idx_t* steps_done, int* converged, double* inertias, void* counts_out);
 /* msm_mbk_run in two halves: _begin queues the run and returns, _end waits and fetches (the host draws the next run's
  * indices in between); one run in flight per handle */
-int msm_mbk_run_begin(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+int msm_mbk_run_begin(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
                       msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, const double* state6);
-int msm_mbk_run_end(msm_mbk_t* h, double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
+int msm_mbk_run_end(msm_mbk_t* h, double* state6, msm_idx_t* steps_done, int* converged, double* inertias, void* counts_out);
 /* The same for a ROW-SHARDED fit (one process per GPU, rows in consecutive blocks): the S batches are global and identical
  * on every rank; a rank passes the rows of each batch that IT owns as local row numbers -- local_idx (host) back to back,
  * offsets[S + 1] (host) delimiting the steps -- and the size B of the whole batch.  Per step: label + fp64 sums / counts /
  * inertia of the local rows, ONE all-reduce of the packed [K m | K | 1] buffer over the library communicator (RCCL on the
  * library stream, device to device), the identical update and convergence step on every rank (every rank stops at the same
  * step: the criterion sees the all-reduced inertia).  One host synchronisation per run; outputs as msm_mbk_run. */
-int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const msm_idx_t* local_idx, const msm_idx_t* offsets,
+int msm_mbk_run_sharded(msm_mbk_t* h, const void* X, msm_idx_t n_local, const msm_idx_t* local_idx, const msm_idx_t* offsets,
                         msm_idx_t S, msm_idx_t B, msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement,
-                        double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out);
+                        double* state6, msm_idx_t* steps_done, int* converged, double* inertias, void* counts_out);
 msm_idx_t msm_mbk_packed_size(msm_mbk_t* h);
 int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device);
-int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int on_device);
+int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, void* counts_out, int on_device);
 /* Sharded step over the library communicator: every rank runs msm_mbk_step(apply_update = 0) on the batch rows it
  * owns (msm_mbk_zero_packed if it owns none), then msm_mbk_allreduce: ONE all-reduce of the device-resident
  * [K*m sums | K counts | inertia] (RCCL on the library stream, nothing staged through the host) and the identical
  * update on every rank.  *batch_inertia = global batch inertia, counts_out (host, K) = updated cumulative counts. */
 int msm_mbk_zero_packed(msm_mbk_t* h);
-int msm_mbk_allreduce(msm_mbk_t* h, double* batch_inertia, float* counts_out);
-int msm_mbk_reassign(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
-                     msm_idx_t n_reassign, float new_count, int on_device);
-int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device);
+int msm_mbk_allreduce(msm_mbk_t* h, double* batch_inertia, void* counts_out);
+int msm_mbk_reassign(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
+                     msm_idx_t n_reassign, double new_count, int on_device);
+int msm_mbk_label(msm_mbk_t* h, const void* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device);
 
 /* ------------------------------------------------------------------------------------------
  * Pre-tICA column scan and scaling.  Replaces the fit / transform arithmetic of

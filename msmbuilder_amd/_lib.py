@@ -145,9 +145,13 @@ def _declare(lib):
         f("msm_kcenters_pass_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, C.c_char_p, _p, _p, _f64p, _i64p, _p, C.c_int)
         f("msm_kcenters_pass_dev_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, C.c_char_p, _p, _p, _i64, _p)
         f("msm_kcenters_select_" + sfx, C.c_int, _p, _i64, _i64, _p, _p, _p, _i64)
-    f("msm_kmeans_label_f32", C.c_int, _p, _i64, _i64, _p, _i64, _p, _f64p, C.c_int)
-    f("msm_kmeans_plusplus_f32", C.c_int, _p, _i64, _i64, _i64, _i64, _p, C.c_int, _p, _p, C.c_int)
+    for sfx in ("f32", "f64"):
+        f("msm_kmeans_label_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, _p, _f64p, C.c_int)
+        f("msm_kmeans_plusplus_" + sfx, C.c_int, _p, _i64, _i64, _i64, _i64, _p, C.c_int, _p, _p, C.c_int)
+        f("msm_mbk_step_" + sfx, C.c_int, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _f64p, _p, _p, C.c_int, C.c_int)
     f("msm_mbk_create", C.c_int, C.POINTER(_p), _i64, _i64)
+    f("msm_mbk_create_f64", C.c_int, C.POINTER(_p), _i64, _i64)
+    f("msm_mbk_is_f64", C.c_int, _p)
     f("msm_mbk_destroy", C.c_int, _p)
     f("msm_mbk_set", C.c_int, _p, _p, _p)
     f("msm_mbk_set_counts", C.c_int, _p, _p)
@@ -162,10 +166,8 @@ def _declare(lib):
     f("msm_mbk_packed_size", _i64, _p)
     f("msm_mbk_export_packed", C.c_int, _p, _p, C.c_int)
     f("msm_mbk_apply_packed", C.c_int, _p, _p, _p, C.c_int)
-    f("msm_mbk_reassign", C.c_int, _p, _p, _i64, _p, _p, _i64, C.c_float, C.c_int)
+    f("msm_mbk_reassign", C.c_int, _p, _p, _i64, _p, _p, _i64, C.c_double, C.c_int)
     f("msm_mbk_label", C.c_int, _p, _p, _i64, _p, _f64p, C.c_int)
-    f("msm_mbk_step_f32", C.c_int, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _f64p, _p, _p, C.c_int,
-      C.c_int)
 
 
 def lib():

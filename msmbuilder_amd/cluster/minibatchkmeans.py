@@ -9,11 +9,21 @@ the same constructor arguments and the SAME host-side ``RandomState`` call seque
 (validation subsample, init subsample, k-means++ draws, one ``randint`` batch per step,
 ``choice`` for starved-centre reassignment), so that a given ``random_state`` walks the
 same minibatches as scikit-learn.  The arithmetic that scales with the data runs on
-the GPU (msmbuilder_amd/csrc/kmeans.hip): nearest-centre labelling as an fp32 MFMA
+the GPU (msmbuilder_amd/csrc/kmeans.hip): nearest-centre labelling as an MFMA
 contraction, the per-centre streaming-mean update, and the final full-data labelling.
 
-Parity definition (DESIGN.md "MiniBatchKMeans"): centres rtol 1e-4, inertia rtol 1e-4,
-labels equal except where the two best squared distances tie to fp32 rounding.
+Element type (round 6): scikit-learn works in the type of X -- float32 rows give float32
+centres, counts and distances, EVERYTHING ELSE (float64, integers, lists) is computed in
+float64 -- and the reference pipeline hands this class the float64 output of
+``tICA.transform`` (msmbuilder/decomposition/tica.py:329-352).  So does this module:
+float32 rows run on ``v_mfma_f32_32x32x2_f32``, float64 rows on ``v_mfma_f64_16x16x4_f64``
+(``kmeans_label_f64_kernel``), with float64 centres / counts / k-means++ potentials, and
+``cluster_centers_`` comes back in the rows' type.  (Rounds 1-5 narrowed float64 input
+to float32.)
+
+Parity definition (DESIGN.md "MiniBatchKMeans"): float32 rows: centres rtol 1e-4, inertia
+rtol 1e-4, labels equal except where the two best squared distances tie to fp32 rounding;
+float64 rows: centres rtol 1e-9, inertia rtol 1e-9, labels equal off exact ties.
 
 Multi-GPU: with ``torch.distributed`` initialised, each rank owns a shard of the frames;
 every step all ranks draw the same global batch, label their share, and one RCCL
@@ -35,8 +45,23 @@ from .base import MultiSequenceClusterMixin
 __all__ = ['MiniBatchKMeans']
 
 
+def _work_dtype(X):
+    """The type scikit-learn computes in for this input (``validate_data(dtype=[np.float64, np.float32])``): float32 stays
+    float32, everything else becomes float64.  Device tensors: float64 stays, every other type (float32, half, bfloat16:
+    types scikit-learn never sees) is computed in float32."""
+    if is_device_array(X):
+        import torch
+        return np.dtype(np.float64) if X.dtype == torch.float64 else np.dtype(np.float32)
+    dt = getattr(X, "dtype", None)
+    return np.dtype(np.float32) if dt == np.float32 else np.dtype(np.float64)
+
+
+def _sfx(dtype):
+    return "f64" if np.dtype(dtype) == np.float64 else "f32"
+
+
 def _rows_to_host(ax, idx):
-    """X[idx] as a host float32 array (device X: gather kernel + small D2H)."""
+    """X[idx] as a host array of X's type (device X: gather kernel + small D2H)."""
     idx = np.ascontiguousarray(idx, dtype=np.int64)
     if not ax.on_device:
         return np.ascontiguousarray(ax.keep[idx])
@@ -47,37 +72,39 @@ def _rows_to_host(ax, idx):
 
 def label_inertia(X, centers):
     """(labels int32, inertia) of every row of X against ``centers`` -- the GPU counterpart of
-    scikit-learn's ``_labels_inertia``.  X: numpy float32 or torch CUDA float32."""
-    ax = X if isinstance(X, Arr) else Arr(X, np.float32)
-    centers = np.ascontiguousarray(centers, dtype=np.float32)
+    scikit-learn's ``_labels_inertia``.  X: numpy or torch CUDA rows, float32 or float64: the arithmetic runs in the
+    rows' type (``_work_dtype``), the centres are converted to it."""
+    ax = X if isinstance(X, Arr) else Arr(X, _work_dtype(X))
+    centers = np.ascontiguousarray(centers, dtype=ax.dtype)
     labels = empty_like_placement(ax, (ax.shape[0],), np.int32)
     if ax.shape[0] == 0:
         return labels, 0.0   # an empty trajectory: nothing to label (and an empty device tensor has no address)
     al = Arr(labels, np.int32)
     inertia = C.c_double(0.0)
-    check(_lib.lib().msm_kmeans_label_f32(ax.vp, ax.shape[0], ax.shape[1], centers.ctypes.data,
-                                          centers.shape[0], al.vp, C.byref(inertia), ax.on_device))
+    fn = getattr(_lib.lib(), "msm_kmeans_label_" + _sfx(ax.dtype))
+    check(fn(ax.vp, ax.shape[0], ax.shape[1], centers.ctypes.data, centers.shape[0], al.vp, C.byref(inertia), ax.on_device))
     return labels, float(inertia.value)
 
 
 def kmeans_plusplus(X, n_clusters, random_state):
-    """Greedy k-means++ seeding of the rows ``X`` (numpy float32 or a torch CUDA tensor), scikit-learn's
+    """Greedy k-means++ seeding of the rows ``X`` (numpy or torch CUDA, float32 or float64), scikit-learn's
     ``_kmeans_plusplus`` draw for draw (sklearn/cluster/_kmeans.py:163-259): first centre by ``choice``, then
     ``2 + log(k)`` candidates per round drawn by inverse-CDF sampling of the current squared distances, keeping the
     candidate with the lowest potential.  The rounds run on the device (``msm_kmeans_plusplus_f32``, csrc/kpp.hip); the
     draws -- one ``choice`` and ``(k - 1) x (2 + log k)`` uniforms -- come from ``random_state`` in scikit-learn's order
     (legacy ``RandomState.uniform`` draws element by element, so one call for all rounds is the same stream as one call
-    per round).  Returns the centres as a host float32 array."""
-    ax = X if isinstance(X, Arr) else Arr(X, np.float32)
+    per round).  Returns the centres as a host array of the rows' type."""
+    ax = X if isinstance(X, Arr) else Arr(X, _work_dtype(X))
     n_samples, n_features = ax.shape
     n_local_trials = 2 + int(np.log(n_clusters))
-    sample_weight = np.ones(n_samples, dtype=np.float32)
+    sample_weight = np.ones(n_samples, dtype=ax.dtype)
     center_id = int(random_state.choice(n_samples, p=sample_weight / sample_weight.sum()))
     u = np.ascontiguousarray(random_state.uniform(size=(max(n_clusters - 1, 0), n_local_trials)), dtype=np.float64)
-    centers = np.empty((n_clusters, n_features), dtype=np.float32)
+    centers = np.empty((n_clusters, n_features), dtype=ax.dtype)
     ids = np.empty(n_clusters, dtype=np.int64)
-    check(_lib.lib().msm_kmeans_plusplus_f32(ax.vp, n_samples, n_features, n_clusters, center_id, u.ctypes.data,
-                                             n_local_trials, centers.ctypes.data, ids.ctypes.data, ax.on_device))
+    fn = getattr(_lib.lib(), "msm_kmeans_plusplus_" + _sfx(ax.dtype))
+    check(fn(ax.vp, n_samples, n_features, n_clusters, center_id, u.ctypes.data, n_local_trials, centers.ctypes.data,
+             ids.ctypes.data, ax.on_device))
     return centers
 
 
@@ -165,11 +192,11 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
             init = self.init
             if is_device_array(init):
                 init = init.detach().cpu().numpy()
-            centers = np.array(init, dtype=np.float32, copy=True, order="C")
+            centers = np.array(init, dtype=ax.dtype, copy=True, order="C")
             if centers.shape != (self.n_clusters, ax.shape[1]):
                 raise ValueError("The shape of the initial centers %s does not match the number of "
                                  "clusters %d / features %d." % (centers.shape, self.n_clusters, ax.shape[1]))
-        return np.ascontiguousarray(centers, dtype=np.float32)
+        return np.ascontiguousarray(centers, dtype=ax.dtype)
 
     def _random_reassign(self):
         """_kmeans.py:2029-2043"""
@@ -266,7 +293,7 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                     print("[MiniBatchKMeans] Reassigning %d cluster centers." % n_reassigns)
                 # reset counts of reassigned centers, but don't reset them too small
                 new_count = float(np.min(weight_sums[~to_reassign]))
-                rows = np.ascontiguousarray(self._rows(ax, shard, batch_idx[new_centers]), dtype=np.float32)
+                rows = np.ascontiguousarray(self._rows(ax, shard, batch_idx[new_centers]), dtype=ax.dtype)
                 which = np.ascontiguousarray(np.nonzero(to_reassign)[0], dtype=np.int64)
                 ridx = np.arange(n_reassigns, dtype=np.int64)
                 check(L.msm_mbk_reassign(self._mbk, rows.ctypes.data, n_reassigns, ridx.ctypes.data,
@@ -362,8 +389,11 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         return done, bool(conv.value)
 
     def _mbk_open(self, centers, counts):
+        """Device state of the element type of ``centers`` (float32 / float64: the rows' type); ``counts`` must match."""
+        assert centers.dtype == counts.dtype and centers.dtype in (np.float32, np.float64)
         h = C.c_void_p()
-        check(_lib.lib().msm_mbk_create(C.byref(h), centers.shape[0], centers.shape[1]))
+        create = _lib.lib().msm_mbk_create_f64 if centers.dtype == np.float64 else _lib.lib().msm_mbk_create
+        check(create(C.byref(h), centers.shape[0], centers.shape[1]))
         self._mbk = h
         check(_lib.lib().msm_mbk_set(h, centers.ctypes.data, counts.ctypes.data))
 
@@ -373,7 +403,7 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         if h is None:
             return None
         K, F = self.n_clusters, self.n_features_in_
-        centers = np.empty((K, F), dtype=np.float32)
+        centers = np.empty((K, F), dtype=self._counts.dtype)
         try:
             check(_lib.lib().msm_mbk_get(h, centers.ctypes.data, self._counts.ctypes.data))
         finally:
@@ -382,13 +412,11 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
 
     @staticmethod
     def _rows(ax, shard, global_idx):
-        """Rows of the (possibly row-sharded) data as a host float32 array."""
-        return shard.gather_rows(lambda loc: _rows_to_host(ax, loc), global_idx, ax.shape[1])
+        """Rows of the (possibly row-sharded) data as a host array of the data's type."""
+        return shard.gather_rows(lambda loc: _rows_to_host(ax, loc), global_idx, ax.shape[1], dtype=ax.dtype)
 
     def fit(self, X, y=None):
-        if isinstance(X, np.ndarray) and X.dtype != np.float32:
-            X = X.astype(np.float32)  # GPU path computes in fp32 (sklearn keeps X's dtype)
-        ax = Arr(X, np.float32)
+        ax = Arr(X, _work_dtype(X))   # float32 stays float32, everything else is computed in float64 (scikit-learn's rule)
         if len(ax.shape) != 2:
             raise ValueError("Expected 2D array")
         # indices drawn ahead by an earlier fit that ended in an exception belong to ITS data and ITS generator: never reuse them
@@ -437,8 +465,8 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
                 init_centers = cluster_centers
                 best_inertia = inertia
 
-        centers = np.ascontiguousarray(init_centers, dtype=np.float32)
-        self._counts = np.zeros(self.n_clusters, dtype=np.float32)
+        centers = np.ascontiguousarray(init_centers, dtype=ax.dtype)
+        self._counts = np.zeros(self.n_clusters, dtype=ax.dtype)
         self._ewa_inertia = None
         self._ewa_inertia_min = None
         self._no_improvement = 0
@@ -493,12 +521,12 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         return self
 
     def partial_fit(self, X, y=None):
-        """One mini-batch update on X itself (sklearn ``MiniBatchKMeans.partial_fit``)."""
-        if isinstance(X, np.ndarray) and X.dtype != np.float32:
-            X = X.astype(np.float32)
-        ax = Arr(X, np.float32)
-        n_samples = ax.shape[0]
+        """One mini-batch update on X itself (sklearn ``MiniBatchKMeans.partial_fit``).  The first call fixes the element
+        type (that of its X, by ``_work_dtype``); later batches are converted to it, like scikit-learn converts to the
+        type of ``cluster_centers_``."""
         has_centers = hasattr(self, "cluster_centers_")
+        ax = Arr(X, self.cluster_centers_.dtype if has_centers else _work_dtype(X))
+        n_samples = ax.shape[0]
         if not has_centers:
             self._check_params_vs_input(n_samples)
             self._random_state = check_random_state(self.random_state)
@@ -506,13 +534,13 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
             self._batch_size = n_samples
             from ..parallel import RowShard
             self.cluster_centers_ = self._init_centroids(ax, RowShard(n_samples), self._random_state)
-            self._counts = np.zeros(self.n_clusters, dtype=np.float32)
+            self._counts = np.zeros(self.n_clusters, dtype=ax.dtype)
             self._n_since_last_reassign = 0
             self.n_steps_ = 0
         self._batch_size = n_samples
         from ..parallel import RowShard
         self.n_features_in_ = ax.shape[1]
-        self._mbk_open(np.ascontiguousarray(self.cluster_centers_, dtype=np.float32), self._counts)
+        self._mbk_open(np.ascontiguousarray(self.cluster_centers_, dtype=ax.dtype), self._counts)
         try:
             self._step(ax, RowShard(n_samples), np.arange(n_samples, dtype=np.int64), self._random_state,
                        self._random_reassign())
@@ -523,11 +551,13 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
         self.n_steps_ += 1
         return self
 
+    def _like_centers(self, X):
+        """X in the element type of the fitted centres (scikit-learn's ``_check_test_data`` converts to it)."""
+        return Arr(X, self.cluster_centers_.dtype)
+
     def predict(self, X):
-        """Index of the closest centre (squared euclidean, fp32 GEMM form) for each row of X."""
-        if isinstance(X, np.ndarray) and X.dtype != np.float32:
-            X = X.astype(np.float32)
-        labels, _ = label_inertia(X, self.cluster_centers_)
+        """Index of the closest centre (squared euclidean, GEMM form, in the centres' element type) for each row of X."""
+        labels, _ = label_inertia(self._like_centers(X), self.cluster_centers_)
         return labels
 
     def fit_predict(self, X, y=None):
@@ -535,9 +565,7 @@ class _MiniBatchKMeans(ClusterMixin, TransformerMixin):
 
     def score(self, X, y=None):
         """Opposite of the k-means objective on X."""
-        if isinstance(X, np.ndarray) and X.dtype != np.float32:
-            X = X.astype(np.float32)
-        _, inertia = label_inertia(X, self.cluster_centers_)
+        _, inertia = label_inertia(self._like_centers(X), self.cluster_centers_)
         return -inertia
 
 

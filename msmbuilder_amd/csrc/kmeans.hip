@@ -14,6 +14,7 @@
 // the row-strided fragment reads), a running per-lane argmin over centre tiles and
 // one wavefront min-reduction (value, lowest index) per row at the end.
 #include "common.h"
+#include "kmeans_f64_dev.h"
 
 #include <algorithm>
 #include <vector>
@@ -24,27 +25,10 @@ constexpr int KR = 128;   // rows per workgroup
 constexpr int KCT = 128;  // centres per tile
 constexpr int KBK = 32;   // features per K-step
 constexpr int KP = KBK + 1;
-constexpr int KNT = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct KmArgs {
-    const float* X;         // [n, m] (or gathered batch)
-    const msm_idx_t* rows;  // optional row gather (batch indices), else nullptr
-    long long n, m, K;
-    const float* C;         // device [K, m]
-    const float* cnorm;     // device [K]
-    int32_t* labels;        // [n]
-    // centre-split launch (small batches): blockIdx.y owns centre tiles [y*jspan, (y+1)*jspan) and
-    // writes its (min value, index) candidates to pv/pi [gridDim.y][n]; a reduce kernel finishes
-    long long jspan;        // 0 = all centres in one workgroup
-    int xcd_ns;             // > 0 (kmeans_label_v4_kernel, large n): a 1-D grid of ceil(rowblocks / 8) x 8 x xcd_ns workgroups in
-                            // which the xcd_ns centre splits of a row block are CONSECUTIVE workgroups of one XCD (see the kernel)
-    float* pv;
-    int* pi;
-    const int* stop;        // optional device flag: non-zero -> the launch does nothing (msm_mbk_run: steps queued
-                            // behind the one at which the convergence criterion fired)
-};
+using KmArgs = KmArgsT<float>;
 
 __device__ __forceinline__ void km_load(float4 (&xa)[4], float4 (&ca)[4], const KmArgs& P,
                                         long long row0, long long j0, int k0, int tid)
@@ -735,23 +719,25 @@ __global__ __launch_bounds__(KNT, 2) void kmeans_label_v4_kernel(KmArgs P)
 // Round 5: two rows per wave in flight and 16-byte loads when the rows allow it (m % 4 == 0, 16-byte aligned bases) -- one row
 // at a time with 4-byte loads and three dependent round trips per row (candidates -> centre row -> sum) ran at 1.7 TB/s
 // (1.5 ms per 1.25M x 512 pass beside a 10.4 ms labelling kernel; profiles/r05_label_wide.txt).
-__global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* __restrict__ partial, int nsplit)
+template <typename T>
+__global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgsT<T> P, double* __restrict__ partial, int nsplit)
 {
     if (P.stop && *P.stop) return;  // uniform
     __shared__ double red[KNT / 64];
+    constexpr int E = 16 / (int)sizeof(T);   // elements of a 16-byte load: 4 floats / 2 doubles
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool vec4 = (P.m & 3) == 0 && ((((uintptr_t)P.X) | ((uintptr_t)P.C)) & 15) == 0;
-    const long long m4 = P.m >> 2;
+    const bool vec4 = (P.m % E) == 0 && ((((uintptr_t)P.X) | ((uintptr_t)P.C)) & 15) == 0;
+    const long long m4 = P.m / E;
     // the row's label: from the splits' candidates (lane q fetches split q's: one round trip, then a butterfly for the lowest
     // (value, index)) or as the labelling kernel wrote it
-    auto cand_load = [&](long long i, float& bv, int& bi) {
-        bv = INFINITY;
+    auto cand_load = [&](long long i, T& bv, int& bi) {
+        bv = (T)INFINITY;
         bi = 0x7fffffff;
         if (nsplit > 1) {
             for (int q0 = 0; q0 < nsplit; q0 += 64) {
                 const int q = q0 + lane;
                 const int qc = q < nsplit ? q : nsplit - 1;
-                const float v = P.pv[(long long)qc * P.n + i];
+                const T v = P.pv[(long long)qc * P.n + i];
                 const int ix = P.pi[(long long)qc * P.n + i];
                 if (q < nsplit && (v < bv || (v == bv && ix < bi))) {
                     bv = v;
@@ -762,11 +748,11 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
             bi = P.labels[i];
         }
     };
-    auto cand_finish = [&](long long i, bool live, float bv, int bi) -> int {
+    auto cand_finish = [&](long long i, bool live, T bv, int bi) -> int {
         if (nsplit <= 1) return bi;
 #pragma unroll
         for (int msk = 32; msk > 0; msk >>= 1) {
-            const float ov = __shfl_xor(bv, msk, 64);
+            const T ov = __shfl_xor(bv, msk, 64);
             const int oi = __shfl_xor(bi, msk, 64);
             if (ov < bv || (ov == bv && oi < bi)) {
                 bv = ov;
@@ -777,22 +763,25 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
         if (live && lane == 0) P.labels[i] = bi;
         return bi;
     };
-    auto row_sum = [&](const float* x, const float* c) -> double {
+    // (float rows: the difference in fp32, its square and the sum in fp64; double rows: all of it in fp64 -- scikit-learn's
+    //  _euclidean_dense_dense works in the rows' own type)
+    auto row_sum = [&](const T* x, const T* c) -> double {
         double s = 0.0;
         if (vec4) {
-            const float4* x4 = reinterpret_cast<const float4*>(x);
-            const float4* c4 = reinterpret_cast<const float4*>(c);
+            struct alignas(16) V { T e[E]; };
+            const V* x4 = reinterpret_cast<const V*>(x);
+            const V* c4 = reinterpret_cast<const V*>(c);
             for (long long k = lane; k < m4; k += 64) {
-                const float4 a = x4[k], b = c4[k];
-                const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-                s += (double)d0 * (double)d0;
-                s += (double)d1 * (double)d1;
-                s += (double)d2 * (double)d2;
-                s += (double)d3 * (double)d3;
+                const V a = x4[k], b = c4[k];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const T d = a.e[e] - b.e[e];
+                    s += (double)d * (double)d;
+                }
             }
         } else {
             for (long long k = lane; k < P.m; k += 64) {
-                const float d = x[k] - c[k];
+                const T d = x[k] - c[k];
                 s += (double)d * (double)d;
             }
         }
@@ -804,7 +793,7 @@ __global__ __launch_bounds__(KNT) void kmeans_inertia_kernel(KmArgs P, double* _
         const long long i1 = i0 + stride;
         const bool has1 = i1 < P.n;
         const long long i1c = has1 ? i1 : i0;
-        float v0, v1;
+        T v0, v1;
         int b0, b1;
         cand_load(i0, v0, b0);
         cand_load(i1c, v1, b1);
@@ -885,8 +874,9 @@ __device__ __forceinline__ void mbk_converge(const MbkConv& cv, double* red)
 // apply != 0: sklearn's streaming-mean update in fp32, in place on centers/counts, and the centre's new ||c||^2
 //             (same lane partition and butterfly as kmeans_cnorm_kernel: bit-identical to a separate launch).
 // sums/cnts (nullable): fp64 batch sums and counts for the multi-GPU all-reduce.
-__global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __restrict__ centers,
-                                                         float* __restrict__ counts, float* __restrict__ cnorm,
+template <typename T>   // T: the rows' type = the type scikit-learn updates in (acc32 / w_old / alpha are "floating" there)
+__global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgsT<T> P, T* __restrict__ centers,
+                                                         T* __restrict__ counts, T* __restrict__ cnorm,
                                                          double* __restrict__ sums,
                                                          double* __restrict__ cnts, int apply, MbkConv cv)
 {
@@ -895,11 +885,11 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
     __shared__ int wcnt[KNT / 64];
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int CH = 4096;
-    const float w_old = counts[j];
+    const T w_old = counts[j];
     long long total = 0;
     for (long long f0 = 0; f0 < P.m; f0 += KNT) {
         const long long f = f0 + tid;
-        float acc32 = (f < P.m) ? centers[(long long)j * P.m + f] * w_old : 0.f;
+        T acc32 = (f < P.m) ? centers[(long long)j * P.m + f] * w_old : (T)0;
         double acc64 = 0.0;
         long long cnt = 0;
         for (long long b0 = 0; b0 < P.n; b0 += CH) {
@@ -923,7 +913,7 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
                 for (int k = 0; k < nmem; ++k) {
                     const long long b = b0 + members[k];
                     const long long r = P.rows ? P.rows[b] : b;
-                    const float x = P.X[r * P.m + f];
+                    const T x = P.X[r * P.m + f];
                     acc32 += x;
                     acc64 += (double)x;
                 }
@@ -933,8 +923,8 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
         if (f < P.m) {
             if (sums) sums[(long long)j * P.m + f] = acc64;
             if (apply && cnt > 0) {
-                const float w_new = w_old + (float)cnt;
-                const float alpha = 1.0f / w_new;
+                const T w_new = w_old + (T)cnt;
+                const T alpha = (T)1 / w_new;
                 centers[(long long)j * P.m + f] = acc32 * alpha;
             }
         }
@@ -942,13 +932,13 @@ __global__ __launch_bounds__(KNT) void mbk_update_kernel(KmArgs P, float* __rest
     __syncthreads();  // the centre row is complete (workgroup-scope visibility)
     if (tid == 0) {
         if (cnts) cnts[j] = (double)total;
-        if (apply && total > 0) counts[j] = w_old + (float)total;
+        if (apply && total > 0) counts[j] = w_old + (T)total;
     }
     if (apply && cnorm && total > 0 && wave == 0) {
-        const volatile float* c = centers + (long long)j * P.m;
-        float sq = 0.f;
+        const volatile T* c = centers + (long long)j * P.m;
+        T sq = 0;
         for (long long f = lane; f < P.m; f += 64) {
-            const float v = c[f];
+            const T v = c[f];
             sq += v * v;
         }
 #pragma unroll
@@ -1111,8 +1101,9 @@ __global__ __launch_bounds__(KNT) void mbk_small_label_kernel(KmArgs P, SmallArg
 
 constexpr int MSU_CAP = 1024;  // batch rows at most (a wave's member list in LDS)
 
-__global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* __restrict__ centers,
-                                                               float* __restrict__ counts, float* __restrict__ cnorm,
+template <typename T>
+__global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgsT<T> P, T* __restrict__ centers,
+                                                               T* __restrict__ counts, T* __restrict__ cnorm,
                                                                double* __restrict__ sums, double* __restrict__ cnts,
                                                                int apply, MbkConv cv)
 {
@@ -1122,8 +1113,8 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
     const long long j = (long long)blockIdx.x * 4 + wave;
     if (j < P.K) {  // uniform over the wave
         constexpr int NCH = 8;  // 64-feature blocks per round (lane = feature of each block)
-        const float w_old = counts[j];
-        float c_first[NCH];  // the first round's centre values: requested before the label scan, not after it
+        const T w_old = counts[j];
+        T c_first[NCH];  // the first round's centre values: requested before the label scan, not after it
         // (all loads of this kernel are unconditional at clamped addresses and masked afterwards: a load under a select
         //  is waited for on the spot, which turns every batch of independent loads into a chain of round trips)
 #pragma unroll
@@ -1161,10 +1152,10 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float sqn = 0.f;  // ||c_new||^2, lane partition of kmeans_cnorm_kernel
+        T sqn = 0;  // ||c_new||^2, lane partition of kmeans_cnorm_kernel
         for (long long f0 = 0; f0 < P.m; f0 += NCH * 64) {
             bool fl[NCH];
-            float c_old[NCH], acc32[NCH];
+            T c_old[NCH], acc32[NCH];
             double acc64[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -1174,12 +1165,12 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (!fl[c]) c_old[c] = 0.f;
+                if (!fl[c]) c_old[c] = 0;
                 acc32[c] = c_old[c] * w_old;
                 acc64[c] = 0.0;
             }
             for (int q0 = 0; q0 < cnt; q0 += 4) {  // up to 4 x NCH row loads in flight
-                float xv[4][NCH];
+                T xv[4][NCH];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const long long row = mrow[wave][q0 + t < cnt ? q0 + t : cnt - 1];
@@ -1194,7 +1185,7 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
                     if (q0 + t < cnt) {
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
-                            const float xq = fl[c] ? xv[t][c] : 0.f;
+                            const T xq = fl[c] ? xv[t][c] : (T)0;
                             acc32[c] += xq;
                             acc64[c] += (double)xq;
                         }
@@ -1203,10 +1194,10 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const long long f = f0 + c * 64 + lane;
-                float c_new = c_old[c];
+                T c_new = c_old[c];
                 if (apply && cnt > 0) {
-                    const float w_new = w_old + (float)cnt;
-                    const float alpha = 1.0f / w_new;
+                    const T w_new = w_old + (T)cnt;
+                    const T alpha = (T)1 / w_new;
                     c_new = acc32[c] * alpha;
                 }
                 if (fl[c]) {
@@ -1218,7 +1209,7 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
         }
         if (lane == 0) {
             if (cnts) cnts[j] = (double)cnt;
-            if (apply && cnt > 0) counts[j] = w_old + (float)cnt;
+            if (apply && cnt > 0) counts[j] = w_old + (T)cnt;
         }
         if (apply && cnorm && cnt > 0) {  // same lane partition and butterfly as kmeans_cnorm_kernel
 #pragma unroll
@@ -1242,32 +1233,35 @@ __global__ __launch_bounds__(KNT) void mbk_small_update_kernel(KmArgs P, float* 
 // Mini-batch rows copied once into a compact [rows][m] buffer: the batch's rows are scattered over the whole data set (one
 // page each for wide rows), and the label, inertia and update kernels of a step each paid those address translations again
 // -- ~35 us per kernel at 1.25M x 512 whatever the arithmetic.  One wave per row, 16-byte lanes when the row allows.
-__global__ __launch_bounds__(KNT) void mbk_gather_kernel(const float* __restrict__ X, const msm_idx_t* __restrict__ rows,
-                                                         long long nrows, long long m, float* __restrict__ out)
+template <typename T>
+__global__ __launch_bounds__(KNT) void mbk_gather_kernel(const T* __restrict__ X, const msm_idx_t* __restrict__ rows,
+                                                         long long nrows, long long m, T* __restrict__ out)
 {
+    constexpr int E = 16 / (int)sizeof(T);
     const int lane = threadIdx.x & 63;
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nrows) return;
-    const float* src = X + rows[i] * m;
-    float* dst = out + i * m;
-    if ((m & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)out)) & 15) == 0) {
-        for (long long f = lane * 4LL; f < m; f += 256) *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(src + f);
+    const T* src = X + rows[i] * m;
+    T* dst = out + i * m;
+    if ((m % E) == 0 && ((((uintptr_t)X) | ((uintptr_t)out)) & 15) == 0) {
+        for (long long f = lane * (long long)E; f < m; f += 64 * E) *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(src + f);
     } else {
         for (long long f = lane; f < m; f += 64) dst[f] = src[f];
     }
 }
 
 // finish a centre-split labelling: lowest (value, index) over the splits
-__global__ void kmeans_label_reduce_kernel(const float* __restrict__ pv, const int* __restrict__ pi, long long n,
+template <typename T>
+__global__ void kmeans_label_reduce_kernel(const T* __restrict__ pv, const int* __restrict__ pi, long long n,
                                            int nsplit, int32_t* __restrict__ labels, const int* __restrict__ stop)
 {
     if (stop && *stop) return;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float bv = pv[i];
+    T bv = pv[i];
     int bi = pi[i];
     for (int s = 1; s < nsplit; ++s) {
-        const float v = pv[(long long)s * n + i];
+        const T v = pv[(long long)s * n + i];
         const int ix = pi[(long long)s * n + i];
         if (v < bv || (v == bv && ix < bi)) {
             bv = v;
@@ -1277,24 +1271,26 @@ __global__ void kmeans_label_reduce_kernel(const float* __restrict__ pv, const i
     labels[i] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
-// ||c_j||^2 in fp32, one wave per centre
-__global__ __launch_bounds__(KNT) void kmeans_cnorm_kernel(const float* __restrict__ C, long long K, long long m,
-                                                           float* __restrict__ cnorm)
+// ||c_j||^2 in the centres' own type, one wave per centre
+template <typename T>
+__global__ __launch_bounds__(KNT) void kmeans_cnorm_kernel(const T* __restrict__ C, long long K, long long m,
+                                                           T* __restrict__ cnorm)
 {
     const int lane = threadIdx.x & 63;
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= K) return;
-    float s = 0.f;
+    T s = 0;
     for (long long f = lane; f < m; f += 64) s += C[j * m + f] * C[j * m + f];
 #pragma unroll
     for (int msk = 32; msk > 0; msk >>= 1) s += __shfl_xor(s, msk, 64);
     if (lane == 0) cnorm[j] = s;
 }
 
-// [inertia (double) | counts (K floats)] gathered into one small buffer for a single D2H per step
+// [inertia (double) | counts (K values of the rows' type)] gathered into one small buffer for a single D2H per step
+template <typename T>
 __global__ __launch_bounds__(KNT) void mbk_finish_kernel(const double* __restrict__ partial, int nb,
-                                                         const float* __restrict__ counts, long long K,
-                                                         double* __restrict__ out_inertia, float* __restrict__ out_counts)
+                                                         const T* __restrict__ counts, long long K,
+                                                         double* __restrict__ out_inertia, T* __restrict__ out_counts)
 {
     __shared__ double red[KNT];
     double s = 0.0;
@@ -1310,17 +1306,18 @@ __global__ __launch_bounds__(KNT) void mbk_finish_kernel(const double* __restric
 }
 
 // centres (+counts) <- (centres * w + batch sums) / (w + n) from all-reduced fp64 sums (multi-GPU)
-__global__ void mbk_apply_kernel(float* __restrict__ centers, float* __restrict__ counts,
+template <typename T>
+__global__ void mbk_apply_kernel(T* __restrict__ centers, T* __restrict__ counts,
                                  const double* __restrict__ packed, long long K, long long m, const int* __restrict__ stop = nullptr)
 {
     if (stop && *stop) return;   // a queued run that has converged: the remaining steps are no-ops on every rank
     const long long j = blockIdx.x;
     const double n = packed[K * m + j];
     if (n <= 0.0) return;
-    const float w_old = counts[j];
-    const float w_new = (float)((double)w_old + n);
+    const T w_old = counts[j];
+    const T w_new = (T)((double)w_old + n);
     for (long long f = threadIdx.x; f < m; f += blockDim.x)
-        centers[j * m + f] = (float)(((double)centers[j * m + f] * (double)w_old + packed[j * m + f]) / (double)w_new);
+        centers[j * m + f] = (T)(((double)centers[j * m + f] * (double)w_old + packed[j * m + f]) / (double)w_new);
     __syncthreads();
     if (threadIdx.x == 0) counts[j] = w_new;
 }
@@ -1333,43 +1330,45 @@ __global__ __launch_bounds__(KNT) void mbk_conv_kernel(MbkConv cv)
     mbk_converge(cv, red);
 }
 
-__global__ void mbk_reassign_kernel(float* __restrict__ centers, float* __restrict__ counts,
-                                    const float* __restrict__ X, long long m, const msm_idx_t* __restrict__ rows,
-                                    const msm_idx_t* __restrict__ which, float new_count)
+template <typename T>
+__global__ void mbk_reassign_kernel(T* __restrict__ centers, T* __restrict__ counts,
+                                    const T* __restrict__ X, long long m, const msm_idx_t* __restrict__ rows,
+                                    const msm_idx_t* __restrict__ which, T new_count)
 {
     const msm_idx_t r = rows[blockIdx.x], j = which[blockIdx.x];
     for (long long f = threadIdx.x; f < m; f += blockDim.x) centers[j * m + f] = X[r * m + f];
     if (threadIdx.x == 0) counts[j] = new_count;
 }
 
-static int km_prepare(const float* centers, msm_idx_t K, msm_idx_t m, DevBuf& dC, float** dCent, float** dNorm)
+template <typename T>
+static int km_prepare(const T* centers, msm_idx_t K, msm_idx_t m, DevBuf& dC, T** dCent, T** dNorm)
 {
-    int rc = dC.reserve(((size_t)K * m + (size_t)K) * sizeof(float));
+    int rc = dC.reserve(((size_t)K * m + (size_t)K) * sizeof(T));
     if (rc) return rc;
-    std::vector<float> cn((size_t)K);
+    std::vector<T> cn((size_t)K);
     // (eight centres side by side: every centre's sum keeps its sequential order, the eight dependent chains overlap --
     //  one chain of 512 fp64 adds per centre was 0.6 ms of a K = 1000 x 512 call)
     msm_idx_t j = 0;
     for (; j + 8 <= K; j += 8) {
         double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const float* c0 = centers + j * m;
+        const T* c0 = centers + j * m;
         for (msm_idx_t f = 0; f < m; ++f)
             for (int q = 0; q < 8; ++q) s8[q] += (double)c0[q * m + f] * (double)c0[q * m + f];
-        for (int q = 0; q < 8; ++q) cn[(size_t)(j + q)] = (float)s8[q];
+        for (int q = 0; q < 8; ++q) cn[(size_t)(j + q)] = (T)s8[q];
     }
     for (; j < K; ++j) {
         double s = 0.0;
         for (msm_idx_t f = 0; f < m; ++f) s += (double)centers[j * m + f] * (double)centers[j * m + f];
-        cn[(size_t)j] = (float)s;
+        cn[(size_t)j] = (T)s;
     }
-    *dCent = dC.as<float>();
+    *dCent = dC.as<T>();
     *dNorm = *dCent + (size_t)K * m;
     // (2 MB of centres from pageable memory: 0.32 ms through hipMemcpyAsync's own staging, 0.1 ms through the library's pinned ring)
     {
-        const int rcu = h2d_bulk(*dCent, centers, (size_t)K * m * sizeof(float));
+        const int rcu = h2d_bulk(*dCent, centers, (size_t)K * m * sizeof(T));
         if (rcu) return rcu;
     }
-    MSM_HIP_CHECK(hipMemcpyAsync(*dNorm, cn.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(*dNorm, cn.data(), (size_t)K * sizeof(T), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // `cn` is a stack-frame vector
     return MSM_OK;
 }
@@ -1400,6 +1399,20 @@ static int km_launch_label(const KmArgs& P, dim3 grid)
     return MSM_OK;
 }
 
+// float64 rows: ONE kernel for every shape (kmeans_f64_dev.h); grid = (row blocks of 128, centre splits)
+static int km_launch_label(const KmArgsT<double>& P, dim3 grid)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_label_f64_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DK_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kmeans_label_f64_kernel, grid, dim3(KNT), DK_LDS, stream(), P);
+    MSM_HIP_CHECK(hipGetLastError());
+    return MSM_OK;
+}
+
 // Large batches of wide rows (the final labelling pass of BASELINE configs[3]: 1.25M x 512 per rank, K = 1000): one workgroup
 // per (row block, centre tile), the tiles of a row block side by side on one XCD, so that the rows are fetched ONCE
 // (kmeans_label_v4_kernel, P.xcd_ns); a workgroup takes FOUR tiles, the later passes over its rows being L2 hits.  Returns the
@@ -1426,6 +1439,7 @@ static int km_xcd_splits(const KmArgs& P)
     const int ns = (int)ceil_div(ctiles, tiles_per);
     return ns > 1 ? ns : 0;
 }
+static int km_xcd_splits(const KmArgsT<double>&) { return 0; }   // (the fp64 kernel takes its splits over blockIdx.y)
 // ... the launch: candidates of every split into pv / pi ([nsplit][n] each); the caller merges them (reduce or inertia kernel)
 static int km_launch_label_xcd(KmArgs& P, int nsplit, float* pv, int* pi)
 {
@@ -1438,24 +1452,54 @@ static int km_launch_label_xcd(KmArgs& P, int nsplit, float* pv, int* pi)
     P.jspan = 0;
     return rc;
 }
+static int km_launch_label_xcd(KmArgsT<double>&, int, double*, int*) { return fail(MSM_ERR_STATE, "kmeans: no XCD-grouped launch for float64 rows"); }
 
-static int km_label_and_inertia(KmArgs& P, double* inertia)
+// Centre splits of a SMALL batch (fewer row blocks than the chip has workgroup slots): the centre tiles are spread over
+// blockIdx.y so that the launch fills the chip; returns the number of splits (1: none) and the centre span of one.
+static int km_small_splits(long long n, long long K, long long* jspan)
+{
+    const long long rowblocks = ceil_div(n, KR), ctiles = ceil_div(K, KCT);   // (KR = DKR = 128, KCT = DKC = 128)
+    int nsplit = 1;
+    if (rowblocks < 256 && ctiles > 1) nsplit = (int)std::min<long long>(ctiles, std::max<long long>(1, 512 / rowblocks));
+    const long long tiles_per = ceil_div(ctiles, nsplit);
+    *jspan = tiles_per * KCT;
+    return (int)ceil_div(ctiles, tiles_per);
+}
+
+template <typename T>
+static int km_label_and_inertia(KmArgsT<T>& P, double* inertia)
 {
     const unsigned grid = (unsigned)ceil_div(P.n, KR);
     int nsplit = km_xcd_splits(P);
+    DevBuf &dPv = pool(PS_W), &dPi = pool(PS_S);
     if (nsplit > 1) {
-        DevBuf &dPv = pool(PS_W), &dPi = pool(PS_S);
         int rc0;
-        if ((rc0 = dPv.reserve((size_t)nsplit * P.n * sizeof(float)))) return rc0;
+        if ((rc0 = dPv.reserve((size_t)nsplit * P.n * sizeof(T)))) return rc0;
         if ((rc0 = dPi.reserve((size_t)nsplit * P.n * sizeof(int)))) return rc0;
-        if ((rc0 = km_launch_label_xcd(P, nsplit, dPv.as<float>(), dPi.as<int>()))) return rc0;
+        if ((rc0 = km_launch_label_xcd(P, nsplit, dPv.as<T>(), dPi.as<int>()))) return rc0;
         if (!inertia)
-            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(P.n, 256)), dim3(256), 0, stream(), P.pv, P.pi, P.n, nsplit,
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel<T>, dim3((unsigned)ceil_div(P.n, 256)), dim3(256), 0, stream(), P.pv, P.pi, P.n, nsplit,
                                P.labels, P.stop);
     } else {
         nsplit = 1;
-        int rc0 = km_launch_label(P, dim3(grid));
-        if (rc0) return rc0;
+        long long jspan = 0;
+        if (sizeof(T) == 8) nsplit = km_small_splits(P.n, P.K, &jspan);   // float64 rows: small batches split their centres
+        int rc0;
+        if (nsplit > 1) {
+            if ((rc0 = dPv.reserve((size_t)nsplit * P.n * sizeof(T)))) return rc0;
+            if ((rc0 = dPi.reserve((size_t)nsplit * P.n * sizeof(int)))) return rc0;
+            P.jspan = jspan;
+            P.pv = dPv.as<T>();
+            P.pi = dPi.as<int>();
+            rc0 = km_launch_label(P, dim3(grid, (unsigned)nsplit));
+            P.jspan = 0;
+            if (rc0) return rc0;
+            if (!inertia)
+                hipLaunchKernelGGL(kmeans_label_reduce_kernel<T>, dim3((unsigned)ceil_div(P.n, 256)), dim3(256), 0, stream(), P.pv, P.pi, P.n,
+                                   nsplit, P.labels, P.stop);
+        } else if ((rc0 = km_launch_label(P, dim3(grid)))) {
+            return rc0;
+        }
     }
     MSM_HIP_CHECK(hipGetLastError());
     if (inertia) {
@@ -1463,7 +1507,7 @@ static int km_label_and_inertia(KmArgs& P, double* inertia)
         DevBuf& dPart = pool(PS_PART);
         int rc = dPart.reserve((size_t)nb * sizeof(double));
         if (rc) return rc;
-        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, dPart.as<double>(), nsplit);   // (merges the splits' candidates)
+        hipLaunchKernelGGL(kmeans_inertia_kernel<T>, dim3(nb), dim3(KNT), 0, stream(), P, dPart.as<double>(), nsplit);   // (merges the splits' candidates)
         MSM_HIP_CHECK(hipGetLastError());
         std::vector<double> h((size_t)nb);
         MSM_HIP_CHECK(hipMemcpyAsync(h.data(), dPart.p, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, stream()));
@@ -1480,14 +1524,17 @@ static int km_label_and_inertia(KmArgs& P, double* inertia)
 using namespace msm;
 
 // Device-resident MiniBatchKMeans state: centres, cumulative counts and ||c||^2 live in HBM for the
-// whole fit; a step moves only the batch indices in and [inertia | counts] out.
+// whole fit; a step moves only the batch indices in and [inertia | counts] out.  `f64`: the rows' (and therefore the
+// centres', counts' and norms') type -- scikit-learn works in the type of X (float32 stays float32, everything else is
+// float64); the typed pointers below are `float*` or `double*` accordingly (cen<T>() ...).
 struct msm_mbk {
     long long K = 0, m = 0;
-    float* centers = nullptr;
-    float* counts = nullptr;
-    float* cnorm = nullptr;
+    int f64 = 0;
+    void* centers = nullptr;
+    void* counts = nullptr;
+    void* cnorm = nullptr;
     double* packed = nullptr;  // [K*m | K | 1] batch sums, counts, inertia (fp64)
-    char* outbuf = nullptr;    // [8 + 4K]
+    char* outbuf = nullptr;    // [8 + sizeof(T) K]
     DevBuf labels, idx, xb, pv, pi, part, rows, which;
     DevBuf arrive;             // small-batch step: per-row-block arrival counters (zero between launches)
     size_t arrive_zeroed = 0;
@@ -1498,6 +1545,10 @@ struct msm_mbk {
     size_t pinned_bytes = 0;
     const char* run_out = nullptr;   // msm_mbk_run_begin .. _end: where the run in flight leaves its results (in `pinned`)
     size_t run_st_bytes = 0;
+    size_t esz() const { return f64 ? sizeof(double) : sizeof(float); }
+    template <typename T> T* cen() { return static_cast<T*>(centers); }
+    template <typename T> T* cnt() { return static_cast<T*>(counts); }
+    template <typename T> T* nrm() { return static_cast<T*>(cnorm); }
 };
 
 namespace {
@@ -1508,41 +1559,31 @@ bool mbk_small_off()
     static const bool off = getenv("MSM_MBK_SMALL") && atoi(getenv("MSM_MBK_SMALL")) == 0;
     return off;
 }
-bool mbk_small_ok(const msm_mbk* h, long long n) { return !mbk_small_off() && h->m <= 32 && n <= 65536; }  // label kernel
+bool mbk_small_ok(const msm_mbk* h, long long n) { return !mbk_small_off() && !h->f64 && h->m <= 32 && n <= 65536; }  // label kernel (fp32 only)
 bool mbk_small_update_ok(long long n)                                                                      // update kernel
 {
     return !mbk_small_off() && n <= MSU_CAP;
 }
-bool mbk_label64_ok(const msm_mbk* h, long long n)                                                         // 64 x 64 label tiles
+bool mbk_label64_ok(const msm_mbk* h, long long n)                                                         // 64 x 64 label tiles (fp32 only)
 {
-    return !mbk_small_off() && n <= 4096 && h->m > 32;
+    return !mbk_small_off() && !h->f64 && n <= 4096 && h->m > 32;
 }
 
 // centre update of a step: one wave per centre for small batches, else one workgroup per centre
-void mbk_launch_update(msm_mbk* h, const KmArgs& P, double* sums, double* cnts, int apply, const MbkConv& cv)
+template <typename T>
+void mbk_launch_update(msm_mbk* h, const KmArgsT<T>& P, double* sums, double* cnts, int apply, const MbkConv& cv)
 {
     if (mbk_small_update_ok(P.n))
-        hipLaunchKernelGGL(mbk_small_update_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), P, h->centers,
-                           h->counts, h->cnorm, sums, cnts, apply, cv);
+        hipLaunchKernelGGL(mbk_small_update_kernel<T>, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), P, h->cen<T>(),
+                           h->cnt<T>(), h->nrm<T>(), sums, cnts, apply, cv);
     else
-        hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->centers,
-                           h->counts, h->cnorm, sums, cnts, apply, cv);
+        hipLaunchKernelGGL(mbk_update_kernel<T>, dim3((unsigned)h->K), dim3(KNT), 4096 * sizeof(int), stream(), P, h->cen<T>(),
+                           h->cnt<T>(), h->nrm<T>(), sums, cnts, apply, cv);
 }
 
-int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n, int32_t* labels_d, double* inertia_dev_partial,
-              int* nb_out, const int* stop = nullptr)
+// float32 rows: the three label paths of rounds 1-5 (small VALU kernel, 64 x 64 tiles, 128 x 128 tiles)
+int mbk_label_f32(msm_mbk* h, KmArgs& P, long long n, int32_t* labels_d, double* inertia_dev_partial, int* nb_out)
 {
-    KmArgs P;
-    memset(&P, 0, sizeof(P));
-    P.X = Xd;
-    P.rows = rows_d;
-    P.n = n;
-    P.m = h->m;
-    P.K = h->K;
-    P.C = h->centers;
-    P.cnorm = h->cnorm;
-    P.labels = labels_d;
-    P.stop = stop;
     if (inertia_dev_partial && mbk_small_ok(h, n)) {  // MiniBatchKMeans' inner loop: the two-launch small-batch step
         const int RB = (int)ceil_div(n, 64);
         int ns = (int)std::max<long long>(1, std::min<long long>(ceil_div(512, RB), ceil_div(h->K, 16)));
@@ -1592,44 +1633,62 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
         hipLaunchKernelGGL(kmeans_label64_kernel, dim3((unsigned)rb, (unsigned)ns), dim3(KNT), KM64_LDS, stream(), P);
         MSM_HIP_CHECK(hipGetLastError());
         if (!inertia_dev_partial) {
-            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(), P.pv, P.pi,
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel<float>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(), P.pv, P.pi,
                                n, ns, labels_d, P.stop);
         } else {
             const int nb = (int)std::min<long long>(ceil_div(n, 4), 1024);
             P.jspan = 0;
-            hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial, ns);
+            hipLaunchKernelGGL(kmeans_inertia_kernel<float>, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial, ns);
             *nb_out = nb;
         }
         MSM_HIP_CHECK(hipGetLastError());
         return MSM_OK;
     }
-    const long long rowblocks = ceil_div(n, KR);
-    const long long ctiles = ceil_div(h->K, KCT);
-    int nsplit = 1;
-    if (rowblocks < 256 && ctiles > 1) {  // small batch: split the centres over workgroups to fill the chip
-        nsplit = (int)std::min<long long>(ctiles, std::max<long long>(1, 512 / rowblocks));
+    return 1;   // not a small-batch shape: the general path
+}
+int mbk_label_f32(msm_mbk*, KmArgsT<double>&, long long, int32_t*, double*, int*) { return 1; }
+
+template <typename T>
+int mbk_label(msm_mbk* h, const T* Xd, const msm_idx_t* rows_d, long long n, int32_t* labels_d, double* inertia_dev_partial,
+              int* nb_out, const int* stop = nullptr)
+{
+    KmArgsT<T> P;
+    memset(&P, 0, sizeof(P));
+    P.X = Xd;
+    P.rows = rows_d;
+    P.n = n;
+    P.m = h->m;
+    P.K = h->K;
+    P.C = h->cen<T>();
+    P.cnorm = h->nrm<T>();
+    P.labels = labels_d;
+    P.stop = stop;
+    {
+        const int rs = mbk_label_f32(h, P, n, labels_d, inertia_dev_partial, nb_out);
+        if (rs <= 0) return rs;
     }
+    long long jspan = 0;
+    int nsplit = km_small_splits(n, h->K, &jspan);   // small batch: split the centres over workgroups to fill the chip
+    const long long rowblocks = ceil_div(n, KR);
     const int xs = nsplit == 1 ? km_xcd_splits(P) : 0;   // large batches of wide rows: see km_xcd_splits
     int rc;
     if (xs > 1) {
         nsplit = xs;
-        if ((rc = h->pv.reserve((size_t)nsplit * n * sizeof(float)))) return rc;
+        if ((rc = h->pv.reserve((size_t)nsplit * n * sizeof(T)))) return rc;
         if ((rc = h->pi.reserve((size_t)nsplit * n * sizeof(int)))) return rc;
-        if ((rc = km_launch_label_xcd(P, nsplit, h->pv.as<float>(), h->pi.as<int>()))) return rc;
+        if ((rc = km_launch_label_xcd(P, nsplit, h->pv.as<T>(), h->pi.as<int>()))) return rc;
         if (!inertia_dev_partial)
-            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel<T>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
                                P.pv, P.pi, n, nsplit, labels_d, P.stop);
     } else if (nsplit > 1) {
-        const long long tiles_per = ceil_div(ctiles, nsplit);
-        nsplit = (int)ceil_div(ctiles, tiles_per);
-        if ((rc = h->pv.reserve((size_t)nsplit * n * sizeof(float)))) return rc;
+        if ((rc = h->pv.reserve((size_t)nsplit * n * sizeof(T)))) return rc;
         if ((rc = h->pi.reserve((size_t)nsplit * n * sizeof(int)))) return rc;
-        P.jspan = tiles_per * KCT;
-        P.pv = h->pv.as<float>();
+        P.jspan = jspan;
+        P.pv = h->pv.as<T>();
         P.pi = h->pi.as<int>();
         if ((rc = km_launch_label(P, dim3((unsigned)rowblocks, (unsigned)nsplit)))) return rc;
         if (!inertia_dev_partial)  // else the inertia kernel below picks the labels from the candidates itself
-            hipLaunchKernelGGL(kmeans_label_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
+            hipLaunchKernelGGL(kmeans_label_reduce_kernel<T>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream(),
                                P.pv, P.pi, n, nsplit, labels_d, P.stop);
     } else {
         if ((rc = km_launch_label(P, dim3((unsigned)rowblocks)))) return rc;
@@ -1638,7 +1697,7 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
     if (inertia_dev_partial) {
         const int nb = (int)std::min<long long>(ceil_div(n, 4), 1024);
         P.jspan = 0;
-        hipLaunchKernelGGL(kmeans_inertia_kernel, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial, nsplit);
+        hipLaunchKernelGGL(kmeans_inertia_kernel<T>, dim3(nb), dim3(KNT), 0, stream(), P, inertia_dev_partial, nsplit);
         MSM_HIP_CHECK(hipGetLastError());
         *nb_out = nb;
     }
@@ -1646,8 +1705,9 @@ int mbk_label(msm_mbk* h, const float* Xd, const msm_idx_t* rows_d, long long n,
 }
 
 // stage the batch: device X -> row indices on device; host X -> gathered rows on device
-int mbk_stage_batch(msm_mbk* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B, int on_device,
-                    const float** Xd, const msm_idx_t** rows_d)
+template <typename T>
+int mbk_stage_batch(msm_mbk* h, const T* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B, int on_device,
+                    const T** Xd, const msm_idx_t** rows_d)
 {
     int rc;
     for (msm_idx_t b = 0; b < B; ++b)
@@ -1656,98 +1716,56 @@ int mbk_stage_batch(msm_mbk* h, const float* X, msm_idx_t n, const msm_idx_t* ba
         if ((rc = h->idx.reserve((size_t)B * sizeof(msm_idx_t)))) return rc;
         MSM_HIP_CHECK(hipMemcpyAsync(h->idx.p, batch_idx, (size_t)B * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));  // batch_idx is caller-owned pageable memory
-        if ((rc = h->xb.reserve((size_t)B * h->m * sizeof(float)))) return rc;
-        hipLaunchKernelGGL(mbk_gather_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
-                           (long long)B, (long long)h->m, h->xb.as<float>());
+        if ((rc = h->xb.reserve((size_t)B * h->m * sizeof(T)))) return rc;
+        hipLaunchKernelGGL(mbk_gather_kernel<T>, dim3((unsigned)ceil_div(B, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
+                           (long long)B, (long long)h->m, h->xb.as<T>());
         MSM_HIP_CHECK(hipGetLastError());
-        *Xd = h->xb.as<float>();
+        *Xd = h->xb.as<T>();
         *rows_d = nullptr;
     } else {
-        std::vector<float> xb((size_t)B * h->m);
+        std::vector<T> xb((size_t)B * h->m);
         for (msm_idx_t b = 0; b < B; ++b)
-            memcpy(xb.data() + (size_t)b * h->m, X + batch_idx[b] * h->m, (size_t)h->m * sizeof(float));
-        if ((rc = h->xb.reserve(xb.size() * sizeof(float)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(h->xb.p, xb.data(), xb.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+            memcpy(xb.data() + (size_t)b * h->m, X + batch_idx[b] * h->m, (size_t)h->m * sizeof(T));
+        if ((rc = h->xb.reserve(xb.size() * sizeof(T)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->xb.p, xb.data(), xb.size() * sizeof(T), hipMemcpyHostToDevice, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-        *Xd = h->xb.as<float>();
+        *Xd = h->xb.as<T>();
         *rows_d = nullptr;
     }
     return MSM_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int msm_mbk_create(msm_mbk_t** out, msm_idx_t K, msm_idx_t m)
+template <typename T>
+void mbk_launch_cnorm(msm_mbk* h)
 {
-    if (!out || K < 1 || m < 1) return fail(MSM_ERR_INVALID, "msm_mbk_create: bad argument");
-    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
-    msm_mbk* h = new msm_mbk();
-    h->K = K;
-    h->m = m;
-    hipError_t e = hipMalloc((void**)&h->centers, (size_t)K * m * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->counts, (size_t)K * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->cnorm, (size_t)K * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->packed, ((size_t)K * m + K + 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->outbuf, 8 + (size_t)K * sizeof(float));
-    if (e != hipSuccess) {
-        msm_mbk_destroy(h);
-        return fail(MSM_ERR_HIP, "msm_mbk_create: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    *out = h;
-    return MSM_OK;
+    hipLaunchKernelGGL(kmeans_cnorm_kernel<T>, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->cen<T>(), h->K, h->m, h->nrm<T>());
+}
+template <typename T>
+void mbk_launch_apply(msm_mbk* h, const int* stop)
+{
+    hipLaunchKernelGGL(mbk_apply_kernel<T>, dim3((unsigned)h->K), dim3(256), 0, stream(), h->cen<T>(), h->cnt<T>(), h->packed, h->K, h->m, stop);
+    mbk_launch_cnorm<T>(h);
+}
+template <typename T>
+void mbk_launch_finish(msm_mbk* h, int nb, double* d_inertia)
+{
+    hipLaunchKernelGGL(mbk_finish_kernel<T>, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->cnt<T>(), h->K,
+                       d_inertia, reinterpret_cast<T*>(h->outbuf + 8));
 }
 
-int msm_mbk_destroy(msm_mbk_t* h)
+template <typename T>
+int mbk_step_t(msm_mbk* h, const T* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
+               double* batch_inertia, T* counts_out, int apply_update, int on_device)
 {
-    if (!h) return MSM_OK;
-    (void)hipStreamSynchronize(stream());
-    if (h->centers) (void)hipFree(h->centers);
-    if (h->counts) (void)hipFree(h->counts);
-    if (h->cnorm) (void)hipFree(h->cnorm);
-    if (h->packed) (void)hipFree(h->packed);
-    if (h->outbuf) (void)hipFree(h->outbuf);
-    if (h->stop) (void)hipFree(h->stop);
-    if (h->pinned) (void)hipHostFree(h->pinned);
-    delete h;
-    return MSM_OK;
-}
-
-int msm_mbk_set(msm_mbk_t* h, const float* centers, const float* counts)
-{
-    if (!h || !centers || !counts) return fail(MSM_ERR_STATE, "msm_mbk_set: null argument");
-    MSM_HIP_CHECK(hipMemcpyAsync(h->centers, centers, (size_t)h->K * h->m * sizeof(float), hipMemcpyHostToDevice, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(h->counts, counts, (size_t)h->K * sizeof(float), hipMemcpyHostToDevice, stream()));
-    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
-    MSM_HIP_CHECK(hipGetLastError());
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    return MSM_OK;
-}
-
-int msm_mbk_get(msm_mbk_t* h, float* centers, float* counts)
-{
-    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_get: null handle");
-    if (centers) MSM_HIP_CHECK(hipMemcpyAsync(centers, h->centers, (size_t)h->K * h->m * sizeof(float), hipMemcpyDeviceToHost, stream()));
-    if (counts) MSM_HIP_CHECK(hipMemcpyAsync(counts, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    return MSM_OK;
-}
-
-int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
-                 double* batch_inertia, float* counts_out, int apply_update, int on_device)
-{
-    if (!h || !X || !batch_idx) return fail(MSM_ERR_STATE, "msm_mbk_step: null argument");
-    if (n < 1 || B < 1) return fail(MSM_ERR_INVALID, "msm_mbk_step: bad shape");
     int rc;
-    const float* Xd;
+    const T* Xd;
     const msm_idx_t* rows_d;
-    if ((rc = mbk_stage_batch(h, X, n, batch_idx, B, on_device, &Xd, &rows_d))) return rc;
+    if ((rc = mbk_stage_batch<T>(h, X, n, batch_idx, B, on_device, &Xd, &rows_d))) return rc;
     if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
     if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
     int nb = 0;
-    if ((rc = mbk_label(h, Xd, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb))) return rc;
-    KmArgs P;
+    if ((rc = mbk_label<T>(h, Xd, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb))) return rc;
+    KmArgsT<T> P;
     memset(&P, 0, sizeof(P));
     P.X = Xd;
     P.rows = rows_d;
@@ -1755,41 +1773,35 @@ int msm_mbk_step(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* bat
     P.m = h->m;
     P.K = h->K;
     P.labels = h->labels.as<int32_t>();
-    mbk_launch_update(h, P, apply_update ? (double*)nullptr : h->packed,
-                      apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update, MbkConv{});
+    mbk_launch_update<T>(h, P, apply_update ? (double*)nullptr : h->packed,
+                         apply_update ? (double*)nullptr : h->packed + (size_t)h->K * h->m, apply_update, MbkConv{});
     MSM_HIP_CHECK(hipGetLastError());
     double* d_inertia = apply_update ? reinterpret_cast<double*>(h->outbuf) : h->packed + (size_t)h->K * h->m + h->K;
-    hipLaunchKernelGGL(mbk_finish_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->counts, h->K,
-                       d_inertia, reinterpret_cast<float*>(h->outbuf + 8));
+    mbk_launch_finish<T>(h, nb, d_inertia);
     MSM_HIP_CHECK(hipGetLastError());
-    std::vector<char> hb(8 + (size_t)h->K * sizeof(float));
+    std::vector<char> hb(8 + (size_t)h->K * sizeof(T));
     if (apply_update) {
         MSM_HIP_CHECK(hipMemcpyAsync(hb.data(), h->outbuf, hb.size(), hipMemcpyDeviceToHost, stream()));
     } else {
         MSM_HIP_CHECK(hipMemcpyAsync(hb.data(), d_inertia, 8, hipMemcpyDeviceToHost, stream()));
-        MSM_HIP_CHECK(hipMemcpyAsync(hb.data() + 8, h->outbuf + 8, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(hb.data() + 8, h->outbuf + 8, (size_t)h->K * sizeof(T), hipMemcpyDeviceToHost, stream()));
     }
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     if (batch_inertia) memcpy(batch_inertia, hb.data(), 8);
-    if (counts_out) memcpy(counts_out, hb.data() + 8, (size_t)h->K * sizeof(float));
+    if (counts_out) memcpy(counts_out, hb.data() + 8, (size_t)h->K * sizeof(T));
     return MSM_OK;
 }
 
-/* msm_mbk_run in two halves: _begin queues the whole run (indices in, S steps, results out) and returns without waiting,
- * _end waits for it and hands the results over.  Between the two the host is free -- MiniBatchKMeans draws the NEXT run's
- * batch indices there (a quarter of a millisecond per 65,536 indices with the legacy RandomState, as long as a large-batch
- * step takes on the device). */
-int msm_mbk_run_begin(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
-                      msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, const double* state6)
+template <typename T>
+int mbk_run_begin_t(msm_mbk* h, const T* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                    msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, const double* state6)
 {
-    if (!h || !X || !batch_idx || !state6) return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
-    if (n < 1 || B < 1 || S < 1 || S > 4096) return fail(MSM_ERR_INVALID, "msm_mbk_run: bad shape");
     for (msm_idx_t b = 0; b < S * B; ++b)
         if (batch_idx[b] < 0 || batch_idx[b] >= n) return fail(MSM_ERR_INVALID, "mbk: batch index out of range");
     int rc;
     const size_t idx_bytes = (size_t)S * B * sizeof(msm_idx_t);
     const size_t st_bytes = (6 + (size_t)S) * sizeof(double);
-    const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(float);
+    const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(T);
     const size_t need = idx_bytes + 64 + out_bytes;  // [indices | initial state | results]
     if (h->pinned_bytes < need) {
         if (h->pinned) (void)hipHostFree(h->pinned);
@@ -1813,16 +1825,16 @@ int msm_mbk_run_begin(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t
     MSM_HIP_CHECK(hipMemcpyAsync(st, st0, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, 2 * sizeof(int), stream()));
     // all S batches into one compact buffer (one launch), so that a step's kernels read contiguous rows
-    if ((rc = h->xb.reserve((size_t)S * B * h->m * sizeof(float)))) return rc;
-    hipLaunchKernelGGL(mbk_gather_kernel, dim3((unsigned)ceil_div(S * B, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
-                       (long long)(S * B), (long long)h->m, h->xb.as<float>());
+    if ((rc = h->xb.reserve((size_t)S * B * h->m * sizeof(T)))) return rc;
+    hipLaunchKernelGGL(mbk_gather_kernel<T>, dim3((unsigned)ceil_div(S * B, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
+                       (long long)(S * B), (long long)h->m, h->xb.as<T>());
     MSM_HIP_CHECK(hipGetLastError());
     for (msm_idx_t s = 0; s < S; ++s) {
-        const float* Xs_ = h->xb.as<float>() + (size_t)s * B * h->m;
+        const T* Xs_ = h->xb.as<T>() + (size_t)s * B * h->m;
         const msm_idx_t* rows_d = nullptr;
         int nb = 0;
-        if ((rc = mbk_label(h, Xs_, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
-        KmArgs P;
+        if ((rc = mbk_label<T>(h, Xs_, rows_d, B, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
+        KmArgsT<T> P;
         memset(&P, 0, sizeof(P));
         P.X = Xs_;
         P.rows = rows_d;
@@ -1842,58 +1854,24 @@ int msm_mbk_run_begin(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t
         cv.batch_size = (double)B;
         cv.alpha = alpha;
         cv.max_no_improvement = (long long)max_no_improvement;
-        mbk_launch_update(h, P, nullptr, nullptr, 1, cv);
+        mbk_launch_update<T>(h, P, nullptr, nullptr, 1, cv);
         MSM_HIP_CHECK(hipGetLastError());
     }
     // out: [state | inertias | stop | counts] through the pinned mirror, one synchronisation for the whole run
     char* o = h->pinned + idx_bytes + 64;
     MSM_HIP_CHECK(hipMemcpyAsync(o, st, st_bytes, hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes, h->stop, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes + 8, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes + 8, h->counts, (size_t)h->K * sizeof(T), hipMemcpyDeviceToHost, stream()));
     h->run_out = o;
     h->run_st_bytes = st_bytes;
     return MSM_OK;
 }
 
-int msm_mbk_run_end(msm_mbk_t* h, double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
+template <typename T>
+int mbk_run_sharded_t(msm_mbk* h, const T* X, msm_idx_t n_local, const msm_idx_t* local_idx, const msm_idx_t* offsets,
+                      msm_idx_t S, msm_idx_t B, msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement,
+                      double* state6, msm_idx_t* steps_done, int* converged, double* inertias, T* counts_out)
 {
-    if (!h || !state6 || !steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run_end: null argument");
-    if (!h->run_out) return fail(MSM_ERR_STATE, "msm_mbk_run_end: no run in flight");
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    const char* o = h->run_out;
-    const size_t st_bytes = h->run_st_bytes;
-    h->run_out = nullptr;
-    const double* so = reinterpret_cast<const double*>(o);
-    for (int i = 0; i < 5; ++i) state6[i] = so[i];
-    state6[5] = so[5];
-    *steps_done = (msm_idx_t)so[5];
-    memcpy(inertias, so + 6, (size_t)(*steps_done) * sizeof(double));
-    *converged = *reinterpret_cast<const int*>(o + st_bytes);
-    if (counts_out) memcpy(counts_out, o + st_bytes + 8, (size_t)h->K * sizeof(float));
-    return MSM_OK;
-}
-
-int msm_mbk_run(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
-                msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
-                msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
-{
-    if (!steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
-    const int rc = msm_mbk_run_begin(h, X, n, batch_idx, S, B, first_step, alpha, max_no_improvement, state6);
-    if (rc) return rc;
-    return msm_mbk_run_end(h, state6, steps_done, converged, inertias, counts_out);
-}
-
-/* msm_mbk_run for a ROW-SHARDED fit (one process per GPU): the S batches are GLOBAL (identical on every rank); this rank
- * passes the rows of each batch that it owns as local row numbers -- local_idx (host) holds them back to back, offsets[S + 1]
- * (host) delimits the steps -- and the batch size B of the whole batch.  Per step: label + fp64 sums / counts / inertia of
- * the local rows, ONE all-reduce of the packed [K m sums | K counts | inertia] buffer over the library communicator (RCCL on
- * the library stream), the identical update and convergence step on every rank.  Nothing returns to the host inside the
- * run; every rank stops at the same step (the criterion sees the all-reduced inertia).  Outputs as msm_mbk_run. */
-int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const msm_idx_t* local_idx, const msm_idx_t* offsets,
-                        msm_idx_t S, msm_idx_t B, msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement,
-                        double* state6, msm_idx_t* steps_done, int* converged, double* inertias, float* counts_out)
-{
-    if (!h || !offsets || !state6 || !steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run_sharded: null argument");
     // Everything that can fail on ONE rank -- argument checks, allocations -- happens before the first collective, and the
     // ranks agree on the outcome with one all-reduced flag: a rank that returned early on its own would leave the others
     // blocked inside the first step's all-reduce.
@@ -1910,7 +1888,7 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
         int rc;
         idx_bytes = (size_t)std::max<msm_idx_t>(total, 1) * sizeof(msm_idx_t);
         st_bytes = (6 + (size_t)S) * sizeof(double);
-        const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(float);
+        const size_t out_bytes = st_bytes + sizeof(int) + 4 + (size_t)h->K * sizeof(T);
         const size_t need = idx_bytes + 64 + out_bytes;
         if (h->pinned_bytes < need) {
             if (h->pinned) (void)hipHostFree(h->pinned);
@@ -1924,7 +1902,7 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
         if ((rc = h->runbuf.reserve(st_bytes))) return rc;
         if ((rc = h->labels.reserve((size_t)B * sizeof(int32_t)))) return rc;
         if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
-        if (total > 0 && (rc = h->xb.reserve((size_t)total * h->m * sizeof(float)))) return rc;
+        if (total > 0 && (rc = h->xb.reserve((size_t)total * h->m * sizeof(T)))) return rc;
         return MSM_OK;
     };
     int rc = prepare();
@@ -1950,8 +1928,8 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
     MSM_HIP_CHECK(hipMemcpyAsync(st, st0, 6 * sizeof(double), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->stop, 0, 2 * sizeof(int), stream()));
     if (total > 0) {
-        hipLaunchKernelGGL(mbk_gather_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
-                           (long long)total, (long long)h->m, h->xb.as<float>());
+        hipLaunchKernelGGL(mbk_gather_kernel<T>, dim3((unsigned)ceil_div(total, 4)), dim3(KNT), 0, stream(), X, h->idx.as<msm_idx_t>(),
+                           (long long)total, (long long)h->m, h->xb.as<T>());
         MSM_HIP_CHECK(hipGetLastError());
     }
     const size_t psz = (size_t)msm_mbk_packed_size(h);
@@ -1960,10 +1938,10 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
         const msm_idx_t Bs = offsets[s + 1] - offsets[s];
         MSM_HIP_CHECK(hipMemsetAsync(h->packed, 0, psz * sizeof(double), stream()));
         if (Bs > 0) {
-            const float* Xs_ = h->xb.as<float>() + (size_t)offsets[s] * h->m;
+            const T* Xs_ = h->xb.as<T>() + (size_t)offsets[s] * h->m;
             int nb = 0;
-            if ((rc = mbk_label(h, Xs_, nullptr, Bs, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
-            KmArgs P;
+            if ((rc = mbk_label<T>(h, Xs_, nullptr, Bs, h->labels.as<int32_t>(), h->part.as<double>(), &nb, h->stop))) return rc;
+            KmArgsT<T> P;
             memset(&P, 0, sizeof(P));
             P.X = Xs_;
             P.n = Bs;
@@ -1971,16 +1949,13 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
             P.K = h->K;
             P.labels = h->labels.as<int32_t>();
             P.stop = h->stop;
-            mbk_launch_update(h, P, h->packed, h->packed + (size_t)h->K * h->m, 0, MbkConv{});
+            mbk_launch_update<T>(h, P, h->packed, h->packed + (size_t)h->K * h->m, 0, MbkConv{});
             MSM_HIP_CHECK(hipGetLastError());
-            hipLaunchKernelGGL(mbk_finish_kernel, dim3(1), dim3(KNT), 0, stream(), h->part.as<double>(), nb, h->counts, h->K,
-                               d_inertia, reinterpret_cast<float*>(h->outbuf + 8));
+            mbk_launch_finish<T>(h, nb, d_inertia);
             MSM_HIP_CHECK(hipGetLastError());
         }
         if ((rc = comm_allreduce_f64(h->packed, psz))) return rc;
-        hipLaunchKernelGGL(mbk_apply_kernel, dim3((unsigned)h->K), dim3(256), 0, stream(), h->centers, h->counts, h->packed, h->K,
-                           h->m, h->stop);
-        hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
+        mbk_launch_apply<T>(h, h->stop);
         MbkConv cv;
         cv.partial = d_inertia;
         cv.nb = 1;
@@ -1998,130 +1973,65 @@ int msm_mbk_run_sharded(msm_mbk_t* h, const float* X, msm_idx_t n_local, const m
     char* o = h->pinned + idx_bytes + 64;
     MSM_HIP_CHECK(hipMemcpyAsync(o, st, st_bytes, hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes, h->stop, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes + 8, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(o + st_bytes + 8, h->counts, (size_t)h->K * sizeof(T), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     const double* so = reinterpret_cast<const double*>(o);
     for (int i = 0; i < 6; ++i) state6[i] = so[i];
     *steps_done = (msm_idx_t)so[5];
     memcpy(inertias, so + 6, (size_t)(*steps_done) * sizeof(double));
     *converged = *reinterpret_cast<const int*>(o + st_bytes);
-    if (counts_out) memcpy(counts_out, o + st_bytes + 8, (size_t)h->K * sizeof(float));
+    if (counts_out) memcpy(counts_out, o + st_bytes + 8, (size_t)h->K * sizeof(T));
     return MSM_OK;
 }
 
-msm_idx_t msm_mbk_packed_size(msm_mbk_t* h) { return h ? (msm_idx_t)(h->K * h->m + h->K + 1) : 0; }
-
-int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device)
+template <typename T>
+int mbk_reassign_t(msm_mbk* h, const T* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which, msm_idx_t n_reassign,
+                   double new_count, int on_device)
 {
-    if (!h || !buf) return fail(MSM_ERR_STATE, "msm_mbk_export_packed: null argument");
-    MSM_HIP_CHECK(hipMemcpyAsync(buf, h->packed, (size_t)msm_mbk_packed_size(h) * sizeof(double),
-                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    return MSM_OK;
-}
-
-int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, float* counts_out, int on_device)
-{
-    if (!h || !buf) return fail(MSM_ERR_STATE, "msm_mbk_apply_packed: null argument");
-    MSM_HIP_CHECK(hipMemcpyAsync(h->packed, buf, (size_t)msm_mbk_packed_size(h) * sizeof(double),
-                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream()));
-    hipLaunchKernelGGL(mbk_apply_kernel, dim3((unsigned)h->K), dim3(256), 0, stream(), h->centers, h->counts, h->packed, h->K, h->m);
-    MSM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
-    MSM_HIP_CHECK(hipGetLastError());
-    if (counts_out) MSM_HIP_CHECK(hipMemcpyAsync(counts_out, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    return MSM_OK;
-}
-
-/* sharded step, exchange half: msm_mbk_step(apply_update = 0) left this rank's [K*m sums | K counts | inertia] of ITS
- * batch rows in the handle's device buffer (msm_mbk_zero_packed for a rank that owns none of them); one all-reduce over
- * the library communicator (RCCL on the library stream, device buffer, in place) and the reduced buffer is applied
- * identically on every rank.  *batch_inertia / counts_out (host, K): the global batch inertia and the updated counts. */
-int msm_mbk_zero_packed(msm_mbk_t* h)
-{
-    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_zero_packed: null handle");
-    MSM_HIP_CHECK(hipMemsetAsync(h->packed, 0, (size_t)msm_mbk_packed_size(h) * sizeof(double), stream()));
-    return MSM_OK;
-}
-
-int msm_mbk_allreduce(msm_mbk_t* h, double* batch_inertia, float* counts_out)
-{
-    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_allreduce: null handle");
-    int rc = comm_allreduce_f64(h->packed, (size_t)msm_mbk_packed_size(h));
-    if (rc) return rc;
-    hipLaunchKernelGGL(mbk_apply_kernel, dim3((unsigned)h->K), dim3(256), 0, stream(), h->centers, h->counts, h->packed, h->K, h->m);
-    MSM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
-    MSM_HIP_CHECK(hipGetLastError());
-    if (batch_inertia)
-        MSM_HIP_CHECK(hipMemcpyAsync(batch_inertia, h->packed + (size_t)h->K * h->m + h->K, sizeof(double), hipMemcpyDeviceToHost, stream()));
-    if (counts_out) MSM_HIP_CHECK(hipMemcpyAsync(counts_out, h->counts, (size_t)h->K * sizeof(float), hipMemcpyDeviceToHost, stream()));
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    return MSM_OK;
-}
-
-int msm_mbk_reassign(msm_mbk_t* h, const float* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
-                     msm_idx_t n_reassign, float new_count, int on_device)
-{
-    if (!h || !X || !rows || !which) return fail(MSM_ERR_STATE, "msm_mbk_reassign: null argument");
-    if (n_reassign <= 0) return MSM_OK;
     int rc;
-    for (msm_idx_t i = 0; i < n_reassign; ++i)
-        if (rows[i] < 0 || rows[i] >= n || which[i] < 0 || which[i] >= h->K) return fail(MSM_ERR_INVALID, "msm_mbk_reassign: index out of range");
-    const float* Xd = X;
+    const T* Xd = X;
     std::vector<msm_idx_t> r2(rows, rows + n_reassign);
     if (!on_device) {  // ship only the chosen rows
-        std::vector<float> xb((size_t)n_reassign * h->m);
+        std::vector<T> xb((size_t)n_reassign * h->m);
         for (msm_idx_t i = 0; i < n_reassign; ++i) {
-            memcpy(xb.data() + (size_t)i * h->m, X + rows[i] * h->m, (size_t)h->m * sizeof(float));
+            memcpy(xb.data() + (size_t)i * h->m, X + rows[i] * h->m, (size_t)h->m * sizeof(T));
             r2[(size_t)i] = i;
         }
-        if ((rc = h->xb.reserve(xb.size() * sizeof(float)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(h->xb.p, xb.data(), xb.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+        if ((rc = h->xb.reserve(xb.size() * sizeof(T)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(h->xb.p, xb.data(), xb.size() * sizeof(T), hipMemcpyHostToDevice, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-        Xd = h->xb.as<float>();
+        Xd = h->xb.as<T>();
     }
     if ((rc = h->rows.reserve((size_t)n_reassign * sizeof(msm_idx_t)))) return rc;
     if ((rc = h->which.reserve((size_t)n_reassign * sizeof(msm_idx_t)))) return rc;
     MSM_HIP_CHECK(hipMemcpyAsync(h->rows.p, r2.data(), (size_t)n_reassign * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(h->which.p, which, (size_t)n_reassign * sizeof(msm_idx_t), hipMemcpyHostToDevice, stream()));
-    hipLaunchKernelGGL(mbk_reassign_kernel, dim3((unsigned)n_reassign), dim3(256), 0, stream(), h->centers, h->counts, Xd,
-                       h->m, h->rows.as<msm_idx_t>(), h->which.as<msm_idx_t>(), new_count);
+    hipLaunchKernelGGL(mbk_reassign_kernel<T>, dim3((unsigned)n_reassign), dim3(256), 0, stream(), h->cen<T>(), h->cnt<T>(), Xd,
+                       h->m, h->rows.as<msm_idx_t>(), h->which.as<msm_idx_t>(), (T)new_count);
     MSM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((unsigned)ceil_div(h->K, 4)), dim3(KNT), 0, stream(), h->centers, h->K, h->m, h->cnorm);
+    mbk_launch_cnorm<T>(h);
     MSM_HIP_CHECK(hipGetLastError());
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
 }
 
-int msm_mbk_set_counts(msm_mbk_t* h, const float* counts)
+template <typename T>
+int mbk_label_t(msm_mbk* h, const T* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device)
 {
-    if (!h || !counts) return fail(MSM_ERR_STATE, "msm_mbk_set_counts: null argument");
-    MSM_HIP_CHECK(hipMemcpyAsync(h->counts, counts, (size_t)h->K * sizeof(float), hipMemcpyHostToDevice, stream()));
-    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-    return MSM_OK;
-}
-
-int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device)
-{
-    if (!h || !X || !labels) return fail(MSM_ERR_STATE, "msm_mbk_label: null argument");
-    if (inertia) *inertia = 0.0;
-    if (n <= 0) return MSM_OK;
     int rc;
-    const float* Xd = X;
+    const T* Xd = X;
     int32_t* lab_d = labels;
     DevBuf &dX = pool(PS_X), &dL = pool(PS_LAB);
     if (!on_device) {
-        if ((rc = dX.reserve((size_t)n * h->m * sizeof(float)))) return rc;
+        if ((rc = dX.reserve((size_t)n * h->m * sizeof(T)))) return rc;
         if ((rc = dL.reserve((size_t)n * sizeof(int32_t)))) return rc;
-        if ((rc = h2d_bulk(dX.p, X, (size_t)n * h->m * sizeof(float)))) return rc;
-        Xd = dX.as<float>();
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * h->m * sizeof(T)))) return rc;
+        Xd = dX.as<T>();
         lab_d = dL.as<int32_t>();
     }
     if ((rc = h->part.reserve(1024 * sizeof(double)))) return rc;
     int nb = 0;
-    if ((rc = mbk_label(h, Xd, nullptr, n, lab_d, inertia ? h->part.as<double>() : nullptr, &nb))) return rc;
+    if ((rc = mbk_label<T>(h, Xd, nullptr, n, lab_d, inertia ? h->part.as<double>() : nullptr, &nb))) return rc;
     if (!on_device) MSM_HIP_CHECK(hipMemcpyAsync(labels, lab_d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
     if (inertia) {
         std::vector<double> hp((size_t)nb);
@@ -2136,8 +2046,8 @@ int msm_mbk_label(msm_mbk_t* h, const float* X, msm_idx_t n, int32_t* labels, do
     return MSM_OK;
 }
 
-int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* centers,
-                         msm_idx_t K, int32_t* labels, double* inertia, int on_device)
+template <typename T>
+int kmeans_label_t(const T* X, msm_idx_t n, msm_idx_t m, const T* centers, msm_idx_t K, int32_t* labels, double* inertia, int on_device)
 {
     if (!X || !centers || !labels) return fail(MSM_ERR_INVALID, "kmeans_label: null pointer");
     if (n < 0 || m < 1 || K < 1) return fail(MSM_ERR_INVALID, "kmeans_label: bad shape");
@@ -2145,10 +2055,10 @@ int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* 
     if (n == 0) return MSM_OK;
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
     DevBuf &dC = pool(PS_Y), &dX = pool(PS_X), &dL = pool(PS_LAB);
-    float *dCent, *dNorm;
-    int rc = km_prepare(centers, K, m, dC, &dCent, &dNorm);
+    T *dCent, *dNorm;
+    int rc = km_prepare<T>(centers, K, m, dC, &dCent, &dNorm);
     if (rc) return rc;
-    KmArgs P;
+    KmArgsT<T> P;
     memset(&P, 0, sizeof(P));
     P.n = n;
     P.m = m;
@@ -2159,34 +2069,33 @@ int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* 
         P.X = X;
         P.labels = labels;
     } else {
-        if ((rc = dX.reserve((size_t)n * m * sizeof(float)))) return rc;
+        if ((rc = dX.reserve((size_t)n * m * sizeof(T)))) return rc;
         if ((rc = dL.reserve((size_t)n * sizeof(int32_t)))) return rc;
-        if ((rc = h2d_bulk(dX.p, X, (size_t)n * m * sizeof(float)))) return rc;
-        P.X = dX.as<float>();
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * m * sizeof(T)))) return rc;
+        P.X = dX.as<T>();
         P.labels = dL.as<int32_t>();
     }
-    if ((rc = km_label_and_inertia(P, inertia))) return rc;
+    if ((rc = km_label_and_inertia<T>(P, inertia))) return rc;
     if (!on_device)
         MSM_HIP_CHECK(hipMemcpyAsync(labels, P.labels, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
 }
 
-int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* batch_idx,
-                     msm_idx_t B, float* centers, float* counts, msm_idx_t K,
-                     double* batch_inertia, double* batch_sums, double* batch_counts,
-                     int apply_update, int on_device)
+template <typename T>
+int mbk_step_stateless_t(const T* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* batch_idx, msm_idx_t B, T* centers, T* counts,
+                         msm_idx_t K, double* batch_inertia, double* batch_sums, double* batch_counts, int apply_update, int on_device)
 {
     if (!X || !batch_idx || !centers || !counts) return fail(MSM_ERR_INVALID, "mbk_step: null pointer");
     if (n < 1 || m < 1 || K < 1 || B < 1) return fail(MSM_ERR_INVALID, "mbk_step: bad shape");
     for (msm_idx_t b = 0; b < B; ++b)
         if (batch_idx[b] < 0 || batch_idx[b] >= n) return fail(MSM_ERR_INVALID, "mbk_step: batch index out of range");
     if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
-    DevBuf &dC = pool(PS_Y), &dXb = pool(PS_X), &dIdx = pool(PS_IDX), &dL = pool(PS_LAB), &dW = pool(PS_W), &dS = pool(PS_S);
-    float *dCent, *dNorm;
-    int rc = km_prepare(centers, K, m, dC, &dCent, &dNorm);
+    DevBuf &dC = pool(PS_Y), &dXb = pool(PS_X), &dIdx = pool(PS_IDX), &dL = pool(PS_LAB), &dW = pool(PS_PADX), &dS = pool(PS_PADY);
+    T *dCent, *dNorm;
+    int rc = km_prepare<T>(centers, K, m, dC, &dCent, &dNorm);
     if (rc) return rc;
-    KmArgs P;
+    KmArgsT<T> P;
     memset(&P, 0, sizeof(P));
     P.n = B;
     P.m = m;
@@ -2202,30 +2111,30 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
         P.rows = dIdx.as<msm_idx_t>();
     } else {
         // gather the batch on the host, ship only B rows
-        std::vector<float> xb((size_t)B * m);
+        std::vector<T> xb((size_t)B * m);
         for (msm_idx_t b = 0; b < B; ++b)
-            memcpy(xb.data() + (size_t)b * m, X + batch_idx[b] * m, (size_t)m * sizeof(float));
-        if ((rc = dXb.reserve(xb.size() * sizeof(float)))) return rc;
-        MSM_HIP_CHECK(hipMemcpyAsync(dXb.p, xb.data(), xb.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+            memcpy(xb.data() + (size_t)b * m, X + batch_idx[b] * m, (size_t)m * sizeof(T));
+        if ((rc = dXb.reserve(xb.size() * sizeof(T)))) return rc;
+        MSM_HIP_CHECK(hipMemcpyAsync(dXb.p, xb.data(), xb.size() * sizeof(T), hipMemcpyHostToDevice, stream()));
         MSM_HIP_CHECK(hipStreamSynchronize(stream()));
-        P.X = dXb.as<float>();
+        P.X = dXb.as<T>();
         P.rows = nullptr;
     }
-    if ((rc = km_label_and_inertia(P, batch_inertia))) return rc;
-    if ((rc = dW.reserve((size_t)K * sizeof(float)))) return rc;
-    MSM_HIP_CHECK(hipMemcpyAsync(dW.p, counts, (size_t)K * sizeof(float), hipMemcpyHostToDevice, stream()));
+    if ((rc = km_label_and_inertia<T>(P, batch_inertia))) return rc;   // (uses PS_W / PS_S for split candidates)
+    if ((rc = dW.reserve((size_t)K * sizeof(T)))) return rc;
+    MSM_HIP_CHECK(hipMemcpyAsync(dW.p, counts, (size_t)K * sizeof(T), hipMemcpyHostToDevice, stream()));
     double *dSums = nullptr, *dCnts = nullptr;
     if (batch_sums || batch_counts) {
         if ((rc = dS.reserve(((size_t)K * m + (size_t)K) * sizeof(double)))) return rc;
         dSums = dS.as<double>();
         dCnts = dSums + (size_t)K * m;
     }
-    hipLaunchKernelGGL(mbk_update_kernel, dim3((unsigned)K), dim3(KNT), 4096 * sizeof(int), stream(), P,
-                       dCent, dW.as<float>(), (float*)nullptr, dSums, dCnts, apply_update, MbkConv{});
+    hipLaunchKernelGGL(mbk_update_kernel<T>, dim3((unsigned)K), dim3(KNT), 4096 * sizeof(int), stream(), P,
+                       dCent, dW.as<T>(), (T*)nullptr, dSums, dCnts, apply_update, MbkConv{});
     MSM_HIP_CHECK(hipGetLastError());
     if (apply_update) {
-        MSM_HIP_CHECK(hipMemcpyAsync(centers, dCent, (size_t)K * m * sizeof(float), hipMemcpyDeviceToHost, stream()));
-        MSM_HIP_CHECK(hipMemcpyAsync(counts, dW.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(centers, dCent, (size_t)K * m * sizeof(T), hipMemcpyDeviceToHost, stream()));
+        MSM_HIP_CHECK(hipMemcpyAsync(counts, dW.p, (size_t)K * sizeof(T), hipMemcpyDeviceToHost, stream()));
     }
     if (batch_sums)
         MSM_HIP_CHECK(hipMemcpyAsync(batch_sums, dSums, (size_t)K * m * sizeof(double), hipMemcpyDeviceToHost, stream()));
@@ -2233,6 +2142,248 @@ int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* 
         MSM_HIP_CHECK(hipMemcpyAsync(batch_counts, dCnts, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
+}
+
+int mbk_create(msm_mbk_t** out, msm_idx_t K, msm_idx_t m, int f64)
+{
+    if (!out || K < 1 || m < 1) return fail(MSM_ERR_INVALID, "msm_mbk_create: bad argument");
+    if (msm_device_count() == 0) return fail(MSM_ERR_NODEVICE, "no HIP device visible");
+    msm_mbk* h = new msm_mbk();
+    h->K = K;
+    h->m = m;
+    h->f64 = f64 ? 1 : 0;
+    const size_t e = h->esz();
+    hipError_t er = hipMalloc(&h->centers, (size_t)K * m * e);
+    if (er == hipSuccess) er = hipMalloc(&h->counts, (size_t)K * e);
+    if (er == hipSuccess) er = hipMalloc(&h->cnorm, (size_t)K * e);
+    if (er == hipSuccess) er = hipMalloc((void**)&h->packed, ((size_t)K * m + K + 1) * sizeof(double));
+    if (er == hipSuccess) er = hipMalloc((void**)&h->outbuf, 8 + (size_t)K * e);
+    if (er != hipSuccess) {
+        msm_mbk_destroy(h);
+        return fail(MSM_ERR_HIP, "msm_mbk_create: hipMalloc failed: %s", hipGetErrorString(er));
+    }
+    *out = h;
+    return MSM_OK;
+}
+
+}  // namespace
+
+// dispatch on the handle's element type
+#define MBK_TYPED(h, CALL_F32, CALL_F64) ((h)->f64 ? (CALL_F64) : (CALL_F32))
+
+extern "C" {
+
+int msm_mbk_create(msm_mbk_t** out, msm_idx_t K, msm_idx_t m) { return mbk_create(out, K, m, 0); }
+int msm_mbk_create_f64(msm_mbk_t** out, msm_idx_t K, msm_idx_t m) { return mbk_create(out, K, m, 1); }
+int msm_mbk_is_f64(msm_mbk_t* h) { return h ? h->f64 : 0; }
+
+int msm_mbk_destroy(msm_mbk_t* h)
+{
+    if (!h) return MSM_OK;
+    (void)hipStreamSynchronize(stream());
+    if (h->centers) (void)hipFree(h->centers);
+    if (h->counts) (void)hipFree(h->counts);
+    if (h->cnorm) (void)hipFree(h->cnorm);
+    if (h->packed) (void)hipFree(h->packed);
+    if (h->outbuf) (void)hipFree(h->outbuf);
+    if (h->stop) (void)hipFree(h->stop);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    delete h;
+    return MSM_OK;
+}
+
+int msm_mbk_set(msm_mbk_t* h, const void* centers, const void* counts)
+{
+    if (!h || !centers || !counts) return fail(MSM_ERR_STATE, "msm_mbk_set: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(h->centers, centers, (size_t)h->K * h->m * h->esz(), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(h->counts, counts, (size_t)h->K * h->esz(), hipMemcpyHostToDevice, stream()));
+    if (h->f64) mbk_launch_cnorm<double>(h);
+    else mbk_launch_cnorm<float>(h);
+    MSM_HIP_CHECK(hipGetLastError());
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_get(msm_mbk_t* h, void* centers, void* counts)
+{
+    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_get: null handle");
+    if (centers) MSM_HIP_CHECK(hipMemcpyAsync(centers, h->centers, (size_t)h->K * h->m * h->esz(), hipMemcpyDeviceToHost, stream()));
+    if (counts) MSM_HIP_CHECK(hipMemcpyAsync(counts, h->counts, (size_t)h->K * h->esz(), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_step(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t B,
+                 double* batch_inertia, void* counts_out, int apply_update, int on_device)
+{
+    if (!h || !X || !batch_idx) return fail(MSM_ERR_STATE, "msm_mbk_step: null argument");
+    if (n < 1 || B < 1) return fail(MSM_ERR_INVALID, "msm_mbk_step: bad shape");
+    return MBK_TYPED(h, mbk_step_t<float>(h, (const float*)X, n, batch_idx, B, batch_inertia, (float*)counts_out, apply_update, on_device),
+                     mbk_step_t<double>(h, (const double*)X, n, batch_idx, B, batch_inertia, (double*)counts_out, apply_update, on_device));
+}
+
+/* msm_mbk_run in two halves: _begin queues the whole run (indices in, S steps, results out) and returns without waiting,
+ * _end waits for it and hands the results over.  Between the two the host is free -- MiniBatchKMeans draws the NEXT run's
+ * batch indices there (a quarter of a millisecond per 65,536 indices with the legacy RandomState, as long as a large-batch
+ * step takes on the device). */
+int msm_mbk_run_begin(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                      msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, const double* state6)
+{
+    if (!h || !X || !batch_idx || !state6) return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
+    if (n < 1 || B < 1 || S < 1 || S > 4096) return fail(MSM_ERR_INVALID, "msm_mbk_run: bad shape");
+    return MBK_TYPED(h, mbk_run_begin_t<float>(h, (const float*)X, n, batch_idx, S, B, first_step, alpha, max_no_improvement, state6),
+                     mbk_run_begin_t<double>(h, (const double*)X, n, batch_idx, S, B, first_step, alpha, max_no_improvement, state6));
+}
+
+int msm_mbk_run_end(msm_mbk_t* h, double* state6, msm_idx_t* steps_done, int* converged, double* inertias, void* counts_out)
+{
+    if (!h || !state6 || !steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run_end: null argument");
+    if (!h->run_out) return fail(MSM_ERR_STATE, "msm_mbk_run_end: no run in flight");
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    const char* o = h->run_out;
+    const size_t st_bytes = h->run_st_bytes;
+    h->run_out = nullptr;
+    const double* so = reinterpret_cast<const double*>(o);
+    for (int i = 0; i < 5; ++i) state6[i] = so[i];
+    state6[5] = so[5];
+    *steps_done = (msm_idx_t)so[5];
+    memcpy(inertias, so + 6, (size_t)(*steps_done) * sizeof(double));
+    *converged = *reinterpret_cast<const int*>(o + st_bytes);
+    if (counts_out) memcpy(counts_out, o + st_bytes + 8, (size_t)h->K * h->esz());
+    return MSM_OK;
+}
+
+int msm_mbk_run(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* batch_idx, msm_idx_t S, msm_idx_t B,
+                msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement, double* state6,
+                msm_idx_t* steps_done, int* converged, double* inertias, void* counts_out)
+{
+    if (!steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run: null argument");
+    const int rc = msm_mbk_run_begin(h, X, n, batch_idx, S, B, first_step, alpha, max_no_improvement, state6);
+    if (rc) return rc;
+    return msm_mbk_run_end(h, state6, steps_done, converged, inertias, counts_out);
+}
+
+/* msm_mbk_run for a ROW-SHARDED fit (one process per GPU): the S batches are GLOBAL (identical on every rank); this rank
+ * passes the rows of each batch that it owns as local row numbers -- local_idx (host) holds them back to back, offsets[S + 1]
+ * (host) delimits the steps -- and the batch size B of the whole batch.  Per step: label + fp64 sums / counts / inertia of
+ * the local rows, ONE all-reduce of the packed [K m sums | K counts | inertia] buffer over the library communicator (RCCL on
+ * the library stream), the identical update and convergence step on every rank.  Nothing returns to the host inside the
+ * run; every rank stops at the same step (the criterion sees the all-reduced inertia).  Outputs as msm_mbk_run. */
+int msm_mbk_run_sharded(msm_mbk_t* h, const void* X, msm_idx_t n_local, const msm_idx_t* local_idx, const msm_idx_t* offsets,
+                        msm_idx_t S, msm_idx_t B, msm_idx_t first_step, double alpha, msm_idx_t max_no_improvement,
+                        double* state6, msm_idx_t* steps_done, int* converged, double* inertias, void* counts_out)
+{
+    if (!h || !offsets || !state6 || !steps_done || !converged || !inertias) return fail(MSM_ERR_STATE, "msm_mbk_run_sharded: null argument");
+    return MBK_TYPED(h, mbk_run_sharded_t<float>(h, (const float*)X, n_local, local_idx, offsets, S, B, first_step, alpha, max_no_improvement,
+                                                 state6, steps_done, converged, inertias, (float*)counts_out),
+                     mbk_run_sharded_t<double>(h, (const double*)X, n_local, local_idx, offsets, S, B, first_step, alpha, max_no_improvement,
+                                                  state6, steps_done, converged, inertias, (double*)counts_out));
+}
+
+msm_idx_t msm_mbk_packed_size(msm_mbk_t* h) { return h ? (msm_idx_t)(h->K * h->m + h->K + 1) : 0; }
+
+int msm_mbk_export_packed(msm_mbk_t* h, double* buf, int on_device)
+{
+    if (!h || !buf) return fail(MSM_ERR_STATE, "msm_mbk_export_packed: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(buf, h->packed, (size_t)msm_mbk_packed_size(h) * sizeof(double),
+                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_apply_packed(msm_mbk_t* h, const double* buf, void* counts_out, int on_device)
+{
+    if (!h || !buf) return fail(MSM_ERR_STATE, "msm_mbk_apply_packed: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(h->packed, buf, (size_t)msm_mbk_packed_size(h) * sizeof(double),
+                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream()));
+    if (h->f64) mbk_launch_apply<double>(h, nullptr);
+    else mbk_launch_apply<float>(h, nullptr);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (counts_out) MSM_HIP_CHECK(hipMemcpyAsync(counts_out, h->counts, (size_t)h->K * h->esz(), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+/* sharded step, exchange half: msm_mbk_step(apply_update = 0) left this rank's [K*m sums | K counts | inertia] of ITS
+ * batch rows in the handle's device buffer (msm_mbk_zero_packed for a rank that owns none of them); one all-reduce over
+ * the library communicator (RCCL on the library stream, device buffer, in place) and the reduced buffer is applied
+ * identically on every rank.  *batch_inertia / counts_out (host, K): the global batch inertia and the updated counts. */
+int msm_mbk_zero_packed(msm_mbk_t* h)
+{
+    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_zero_packed: null handle");
+    MSM_HIP_CHECK(hipMemsetAsync(h->packed, 0, (size_t)msm_mbk_packed_size(h) * sizeof(double), stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_allreduce(msm_mbk_t* h, double* batch_inertia, void* counts_out)
+{
+    if (!h) return fail(MSM_ERR_STATE, "msm_mbk_allreduce: null handle");
+    int rc = comm_allreduce_f64(h->packed, (size_t)msm_mbk_packed_size(h));
+    if (rc) return rc;
+    if (h->f64) mbk_launch_apply<double>(h, nullptr);
+    else mbk_launch_apply<float>(h, nullptr);
+    MSM_HIP_CHECK(hipGetLastError());
+    if (batch_inertia)
+        MSM_HIP_CHECK(hipMemcpyAsync(batch_inertia, h->packed + (size_t)h->K * h->m + h->K, sizeof(double), hipMemcpyDeviceToHost, stream()));
+    if (counts_out) MSM_HIP_CHECK(hipMemcpyAsync(counts_out, h->counts, (size_t)h->K * h->esz(), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_reassign(msm_mbk_t* h, const void* X, msm_idx_t n, const msm_idx_t* rows, const msm_idx_t* which,
+                     msm_idx_t n_reassign, double new_count, int on_device)
+{
+    if (!h || !X || !rows || !which) return fail(MSM_ERR_STATE, "msm_mbk_reassign: null argument");
+    if (n_reassign <= 0) return MSM_OK;
+    for (msm_idx_t i = 0; i < n_reassign; ++i)
+        if (rows[i] < 0 || rows[i] >= n || which[i] < 0 || which[i] >= h->K) return fail(MSM_ERR_INVALID, "msm_mbk_reassign: index out of range");
+    return MBK_TYPED(h, mbk_reassign_t<float>(h, (const float*)X, n, rows, which, n_reassign, new_count, on_device),
+                     mbk_reassign_t<double>(h, (const double*)X, n, rows, which, n_reassign, new_count, on_device));
+}
+
+int msm_mbk_set_counts(msm_mbk_t* h, const void* counts)
+{
+    if (!h || !counts) return fail(MSM_ERR_STATE, "msm_mbk_set_counts: null argument");
+    MSM_HIP_CHECK(hipMemcpyAsync(h->counts, counts, (size_t)h->K * h->esz(), hipMemcpyHostToDevice, stream()));
+    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+    return MSM_OK;
+}
+
+int msm_mbk_label(msm_mbk_t* h, const void* X, msm_idx_t n, int32_t* labels, double* inertia, int on_device)
+{
+    if (!h || !X || !labels) return fail(MSM_ERR_STATE, "msm_mbk_label: null argument");
+    if (inertia) *inertia = 0.0;
+    if (n <= 0) return MSM_OK;
+    return MBK_TYPED(h, mbk_label_t<float>(h, (const float*)X, n, labels, inertia, on_device),
+                     mbk_label_t<double>(h, (const double*)X, n, labels, inertia, on_device));
+}
+
+int msm_kmeans_label_f32(const float* X, msm_idx_t n, msm_idx_t m, const float* centers,
+                         msm_idx_t K, int32_t* labels, double* inertia, int on_device)
+{
+    return kmeans_label_t<float>(X, n, m, centers, K, labels, inertia, on_device);
+}
+
+int msm_kmeans_label_f64(const double* X, msm_idx_t n, msm_idx_t m, const double* centers,
+                         msm_idx_t K, int32_t* labels, double* inertia, int on_device)
+{
+    return kmeans_label_t<double>(X, n, m, centers, K, labels, inertia, on_device);
+}
+
+int msm_mbk_step_f32(const float* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* batch_idx,
+                     msm_idx_t B, float* centers, float* counts, msm_idx_t K,
+                     double* batch_inertia, double* batch_sums, double* batch_counts,
+                     int apply_update, int on_device)
+{
+    return mbk_step_stateless_t<float>(X, n, m, batch_idx, B, centers, counts, K, batch_inertia, batch_sums, batch_counts, apply_update, on_device);
+}
+
+int msm_mbk_step_f64(const double* X, msm_idx_t n, msm_idx_t m, const msm_idx_t* batch_idx,
+                     msm_idx_t B, double* centers, double* counts, msm_idx_t K,
+                     double* batch_inertia, double* batch_sums, double* batch_counts,
+                     int apply_update, int on_device)
+{
+    return mbk_step_stateless_t<double>(X, n, m, batch_idx, B, centers, counts, K, batch_inertia, batch_sums, batch_counts, apply_update, on_device);
 }
 
 }  // extern "C"

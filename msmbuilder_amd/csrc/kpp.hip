@@ -38,35 +38,38 @@ constexpr int KPP_NT = 256;
 constexpr int KPP_RPB = 1024;   // rows per block (4 per thread)
 constexpr int KPP_LMAX = 16;    // candidates per round: 2 + log K <= 16 up to K = 1.2 million
 
-struct KppArgs {
-    const float* X;      // [n][F]
+template <typename T>   // T: the rows' type.  scikit-learn keeps distances, potentials' inputs and centres in it (float32 rows:
+struct KppArgsT {       // float64-upcast arithmetic rounded to float32; float64 rows: float64 throughout)
+    const T* X;          // [n][F]
     long long n;
     int F, L;
-    float* dbuf;         // [2][L][n] candidate distances (after the min with `closest`), double-buffered over rounds
+    T* dbuf;             // [2][L][n] candidate distances (after the min with `closest`), double-buffered over rounds
     double* cuml;        // [n] inclusive scan of `closest` inside each block
     double* bsum;        // [nb] block totals
     double* ppart;       // [nb][L] per-block potentials of the candidates
     const double* u;     // [K - 1][L] uniforms
     long long* cand;     // [L] candidate rows of the round
     int* best;           // [1] index (0 .. L - 1) of the previous round's winner inside dbuf
-    double* pot;         // [1] current potential (float32-rounded like scikit-learn's)
-    float* centers;      // [K][F]
+    double* pot;         // [1] current potential (rounded to T like scikit-learn's)
+    T* centers;          // [K][F]
     long long* ids;      // [K]
-    float* cglob;        // [L][F] the round's candidate rows when they do not fit the LDS tile (else null)
+    T* cglob;            // [L][F] the round's candidate rows when they do not fit the LDS tile (else null)
     double* bpre;        // [nb] prefix of the block totals when nb doubles do not fit LDS (else null)
 };
 
 // `closest` of round r = the winning candidate's row of the previous round's buffer
-__device__ __forceinline__ const float* kpp_closest(const KppArgs& P, int round)
+template <typename T>
+__device__ __forceinline__ const T* kpp_closest(const KppArgsT<T>& P, int round)
 {
     return P.dbuf + ((size_t)((round + 1) & 1) * P.L + (size_t)(*P.best)) * (size_t)P.n;
 }
 
 // 1) blockwise float64 inclusive scan of `closest`
-__global__ __launch_bounds__(KPP_NT) void kpp_scan_kernel(KppArgs P, int round)
+template <typename T>
+__global__ __launch_bounds__(KPP_NT) void kpp_scan_kernel(KppArgsT<T> P, int round)
 {
     __shared__ double wsum[KPP_NT / 64];
-    const float* closest = kpp_closest(P, round);
+    const T* closest = kpp_closest(P, round);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long i0 = (long long)blockIdx.x * KPP_RPB + tid * 4;
     double v[4];
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(KPP_NT) void kpp_scan_kernel(KppArgs P, int round)
 }
 
 // 2) the round's candidates: searchsorted(cumsum(closest), u * pot), side = 'left', clipped to n - 1
-__global__ __launch_bounds__(KPP_NT) void kpp_pick_kernel(KppArgs P, int round, int nb)
+template <typename T>
+__global__ __launch_bounds__(KPP_NT) void kpp_pick_kernel(KppArgsT<T> P, int round, int nb)
 {
     extern __shared__ double pre_lds[];   // [nb] inclusive prefix of the block totals (or P.bpre: seeding samples beyond 7.3M rows)
     double* pre = P.bpre ? P.bpre : pre_lds;
@@ -145,15 +149,16 @@ __global__ __launch_bounds__(KPP_NT) void kpp_pick_kernel(KppArgs P, int round, 
 }
 
 // 3) distances of every row to the candidates, the min with `closest`, per-block potentials
-template <bool FIRST>
-__global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgs P, int round, long long first)
+template <typename T, bool FIRST>
+__global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgsT<T> P, int round, long long first)
 {
-    extern __shared__ float cs_lds[];   // [L][F] candidate rows (or P.cglob, gathered by kpp_gather_kernel: wide rows)
+    extern __shared__ __attribute__((aligned(16))) char cs_lds_raw[];   // [L][F] candidate rows (or P.cglob, gathered by kpp_gather_kernel: wide rows)
+    T* cs_lds = reinterpret_cast<T*>(cs_lds_raw);
     __shared__ double cc[KPP_LMAX];
     __shared__ double red[KPP_LMAX][KPP_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = FIRST ? 1 : P.L, F = P.F;
-    const float* cs = P.cglob ? P.cglob : cs_lds;
+    const T* cs = P.cglob ? P.cglob : cs_lds;
     if (!P.cglob) {
         for (int e = tid; e < L * F; e += KPP_NT) {
             const int j = e / F, f = e - j * F;
@@ -168,15 +173,15 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgs P, int round, 
         cc[tid] = s;
     }
     __syncthreads();
-    const float* closest = FIRST ? nullptr : kpp_closest(P, round);
-    float* out = P.dbuf + (size_t)(round & 1) * P.L * (size_t)P.n;
+    const T* closest = FIRST ? nullptr : kpp_closest(P, round);
+    T* out = P.dbuf + (size_t)(round & 1) * P.L * (size_t)P.n;
     double pot[KPP_LMAX];
 #pragma unroll
     for (int j = 0; j < KPP_LMAX; ++j) pot[j] = 0.0;
     for (int q = 0; q < 4; ++q) {
         const long long i = (long long)blockIdx.x * KPP_RPB + q * KPP_NT + tid;   // coalesced over the block
         if (i >= P.n) continue;
-        const float* x = P.X + (size_t)i * F;
+        const T* x = P.X + (size_t)i * F;
         double xx = 0.0, dot[KPP_LMAX];
 #pragma unroll
         for (int j = 0; j < KPP_LMAX; ++j) dot[j] = 0.0;
@@ -187,14 +192,14 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgs P, int round, 
             for (int j = 0; j < KPP_LMAX; ++j)
                 if (j < L) dot[j] = fma(xv, (double)cs[j * F + f], dot[j]);
         }
-        const float cl = FIRST ? INFINITY : closest[i];
+        const T cl = FIRST ? (T)INFINITY : closest[i];
 #pragma unroll
         for (int j = 0; j < KPP_LMAX; ++j)
             if (j < L) {
-                double d = -2.0 * dot[j];   // scikit-learn: d = -2 X Y^T; d += XX (candidates); d += YY (rows); max(d, 0); float32
+                double d = -2.0 * dot[j];   // scikit-learn: d = -2 X Y^T; d += XX (candidates); d += YY (rows); max(d, 0); (float32 rows: -> float32)
                 d += cc[j];
                 d += xx;
-                float df = (float)(d > 0.0 ? d : 0.0);
+                T df = (T)(d > 0.0 ? d : 0.0);
                 df = df < cl ? df : cl;
                 out[(size_t)j * P.n + i] = df;
                 pot[j] += (double)df;
@@ -218,15 +223,18 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_kernel(KppArgs P, int round, 
 // MiniBatchKMeans(k=1000) fit of 1M x 512 spent 1.1 of its 1.28 s there (scripts/clusterprobe.py).  Same float64 formula;
 // the features are summed lane-strided and by a butterfly instead of front to back (scikit-learn's order is its BLAS's).
 constexpr int KPP_WROWS = 32;   // rows per workgroup (8 per wave)
-template <bool FIRST>
-__global__ __launch_bounds__(KPP_NT) void kpp_dist_wide_kernel(KppArgs P, int round, long long first)
+template <typename T, bool FIRST>
+__global__ __launch_bounds__(KPP_NT) void kpp_dist_wide_kernel(KppArgsT<T> P, int round, long long first)
 {
-    extern __shared__ __attribute__((aligned(16))) float cs_lds_w[];   // [L][F] candidate rows (or P.cglob)
+    extern __shared__ __attribute__((aligned(16))) char cs_lds_w_raw[];   // [L][F] candidate rows (or P.cglob)
+    T* cs_lds_w = reinterpret_cast<T*>(cs_lds_w_raw);
+    constexpr int E = 16 / (int)sizeof(T);   // elements of a 16-byte load
+    struct alignas(16) V16 { T e[E]; };
     __shared__ double cc[KPP_LMAX];
     __shared__ double red[KPP_LMAX][KPP_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = FIRST ? 1 : P.L, F = P.F;
-    const float* cs = P.cglob ? P.cglob : cs_lds_w;
+    const T* cs = P.cglob ? P.cglob : cs_lds_w;
     if (!P.cglob) {
         for (int e = tid; e < L * F; e += KPP_NT) {
             const int j = e / F, f = e - j * F;
@@ -243,35 +251,30 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_wide_kernel(KppArgs P, int ro
         if (lane == 0) cc[j] = s;
     }
     __syncthreads();
-    const float* closest = FIRST ? nullptr : kpp_closest(P, round);
-    float* out = P.dbuf + (size_t)(round & 1) * P.L * (size_t)P.n;
-    const bool vec4 = (F & 3) == 0 && ((((uintptr_t)P.X) | ((uintptr_t)cs)) & 15) == 0;
+    const T* closest = FIRST ? nullptr : kpp_closest(P, round);
+    T* out = P.dbuf + (size_t)(round & 1) * P.L * (size_t)P.n;
+    const bool vec4 = (F % E) == 0 && ((((uintptr_t)P.X) | ((uintptr_t)cs)) & 15) == 0;
     double pot[KPP_LMAX];
 #pragma unroll
     for (int j = 0; j < KPP_LMAX; ++j) pot[j] = 0.0;
     for (int q = 0; q < KPP_WROWS / (KPP_NT / 64); ++q) {
         const long long i = (long long)blockIdx.x * KPP_WROWS + q * (KPP_NT / 64) + wave;   // uniform over the wave
         if (i >= P.n) break;
-        const float* x = P.X + (size_t)i * F;
+        const T* x = P.X + (size_t)i * F;
         double xx = 0.0, dot[KPP_LMAX];
 #pragma unroll
         for (int j = 0; j < KPP_LMAX; ++j) dot[j] = 0.0;
         if (vec4) {
-            for (int f4 = lane; f4 < (F >> 2); f4 += 64) {
-                const float4 xv = reinterpret_cast<const float4*>(x)[f4];
-                const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w;
-                xx = fma(x0, x0, xx);
-                xx = fma(x1, x1, xx);
-                xx = fma(x2, x2, xx);
-                xx = fma(x3, x3, xx);
+            for (int f4 = lane; f4 < F / E; f4 += 64) {
+                const V16 xv = reinterpret_cast<const V16*>(x)[f4];
+#pragma unroll
+                for (int e = 0; e < E; ++e) xx = fma((double)xv.e[e], (double)xv.e[e], xx);
 #pragma unroll
                 for (int j = 0; j < KPP_LMAX; ++j)
                     if (j < L) {
-                        const float4 cv = reinterpret_cast<const float4*>(cs + (size_t)j * F)[f4];
-                        dot[j] = fma(x0, (double)cv.x, dot[j]);
-                        dot[j] = fma(x1, (double)cv.y, dot[j]);
-                        dot[j] = fma(x2, (double)cv.z, dot[j]);
-                        dot[j] = fma(x3, (double)cv.w, dot[j]);
+                        const V16 cv = reinterpret_cast<const V16*>(cs + (size_t)j * F)[f4];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) dot[j] = fma((double)xv.e[e], (double)cv.e[e], dot[j]);
                     }
             }
         } else {
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_wide_kernel(KppArgs P, int ro
         }
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) xx += __shfl_xor(xx, m, 64);
-        const float cl = FIRST ? INFINITY : closest[i];
+        const T cl = FIRST ? (T)INFINITY : closest[i];
 #pragma unroll
         for (int j = 0; j < KPP_LMAX; ++j)
             if (j < L) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_wide_kernel(KppArgs P, int ro
                 double d = -2.0 * dj;   // scikit-learn's order of the three terms (kpp_dist_kernel)
                 d += cc[j];
                 d += xx;
-                float df = (float)(d > 0.0 ? d : 0.0);
+                T df = (T)(d > 0.0 ? d : 0.0);
                 df = df < cl ? df : cl;
                 if (lane == 0) {
                     out[(size_t)j * P.n + i] = df;
@@ -311,15 +314,19 @@ __global__ __launch_bounds__(KPP_NT) void kpp_dist_wide_kernel(KppArgs P, int ro
 }
 
 // 3') wide rows: the round's candidate rows into one device buffer (read by every block of kpp_dist_kernel through the L2)
-__global__ __launch_bounds__(KPP_NT) void kpp_gather_kernel(KppArgs P, int L, long long first)
+// (`round0`: the one candidate of round 0 is row `first`; every later round reads P.cand -- also when it has ONE candidate:
+//  ADVICE r5, the kernel used to take `L == 1` for "round 0")
+template <typename T>
+__global__ __launch_bounds__(KPP_NT) void kpp_gather_kernel(KppArgsT<T> P, int round0, long long first)
 {
     const int j = blockIdx.x;
-    const long long row = L == 1 ? first : P.cand[j];
+    const long long row = round0 ? first : P.cand[j];
     for (int f = threadIdx.x; f < P.F; f += KPP_NT) P.cglob[(size_t)j * P.F + f] = P.X[(size_t)row * P.F + f];
 }
 
 // 4) potentials -> the winner (first minimum), the new centre, the new current potential
-__global__ __launch_bounds__(KPP_NT) void kpp_best_kernel(KppArgs P, int round, int nb, long long first)
+template <typename T>
+__global__ __launch_bounds__(KPP_NT) void kpp_best_kernel(KppArgsT<T> P, int round, int nb, long long first)
 {
     __shared__ double part[KPP_LMAX][KPP_NT];
     __shared__ int bsel;
@@ -339,10 +346,10 @@ __global__ __launch_bounds__(KPP_NT) void kpp_best_kernel(KppArgs P, int round, 
     if (tid == 0) {
         int b = 0;
         for (int j = 1; j < L; ++j)
-            if ((float)part[j][0] < (float)part[b][0]) b = j;   // float32 potentials like scikit-learn's, first minimum
+            if ((T)part[j][0] < (T)part[b][0]) b = j;   // potentials in the rows' type like scikit-learn's, first minimum
         bsel = b;
         *P.best = b;
-        *P.pot = (double)(float)part[b][0];
+        *P.pot = (double)(T)part[b][0];
         P.ids[round] = round == 0 ? first : P.cand[b];
     }
     __syncthreads();
@@ -356,13 +363,14 @@ __global__ __launch_bounds__(KPP_NT) void kpp_best_kernel(KppArgs P, int round, 
 
 using namespace msm;
 
-extern "C" {
+namespace {
 
-/* k-means++ seeds of the n x F float32 rows X (host or device per on_device): centre 0 = row `first`, then K - 1 rounds with
+/* k-means++ seeds of the n x F rows X (host or device per on_device): centre 0 = row `first`, then K - 1 rounds with
  * L candidates each, drawn with the uniforms u[(K - 1) * L] (host, float64, in [0, 1)): scikit-learn's `_kmeans_plusplus`
- * given the same draws.  centers[K * F] (float32) and ids[K] (rows of X) are host arrays. */
-int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t K, msm_idx_t first, const double* u, int L,
-                            float* centers, msm_idx_t* ids, int on_device)
+ * given the same draws.  centers[K * F] (the rows' type) and ids[K] (rows of X) are host arrays. */
+template <typename T>
+int kmeans_plusplus_t(const T* X, msm_idx_t n, msm_idx_t F, msm_idx_t K, msm_idx_t first, const double* u, int L,
+                      T* centers, msm_idx_t* ids, int on_device)
 {
     if (!X || !centers || !ids || (K > 1 && !u)) return fail(MSM_ERR_INVALID, "kmeans_plusplus: null pointer");
     if (n < 1 || F < 1 || K < 1 || K > n || first < 0 || first >= n) return fail(MSM_ERR_INVALID, "kmeans_plusplus: bad shape");
@@ -372,33 +380,33 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     const int nb = (int)ceil_div(n, KPP_RPB);
     const bool wrows = F >= 32 && ceil_div(n, KPP_WROWS) <= 0x7fffffffLL;   // a wave per row (kpp_dist_wide_kernel)
     const int nbd = wrows ? (int)ceil_div(n, KPP_WROWS) : nb;                // workgroups (= potential partials) of the distance kernel
-    const bool wide = (size_t)L * F * sizeof(float) > 60000;   // candidate rows beyond the LDS staging tile: through a device buffer
+    const bool wide = (size_t)L * F * sizeof(T) > 60000;   // candidate rows beyond the LDS staging tile: through a device buffer
     const bool longpre = nb > 7168;                            // block prefix beyond LDS: in device memory
     DevBuf &dX = pool(PS_X), &dW = pool(PS_W), &dO = pool(PS_OUT);
     int rc;
-    const float* Xd = X;
+    const T* Xd = X;
     if (!on_device) {
-        if ((rc = dX.reserve((size_t)n * F * sizeof(float)))) return rc;
-        if ((rc = h2d_bulk(dX.p, X, (size_t)n * F * sizeof(float)))) return rc;
-        Xd = dX.as<float>();
+        if ((rc = dX.reserve((size_t)n * F * sizeof(T)))) return rc;
+        if ((rc = h2d_bulk(dX.p, X, (size_t)n * F * sizeof(T)))) return rc;
+        Xd = dX.as<T>();
     }
-    // workspace: dbuf [2][L][n] f32 | cuml [n] f64 | bsum [nb] | ppart [nb][L] | u [(K-1) L] | pot | cand [L] i64 | best
+    // workspace: dbuf [2][L][n] T | cuml [n] f64 | bsum [nb] | ppart [nb][L] | u [(K-1) L] | pot | cand [L] i64 | best
     const size_t nu = (size_t)(K - 1) * L;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_dbuf = take(2 * (size_t)L * n * sizeof(float)), o_cuml = take((size_t)n * sizeof(double)),
+    const size_t o_dbuf = take(2 * (size_t)L * n * sizeof(T)), o_cuml = take((size_t)n * sizeof(double)),
                  o_bsum = take((size_t)nb * sizeof(double)), o_pp = take((size_t)nbd * L * sizeof(double)),
                  o_u = take(std::max<size_t>(nu, 1) * sizeof(double)), o_pot = take(sizeof(double)), o_cand = take(L * sizeof(long long)),
-                 o_best = take(sizeof(int)), o_cg = take(wide ? (size_t)L * F * sizeof(float) : 0), o_bpre = take(longpre ? (size_t)nb * sizeof(double) : 0);
+                 o_best = take(sizeof(int)), o_cg = take(wide ? (size_t)L * F * sizeof(T) : 0), o_bpre = take(longpre ? (size_t)nb * sizeof(double) : 0);
     if ((rc = dW.reserve(off))) return rc;
-    if ((rc = dO.reserve((size_t)K * F * sizeof(float) + (size_t)K * sizeof(long long)))) return rc;
+    if ((rc = dO.reserve((size_t)K * F * sizeof(T) + (size_t)K * sizeof(long long)))) return rc;
     char* w = dW.as<char>();
-    KppArgs P;
+    KppArgsT<T> P;
     P.X = Xd;
     P.n = n;
     P.F = (int)F;
     P.L = L;
-    P.dbuf = reinterpret_cast<float*>(w + o_dbuf);
+    P.dbuf = reinterpret_cast<T*>(w + o_dbuf);
     P.cuml = reinterpret_cast<double*>(w + o_cuml);
     P.bsum = reinterpret_cast<double*>(w + o_bsum);
     P.ppart = reinterpret_cast<double*>(w + o_pp);
@@ -406,30 +414,46 @@ int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t 
     P.pot = reinterpret_cast<double*>(w + o_pot);
     P.cand = reinterpret_cast<long long*>(w + o_cand);
     P.best = reinterpret_cast<int*>(w + o_best);
-    P.centers = dO.as<float>();
-    P.ids = reinterpret_cast<long long*>(dO.as<char>() + (size_t)K * F * sizeof(float));
-    P.cglob = wide ? reinterpret_cast<float*>(w + o_cg) : nullptr;
+    P.centers = dO.as<T>();
+    P.ids = reinterpret_cast<long long*>(dO.as<char>() + (size_t)K * F * sizeof(T));
+    P.cglob = wide ? reinterpret_cast<T*>(w + o_cg) : nullptr;
     P.bpre = longpre ? reinterpret_cast<double*>(w + o_bpre) : nullptr;
     if (nu) MSM_HIP_CHECK(hipMemcpyAsync(w + o_u, u, nu * sizeof(double), hipMemcpyHostToDevice, stream()));
-    const size_t lds_c = wide ? 0 : (size_t)L * F * sizeof(float), lds_pre = longpre ? 0 : (size_t)nb * sizeof(double);
+    const size_t lds_c = wide ? 0 : (size_t)L * F * sizeof(T), lds_pre = longpre ? 0 : (size_t)nb * sizeof(double);
     // round 0: distances to the first centre = `closest`, its potential
-    if (wide) hipLaunchKernelGGL(kpp_gather_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, 1, (long long)first);
-    if (wrows) hipLaunchKernelGGL(kpp_dist_wide_kernel<true>, dim3(nbd), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
-    else hipLaunchKernelGGL(kpp_dist_kernel<true>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
-    hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, 0, nbd, (long long)first);
+    if (wide) hipLaunchKernelGGL(kpp_gather_kernel<T>, dim3(1), dim3(KPP_NT), 0, stream(), P, 1, (long long)first);
+    if (wrows) hipLaunchKernelGGL((kpp_dist_wide_kernel<T, true>), dim3(nbd), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
+    else hipLaunchKernelGGL((kpp_dist_kernel<T, true>), dim3(nb), dim3(KPP_NT), lds_c, stream(), P, 0, (long long)first);
+    hipLaunchKernelGGL(kpp_best_kernel<T>, dim3(1), dim3(KPP_NT), 0, stream(), P, 0, nbd, (long long)first);
     for (int r = 1; r < (int)K; ++r) {
-        hipLaunchKernelGGL(kpp_scan_kernel, dim3(nb), dim3(KPP_NT), 0, stream(), P, r);
-        hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(KPP_NT), lds_pre, stream(), P, r, nb);
-        if (wide) hipLaunchKernelGGL(kpp_gather_kernel, dim3((unsigned)L), dim3(KPP_NT), 0, stream(), P, L, (long long)first);
-        if (wrows) hipLaunchKernelGGL(kpp_dist_wide_kernel<false>, dim3(nbd), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
-        else hipLaunchKernelGGL(kpp_dist_kernel<false>, dim3(nb), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
-        hipLaunchKernelGGL(kpp_best_kernel, dim3(1), dim3(KPP_NT), 0, stream(), P, r, nbd, (long long)first);
+        hipLaunchKernelGGL(kpp_scan_kernel<T>, dim3(nb), dim3(KPP_NT), 0, stream(), P, r);
+        hipLaunchKernelGGL(kpp_pick_kernel<T>, dim3(1), dim3(KPP_NT), lds_pre, stream(), P, r, nb);
+        if (wide) hipLaunchKernelGGL(kpp_gather_kernel<T>, dim3((unsigned)L), dim3(KPP_NT), 0, stream(), P, 0, (long long)first);
+        if (wrows) hipLaunchKernelGGL((kpp_dist_wide_kernel<T, false>), dim3(nbd), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
+        else hipLaunchKernelGGL((kpp_dist_kernel<T, false>), dim3(nb), dim3(KPP_NT), lds_c, stream(), P, r, (long long)first);
+        hipLaunchKernelGGL(kpp_best_kernel<T>, dim3(1), dim3(KPP_NT), 0, stream(), P, r, nbd, (long long)first);
     }
     MSM_HIP_CHECK(hipGetLastError());
-    MSM_HIP_CHECK(hipMemcpyAsync(centers, P.centers, (size_t)K * F * sizeof(float), hipMemcpyDeviceToHost, stream()));
+    MSM_HIP_CHECK(hipMemcpyAsync(centers, P.centers, (size_t)K * F * sizeof(T), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipMemcpyAsync(ids, P.ids, (size_t)K * sizeof(long long), hipMemcpyDeviceToHost, stream()));
     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
     return MSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msm_kmeans_plusplus_f32(const float* X, msm_idx_t n, msm_idx_t F, msm_idx_t K, msm_idx_t first, const double* u, int L,
+                            float* centers, msm_idx_t* ids, int on_device)
+{
+    return kmeans_plusplus_t<float>(X, n, F, K, first, u, L, centers, ids, on_device);
+}
+
+int msm_kmeans_plusplus_f64(const double* X, msm_idx_t n, msm_idx_t F, msm_idx_t K, msm_idx_t first, const double* u, int L,
+                            double* centers, msm_idx_t* ids, int on_device)
+{
+    return kmeans_plusplus_t<double>(X, n, F, K, first, u, L, centers, ids, on_device);
 }
 
 }  // extern "C"

@@ -11,6 +11,7 @@ small ``.npz`` fixtures next to this script:
                          the reference's libdistance headers (oracle/_ref)
 * libdistance_golden.npz msmbuilder/libdistance/src/*.hpp compiled (oracle/_ref)
 * transition_golden.npz  msmbuilder/msm/core.py (_transition_counts)
+* mbkm_f64_golden.npz    the same on FLOAT64 rows (round 6; inputs regenerated from seeds)
 * mbkm_golden.npz        scikit-learn MiniBatchKMeans (the third-party
                          arithmetic behind msmbuilder.cluster.MiniBatchKMeans,
                          cluster/__init__.py:67-69; unpinned upstream)
@@ -36,6 +37,7 @@ REF = "/root/reference/msmbuilder"
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
 
 
 def _load(name, path, package=None):
@@ -290,6 +292,41 @@ def kpp_golden():
     print("mbkm_golden.npz: + k-means++ seeds of 6000 x 10, K = 200 from scikit-learn", sklearn.__version__)
 
 
+from seeds import mbkm_f64_data  # noqa: E402  (tests/golden/seeds.py: shared with the tests)
+
+
+def mbkm_f64_golden():
+    """Round 6: scikit-learn MiniBatchKMeans on FLOAT64 rows -- the type the reference pipeline feeds it
+    (cluster/__init__.py:67-69 <- tica.py:329-352) -- captured so that the float64 GPU path is pinned without a live
+    scikit-learn: explicit init and k-means++ init on 20,000 x 16, and K = 1000 with k-means++ on a 100,000 x 10 projection.
+    Stored: centres, counts, inertia, n_steps, labels (and the k-means++ seeds' row ids); the inputs come from
+    `mbkm_f64_data` seeds."""
+    import sklearn
+    from sklearn.cluster import MiniBatchKMeans, kmeans_plusplus as sk_kpp
+    g = {"sklearn_version": np.array(sklearn.__version__)}
+    X, init = mbkm_f64_data("small")
+    assert X.dtype == np.float64
+    a = MiniBatchKMeans(n_clusters=25, init=init, n_init=1, batch_size=512, max_iter=3, random_state=5).fit(X)
+    b = MiniBatchKMeans(n_clusters=25, n_init=1, batch_size=512, max_iter=3, random_state=5).fit(X)
+    for tag, m in (("a_", a), ("b_", b)):
+        assert m.cluster_centers_.dtype == np.float64
+        g[tag + "centers"], g[tag + "counts"] = m.cluster_centers_, m._counts
+        g[tag + "inertia"], g[tag + "n_steps"] = np.float64(m.inertia_), np.int64(m.n_steps_)
+        g[tag + "labels"] = m.labels_.astype(np.int32)
+    cs, ids = sk_kpp(X, 25, random_state=np.random.RandomState(7))
+    g["kpp_ids"] = np.asarray(ids, dtype=np.int64)
+    Y, _ = mbkm_f64_data("proj")
+    c = MiniBatchKMeans(n_clusters=1000, n_init=1, batch_size=1024, max_iter=2, random_state=3).fit(Y)
+    g["c_centers"], g["c_counts"] = c.cluster_centers_, c._counts
+    g["c_inertia"], g["c_n_steps"] = np.float64(c.inertia_), np.int64(c.n_steps_)
+    g["c_labels"] = c.labels_.astype(np.int32)
+    _, ids = sk_kpp(Y[:3072], 1000, random_state=np.random.RandomState(7))
+    g["c_kpp_ids"] = np.asarray(ids, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "mbkm_f64_golden.npz"), **g)
+    print("mbkm_f64_golden.npz: sklearn", sklearn.__version__, "steps", g["a_n_steps"], g["b_n_steps"], g["c_n_steps"],
+          "inertia", g["a_inertia"], g["b_inertia"], g["c_inertia"])
+
+
 def transition_golden():
     """msmbuilder.msm._transition_counts itself (msm/core.py:487-596), loaded by file path with a stub
     for the compiled _ratematrix extension and the numpy aliases (np.int / np.float) it still uses."""
@@ -364,7 +401,10 @@ if __name__ == "__main__":
         transition_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "kpp":
         kpp_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mbkm_f64":
+        mbkm_f64_golden()
     else:
         main()
         transition_golden()
         kpp_golden()
+        mbkm_f64_golden()
