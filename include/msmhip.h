@@ -73,6 +73,9 @@ int msm_device_info(char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 /* device memory helpers (so callers without torch can keep data resident) */
 int msm_malloc(void** dptr, size_t bytes);
 int msm_free(void* dptr);
+/* Blocking copies; bytes == 0 is a no-op whatever the pointers (an empty array has no address).  Large copies go through the
+ * library's pinned staging ring, which has ONE submitter: like every other entry point these two must not be called from a
+ * second host thread while another call of this library is in progress. */
 int msm_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int msm_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int msm_memcpy_d2d(void* dst, const void* src, size_t bytes);

@@ -383,6 +383,7 @@ int msm_free(void* dptr)
 
 int msm_memcpy_h2d(void* dst, const void* src, size_t bytes)
 {
+    if (bytes == 0) return MSM_OK;   // (an empty tensor has a null data pointer: a zero-length copy is not an error)
     if (!dst || !src) return fail(MSM_ERR_INVALID, "msm_memcpy_h2d: null pointer");
     const int rc = h2d_bulk(dst, src, bytes);   // (large copies through the pinned ring: 50+ GB/s against ~10 from pageable memory)
     if (rc) return rc;
@@ -392,6 +393,7 @@ int msm_memcpy_h2d(void* dst, const void* src, size_t bytes)
 
 int msm_memcpy_d2h(void* dst, const void* src, size_t bytes)
 {
+    if (bytes == 0) return MSM_OK;
     if (!dst || !src) return fail(MSM_ERR_INVALID, "msm_memcpy_d2h: null pointer");
     return d2h_bulk(dst, src, bytes);   // blocking
 }
@@ -402,11 +404,16 @@ int msm_upload_list(void* dst, const void* const* src, const msm_idx_t* nbytes, 
 {
     if (!dst || (n > 0 && (!src || !nbytes)) || n < 0) return fail(MSM_ERR_INVALID, "msm_upload_list: bad argument");
     char* d = static_cast<char*>(dst);
+    // the FIRST copy that moves bytes orders the copy stream behind the caller's stream (the destination may be a block the
+    // caching allocator recycled from a tensor whose kernels are still queued); the later ones follow it on the copy stream.
+    // (tied to i == 0, an empty first buffer left every copy unordered.)
+    bool first_done = false;
     for (msm_idx_t i = 0; i < n; ++i) {
         if (nbytes[i] < 0 || (nbytes[i] > 0 && !src[i])) return fail(MSM_ERR_INVALID, "msm_upload_list: bad buffer %lld", (long long)i);
         if (nbytes[i] > 0) {
-            const int rc = h2d_bulk(d, src[i], (size_t)nbytes[i], i == 0);
+            const int rc = h2d_bulk(d, src[i], (size_t)nbytes[i], !first_done);
             if (rc) return rc;
+            first_done = true;
         }
         d += nbytes[i];
     }

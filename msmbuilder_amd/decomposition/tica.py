@@ -492,11 +492,16 @@ class tICA(BaseEstimator, TransformerMixin):
         # (a materialised list of host arrays goes down whole: the library stages it in 512 MiB groups through two buffers
         #  and copies group g + 1 while group g is accumulated -- splitting it here would put a synchronisation between the
         #  groups; a lazily loading iterable is consumed ~1 GiB at a time so that it is never held in memory at once)
+        #  -- and so is a list whose members need a converted copy in _prepare (non-contiguous, float16, integers, lists of
+        #  lists): those copies are held together for one _fit_many call, so only ~1 GiB of them goes into one call)
         lazy = not isinstance(sequences, (list, tuple))
         for X in sequences:
             group.append(X)
-            if lazy and not getattr(X, "is_cuda", False):
-                group_bytes += int(np.prod(X.shape)) * int(getattr(getattr(X, "dtype", None), "itemsize", 8) or 8)
+            if not getattr(X, "is_cuda", False):
+                conforming = (isinstance(X, np.ndarray) and X.ndim == 2 and X.flags.c_contiguous
+                              and X.dtype in (np.float32, np.float64))
+                if lazy or not conforming:
+                    group_bytes += int(np.prod(np.shape(X))) * int(getattr(getattr(X, "dtype", None), "itemsize", 8) or 8)
             if group_bytes >= _BATCH_BYTES or len(group) >= 4096:
                 self._fit_many(group)
                 group, group_bytes = [], 0
@@ -893,7 +898,7 @@ class tICA(BaseEstimator, TransformerMixin):
         into a quarter of the free device memory crosses PCIe ONCE: it is uploaded back to back into one device buffer
         (``msm_upload_list``), fitted and projected there, and the projection comes back as one array cut per trajectory
         -- ``fit`` followed by ``transform`` on host arrays would upload every frame twice."""
-        staged = self._stage_host_list(sequences)
+        staged = self._stage_host_list(sequences, self.n_components)
         if staged is None:
             self.fit(sequences)
             return self.transform(sequences)
@@ -907,10 +912,11 @@ class tICA(BaseEstimator, TransformerMixin):
         return _lib.cut_rows(Y, lens)
 
     @staticmethod
-    def _stage_host_list(sequences):
+    def _stage_host_list(sequences, n_components=None):
         """(device tensor [total, F], row counts) holding a list of C-contiguous float32 / float64 numpy trajectories of one
         width back to back, or None when the list does not qualify (other types, mixed dtypes / widths, torch without a
-        device, more bytes than a quarter of the free device memory)."""
+        device, the staged rows PLUS the [total, k] float64 projection that fit_transform allocates beside them -- k = F when
+        ``n_components`` is None: twice the bytes of float32 rows -- beyond a quarter of the free device memory)."""
         if not isinstance(sequences, (list, tuple)) or len(sequences) < 1:
             return None
         head = sequences[0]
@@ -933,9 +939,13 @@ class tICA(BaseEstimator, TransformerMixin):
         lens = [int(X.shape[0]) for X in sequences]
         total = sum(lens)
         nbytes = total * F * head.dtype.itemsize
-        if total == 0 or nbytes > free_bytes // 4:
+        k = F if n_components is None else min(int(n_components), F)
+        if total == 0 or nbytes + total * k * 8 > free_bytes // 4:
             return None
-        Xd = torch.empty((total, F), dtype=torch.float32 if head.dtype == np.float32 else torch.float64, device=dev)
+        try:
+            Xd = torch.empty((total, F), dtype=torch.float32 if head.dtype == np.float32 else torch.float64, device=dev)
+        except RuntimeError:   # (torch's out-of-memory error: the caller falls back to fit + transform, staged in groups)
+            return None
         n = len(sequences)
         src = (C.c_void_p * n)(*[X.ctypes.data if X.shape[0] else None for X in sequences])
         nb = (C.c_int64 * n)(*[int(X.nbytes) for X in sequences])

@@ -174,6 +174,16 @@ def library_comm():
                 if rc == 0:
                     rc = L.msm_comm_selftest(int(os.environ.get("MSM_COMM_TIMEOUT_S", "180")))
                     err = _lib.last_error() if rc else ""
+                if rc and "new stream" in err:
+                    # a collective that could not be aborted still blocks the stream the library (= torch's current stream)
+                    # was on: everything queued behind it -- the flag exchange right below, the host transport -- would wait
+                    # for ever, and with this rank every other rank inside that all_reduce.  Move this thread, and with it
+                    # the library, to a fresh stream BEFORE touching torch again (this used to happen after the
+                    # flag exchange, i.e. too late).
+                    global _fresh_stream
+                    _fresh_stream = torch.cuda.Stream()
+                    torch.cuda.set_stream(_fresh_stream)
+                    _lib.set_stream(_fresh_stream.cuda_stream)
                 flags = torch.zeros(w, device="cuda")
                 flags[r] = 1.0 if rc == 0 else 0.0
                 dist.all_reduce(flags, op=dist.ReduceOp.SUM)
@@ -185,14 +195,6 @@ def library_comm():
                     if rc:
                         warnings.warn("libmsmhip RCCL communicator, rank %d of %d: %s" % (r, w, err))
                     L.msm_comm_destroy()
-                    if rc and "new stream" in err:
-                        # a collective that could not be aborted still blocks the stream the library was on: everything
-                        # queued behind it (the host transport included) would wait for ever -- move this thread, and with
-                        # it the library, to a fresh stream
-                        global _fresh_stream
-                        _fresh_stream = torch.cuda.Stream()
-                        torch.cuda.set_stream(_fresh_stream)
-                        _lib.set_stream(_fresh_stream.cuda_stream)
         if kind is None and want == "rccl":
             raise RuntimeError("libmsmhip could not create its RCCL communicator (failed ranks: %s): %s"
                                % ([f["rank"] for f in _comm_failures], _lib.last_error()))
