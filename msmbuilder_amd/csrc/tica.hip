@@ -30,6 +30,7 @@
 
 #include "tica_cg_dev.h"   // staging helpers (ChunkCtx, Stage32) and tica_mfma_f32_kernel, the fp32 C/G kernel
 #include "tica_sym_dev.h"   // tica_sym_f32_kernel (sum/difference form, the bench kernel) and tica_export_sym_kernel
+#include "tica_symw_dev.h"   // tica_symw_f32_kernel (sum/difference form for F <= 256: a workgroup owns all of H and D) and its export
 #include "tica_f64_dev.h"   // tica_mfma_f64_kernel (fp64 MFMA)
 #include "tica_img_pack_dev.h"   // tica_img_kernel (packing pre-pass of the bf16 image path) and tica_img_steps_kernel
 #include "tica_colsum_dev.h"   // column sums, folded sums, mean shift and export kernels
@@ -44,6 +45,10 @@ struct msm_tica {
     int sym = 0, ntiles_sym = 0, S_sym = 0;                // symmetric fp32 kernel: upper tiles, slab / column-sum ROWS (cohorts, + 1 with a remainder cohort)
     int sym_cohorts = 0, sym_grid = 0;                     // ... whole cohorts, workgroups of a launch (sym_grid > sym_cohorts * ntiles_sym: remainder cohort)
     double* slabs_sym = nullptr;                           // [S_sym * ntiles_sym][2][TM*TM]: H and D blocks
+    // whole-matrix sum/difference kernel (tica_symw_dev.h; fp32 mode, F <= 256): variant (SymwA ..), its padded width /
+    // group width / interleave, workgroups of a launch (= slab rows), slabs [symw_S][2][FP*FP], rows in use since the last reset
+    int symw = 0, symw_var = 0, symw_FP = 0, symw_W = 0, symw_IL = 0, symw_KS = 0, symw_S = 0, symw_used = 0;
+    double* slabs_w = nullptr;
     double* slabs = nullptr;    // [G][TM*TM]
     double* base = nullptr;     // packed [2FF+2F] imported state
     double* colpart = nullptr;  // [NCB][2][F]
@@ -107,6 +112,9 @@ int tica_zero(msm_tica* h)
     MSM_HIP_CHECK(hipMemsetAsync(h->slabs, 0, (size_t)h->G * TM * TM * sizeof(double), stream()));
     if (h->slabs_sym)
         MSM_HIP_CHECK(hipMemsetAsync(h->slabs_sym, 0, (size_t)h->S_sym * h->ntiles_sym * 2 * TM * TM * sizeof(double), stream()));
+    if (h->slabs_w && h->symw_used > 0)   // (only the rows a launch has touched: 512 slabs of 2 x 192 x 192 doubles are 300 MB)
+        MSM_HIP_CHECK(hipMemsetAsync(h->slabs_w, 0, (size_t)h->symw_used * 2 * h->symw_FP * h->symw_FP * sizeof(double), stream()));
+    h->symw_used = 0;
     MSM_HIP_CHECK(hipMemsetAsync(h->base, 0, FF2 * sizeof(double), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->colpart, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
     MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
@@ -180,11 +188,14 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // (a bf16 mode whose 256-wide tiles do not fit one resident round -- beyond 3,840 features -- runs the fp32 C/G kernel:
     //  the mode is an accuracy floor, not a promise of the bf16 pipe; bfloat16-stored rows there take the fp64 kernel)
     const bool use32 = dtype_bytes == 4 && (h->mode == MSM_TICA_F32 || (bfmode && !useimg));
-    const int bk = (use32 || useimg) ? BK32 : BK64;
-    const bool usesym = (use32 && h->mode == MSM_TICA_F32 && h->sym && aligned) || useimg;  // pair semantics: sum/difference slabs (H/D kernel: 16-byte aligned rows only)
-    const int S = useimg ? h->S_img : usesym ? h->sym_cohorts : use32 ? h->S32 : h->S64;  // one resident round
+    // F <= 256, fp32 mode: the whole-matrix sum/difference kernel (any alignment a float row can have; tica_symw_dev.h)
+    const bool usesymw = use32 && h->mode == MSM_TICA_F32 && h->symw;
+    const int bk = usesymw ? h->symw_KS : (use32 || useimg) ? BK32 : BK64;
+    const bool usesym = !usesymw && ((use32 && h->mode == MSM_TICA_F32 && h->sym && h->slabs_sym && aligned) || useimg);  // sum/difference slabs (H/D kernel: 16-byte aligned rows only)
+    const bool pairsem = usesym || usesymw;   // pair semantics: a frame counts once per valid pair it is in
+    const int S = usesymw ? h->symw_S : useimg ? h->S_img : usesym ? h->sym_cohorts : use32 ? h->S32 : h->S64;  // one resident round
     const bool symrem = usesym && !useimg && h->sym_grid > S * h->ntiles_sym;              // ... + a remainder cohort
-    const int G = symrem ? h->sym_grid : S * (usesym ? h->ntiles_sym : h->ntiles);
+    const int G = usesymw ? S : symrem ? h->sym_grid : S * (usesym ? h->ntiles_sym : h->ntiles);
     long long kc = ceil_div(total, S);
     kc = ceil_div(kc, bk) * bk;
     if (kc > KCMAX) kc = KCMAX;
@@ -193,7 +204,16 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // column sums of a 6.25M-frame fit at 100 MB)
     if (useimg && kc > 1024) kc = 1024;
     if (kc < bk) kc = bk;
-    if (kc == KCMAX && total < 16LL * KCMAX * S && !useimg) {
+    if (usesymw) {
+        // every workgroup is a cohort of its own and a trajectory is cut into whole chunks: with about one chunk per
+        // workgroup the launch lasts as long as the workgroups that got two (2M x 171 as 200 x 10,000: 600 chunks on 512
+        // workgroups, 1.9 ms where the flops need 1.1).  Eight chunks per workgroup and more, but chunks of at least four
+        // K-steps / 256 frames (a chunk starts with an exposed load).
+        const long long kmin = std::min<long long>(KCMAX, std::max<long long>(256, 4LL * bk));
+        kc = ceil_div(ceil_div(total, 8LL * S), bk) * bk;
+        kc = std::min<long long>(KCMAX, std::max<long long>(kc, kmin));
+    }
+    if (kc == KCMAX && total < 16LL * KCMAX * S && !useimg && !usesymw) {
         // Few chunks per cohort (one rank's share of a strong-scaled fit: 1.25M frames = 7.35 chunks of 4096 per cohort, the
         // busiest cohort does 8): cohorts take chunks round-robin, so the launch lasts as long as the fullest one.  Try smaller
         // chunks and keep the size whose fullest cohort -- plus ~16 frames' worth of prologue per chunk -- is lightest.
@@ -366,9 +386,9 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
                 const long long nt = std::max<long long>(0, g.oe - std::max<long long>(g.ob, h->lag));
                 n_call += n0;
                 nmean += n0 + nt;
-                nw_call += (segs && !usesym) ? n0 + nt : 2 * n0;
+                nw_call += (segs && !pairsem) ? n0 + nt : 2 * n0;
             }
-            const int what = !segs ? (SH_A_a | SH_B_b | SH_W_ab) : usesym ? (SH_A_a | SH_W_a) : (SH_A_a | SH_W_ab);
+            const int what = !segs ? (SH_A_a | SH_B_b | SH_W_ab) : pairsem ? (SH_A_a | SH_W_a) : (SH_A_a | SH_W_ab);
             hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(512), 0, stream(), h->coltmp,
                                h->shsum, h->shift, h->F, 1.0 / (double)std::max<long long>(1, nmean), set_r, what);
             MSM_HIP_CHECK(hipGetLastError());
@@ -508,7 +528,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             else
                 hipLaunchKernelGGL(tica_colsum_kernel<double>, dim3(NCB), dim3(NT), 0, stream(), Q);
             hipLaunchKernelGGL(tica_shift_kernel, dim3((unsigned)ceil_div(h->F, 64)), dim3(512), 0, stream(), h->coltmp,
-                               h->shsum, h->shift, h->F, 0.0, 0, usesym ? (SH_B_a | SH_W_a) : SH_B_a);
+                               h->shsum, h->shift, h->F, 0.0, 0, pairsem ? (SH_B_a | SH_W_a) : SH_B_a);
             MSM_HIP_CHECK(hipGetLastError());
             MSM_HIP_CHECK(hipMemsetAsync(h->coltmp, 0, (size_t)NCB * 2 * h->F * sizeof(double), stream()));
         }
@@ -627,6 +647,27 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             MSM_HIP_CHECK(hipGetLastError());
             c0 = c1;
         }
+    } else if (usesymw) {
+        SymwArgs WA;
+        WA.T = P;
+        WA.slabs = h->slabs_w;
+        const bool vec = h->F >= 4;   // 16-byte pieces at any 4-byte alignment; rows of 1-3 floats element by element
+        switch (h->symw_var) {
+#define MSM_SYMW_LAUNCH(CFG)                                                                                      \
+            if (vec) hipLaunchKernelGGL((tica_symw_f32_kernel<CFG, true>), dim3(G), dim3(CFG::NTH), CFG::LDS, stream(), WA); \
+            else hipLaunchKernelGGL((tica_symw_f32_kernel<SymwA, false>), dim3(G), dim3(SymwA::NTH), SymwA::LDS, stream(), WA); \
+            break;
+            case 0: MSM_SYMW_LAUNCH(SymwA)
+            case 1: MSM_SYMW_LAUNCH(SymwB)
+            case 2: MSM_SYMW_LAUNCH(SymwC)
+            case 3: MSM_SYMW_LAUNCH(SymwD)
+            case 4: MSM_SYMW_LAUNCH(SymwE)
+            case 6: MSM_SYMW_LAUNCH(SymwG)
+            case 7: MSM_SYMW_LAUNCH(SymwH)
+            default: MSM_SYMW_LAUNCH(SymwF)
+#undef MSM_SYMW_LAUNCH
+        }
+        h->symw_used = std::max(h->symw_used, (int)std::min<long long>(G, P.nchunks));
     } else if (usesym) {
         if (symrem) {
             if (fold)
@@ -690,7 +731,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         if (rc) return rc;
     }
     if (usesym) h->slabs_dirty = true;
-    else h->cg_dirty = true;
+    else if (!usesymw) h->cg_dirty = true;
     h->last_folded = fold;
     for (msm_idx_t s = 0; s < n_seq; ++s) {
         const SegInfo g = seg_of(s);
@@ -702,7 +743,8 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     return MSM_OK;
 }
 
-int tica_export_device(msm_tica* h)
+// queues slabs / column partials / base -> h->packed (raw moments, un-shifted); no synchronisation
+int tica_export_queue(msm_tica* h)
 {
     const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
@@ -710,9 +752,14 @@ int tica_export_device(msm_tica* h)
     hipLaunchKernelGGL(tica_export_cols_kernel, dim3((unsigned)ceil_div(2 * (int64_t)h->F, 64)), dim3(256), 0, stream(), h->colpart, h->base,
                        h->packed, h->F);
     MSM_HIP_CHECK(hipGetLastError());
-    if (h->sym) {
+    if (h->sym && h->slabs_sym) {
         hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div((size_t)h->ntiles_sym * TM * TM, 256)), dim3(256), 0, stream(),
                            h->slabs_sym, h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
+        MSM_HIP_CHECK(hipGetLastError());
+    }
+    if (h->symw_used > 0) {
+        hipLaunchKernelGGL(tica_export_symw_kernel, dim3((unsigned)ceil_div((size_t)h->F * h->F, 256)), dim3(256), 0, stream(),
+                           h->slabs_w, h->packed, h->F, h->symw_FP, h->symw_W, h->symw_IL, h->symw_used);
         MSM_HIP_CHECK(hipGetLastError());
     }
     if (h->have_shift) {  // restore the raw moments from the shifted ones (fp64)
@@ -720,6 +767,16 @@ int tica_export_device(msm_tica* h)
         hipLaunchKernelGGL(tica_unshift_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->packed,
                            h->shsum, h->shift, (double)h->n_sh, (double)h->nw_sh, h->F, h->sym);
         MSM_HIP_CHECK(hipGetLastError());
+    }
+    return MSM_OK;
+}
+
+int tica_export_device(msm_tica* h)
+{
+    const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
+    {
+        const int rcq = tica_export_queue(h);
+        if (rcq) return rcq;
     }
     const double cnt[2] = {(double)h->n_obs, (double)h->n_seq};
     MSM_HIP_CHECK(hipMemcpyAsync(h->packed + total, cnt, sizeof(cnt), hipMemcpyHostToDevice, stream()));
@@ -776,6 +833,41 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     if (h->S32 < 1) h->S32 = 1;
     if (h->S64 < 1) h->S64 = 1;
     {
+        // whole-matrix sum/difference kernel (round 6): fp32 mode, F <= 256.  MSM_TICA_SYM=0 (raw lagged moment wanted) and
+        // MSM_TICA_SYMW=0 (A/B switch of the tests) leave the 128-wide kernels of rounds 1-5 in charge.
+        const char* sym_env = getenv("MSM_TICA_SYM");
+        const char* symw_env = getenv("MSM_TICA_SYMW");
+        const bool off = (sym_env && atoi(sym_env) == 0) || (symw_env && atoi(symw_env) == 0);
+        if (mode == MSM_TICA_F32 && !off && n_features <= 256) {
+            int occ = 0;
+#define MSM_SYMW_SETUP(VAR, CFG)                                                                                  \
+            {                                                                                                     \
+                h->symw_var = VAR; h->symw_FP = CFG::FP; h->symw_W = CFG::W; h->symw_IL = CFG::IL; h->symw_KS = CFG::KS; \
+                MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_symw_f32_kernel<CFG, true>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)CFG::LDS));    \
+                MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tica_symw_f32_kernel<CFG, true>, CFG::NTH, CFG::LDS)); \
+            }
+            if (n_features <= 16) MSM_SYMW_SETUP(0, SymwA)
+            else if (n_features <= 32) MSM_SYMW_SETUP(1, SymwB)
+            else if (n_features <= 64) MSM_SYMW_SETUP(2, SymwC)
+            else if (n_features <= 96) MSM_SYMW_SETUP(6, SymwG)
+            else if (n_features <= 128) MSM_SYMW_SETUP(3, SymwD)
+            else if (n_features <= 160) MSM_SYMW_SETUP(7, SymwH)
+            else if (n_features <= 192) MSM_SYMW_SETUP(4, SymwE)
+            else MSM_SYMW_SETUP(5, SymwF)
+#undef MSM_SYMW_SETUP
+            if (n_features < 4) {
+                MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_symw_f32_kernel<SymwA, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SymwA::LDS));
+                MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tica_symw_f32_kernel<SymwA, false>, SymwA::NTH, SymwA::LDS));
+            }
+            if (occ < 1) occ = 1;
+            h->symw_S = occ * num_cus();
+            h->symw = 1;
+            h->sym = 1;   // the exported lagged moment is the symmetrised one
+        }
+    }
+    if (!h->symw) {
         // symmetric fp32 kernel (H/D blocks of the upper tiles): two 64-KiB workgroups per CU
         const char* sym_env = getenv("MSM_TICA_SYM");
         const bool sym_off = sym_env && atoi(sym_env) == 0;
@@ -841,7 +933,12 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
     const size_t FF2 = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void**)&h->slabs, (size_t)h->G * TM * TM * sizeof(double));
-    if (e == hipSuccess && h->sym) e = hipMalloc((void**)&h->slabs_sym, (size_t)h->S_sym * h->ntiles_sym * 2 * TM * TM * sizeof(double));
+    if (e == hipSuccess && h->sym && !h->symw) e = hipMalloc((void**)&h->slabs_sym, (size_t)h->S_sym * h->ntiles_sym * 2 * TM * TM * sizeof(double));
+    if (e == hipSuccess && h->symw) {
+        const size_t wb = (size_t)h->symw_S * 2 * h->symw_FP * h->symw_FP * sizeof(double);
+        e = hipMalloc((void**)&h->slabs_w, wb);
+        if (e == hipSuccess) e = hipMemsetAsync(h->slabs_w, 0, wb, stream());   // (once: a reset zeroes only the rows a launch has used)
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&h->base, FF2 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->colpart, (size_t)NCB * 2 * h->F * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&h->coltmp, (size_t)NCB * 2 * h->F * sizeof(double));
@@ -874,6 +971,7 @@ int msm_tica_destroy(msm_tica_t* h)
     (void)hipStreamSynchronize(stream());
     if (h->slabs) (void)hipFree(h->slabs);
     if (h->slabs_sym) (void)hipFree(h->slabs_sym);
+    if (h->slabs_w) (void)hipFree(h->slabs_w);
     if (h->base) (void)hipFree(h->base);
     if (h->colpart) (void)hipFree(h->colpart);
     if (h->coltmp) (void)hipFree(h->coltmp);
@@ -1213,20 +1311,7 @@ int tica_reduce_device(msm_tica* h, double shrinkage, long long n_rblw, const do
     const long long npairs = h->n_obs - (long long)h->lag * h->n_seq;
     if (h->n_obs <= 0 || npairs <= 0) return fail(MSM_ERR_STATE, "the model must be fit() before use");
     // the packed raw moments (slab sums, un-shifted) stay on the device
-    const size_t total = 2 * (size_t)h->F * h->F + 2 * (size_t)h->F;
-    hipLaunchKernelGGL(tica_export_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
-                       h->slabs, h->colpart, h->base, h->packed, h->F, h->T, h->ntiles, h->cg_dirty ? h->S : 0);
-    hipLaunchKernelGGL(tica_export_cols_kernel, dim3((unsigned)ceil_div(2 * (int64_t)h->F, 64)), dim3(256), 0, stream(), h->colpart, h->base,
-                       h->packed, h->F);
-    if (h->sym) {
-        hipLaunchKernelGGL(tica_export_sym_kernel, dim3((unsigned)ceil_div((size_t)h->ntiles_sym * TM * TM, 256)), dim3(256), 0, stream(),
-                           h->slabs_sym, h->packed, h->F, h->T, h->ntiles_sym, h->S_sym);
-    }
-    if (h->have_shift) {
-        const size_t ff2 = 2 * (size_t)h->F * h->F;
-        hipLaunchKernelGGL(tica_unshift_kernel, dim3((unsigned)ceil_div(ff2, 256)), dim3(256), 0, stream(), h->packed,
-                           h->shsum, h->shift, (double)h->n_sh, (double)h->nw_sh, h->F, h->sym);
-    }
+    if ((rc = tica_export_queue(h))) return rc;
     MSM_HIP_CHECK(hipGetLastError());
     MSM_HIP_CHECK(hipMemsetAsync(b->ints, 0, 8 * sizeof(int), stream()));
     if (scale_host) MSM_HIP_CHECK(hipMemcpyAsync(b->scale, scale_host, h->F * sizeof(double), hipMemcpyHostToDevice, stream()));

@@ -178,7 +178,7 @@ class tICA(BaseEstimator, TransformerMixin):
         self.n_sequences_ = 0
         self._release()
         _lib.ensure_device()
-        self._handle_key = (int(n_features), int(self.lag_time), _mode_from_env(), os.environ.get("MSM_TICA_SYM", ""))
+        self._handle_key = (int(n_features), int(self.lag_time), _mode_from_env(), os.environ.get("MSM_TICA_SYM", "") + "/" + os.environ.get("MSM_TICA_SYMW", ""))
         self._handle = _acquire_handle(*self._handle_key)
         self._outer_0_to_T_lagged = np.zeros((n_features, n_features))
         self._sum_0_to_TminusTau = np.zeros(n_features)
@@ -204,7 +204,7 @@ class tICA(BaseEstimator, TransformerMixin):
         """(Re)create the device handle from the host mirrors (after unpickling)."""
         if self._handle is None and self._initialized:
             _lib.ensure_device()
-            self._handle_key = (int(self.n_features), int(self.lag_time), _mode_from_env(), os.environ.get("MSM_TICA_SYM", ""))
+            self._handle_key = (int(self.n_features), int(self.lag_time), _mode_from_env(), os.environ.get("MSM_TICA_SYM", "") + "/" + os.environ.get("MSM_TICA_SYMW", ""))
             h = self._handle = _acquire_handle(*self._handle_key)
             c = np.ascontiguousarray(self._outer_0_to_T_lagged, dtype=np.float64)
             g = np.ascontiguousarray(self._outer_gram_sum, dtype=np.float64)

@@ -10,6 +10,13 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _tile_kernel(monkeypatch):
+    """The folded column sums belong to the 128-tile sum/difference kernel; at F <= 256 the whole-matrix kernel of round 6
+    (tica_symw_dev.h, which has a column-sum pass of its own ahead of it) would take these shapes: switched off here."""
+    monkeypatch.setenv("MSM_TICA_SYMW", "0")
+
 ATOL_SCALE = 1e-6   # accumulators relative to max|G| (tests/test_gpu_tica.py)
 
 
