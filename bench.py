@@ -106,6 +106,15 @@ def executed_flop_per_frame(F, sym):
     return 2.0 * 128 * 128 * tiles, tiles
 
 
+def executed_flop_per_frame_symw(F):
+    """Whole-matrix sum/difference kernel (F <= 256, csrc/tica_symw_dev.h): 16 x 16 MFMA blocks of the upper triangle of H and
+    of D, the columns in groups of 16 / 32 / 64 (the variant table of tica.hip)."""
+    il, ng = ((1, 1) if F <= 16 else (2, 1) if F <= 32 else (4, 1) if F <= 64 else (2, 3) if F <= 96 else (4, 2) if F <= 128
+              else (2, 5) if F <= 160 else (4, 3) if F <= 192 else (4, 4))
+    nblk = ng * (il * (il + 1) // 2) + (ng * (ng - 1) // 2) * il * il
+    return 2.0 * 16 * 16 * 2 * nblk, nblk
+
+
 def kernel_ms_of(tica, _lib):
     ms = C.c_float(0.0)
     _lib.check(_lib.lib().msm_tica_last_kernel_ms(tica._handle, C.byref(ms)))
@@ -676,12 +685,41 @@ def main():
                 e2 = m2.eigenvalues_
                 torch.cuda.synchronize()
                 t2 = time.perf_counter() - t2
-            ex2, _t = executed_flop_per_frame(128, False)
-            out["config2"] = {"workload": "1,000,000 x 128 fp32, one trajectory, lag 100", "kernel": "tica_mfma_f32_kernel",
+            sym2 = bool(m2._lagged_symmetrised)
+            ex2 = executed_flop_per_frame_symw(128)[0] if sym2 else executed_flop_per_frame(128, False)[0]
+            out["config2"] = {"workload": "1,000,000 x 128 fp32, one trajectory, lag 100",
+                              "kernel": "tica_symw_f32_kernel" if sym2 else "tica_mfma_f32_kernel",
                               "kernel_ms": ms2, "executed_TFLOPs": ex2 * 1e6 / ms2 / 1e9, "frac": ex2 * 1e6 / ms2 / 1e9 / PEAK_TFLOPS["f32"],
+                              "algorithmic_TFLOPs": 4.0 * 128 * 128 * 1e6 / ms2 / 1e9,
                               "accumulate_frames_per_s": 1e6 / ms2 * 1e3, "fit_plus_solve_ms": 1e3 * t2,
                               "top_eigenvalues": [float(x) for x in e2[:3]]}
             del X2, m2
+            # --- BASELINE configs[2]'s and configs[0]'s WIDTHS through the accumulation (round 6): 2M x 171 (contact
+            # features of a 21-residue peptide, featurizer.py:1149-1179) as 200 x 10,000, lag 100, and 8M x 4 (dihedral sin / cos,
+            # featurizer.py:572-657) as 800 x 10,000, lag 10 -- executed = the MFMA blocks the kernel issues, algorithmic = 4 F^2
+            for tag, Fw, nw, lagw in (("config3_width", 171, 200, 100), ("config1_width", 4, 800, 10)):
+                Xw = synth(torch, nw, 10_000, Fw, 7 + Fw, dev)
+                seqs_w = list(Xw.view(nw, 10_000, Fw).unbind(0))
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    kms, fts = [], []
+                    for it in range(5):
+                        torch.cuda.synchronize()
+                        tw = time.perf_counter()
+                        mw = tICA(n_components=min(args.components, Fw), lag_time=lagw).fit(seqs_w)
+                        torch.cuda.synchronize()
+                        fts.append(time.perf_counter() - tw)
+                        kms.append(kernel_ms_of(mw, _lib))
+                symw_on = bool(mw._lagged_symmetrised)
+                exw = executed_flop_per_frame_symw(Fw)[0] if (symw_on and Fw <= 256) else executed_flop_per_frame(Fw, symw_on)[0]
+                kmw, nfw = min(kms[2:]), nw * 10_000
+                out[tag] = {"workload": "%d x %d fp32 as %d x 10,000, lag %d" % (nfw, Fw, nw, lagw),
+                            "kernel": "tica_symw_f32_kernel" if (symw_on and Fw <= 256) else "128-wide tile kernels",
+                            "kernel_ms": kmw, "fit_ms": 1e3 * min(fts[2:]), "accumulate_frames_per_s": nfw / kmw * 1e3,
+                            "executed_TFLOPs": exw * nfw / kmw / 1e9, "frac_of_fp32_mfma_peak": exw * nfw / kmw / 1e9 / PEAK_TFLOPS["f32"],
+                            "algorithmic_TFLOPs": 4.0 * Fw * Fw * nfw / kmw / 1e9,
+                            "rows_TBps": nfw * Fw * 4 / kmw / 1e9, "hbm_peak_TBps": 8.0}
+                del Xw, seqs_w, mw
             # --- SURVEY 8(d)'s C3 stress variant: KCenters(200) and assign_nearest on RAW contact-like features, 280,000 x 171
             # float32 as 28 trajectories x 10,000, no tICA in front (odd row length: the scalar-staged exact kernels)
             gC = torch.Generator(device=dev).manual_seed(171)

@@ -174,14 +174,18 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     // chunk size: every cohort gets work, fp32 partials stay <= KCMAX frames
     const bool bfmode = (h->mode == MSM_TICA_BF16 || h->mode == MSM_TICA_BF16X2);
     const bool useimg = bfmode && h->img_on && (dtype_bytes == 4 || dtype_bytes == 2);  // packed bf16 image + 256 x 256 tiles
-    // Round 5, MSM_TICA_IMG_FUSED=1 (read per launch): bfloat16-STORED rows of whole 256-feature panels skip the image -- the MFMA
-    // kernel's load role stages the raw rows in LDS and forms the packets itself (tica_img_fused_kernel; its slabs equal the
-    // packed-image pipeline's bit for bit).  Half the fabric traffic and no ring, but NOT faster (1M x 2048: 13.9 ms + a
-    // column-sum pass against 12.3 ms; DESIGN 3.2c has the measurements), so the packed image stays the default.
+    // The FUSED kernel (round 5): bfloat16-STORED rows of whole 256-feature panels skip the image -- the MFMA kernel's load role
+    // stages the raw rows in LDS and forms the packets itself (tica_img_fused_kernel; its slabs equal the packed-image
+    // pipeline's bit for bit).  Half the fabric traffic and no ring.  Round 6 (VERDICT r5 #3a): it is the DEFAULT where it is
+    // faster -- up to 512 features -- and the packed image from 768 (scripts/fusedprobe.py, profiles/r06_fused_probe.txt,
+    // fit wall time fused / image, bf16 | bf16x2: F = 256 0.80 | 0.77, 512 0.88 | 0.84, 768 1.08 | 0.98, 1024 1.09 | 1.06,
+    // 1536 1.27 | 1.00, 2048 1.35 | 1.22: a unit of H or D needs x_t AND x_{t+tau} of both panels, and from three panels per
+    // side the raw rows' three trips through the LDS cost more than the image's write and read).
+    // MSM_TICA_IMG_FUSED=0 / 1 (read per launch) forces either.
     bool usefused = false;
     if (useimg && dtype_bytes == 2 && h->F % 256 == 0 && ld % 8 == 0) {
         const char* fe = getenv("MSM_TICA_IMG_FUSED");
-        usefused = fe && atoi(fe) == 1;
+        usefused = fe ? atoi(fe) == 1 : h->F <= 512;
         for (msm_idx_t s = 0; s < n_seq && usefused; ++s)
             if (((uintptr_t)ptrs[s]) & 15) usefused = false;   // 16-byte LDS-direct row pieces
     }

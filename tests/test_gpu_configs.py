@@ -226,6 +226,26 @@ def test_config5_fused_kernel_bit_identical_to_image_path(gpu, monkeypatch, mode
         assert np.array_equal(a, b)
 
 
+def test_config5_fused_is_the_default_up_to_512_features(gpu, monkeypatch):
+    """Round 6 (VERDICT r5 #3a): the fused kernel wins up to 512 features and loses from 768 (profiles/r06_fused_probe.txt), so
+    that is where the default switches; MSM_TICA_IMG_FUSED still forces either."""
+    import ctypes as C
+    import torch
+    from msmbuilder_amd import tICA, _lib
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", "bf16")
+    monkeypatch.delenv("MSM_TICA_IMG_FUSED", raising=False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for F, want in ((256, 1), (512, 1), (768, 0), (1024, 0)):
+        X = (torch.randn(6000, F, generator=g, device="cuda") + 1.0).to(torch.bfloat16)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=3, lag_time=10).fit([X[:4000], X[4000:]])
+        flag = C.c_int(-1)
+        _lib.check(_lib.lib().msm_tica_last_img_fused(m._handle, C.byref(flag)))
+        assert flag.value == want, (F, flag.value)
+        assert np.isfinite(m.eigenvalues_).all()
+
+
 def test_config5_per_gpu_share_6250000_x_2048_bf16_stored(gpu, monkeypatch):
     """BASELINE configs[4] at the size ONE of its 8 GPUs holds: 6,250,000 x 2048, bfloat16-STORED (25.6 GB), lag 100,
     through the bf16 image path in both of its modes.  Reference: an independent float64 contraction of the stored values
