@@ -370,6 +370,9 @@ int msm_kcenters_fit_sharded_f64(const double* X, msm_idx_t n_local, msm_idx_t m
  * rounded-up distance)}.  bench.py derives its bytes-per-pass figure from it (exact re-evaluations of screen candidates
  * and the updates are not counted: a lower bound on the traffic). */
 int msm_kcenters_last_stats(msm_idx_t* out5);
+/* Wide screened passes (round 6: float32 rows, float64 rows of more than 16 features; csrc/distance_wscreen_dev.h), with
+ * MSM_KC_STATS=1 in the environment of the fit: out2 = {rows re-evaluated exactly over all screened passes, rows that changed}. */
+int msm_kcenters_last_wide_stats(msm_idx_t* out2);
 
 /* ---- k-means labelling / mini-batch step (GEMM form on MFMA) ----
  * Element type: scikit-learn (the arithmetic behind msmbuilder.cluster.MiniBatchKMeans, cluster/__init__.py:67-69) works

@@ -109,6 +109,7 @@ def _declare(lib):
     for sfx in ("f32", "f64"):
         f("msm_kcenters_fit_sharded_" + sfx, C.c_int, _p, _i64, _i64, _i64, C.c_char_p, _i64, _i64, _p, _p, _p, _p, _f64p)
     f("msm_kcenters_last_stats", C.c_int, _i64p)
+    f("msm_kcenters_last_wide_stats", C.c_int, _i64p)
     f("msm_tica_export_sums", C.c_int, _p, _p, _p)
     f("msm_tica_reduce", C.c_int, _p, C.c_double, _i64, _p, _p, _p, _p)
     f("msm_tica_backsolve", C.c_int, _p, _p, _i64, _p)

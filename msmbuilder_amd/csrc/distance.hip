@@ -353,12 +353,14 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
 }  // namespace msm
 #include "distance_screen_dev.h"   // kcenters_screen_pass_kernel, ksc_convert_kernel: k-centers passes screened on a low-precision copy
 #include "distance_kcbatch_dev.h"   // kcb_* kernels: several centres per pass (threshold lists), single GPU and row-sharded
+#include "distance_wscreen_dev.h"   // kcenters_wscreen_pass_kernel: screened passes of wide rows / float32 rows on a feature-major byte copy
 namespace msm {
 
 
 // what the last k-centers fit streamed (for bench.py's bytes-per-pass figure): pass counts and the bytes a pass reads per row
 struct KcStats {
     long long rows = 0, plain_passes = 0, screened_passes = 0, plain_row_bytes = 0, screen_row_bytes = 0, batch_fallbacks = 0;
+    long long wide_candidates = 0, wide_updates = 0;   // wide screened passes: rows re-evaluated exactly / rows that changed
 };
 static KcStats g_kc_stats;
 
@@ -432,6 +434,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
         P.m = m = mp;
     }
     P.vecw = row_vecw<T>(P.X, m, false);
+    const int nblk0 = nblk;   // (the partial buffers hold two arrays of this many entries)
     if (P.vecw == 0 && wide_ok<T>(P.X, P.X, m, false)) P.nblk = nblk = std::min(nblk, wide_grid(n));
     KcPartial* part = dPart.as<KcPartial>();
     const bool screen = sizeof(T) == 8 && mid == M_EUCLIDEAN && P.vecw > 0 && n >= 65536 && K > 8;
@@ -529,6 +532,74 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                     MSM_KSC(1) MSM_KSC(2) MSM_KSC(3) MSM_KSC(4) MSM_KSC(5) MSM_KSC(6) MSM_KSC(7) MSM_KSC(8)
 #undef MSM_KSC
                 }
+            }
+        }
+    } else if (mid == M_EUCLIDEAN && n >= 65536 && K > 8 && m <= 4096 && (size_t)m * sizeof(T) > 64 &&
+               !(getenv("MSM_KC_WSCREEN") && atoi(getenv("MSM_KC_WSCREEN")) == 0)) {   // (read per fit: the tests' A/B switch)
+        // Round 6: everything the register-resident screen above does not take -- float32 rows of any length, float64 rows of
+        // more than 16 features -- is screened on a FEATURE-major byte copy (distance_wscreen_dev.h): a few plain passes
+        // (most rows still change), then m + 8 bytes per row and pass instead of m sizeof(T) + 16.  Bit-identical results.
+        constexpr int KWS_PROBE = 4;
+        KscBufs& B = ksc_bufs();
+        const int nb4 = (int)((m + 3) / 4);
+        msm_idx_t it = 0;
+        for (; it < K && it < KWS_PROBE; ++it) {
+            P.it = (int)it;
+            P.prev = part + (size_t)((it + 1) & 1) * nblk;
+            P.next = part + (size_t)(it & 1) * nblk;
+            launch_kc<T>(mid, nblk, P);
+        }
+        if (it < K) {
+            const size_t qbytes = (size_t)nb4 * n * sizeof(unsigned);
+            if ((rc = B.xf.reserve(qbytes + (size_t)n * sizeof(float) + (size_t)n * sizeof(unsigned short) + 64))) return rc;
+            if ((rc = B.misc.reserve(64 + (size_t)m * sizeof(double)))) return rc;   // [gmax2 | stats[2] | ... | c0[m]]
+            MSM_HIP_CHECK(hipMemsetAsync(B.misc.p, 0, 64, stream()));
+            KwsArgs S;
+            memset(&S, 0, sizeof(S));
+            S.X = P.X;
+            S.q = B.xf.as<unsigned>();
+            S.curf = reinterpret_cast<float*>(static_cast<char*>(B.xf.p) + qbytes);
+            S.sf = reinterpret_cast<unsigned short*>(static_cast<char*>(B.xf.p) + qbytes + (size_t)n * sizeof(float));
+            S.gmax2 = B.misc.as<unsigned long long>();
+            const bool want_stats = getenv("MSM_KC_STATS") && atoi(getenv("MSM_KC_STATS")) == 1;   // diagnostics (scripts/kcwide.py)
+            S.stats = want_stats ? S.gmax2 + 1 : nullptr;   // (every candidate lane adds to ONE word: tens of thousands of atomics per pass)
+            S.c0 = reinterpret_cast<double*>(static_cast<char*>(B.misc.p) + 64);
+            S.n = n;
+            S.m = m;
+            S.nb4 = nb4;
+            S.nblk = nblk;
+            S.dist = P.dist;
+            S.labels = P.labels;
+            S.ids = P.ids;
+            hipLaunchKernelGGL(kws_origin_kernel<T>, dim3(1), dim3(256), 0, stream(), static_cast<const T*>(P.X), P.ids, (long long)m,
+                               const_cast<double*>(S.c0), S.gmax2);
+            const int crows = std::max(1, std::min(KWS_CROWS, KWS_CWORDS / (nb4 + 1)));   // rows a workgroup transposes at a time
+            const int gconv = (int)std::min<long long>(ceil_div(n, crows), 16LL * num_cus());
+            hipLaunchKernelGGL(kws_convert_kernel<T>, dim3(gconv), dim3(DT), (size_t)m * sizeof(double), stream(), S, crows);
+            MSM_HIP_CHECK(hipGetLastError());
+            g_kc_stats.plain_passes = it;
+            g_kc_stats.screened_passes = K - it;
+            g_kc_stats.screen_row_bytes = (long long)(4 * nb4 + 2 + 4);   // byte planes + scale + rounded-up distance
+            const size_t lds = (size_t)4 * nb4 * sizeof(float) + (size_t)m * sizeof(T);
+            const int kr = nb4 <= 4 ? 8 : nb4 <= 16 ? 4 : 2;   // rows per thread (x 4 / 8 / 16 planes per trip: distance_wscreen_dev.h)
+            const int gpass = (int)std::min<long long>(ceil_div(n, (long long)kr * DT), nblk0);
+            // (the screened passes write `gpass` partials into arrays `nblk0` apart; the plain passes before them wrote `nblk`
+            //  partials `nblk` apart: the first screened pass reads those)
+            for (; it < K; ++it) {
+                S.it = (int)it;
+                S.prev = it == KWS_PROBE ? part + (size_t)((it + 1) & 1) * nblk : part + (size_t)((it + 1) & 1) * nblk0;
+                S.next = part + (size_t)(it & 1) * nblk0;
+                S.nblk = it == KWS_PROBE ? nblk : gpass;
+                if (kr == 8) hipLaunchKernelGGL((kcenters_wscreen_pass_kernel<T, 8, 4>), dim3(gpass), dim3(DT), lds, stream(), S);
+                else if (kr == 4) hipLaunchKernelGGL((kcenters_wscreen_pass_kernel<T, 4, 8>), dim3(gpass), dim3(DT), lds, stream(), S);
+                else hipLaunchKernelGGL((kcenters_wscreen_pass_kernel<T, 2, 24>), dim3(gpass), dim3(DT), lds, stream(), S);
+            }
+            if (want_stats) {   // one more round trip
+                unsigned long long hs[2] = {0, 0};
+                MSM_HIP_CHECK(hipMemcpyAsync(hs, S.stats, sizeof(hs), hipMemcpyDeviceToHost, stream()));
+                MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                g_kc_stats.wide_candidates = (long long)hs[0];
+                g_kc_stats.wide_updates = (long long)hs[1];
             }
         }
     } else
@@ -1162,6 +1233,14 @@ int msm_kcenters_last_stats(msm_idx_t* out5)
     out5[2] = g_kc_stats.screened_passes;
     out5[3] = g_kc_stats.plain_row_bytes;
     out5[4] = g_kc_stats.screen_row_bytes;
+    return MSM_OK;
+}
+
+int msm_kcenters_last_wide_stats(msm_idx_t* out2)
+{
+    if (!out2) return fail(MSM_ERR_INVALID, "msm_kcenters_last_wide_stats: null pointer");
+    out2[0] = g_kc_stats.wide_candidates;
+    out2[1] = g_kc_stats.wide_updates;
     return MSM_OK;
 }
 
