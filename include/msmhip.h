@@ -176,6 +176,10 @@ int msm_tica_last_folded(msm_tica_t* h, int* flag);
  * (tica.py:402-422 in one streamed pass + a column-sum pass).  Bit-identical accumulators to the packed-image pipeline on such
  * input, half its fabric traffic, no image ring -- and measured slower, hence not the default. */
 int msm_tica_last_img_fused(msm_tica_t* h, int* flag);
+/* 1 when the most recent accumulation launch of a bf16 / bf16x2 handle packed its later super-chunks of the image INSIDE the
+ * multiply kernel (round 6, the carried pack: whole 256-feature panels, 16-byte aligned rows, more than one super-chunk;
+ * MSM_TICA_IMG_CARRY=0 disables): the packets, and hence the accumulators, are the pre-pass kernel's bit for bit. */
+int msm_tica_last_img_carried(msm_tica_t* h, int* flag);
 /* profiling: {shader-clock start, end, 100 MHz wall-clock start, end} of workgroup 0 of that launch */
 int msm_tica_debug_clocks(msm_tica_t* h, long long* out4);
 /* profiling builds (csrc built with -DMSM_TICA_PROFILE) only: out64[8 + 8*slot + i] = shader cycles wave 0 of

@@ -92,6 +92,7 @@ def _declare(lib):
     f("msm_tica_project_host_list", C.c_int, C.POINTER(_p), _i64p, _i64, C.c_int, _i64, _p, _p, _i64, _p, C.c_int)
     f("msm_tica_last_folded", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_last_img_fused", C.c_int, _p, C.POINTER(C.c_int))
+    f("msm_tica_last_img_carried", C.c_int, _p, C.POINTER(C.c_int))
     f("msm_tica_allreduce", C.c_int, _p)
     f("msm_tica_counts", C.c_int, _p, _i64p, _i64p)
     f("msm_comm_rccl_available", C.c_int)

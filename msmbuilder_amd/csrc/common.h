@@ -52,7 +52,7 @@ struct DevBuf {
 DevBuf& pool(int slot);
 enum PoolSlot { PS_X = 0, PS_Y, PS_IDX, PS_LAB, PS_MIN, PS_PART, PS_OUT, PS_IDS, PS_SUM, PS_PAR, PS_W, PS_S, PS_PADX, PS_PADY, PS_COUNT };
 
-// runtime.hip: the bf16 image path's process-lifetime ring (nullptr + msm_last_error on failure); MSM_TICA_IMG_RING_MB, 1 GB
+// runtime.hip: the bf16 image path's process-lifetime ring (nullptr + msm_last_error on failure); MSM_TICA_IMG_RING_MB, 2 GB
 struct ImgRing {
     char* p = nullptr;
     size_t bytes = 0;

@@ -279,7 +279,7 @@ ImgRing* img_ring()
     if (P) return P;
     ImgRing* q = new ImgRing();
     const char* e = getenv("MSM_TICA_IMG_RING_MB");
-    size_t mb = e ? (size_t)atoll(e) : 1024;
+    size_t mb = e ? (size_t)atoll(e) : 2048;   // (round 6: two halves of 1 GB, the carried pack fills one while the other is multiplied)
     if (mb < 64) mb = 64;
     if (mb > 65536) mb = 65536;
     q->bytes = mb << 20;

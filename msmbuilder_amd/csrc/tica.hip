@@ -66,7 +66,9 @@ struct msm_tica {
     bool slabs_dirty = false;   // slabs_sym hold something since the last reset (a rejected folded launch must be able to undo itself)
     DevBuf snap;                // ... from this copy
     DevBuf foldimg;             // bf16 image path: [nchunks][F] per-chunk sums of the left frames
-    DevBuf imgsteps;            // fused bf16 kernel: the launch's K-step records (tica_img_steps_kernel)
+    DevBuf imgsteps;            // fused bf16 kernel / carried pack: the launch's K-step records (tica_img_steps_kernel)
+    DevBuf colsteps;            // carried pack: [pack steps of a super-chunk][Fp] fp64 column sums of the left frames
+    int last_carried = 0;       // the last accumulate packed its later super-chunks inside the multiply (msm_tica_last_img_carried)
     int last_fused = 0;         // the last accumulate ran the fused kernel (msm_tica_last_img_fused)
     long long n_sh = 0, nw_sh = 0;  // shifted pairs, and the total weight of their Gram terms (2 n_sh for whole trajectories)
     long long n_obs = 0, n_seq = 0;
@@ -104,6 +106,7 @@ constexpr size_t LDS32 = 2 * 2 * BK32 * TM * sizeof(float);  // 64 KiB
 constexpr size_t LDSSYM = 4 * BK32 * TM * sizeof(float) + 2 * TM * sizeof(float);  // 64 KiB: the (u, d) images for columns I and J, + 1 KiB: the shift row
 constexpr int IMG_LAG = 1;                                    // tica_img_pp_kernel: load batches left in flight (tica_img_dev.h)
 constexpr size_t IMG_PP_LDS = (size_t)(3 + IMG_LAG) * IMG_SLOT;  // 128 KiB: a ring of four K-steps
+constexpr size_t IMG_PP_CARRY_LDS = IMG_PP_LDS + 4 * 8192;       // + the carrier waves' private 8 KiB each: all 160 KiB
 constexpr size_t LDS64 = 2 * 2 * BK64 * P64 * sizeof(double);  // 72 KiB (double-buffered, pitch 144)
 
 int tica_zero(msm_tica* h)
@@ -548,7 +551,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         int rc = h->imgsteps.reserve((size_t)nsteps * sizeof(ImgStep));
         if (rc) return rc;
         if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
-        hipLaunchKernelGGL(tica_img_steps_kernel, dim3((unsigned)P.nchunks), dim3(64), 0, stream(), P.chunks, (long long)ld, h->lag, x2 ? 1 : 0,
+        hipLaunchKernelGGL(tica_img_steps_kernel, dim3((unsigned)P.nchunks), dim3(64), 0, stream(), P.chunks, (long long)ld * 2, h->lag, x2 ? 1 : 0,
                            h->imgsteps.as<ImgStep>());
         MSM_HIP_CHECK(hipGetLastError());
         ImgFusedArgs FA;
@@ -585,54 +588,122 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         if (!ring) return MSM_ERR_HIP;
         const int nimg = x2 ? 4 : 2;
         const size_t gbytes = (size_t)Fp * 16;                                  // one 8-pair group of ONE image
-        long long slot_groups = (long long)(ring->bytes / (gbytes * nimg));
-        slot_groups -= slot_groups % 4;
         const long long max_chunk_groups = ceil_div(kc, 32) * 4;
+        const std::vector<TicaChunk>& tab = img_tab;
+        // Round 6, the CARRIED pack (tica_img_dev.h): the multiply of super-chunk k packs super-chunk k + 1 into the other
+        // half of the ring in its load role; only the first (short) super-chunk takes the pre-pass kernel.  Whole 256-feature
+        // panels of 16-byte aligned rows, launches of more than one super-chunk, and few enough items per multiply step: a
+        // workgroup starts a quad of items in one multiply step and converts it in the next, so rho = (quads per pack step) /
+        // (units x multiply steps per pack step) is the share of its steps that carry when two consecutive super-chunks are
+        // equally long -- beyond ~0.9 the drain loop would do the packing with the matrix pipes idle (float32 rows of 256
+        // features in mode bf16).  MSM_TICA_IMG_CARRY=0 restores pack / multiply turns.
+        // Default from 1,024 features, where it wins with the folded column sums (scripts/carryabl.py, profiles/r06_carry.txt:
+        // fit of 1M x 2048 bfloat16 rows 11.1 -> 10.5 ms, bf16x2 32.8 -> 28.8 ms; 768 features 7.15 -> 7.31 ms: the items' fp64
+        // column sums cost what the overlap saves); MSM_TICA_IMG_CARRY=1 forces it at any width it can run.
+        bool carry = h->F % 256 == 0 && ((long long)ld * dtype_bytes) % 16 == 0 && h->ntile2 <= h->img_grid;
+        bool prepass_all = false;   // MSM_TICA_IMG_CARRY=2 (A/B switch of the tests): the carried pack's super-chunks and ring halves, every one packed by the pre-pass kernel
+        {
+            const char* ce = getenv("MSM_TICA_IMG_CARRY");
+            if (ce && atoi(ce) == 0) carry = false;
+            if (!ce && h->F < 1024) carry = false;
+            if (ce && atoi(ce) == 2) prepass_all = true;
+            for (size_t c = 0; c < tab.size() && carry; ++c)
+                if (((uintptr_t)tab[c].base) & 15) carry = false;
+        }
+        const int cy_nb = Fp / (dtype_bytes == 2 ? 64 : 32);
+        const double rho = 1.0 * cy_nb / (4.0 * h->ntile2 * (x2 ? 2 : 1));
+        if (rho > 0.9) carry = false;
+        long long slot_groups = (long long)((carry ? ring->bytes / 2 : ring->bytes) / (gbytes * nimg));
+        slot_groups -= slot_groups % 4;
+        if (carry && (slot_groups < 2 * max_chunk_groups || img_groups <= 2 * max_chunk_groups)) {   // (nothing to take turns with)
+            carry = false;
+            slot_groups = (long long)(ring->bytes / (gbytes * nimg));
+            slot_groups -= slot_groups % 4;
+        }
         if (slot_groups < max_chunk_groups)
             return fail(MSM_ERR_INVALID, "bf16 image ring too small for %d features (MSM_TICA_IMG_RING_MB)", h->F);
-        const size_t one = (size_t)slot_groups * gbytes;                        // bytes of one image inside the ring
-        if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
-        const std::vector<TicaChunk>& tab = img_tab;
-        for (size_t c0 = 0; c0 < tab.size() && img_groups > 0;) {
-            // chunks [c0, c1): as many as fit the ring
-            const long long g_start = tab[c0].g0;
-            size_t c1 = c0;
-            long long g_end = g_start;
-            while (c1 < tab.size()) {
-                const long long ge = c1 + 1 < tab.size() ? tab[c1 + 1].g0 : img_groups;
-                if (ge - g_start > slot_groups) break;
-                g_end = ge;
-                ++c1;
+        const size_t one = (size_t)slot_groups * gbytes;                        // bytes of one image inside the ring (half)
+        // super-chunks: whole chunks, as many as a slot holds; carried: the first one short (its pre-pass is the only one
+        // the matrix pipes wait for) but long enough to carry the second, and at most an eighth of the launch each so that
+        // short launches overlap as well
+        struct SuperChunk { size_t c0, c1; long long g0, g1; };
+        std::vector<SuperChunk> scs;
+        {
+            long long cap = slot_groups;
+            if (carry) {
+                long long want = ceil_div(ceil_div(img_groups, 8), 4) * 4;
+                want = std::max<long long>(want, 4 * max_chunk_groups);
+                cap = std::min(cap, want);
             }
-            ImgArgs IA;
-            memset(&IA, 0, sizeof(IA));
-            IA.chunks = P.chunks + c0;
-            IA.nchunks = (long long)(c1 - c0);
-            IA.ld = ld;
-            IA.F = h->F;
-            IA.Fp = Fp;
-            IA.lag = h->lag;
-            IA.dtype_bytes = dtype_bytes;
-            IA.shift = P.shift;
-            IA.colA = fold ? h->foldimg.as<double>() + c0 * (size_t)h->F : nullptr;
-            IA.g_off = g_start;
-            IA.u_hi = reinterpret_cast<bf16x8*>(ring->p);
-            IA.d_hi = reinterpret_cast<bf16x8*>(ring->p + one);
-            IA.u_mid = x2 ? reinterpret_cast<bf16x8*>(ring->p + 2 * one) : nullptr;
-            IA.d_mid = x2 ? reinterpret_cast<bf16x8*>(ring->p + 3 * one) : nullptr;
-            const dim3 g1((unsigned)(c1 - c0), (unsigned)h->T2);
-            if (x2)
-                hipLaunchKernelGGL(tica_img_kernel<true>, g1, dim3(256), 0, stream(), IA);
-            else
-                hipLaunchKernelGGL(tica_img_kernel<false>, g1, dim3(256), 0, stream(), IA);
+            const long long first_cap = carry ? std::max<long long>(max_chunk_groups, (long long)(cap * std::max(0.25, std::min(1.0, 1.15 * rho)))) : cap;
+            for (size_t c0 = 0; c0 < tab.size() && img_groups > 0;) {
+                const long long lim = (carry && scs.empty()) ? first_cap : cap;
+                SuperChunk sc;
+                sc.c0 = c0;
+                sc.g0 = tab[c0].g0;
+                sc.c1 = c0;
+                sc.g1 = sc.g0;
+                while (sc.c1 < tab.size()) {
+                    const long long ge = sc.c1 + 1 < tab.size() ? tab[sc.c1 + 1].g0 : img_groups;
+                    if (ge - sc.g0 > lim && sc.c1 > c0) break;
+                    if (ge - sc.g0 > slot_groups) break;
+                    sc.g1 = ge;
+                    ++sc.c1;
+                }
+                scs.push_back(sc);
+                c0 = sc.c1;
+            }
+            if (scs.size() < 2) carry = false;
+        }
+        if (h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));
+        if (carry) {
+            // the launch's 32-pair step records (the table the fused kernel uses, with this launch's row size)
+            int rc = h->imgsteps.reserve((size_t)(img_groups / 4) * sizeof(ImgStep));
+            if (rc) return rc;
+            hipLaunchKernelGGL(tica_img_steps_kernel, dim3((unsigned)P.nchunks), dim3(64), 0, stream(), P.chunks, (long long)ld * dtype_bytes, h->lag, 0,
+                               h->imgsteps.as<ImgStep>());
             MSM_HIP_CHECK(hipGetLastError());
+            if (fold) {
+                long long np_max = 0;
+                for (const SuperChunk& sc : scs) np_max = std::max(np_max, (sc.g1 - sc.g0) / 4);
+                if ((rc = h->colsteps.reserve((size_t)np_max * Fp * sizeof(double)))) return rc;
+            }
+        }
+        h->last_carried = 0;
+        for (size_t k = 0; k < scs.size(); ++k) {
+            const SuperChunk& sc = scs[k];
+            char* const half = ring->p + ((carry && (k & 1)) ? ring->bytes / 2 : 0);
+            if (!carry || k == 0 || prepass_all) {
+                ImgArgs IA;
+                memset(&IA, 0, sizeof(IA));
+                IA.chunks = P.chunks + sc.c0;
+                IA.nchunks = (long long)(sc.c1 - sc.c0);
+                IA.ld = ld;
+                IA.F = h->F;
+                IA.Fp = Fp;
+                IA.lag = h->lag;
+                IA.dtype_bytes = dtype_bytes;
+                IA.shift = P.shift;
+                IA.colA = fold ? h->foldimg.as<double>() + sc.c0 * (size_t)h->F : nullptr;
+                IA.g_off = sc.g0;
+                IA.u_hi = reinterpret_cast<bf16x8*>(half);
+                IA.d_hi = reinterpret_cast<bf16x8*>(half + one);
+                IA.u_mid = x2 ? reinterpret_cast<bf16x8*>(half + 2 * one) : nullptr;
+                IA.d_mid = x2 ? reinterpret_cast<bf16x8*>(half + 3 * one) : nullptr;
+                const dim3 g1((unsigned)(sc.c1 - sc.c0), (unsigned)h->T2);
+                if (x2)
+                    hipLaunchKernelGGL(tica_img_kernel<true>, g1, dim3(256), 0, stream(), IA);
+                else
+                    hipLaunchKernelGGL(tica_img_kernel<false>, g1, dim3(256), 0, stream(), IA);
+                MSM_HIP_CHECK(hipGetLastError());
+            }
             ImgMfmaArgs MA;
             memset(&MA, 0, sizeof(MA));
-            MA.u_hi = IA.u_hi;
-            MA.d_hi = IA.d_hi;
-            MA.u_mid = IA.u_mid;
-            MA.d_mid = IA.d_mid;
-            MA.nsteps = x2 ? (g_end - g_start) / 2 : (g_end - g_start) / 4;
+            MA.u_hi = reinterpret_cast<bf16x8*>(half);
+            MA.d_hi = reinterpret_cast<bf16x8*>(half + one);
+            MA.u_mid = x2 ? reinterpret_cast<bf16x8*>(half + 2 * one) : nullptr;
+            MA.d_mid = x2 ? reinterpret_cast<bf16x8*>(half + 3 * one) : nullptr;
+            MA.nsteps = x2 ? (sc.g1 - sc.g0) / 2 : (sc.g1 - sc.g0) / 4;
             MA.Fp = Fp;
             MA.T = h->T;
             MA.T2 = h->T2;
@@ -644,12 +715,52 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             // fp32 kernels' before the merge costs accuracy that matters (stated tolerance of the mode: 1e-3)
             MA.kflush_steps = std::max(1, x2 ? P.kflush / 16 : 8 * P.kflush / 32);
             MA.slabs = h->slabs_sym;
-            if (x2)
-                hipLaunchKernelGGL((tica_img_pp_kernel<true, IMG_LAG>), dim3((unsigned)h->img_grid), dim3(IMG_NT), IMG_PP_LDS, stream(), MA);
-            else
-                hipLaunchKernelGGL((tica_img_pp_kernel<false, IMG_LAG>), dim3((unsigned)h->img_grid), dim3(IMG_NT), IMG_PP_LDS, stream(), MA);
+            const bool carries = carry && !prepass_all && k + 1 < scs.size();
+            if (carries) {
+                const SuperChunk& nx = scs[k + 1];
+                char* const other = ring->p + ((k & 1) ? 0 : ring->bytes / 2);
+                MA.cy.psteps = h->imgsteps.as<ImgStep>() + nx.g0 / 4;
+                MA.cy.shift = P.shift;
+                MA.cy.u_hi = reinterpret_cast<bf16x8*>(other);
+                MA.cy.d_hi = reinterpret_cast<bf16x8*>(other + one);
+                MA.cy.u_mid = x2 ? reinterpret_cast<bf16x8*>(other + 2 * one) : nullptr;
+                MA.cy.d_mid = x2 ? reinterpret_cast<bf16x8*>(other + 3 * one) : nullptr;
+                MA.cy.colS = fold ? h->colsteps.as<double>() : nullptr;
+                MA.cy.row_bytes = (long long)ld * dtype_bytes;
+                MA.cy.lag_bytes = (long long)h->lag * ld * dtype_bytes;
+                MA.cy.np = (int)((nx.g1 - nx.g0) / 4);
+                MA.cy.nb = cy_nb;
+                // a workgroup's multiply steps / its quads (every workgroup multiplies ~ nsteps x units / grid steps)
+                const long long wsteps = MA.nsteps * h->ntile2 / h->img_grid;
+                const long long wquads = ceil_div(ceil_div((long long)MA.cy.np * cy_nb, 4), h->img_grid);
+                MA.cy.stride = (int)std::max<long long>(1, wsteps / std::max<long long>(1, wquads));
+                {
+                    const char* ae = getenv("MSM_TICA_IMG_CARRY_ABL");   // timing ablations only (tica_img_dev.h, img_carry_phase)
+                    MA.cy.pad = ae ? atoi(ae) : 0;
+                }
+                h->last_carried = 1;
+            }
+#define MSM_IMG_PP_LAUNCH(X2_, CY_) \
+            hipLaunchKernelGGL((tica_img_pp_kernel<X2_, IMG_LAG, false, 0, CY_>), dim3((unsigned)h->img_grid), dim3(IMG_NT), (CY_) ? IMG_PP_CARRY_LDS : IMG_PP_LDS, stream(), MA)
+            if (!carries) {
+                if (x2) MSM_IMG_PP_LAUNCH(true, 0);
+                else MSM_IMG_PP_LAUNCH(false, 0);
+            } else if (dtype_bytes == 2) {
+                if (x2) MSM_IMG_PP_LAUNCH(true, 2);
+                else MSM_IMG_PP_LAUNCH(false, 2);
+            } else {
+                if (x2) MSM_IMG_PP_LAUNCH(true, 4);
+                else MSM_IMG_PP_LAUNCH(false, 4);
+            }
+#undef MSM_IMG_PP_LAUNCH
             MSM_HIP_CHECK(hipGetLastError());
-            c0 = c1;
+            if (carries && fold) {
+                const SuperChunk& nx = scs[k + 1];
+                hipLaunchKernelGGL(tica_img_colsum_steps_kernel, dim3((unsigned)(nx.c1 - nx.c0), (unsigned)ceil_div(h->F, 256)), dim3(256), 0, stream(),
+                                   P.chunks + nx.c0, (long long)(nx.c1 - nx.c0), nx.g0, nx.g1, h->colsteps.as<double>(), h->F, Fp,
+                                   h->foldimg.as<double>() + nx.c0 * (size_t)h->F);
+                MSM_HIP_CHECK(hipGetLastError());
+            }
         }
     } else if (usesymw) {
         SymwArgs WA;
@@ -919,6 +1030,14 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_LDS));
             MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<true, IMG_LAG>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<false, IMG_LAG, false, 0, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_CARRY_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<true, IMG_LAG, false, 0, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_CARRY_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<false, IMG_LAG, false, 0, 4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_CARRY_LDS));
+            MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_pp_kernel<true, IMG_LAG, false, 0, 4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_PP_CARRY_LDS));
             MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_fused_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_FUSED_LDS));
             MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_img_fused_kernel<true>),
@@ -1170,6 +1289,13 @@ int msm_tica_last_folded(msm_tica_t* h, int* flag)
 {
     if (!h || !flag) return fail(MSM_ERR_STATE, "null argument");
     *flag = h->last_folded ? 1 : 0;
+    return MSM_OK;
+}
+
+int msm_tica_last_img_carried(msm_tica_t* h, int* flag)
+{
+    if (!h || !flag) return fail(MSM_ERR_INVALID, "msm_tica_last_img_carried: null argument");
+    *flag = h->last_carried;
     return MSM_OK;
 }
 

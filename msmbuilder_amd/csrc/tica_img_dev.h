@@ -28,10 +28,35 @@ namespace msm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float img_f32x16 __attribute__((ext_vector_type(16)));
 typedef float img_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned img_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int IMG_TM = 128;                       // slab sub-tile (the sum/difference slab layout of tica.hip)
 constexpr int IMG_NT = 512;                       // 8 waves: 4 (rows) x 2 (columns), each 64 x 128 outputs
 constexpr int IMG_SLOT = 2 * 4 * 256 * 16;        // one K-step in LDS: [A, B][4 packet rows][256 features] 16-byte packets = 32 KiB
+
+// a K-step of raw rows (fused kernel, carried pack): where its first pair's x_t row is and how many of its pairs exist
+struct ImgStep {
+    const void* rowa;   // x_t row of the step's first pair (trajectory-relative)
+    int nvalid;         // pairs of this step that exist (0 .. pairs per step); the rest are zero packets
+    int pad;
+};
+
+// Round 6: the CARRIED pack (see img_carry_* below): what the multiply of super-chunk k packs for super-chunk k + 1
+struct ImgCarry {
+    const ImgStep* psteps;   // [np] 32-pair pack steps of the carried super-chunk
+    const float* shift;      // [F] reference row r, or nullptr
+    bf16x8* u_hi;            // [4 np][Fp] packets: the carried super-chunk's images (the OTHER half of the ring)
+    bf16x8* d_hi;
+    bf16x8* u_mid;           // bf16x2 only
+    bf16x8* d_mid;
+    double* colS;            // [np][Fp] fp64 sums of each step's left frames (folded column sums), or nullptr
+    long long row_bytes;     // ld * sizeof(element)
+    long long lag_bytes;     // lag * row_bytes
+    int np;                  // pack steps to carry; 0: nothing
+    int nb;                  // items per step: Fp / 64 (bfloat16 rows) or Fp / 32 (float32 rows)
+    int stride;              // K-steps of the multiply between two item quads of a workgroup (>= 2)
+    int pad;
+};
 
 struct ImgMfmaArgs {
     const bf16x8* u_hi;
@@ -43,6 +68,7 @@ struct ImgMfmaArgs {
     int main_steps;    // ping-pong kernel: K-steps of each full cohort (see img_main_steps); the remainder cohort takes the rest
     double* slabs;     // sum/difference layout: [(S + 1) * ntiles_sym][2][TM * TM]
     long long wrap;    // micro-benchmark only (WRAP kernels): K-step s is READ from step s % wrap -- a cache-resident image
+    ImgCarry cy;       // CARRY kernels only
 };
 
 // persistent block id -> XCD-contiguous linear id (blocks land on XCD blockIdx % 8); bijective for any grid
@@ -109,6 +135,206 @@ __device__ __forceinline__ void img_flush(img_f32x16 (&acc)[2][4], const ImgMfma
             for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
 }
 
+
+// =====================================================================================================================
+// Round 6: the CARRIED pack (VERDICT r5 #3b).
+//
+// The packing pre-pass (tica_img_kernel, tica_img_pack_dev.h) is HBM-bound and ran serialised in front of every multiply:
+// 8 x 0.58 ms of a 12.1 ms fit of 1M x 2048, with the matrix pipes idle (running it beside the multiply on other CUs was
+// measured slower in round 5: it needs the whole chip's memory pipelines).  But the pack is little work per MULTIPLY step:
+// a super-chunk of N pairs is packed once and multiplied by U = 72 units, i.e. a workgroup that multiplies a K-step would
+// have to pack 1/18 of a K-step's worth of rows beside it.  So the multiply of super-chunk k packs super-chunk k + 1 into
+// the other half of the ring, in the load role of waves 4-7 (the role that already issues the LDS-DMA loads and reads the
+// fragments beside the partner wave's MFMAs); only the first super-chunk of a launch still takes the pre-pass kernel.
+//
+//   * An ITEM = one 32-pair pack step x one 128-byte column block (64 bfloat16 / 32 float32 features): 64 row pieces, the
+//     step's x_t rows and its x_{t+tau} rows, brought into a wave-private 8 KiB of LDS by 8 LDS-DMA instructions (8 lanes per
+//     piece; a padding pair re-reads the step's last valid pair).  One load phase later (the wave's own vmcnt wait at the
+//     end of its MFMA phase covers the pieces: they are older than that phase's image loads) lane (c, g) reads features
+//     NF c .. NF c + NF - 1 of pairs 8 g .. 8 g + 7 (ds_read_b64; rows of odd g sit at the neighbouring position, so the two
+//     g of a lane group use different bank halves), forms u and d with tica_img_kernel's arithmetic -- the packets are the
+//     pre-pass kernel's bit for bit -- writes them XOR-swizzled into the same 8 KiB and stores them as 1 KiB-contiguous
+//     wave stores.  The step's fp64 column sums of the left frames (the folded sums) are reduced over the four g by
+//     shuffles and stored per (step, feature); tica_img_colsum_steps_kernel adds a chunk's steps afterwards.
+//   * The four carrier waves take the four items of a QUAD in the same phases; workgroup p (XCD-linear) takes quads p,
+//     p + G, ...: `stride` multiply steps apart, and whatever is left when its segments end is packed in a drain loop, so
+//     every item is packed whatever the step counts are.
+//   * LDS: the ring's 128 KiB + 4 x 8 KiB = all 160 KiB (LDS-DMA reaches every byte of it: scripts/micro/lds_dma_high.hip).
+// =====================================================================================================================
+struct ImgCarryState {
+    int next;      // next pack step of this workgroup's column blocks
+    int pending;   // pack step whose pieces are in the private areas (-1: none)
+    int wait;      // multiply steps until the next quad may be issued
+    int step;      // distance between this workgroup's pack steps: the workgroups that share its column blocks
+    int blk;       // this wave's column block (constant: the lane's reference-row entries stay in registers)
+};
+// Order inside the carrier's load phase: the carried operations AHEAD of the step's image loads, the item converted one
+// multiply step after its pieces were issued (the wave's plain end-of-phase wait, vmcnt in order, covers them).  The other
+// order was built and measured -- pieces and stores BEHIND the image loads, two end-of-phase waits with an allowance for
+// them, conversion three steps later, so that no wait ever stands on an HBM read: 1M x 2048 bfloat16 rows 12.3 -> 12.9 ms
+// against 9.5 -> 10.1 ms for this order (scripts/carryabl.py, profiles/r06_carry.txt): what the carried pack costs is
+// not the latency of its pieces but its instructions, which a load-role wave issues in the gaps of its partner's MFMAs,
+// and its 12 GB of traffic beside the multiply's image loads.
+
+template <int ESZ>
+__device__ __forceinline__ void img_carry_issue(const ImgCarry& C, char* priv, int ps, int blk)
+{
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));   // (the lane's offsets are computed HERE, per item: hoisted out of the K loop they are 30 registers spilled for its whole length)
+    typedef const __attribute__((address_space(4))) ImgStep* step_cptr;
+    const step_cptr dp = (step_cptr)(uintptr_t)(C.psteps + ps);
+    const unsigned long long rowa = (unsigned long long)(uintptr_t)dp->rowa;
+    const int last = dp->nvalid - 1;   // >= 0: a pack step holds at least one pair
+    const unsigned coloff = (unsigned)blk * 128u + (unsigned)(lane & 7) * 16u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // LDS position 8 j + (lane >> 3) of [x_t rows | x_{t+tau} rows] holds pair (position ^ bit 3 of it)
+        int pr = (8 * j + (lane >> 3)) & 31;
+        pr ^= (pr >> 3) & 1;
+        const int pe = pr < last ? pr : last;
+        const unsigned long long ga = rowa + (unsigned long long)(unsigned)pe * (unsigned long long)C.row_bytes +
+                                      (j >= 4 ? (unsigned long long)C.lag_bytes : 0ull) + coloff;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(global_ptr<char>)ga,
+                                         (__attribute__((address_space(3))) void*)(priv + j * 1024), 16, 0, 0);
+    }
+}
+
+template <bool X2, int ESZ>
+struct ImgCarryGeom {
+    static constexpr int NF = ESZ == 2 ? 4 : 2;      // features per lane
+    static constexpr int W = 16 * NF;                // features per item
+    static constexpr int RB = W * 16;                // bytes of one 8-pair group of one image: W packets
+    static constexpr int IMGB = 4 * RB;              // ... of the item's four groups
+    static constexpr int NSETS = (X2 && ESZ == 2) ? 2 : 1;   // bf16x2 on bfloat16 rows: four images of 4 KiB: u images, then d images
+    static constexpr int NI = X2 ? (ESZ == 2 ? 2 : 4) : 2;   // images per set
+};
+
+template <bool X2, int ESZ, bool TAIL>
+__device__ __forceinline__ void img_carry_convert_body(const ImgCarry& C, char* priv, int ps, int blk, int nvalid, int Fp, const float (&r)[4])
+{
+    typedef ImgCarryGeom<X2, ESZ> GM;
+    constexpr int NF = GM::NF, W = GM::W, RB = GM::RB, IMGB = GM::IMGB, NSETS = GM::NSETS, NI = GM::NI;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));   // (see img_carry_issue)
+    const int c = lane & 15, g = lane >> 4;
+    img_u32x2 ra[8], rb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int pos = 8 * g + (e ^ (g & 1));
+        ra[e] = *reinterpret_cast<const img_u32x2*>(priv + pos * 128 + 8 * c);
+        rb[e] = *reinterpret_cast<const img_u32x2*>(priv + 4096 + pos * 128 + 8 * c);
+    }
+    auto raw = [&](const img_u32x2& w, int q) -> float {
+        if (ESZ == 4) return __uint_as_float(q == 0 ? w.x : w.y);
+        const unsigned v = q < 2 ? w.x : w.y;
+        return (q & 1) ? __uint_as_float(v & 0xffff0000u) : __uint_as_float(v << 16);
+    };
+    // the folded column sums: fp64 sums of the left frames (raw values), over the lane's 8 pairs, then over the four g
+    double cs[NF];
+    if (C.colS) {
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+            cs[q] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double v = (double)raw(ra[e], q);
+                cs[q] += (!TAIL || 8 * g + e < nvalid) ? v : 0.0;
+            }
+            cs[q] += __shfl_xor(cs[q], 16, 64);
+            cs[q] += __shfl_xor(cs[q], 32, 64);
+        }
+    }
+    // packets, written XOR-swizzled (conflict-free ds_write_b128 and read-back), tica_img_kernel's arithmetic
+    auto swz = [&](int sl) -> int { return NF == 4 ? (sl ^ ((sl >> 3) & 7)) : (sl ^ ((sl >> 3) & 1)); };
+#pragma unroll
+    for (int set = 0; set < NSETS; ++set) {
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+            bf16x8 uh, dh, um, dm;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = !TAIL || 8 * g + e < nvalid;
+                const float a = raw(ra[e], q), b = raw(rb[e], q);
+                float u, d;
+                if (ESZ == 2) {
+                    u = ok ? (a + b) - 2.f * r[q] : 0.f;
+                    d = ok ? a - b : 0.f;
+                } else {
+                    const float ya = ok ? a - r[q] : 0.f, yb = ok ? b - r[q] : 0.f;
+                    u = ya + yb;
+                    d = ya - yb;
+                }
+                const __bf16 u1 = (__bf16)u, d1 = (__bf16)d;
+                uh[e] = u1;
+                dh[e] = d1;
+                if (X2) {
+                    um[e] = (__bf16)(u - (float)u1);
+                    dm[e] = (__bf16)(d - (float)d1);
+                }
+            }
+            char* w = priv + g * RB + swz(NF * c + q) * 16;
+            if (!X2) {
+                *reinterpret_cast<bf16x8*>(w) = uh;
+                *reinterpret_cast<bf16x8*>(w + IMGB) = dh;
+            } else if (ESZ == 4) {
+                *reinterpret_cast<bf16x8*>(w) = uh;
+                *reinterpret_cast<bf16x8*>(w + IMGB) = dh;
+                *reinterpret_cast<bf16x8*>(w + 2 * IMGB) = um;
+                *reinterpret_cast<bf16x8*>(w + 3 * IMGB) = dm;
+            } else if (set == 0) {
+                *reinterpret_cast<bf16x8*>(w) = uh;
+                *reinterpret_cast<bf16x8*>(w + IMGB) = um;
+            } else {
+                *reinterpret_cast<bf16x8*>(w) = dh;
+                *reinterpret_cast<bf16x8*>(w + IMGB) = dm;
+            }
+        }
+        // read back by packet row, store 1 KiB per wave-instruction
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            bf16x8* img = !X2 ? (i == 0 ? C.u_hi : C.d_hi)
+                        : ESZ == 4 ? (i == 0 ? C.u_hi : i == 1 ? C.d_hi : i == 2 ? C.u_mid : C.d_mid)
+                        : set == 0 ? (i == 0 ? C.u_hi : C.u_mid) : (i == 0 ? C.d_hi : C.d_mid);
+#pragma unroll
+            for (int k = 0; k < IMGB / 1024; ++k) {
+                const int gg = NF == 4 ? k : 2 * k + (lane >> 5);
+                const int sr = NF == 4 ? lane : (lane & 31);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(priv + i * IMGB + gg * RB + swz(sr) * 16);
+                img[(size_t)(4 * (long long)ps + gg) * (size_t)Fp + (size_t)(blk * W + sr)] = v;
+            }
+        }
+    }
+    // one store instruction: the shuffles left all four g with the same sums, lane (c, g) stores the sum of feature NF c + g
+    if (C.colS) {
+        double* dst = C.colS + (size_t)ps * (size_t)Fp + (size_t)(blk * W + NF * c);
+        if (NF == 4) dst[g] = g == 0 ? cs[0] : g == 1 ? cs[1] : g == 2 ? cs[NF - 2] : cs[NF - 1];
+        else if (g < 2) dst[g] = g == 0 ? cs[0] : cs[1];
+    }
+}
+
+// one load phase of a carrier wave, ahead of the step's fragments and image loads: convert the pending item (its pieces were
+// covered by the wave's last end-of-phase wait), then issue the next one when it is due
+template <bool X2, int ESZ>
+__device__ __forceinline__ void img_carry_phase(const ImgCarry& C, ImgCarryState& cs, char* priv, int Fp, const float (&r)[4], bool drain)
+{
+    if (cs.pending >= 0) {
+        typedef const __attribute__((address_space(4))) ImgStep* step_cptr;
+        const int nvalid = ((step_cptr)(uintptr_t)(C.psteps + cs.pending))->nvalid;
+        if (!(C.pad & 2)) {   // (pad: timing ablations of scripts/carryabl.py -- 1 no pieces, 2 no conversion; the results are then wrong)
+            if (__builtin_expect(nvalid >= 32, 1)) img_carry_convert_body<X2, ESZ, false>(C, priv, cs.pending, cs.blk, nvalid, Fp, r);
+            else img_carry_convert_body<X2, ESZ, true>(C, priv, cs.pending, cs.blk, nvalid, Fp, r);
+        }
+        cs.pending = -1;
+    }
+    --cs.wait;
+    if (cs.next < C.np && (drain || cs.wait <= 0)) {
+        if (!(C.pad & 1)) img_carry_issue<ESZ>(C, priv, cs.next, cs.blk);
+        cs.pending = cs.next;
+        cs.next += cs.step;
+        cs.wait = C.stride;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The ping-pong kernel.  Phases are separated by workgroup barriers; K-step s of a cohort's share occupies phases 2n and
 // 2n + 1 (n = s - s0):
@@ -122,8 +348,9 @@ __device__ __forceinline__ void img_flush(img_f32x16 (&acc)[2][4], const ImgMfma
 // LAG = 0: a load has one phase (~600 cycles) to land before its issuer waits for it; LAG = 1: three phases.
 // ---------------------------------------------------------------------------------------------------------------------
 // One SEGMENT of a workgroup's work: K-steps [s0, s1) of one unit, merged into slab row `cohort`.
-template <bool X2, int LAG, bool WRAP, int ABL>
-__device__ __forceinline__ void img_pp_segment(const ImgMfmaArgs& P, char* smem, int unit, int cohort, int s0, int s1)
+template <bool X2, int LAG, bool WRAP, int ABL, int CARRY = 0>   // CARRY: 0, or the element size of the rows the load role packs (2 / 4)
+__device__ __forceinline__ void img_pp_segment(const ImgMfmaArgs& P, char* smem, int unit, int cohort, int s0, int s1,
+                                               ImgCarryState* cst = nullptr, const float (*cr)[4] = nullptr)
 {
     constexpr int D = 2 + LAG, NS = D + 1;
     const int tid = threadIdx.x;
@@ -258,6 +485,8 @@ __device__ __forceinline__ void img_pp_segment(const ImgMfmaArgs& P, char* smem,
     } else {
         if (ABL & 2) frags(0, true);
         for (int s = s0; s < s1; ++s) {
+            // (carried pack first: the fragments' 48 registers are not live beside the item's)
+            if (CARRY) img_carry_phase<X2, CARRY ? CARRY : 2>(P.cy, *cst, smem + NS * IMG_SLOT + wi * 8192, P.Fp, *cr, false);
             frags(slot);                               // phase 2n
             issue(s + D, slot_ld);
             IMG_PP_BARRIER();
@@ -282,21 +511,53 @@ __device__ __forceinline__ void img_pp_segment(const ImgMfmaArgs& P, char* smem,
 // other in the XCD-linear order.  The other R = G % U workgroups (40 of 256 at 2,048 features, which round 3 left idle)
 // form a REMAINDER cohort that takes the rest of the steps in ceil(U / R) rounds of R units (slab row S): with
 // main_steps = rounds x (remainder's steps) every workgroup multiplies for the same time.
-template <bool X2, int LAG, bool WRAP = false, int ABL = 0>   // ABL: micro-benchmark ablations (1: no loads, 2: no fragment reads, 4: no barriers, 8: no priority)
+template <bool X2, int LAG, bool WRAP = false, int ABL = 0, int CARRY = 0>   // ABL: micro-benchmark ablations (1: no loads, 2: no fragment reads, 4: no barriers, 8: no priority)
 __global__ __launch_bounds__(IMG_NT, 1) void tica_img_pp_kernel(ImgMfmaArgs P)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][A, B][4][256] packets -- the ONLY LDS object
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NS][A, B][4][256] packets (+ CARRY: 4 x 8 KiB) -- the ONLY LDS object
     const int U = P.ntile2, G = (int)gridDim.x;
     const int S = G / U, R = G - S * U;
     const int p = img_xcd_linear_id();
+    // carried pack: workgroup p takes the column blocks 4 bg .. 4 bg + 3 (one per carrier wave), bg = p mod (blocks / 4), of every
+    // J-th pack step, J = the workgroups that share bg
+    ImgCarryState cst;
+    float cr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (CARRY) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nbg = P.cy.nb >> 2, bg = p % nbg;
+        cst.next = p / nbg;
+        cst.step = (G - bg + nbg - 1) / nbg;
+        cst.blk = 4 * bg + (wave & 3);
+        cst.pending = -1;
+        cst.wait = 1;
+        if (wave >= 4 && P.cy.shift) {
+            constexpr int NF = CARRY == 4 ? 2 : 4;
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int q = 0; q < NF; ++q) cr[q] = P.cy.shift[cst.blk * 16 * NF + NF * (lane & 15) + q];
+#pragma unroll
+            for (int q = 0; q < NF; ++q) asm volatile("" : "+v"(cr[q]));   // (the compiler's wait for these loads is HERE, not at every use in the K loop)
+        }
+    }
     if (p < S * U) {
         const int cohort = p / U;
         const int s1 = (R == 0 && cohort == S - 1) ? (int)P.nsteps : (cohort + 1) * P.main_steps;   // (no remainder cohort: the last one takes the odd steps)
-        img_pp_segment<X2, LAG, WRAP, ABL>(P, smem, p - cohort * U, cohort, cohort * P.main_steps, s1);
+        img_pp_segment<X2, LAG, WRAP, ABL, CARRY>(P, smem, p - cohort * U, cohort, cohort * P.main_steps, s1, &cst, &cr);
     } else {
         const int r = p - S * U;
         for (int unit = r; unit < U; unit += R)
-            img_pp_segment<X2, LAG, WRAP, ABL>(P, smem, unit, S, S * P.main_steps, (int)P.nsteps);
+            img_pp_segment<X2, LAG, WRAP, ABL, CARRY>(P, smem, unit, S, S * P.main_steps, (int)P.nsteps, &cst, &cr);
+    }
+    if (CARRY) {
+        // drain: the quads this workgroup's steps did not reach (every segment ended with vmcnt(0) + a barrier)
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (wave >= 4) {
+            constexpr int NS = 3 + LAG;
+            while (cst.pending >= 0 || cst.next < P.cy.np) {
+                img_carry_phase<X2, CARRY ? CARRY : 2>(P.cy, cst, smem + NS * IMG_SLOT + (wave & 3) * 8192, P.Fp, cr, true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
     }
 }
 
@@ -332,12 +593,6 @@ __global__ __launch_bounds__(IMG_NT, 1) void tica_img_pp_kernel(ImgMfmaArgs P)
 //     A(t) is written in phase 2 (t - 2), B(t) in 2 (t - 2) + 1; first read in phase 2 t - 1 (RAW: two barriers between);
 //     the slot of step t is last read in phase 2 t and rewritten from phase 2 (t + 1) (WAR: one barrier between).
 // =====================================================================================================================
-struct ImgStep {
-    const void* rowa;   // x_t row of the step's first pair (trajectory-relative, bfloat16)
-    int nvalid;         // pairs of this step that exist (0 .. pairs per step); the rest are zero packets
-    int pad;
-};
-
 struct ImgFusedArgs {
     const ImgStep* steps;   // [nsteps]
     const float* shift;     // [F] reference row r, or nullptr
@@ -347,8 +602,6 @@ struct ImgFusedArgs {
     int T, T2, ntiles_sym, ntile2, S, kflush_steps, main_steps;
     double* slabs;
 };
-
-typedef unsigned img_u32x2 __attribute__((ext_vector_type(2)));
 
 // img_flush for the permuted slot layout: tile position p of a 32-block is feature beta(p) = 4 (p & 7) + (p >> 3)
 __device__ __forceinline__ void img_flush_perm(img_f32x16 (&acc)[2][4], double* slabs, int ntiles_sym, int T, int cohort, int which, int I, int J,

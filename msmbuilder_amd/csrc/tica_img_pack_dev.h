@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void tica_img_kernel(ImgArgs P)
 // Round 5, fused kernel (tica_img_dev.h): the K-step records {row of the step's first pair, valid pairs} from the chunk table.
 // A chunk's pairs are padded to whole 32-pair steps exactly as tica_img_kernel padded the image (g0 = the chunk's first
 // 8-pair group); bf16x2 splits a 32-pair step into two 16-pair steps (the second may hold no pair: nvalid 0).
-__global__ void tica_img_steps_kernel(const TicaChunk* __restrict__ chunks, long long ld, int lag, int x2, ImgStep* __restrict__ steps)
+// (round 6: `row_bytes` = ld x the element size -- the carried pack's 32-pair step records, x2 = 0, are the same table for
+//  float32 rows)
+__global__ void tica_img_steps_kernel(const TicaChunk* __restrict__ chunks, long long row_bytes, int lag, int x2, ImgStep* __restrict__ steps)
 {
     const TicaChunk ch = chunks[blockIdx.x];
     long long nv = ch.len - lag - ch.row0;
@@ -194,15 +196,30 @@ __global__ void tica_img_steps_kernel(const TicaChunk* __restrict__ chunks, long
     if (nv < 0) nv = 0;
     const long long n32 = (nv + 31) / 32, first = ch.g0 / 4;
     for (long long j = threadIdx.x; j < n32; j += blockDim.x) {
-        const char* base = (const char*)ch.base + (size_t)(ch.row0 + j * 32) * (size_t)ld * 2;
+        const char* base = (const char*)ch.base + (size_t)(ch.row0 + j * 32) * (size_t)row_bytes;
         const int n = (int)(nv - j * 32 < 32 ? nv - j * 32 : 32);
         if (!x2) {
             steps[first + j] = ImgStep{base, n, 0};
         } else {
             steps[2 * (first + j)] = ImgStep{base, n < 16 ? n : 16, 0};
-            steps[2 * (first + j) + 1] = n > 16 ? ImgStep{base + (size_t)16 * (size_t)ld * 2, n - 16, 0} : ImgStep{base, 0, 0};
+            steps[2 * (first + j) + 1] = n > 16 ? ImgStep{base + (size_t)16 * (size_t)row_bytes, n - 16, 0} : ImgStep{base, 0, 0};
         }
     }
+}
+
+// Carried pack (tica_img_dev.h): a chunk's folded column sums = the sum of its pack steps' (fp64, in step order).
+// chunks: the carried super-chunk's entries of the chunk table; its groups are [g_start, g_end).
+__global__ void tica_img_colsum_steps_kernel(const TicaChunk* __restrict__ chunks, long long nchunks, long long g_start, long long g_end,
+                                             const double* __restrict__ colS, int F, int Fp, double* __restrict__ colA)
+{
+    const long long cix = blockIdx.x;
+    const int f = blockIdx.y * 256 + threadIdx.x;
+    if (f >= F) return;
+    const long long s0 = (chunks[cix].g0 - g_start) / 4;
+    const long long s1 = ((cix + 1 < nchunks ? chunks[cix + 1].g0 : g_end) - g_start) / 4;
+    double a = 0.0;
+    for (long long s = s0; s < s1; ++s) a += colS[(size_t)s * (size_t)Fp + f];
+    colA[(size_t)cix * F + f] = a;
 }
 
 }  // namespace msm

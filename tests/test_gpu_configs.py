@@ -206,6 +206,7 @@ def test_config5_fused_kernel_bit_identical_to_image_path(gpu, monkeypatch, mode
              + torch.randn(n, F, generator=g, device="cuda")).to(torch.bfloat16) for n in lens]
     monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
     monkeypatch.setenv("MSM_TICA_FOLD", "0")      # both paths take the same column-sum pass: every exported word comparable
+    monkeypatch.setenv("MSM_TICA_IMG_CARRY", "0")  # one super-chunk, one launch, like the fused kernel's: the same fp32 partial sums (the carried pack cuts a launch into several)
     out = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("MSM_TICA_IMG_FUSED", fused)
@@ -224,6 +225,50 @@ def test_config5_fused_kernel_bit_identical_to_image_path(gpu, monkeypatch, mode
         assert np.abs(out[fused][0]).max() > 0 and np.isfinite(out[fused][1]).all()
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x2"])
+@pytest.mark.parametrize("stored,F,lag", [("bfloat16", 2048, 100), ("float32", 2048, 100), ("bfloat16", 768, 7), ("float32", 1536, 33)])
+@pytest.mark.parametrize("fold", ["0", "2"])
+def test_config5_carried_pack_bit_identical_to_prepass(gpu, monkeypatch, mode, stored, F, lag, fold):
+    """Round 6 (VERDICT r5 #3b): the multiply of super-chunk k packs super-chunk k + 1 of the image in its load role (the
+    carried pack, tica_img_dev.h); only the first super-chunk takes the pre-pass kernel.  The packets are the pre-pass
+    kernel's bit for bit, so every accumulator is too.  Ragged trajectories (1, 12, 17 and 31 pairs in a last K-step, one
+    of lag + 1 rows, one too short) beside long ones: several super-chunks.  With folded column sums (fold 2) the sums of the
+    left frames come from the carried items per pack step: the same sums in another fp64 order."""
+    import ctypes as C
+    import torch
+    from msmbuilder_amd import tICA, _lib
+    g = torch.Generator(device="cuda").manual_seed(F + lag)
+    lens = [9000, 3 * 32 + lag + 1, 40 * 32 + lag + 12, 7000 + lag + 17, 1500 * 2 + lag + 31 - 8, lag + 1, lag, 4096 + lag, 12000, 5000 + lag + 1]
+    base = 3.0 * torch.randn(F, generator=g, device="cuda")
+    seqs = [(base + torch.randn(n, F, generator=g, device="cuda").cumsum(0) * 0.05
+             + torch.randn(n, F, generator=g, device="cuda")) for n in lens]
+    if stored == "bfloat16":
+        seqs = [s.to(torch.bfloat16) for s in seqs]
+    monkeypatch.setenv("MSMBUILDER_AMD_TICA_MODE", mode)
+    monkeypatch.setenv("MSM_TICA_FOLD", fold)
+    monkeypatch.setenv("MSM_TICA_IMG_FUSED", "0")
+    out = {}
+    for carry in ("1", "2"):      # 2: the same super-chunks and ring halves, every one packed by the pre-pass kernel
+        monkeypatch.setenv("MSM_TICA_IMG_CARRY", carry)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = tICA(n_components=3, lag_time=lag).fit(seqs)
+            flag = C.c_int(-1)
+            _lib.check(_lib.lib().msm_tica_last_img_carried(m._handle, C.byref(flag)))
+            assert flag.value == (1 if carry == "1" else 0)
+            m.partial_fit(seqs[0])     # on top of existing slabs; a single trajectory: still several super-chunks
+        m._pull()
+        out[carry] = [np.array(getattr(m, a)) for a in ("_outer_0_to_T_lagged", "_outer_gram_sum", "_sum_0_to_TminusTau",
+                                                         "_sum_tau_to_T")] + [np.asarray(m.eigenvalues_)]
+        assert m.n_observations_ == sum(n for n in lens if n > lag) + lens[0]
+        assert np.abs(out[carry][0]).max() > 0 and np.isfinite(out[carry][1]).all()
+    for i, (a, b) in enumerate(zip(out["1"], out["2"])):
+        if fold == "0":
+            assert np.array_equal(a, b), i
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-11 * np.abs(b).max())
 
 
 def test_config5_fused_is_the_default_up_to_512_features(gpu, monkeypatch):
