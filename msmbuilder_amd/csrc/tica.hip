@@ -48,6 +48,7 @@ struct msm_tica {
     // whole-matrix sum/difference kernel (tica_symw_dev.h; fp32 mode, F <= 256): variant (SymwA ..), its padded width /
     // group width / interleave, workgroups of a launch (= slab rows), slabs [symw_S][2][FP*FP], rows in use since the last reset
     int symw = 0, symw_var = 0, symw_FP = 0, symw_W = 0, symw_IL = 0, symw_KS = 0, symw_S = 0, symw_used = 0;
+    int symw64 = 0, symw_S64 = 0;   // ... float64 rows take the same variant on doubles (F <= 128); its resident workgroups
     double* slabs_w = nullptr;
     double* slabs = nullptr;    // [G][TM*TM]
     double* base = nullptr;     // packed [2FF+2F] imported state
@@ -196,11 +197,13 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     //  the mode is an accuracy floor, not a promise of the bf16 pipe; bfloat16-stored rows there take the fp64 kernel)
     const bool use32 = dtype_bytes == 4 && (h->mode == MSM_TICA_F32 || (bfmode && !useimg));
     // F <= 256, fp32 mode: the whole-matrix sum/difference kernel (any alignment a float row can have; tica_symw_dev.h)
-    const bool usesymw = use32 && h->mode == MSM_TICA_F32 && h->symw;
+    // ... and float64 rows of up to 128 features on the same slabs (tica_symw_f64_kernel: the fp64 matrix pipe)
+    const bool symw64 = dtype_bytes == 8 && h->mode == MSM_TICA_F32 && h->symw64;
+    const bool usesymw = (use32 && h->mode == MSM_TICA_F32 && h->symw) || symw64;
     const int bk = usesymw ? h->symw_KS : (use32 || useimg) ? BK32 : BK64;
     const bool usesym = !usesymw && ((use32 && h->mode == MSM_TICA_F32 && h->sym && h->slabs_sym && aligned) || useimg);  // sum/difference slabs (H/D kernel: 16-byte aligned rows only)
     const bool pairsem = usesym || usesymw;   // pair semantics: a frame counts once per valid pair it is in
-    const int S = usesymw ? h->symw_S : useimg ? h->S_img : usesym ? h->sym_cohorts : use32 ? h->S32 : h->S64;  // one resident round
+    const int S = symw64 ? std::min(h->symw_S, h->symw_S64) : usesymw ? h->symw_S : useimg ? h->S_img : usesym ? h->sym_cohorts : use32 ? h->S32 : h->S64;  // one resident round
     const bool symrem = usesym && !useimg && h->sym_grid > S * h->ntiles_sym;              // ... + a remainder cohort
     const int G = usesymw ? S : symrem ? h->sym_grid : S * (usesym ? h->ntiles_sym : h->ntiles);
     long long kc = ceil_div(total, S);
@@ -380,7 +383,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
             if (n_rows[s] > h->lag && n_rows[s] < 2 * (long long)h->lag) fold = false;
         if (2 * (long long)h->lag * nvalid > total / 4) fold = false;   // the boundary rows would be a pass of their own
     }
-    const bool shifted = h->shift_on && (use32 || useimg);
+    const bool shifted = h->shift_on && (use32 || useimg || symw64);
     // 1b) mean shift bookkeeping (fp32 / bf16 kernels): the raw column sums of what this launch accumulates under the
     //     shift, and -- first shifted launch of the handle, `set_r` -- the reference row r = this launch's column means
     auto shift_and_merge = [&](int set_r) -> int {
@@ -766,7 +769,21 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         SymwArgs WA;
         WA.T = P;
         WA.slabs = h->slabs_w;
-        const bool vec = h->F >= 4;   // 16-byte pieces at any 4-byte alignment; rows of 1-3 floats element by element
+        const bool vec = h->F >= (symw64 ? 2 : 4);   // 16-byte pieces at any 4-byte alignment; rows of 1-3 floats (a single double) element by element
+        if (symw64) {
+            switch (h->symw_var) {
+#define MSM_SYMW_LAUNCH64(CFG)                                                                                       \
+                if (vec) hipLaunchKernelGGL((tica_symw_f64_kernel<CFG, true>), dim3(G), dim3(CFG::NTH), CFG::LDS64, stream(), WA); \
+                else hipLaunchKernelGGL((tica_symw_f64_kernel<SymwA, false>), dim3(G), dim3(SymwA::NTH), SymwA::LDS64, stream(), WA); \
+                break;
+                case 0: MSM_SYMW_LAUNCH64(SymwA)
+                case 1: MSM_SYMW_LAUNCH64(SymwB)
+                case 2: MSM_SYMW_LAUNCH64(SymwC)
+                case 6: MSM_SYMW_LAUNCH64(SymwG)
+                default: MSM_SYMW_LAUNCH64(SymwD)
+#undef MSM_SYMW_LAUNCH64
+            }
+        } else
         switch (h->symw_var) {
 #define MSM_SYMW_LAUNCH(CFG)                                                                                      \
             if (vec) hipLaunchKernelGGL((tica_symw_f32_kernel<CFG, true>), dim3(G), dim3(CFG::NTH), CFG::LDS, stream(), WA); \
@@ -977,6 +994,34 @@ int msm_tica_create(msm_tica_t** out, msm_idx_t n_features, msm_idx_t lag_time, 
                 MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tica_symw_f32_kernel<SymwA, false>, SymwA::NTH, SymwA::LDS));
             }
             if (occ < 1) occ = 1;
+            // float64 rows (F <= 128): the same variant on doubles, the same slabs; the launch grid is the smaller of the two
+            {
+                const char* e64 = getenv("MSM_TICA_SYMW64");   // (A/B switch of the tests)
+                if (n_features <= 128 && !(e64 && atoi(e64) == 0)) {
+                    int occ64 = 0;
+#define MSM_SYMW_SETUP64(CFG)                                                                                          \
+                    {                                                                                                  \
+                        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_symw_f64_kernel<CFG, true>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)CFG::LDS64)); \
+                        MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ64, tica_symw_f64_kernel<CFG, true>, CFG::NTH, CFG::LDS64)); \
+                    }
+                    if (n_features <= 16) MSM_SYMW_SETUP64(SymwA)
+                    else if (n_features <= 32) MSM_SYMW_SETUP64(SymwB)
+                    else if (n_features <= 64) MSM_SYMW_SETUP64(SymwC)
+                    else if (n_features <= 96) MSM_SYMW_SETUP64(SymwG)
+                    else MSM_SYMW_SETUP64(SymwD)
+#undef MSM_SYMW_SETUP64
+                    if (n_features < 2) {
+                        MSM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tica_symw_f64_kernel<SymwA, false>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SymwA::LDS64));
+                        MSM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ64, tica_symw_f64_kernel<SymwA, false>, SymwA::NTH, SymwA::LDS64));
+                    }
+                    if (occ64 >= 1) {
+                        h->symw64 = 1;
+                        h->symw_S64 = occ64 * num_cus();
+                    }
+                }
+            }
             h->symw_S = occ * num_cus();
             h->symw = 1;
             h->sym = 1;   // the exported lagged moment is the symmetrised one

@@ -38,6 +38,24 @@
 namespace msm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double raw_f64x2 __attribute__((ext_vector_type(2)));
+
+// the element type of a variant: float (v_mfma_f32_16x16x4_f32) or double (v_mfma_f64_16x16x4_f64: the same 16 x 4 operand and
+// 16 x 16 result layout, one double per lane and operand).  Round 6, float64 rows of up to 128 features: every float64 row
+// went to the 128-wide fp64 tile kernel, 13 - 17 ms per 8M frames whatever the width (profiles/r05_narrow_probe.txt).
+template <typename T>
+struct SymwTy;
+template <>
+struct SymwTy<float> {
+    typedef f32x4 acc_t;
+    static constexpr int EPP = 4;   // elements per 16-byte piece
+};
+template <>
+struct SymwTy<double> {
+    typedef f64x4 acc_t;
+    static constexpr int EPP = 2;
+};
 
 template <int IL_, int NG_, int KS_, int NW_, bool FSPLIT_>
 struct SymwCfg {
@@ -53,6 +71,19 @@ struct SymwCfg {
     static constexpr bool NVX = PLANE % (4 * NTH) == 0;      // ... a whole number of them for every thread
     static constexpr size_t LDS = (size_t)(2 * 2 * PLANE + FP) * sizeof(float);   // [2 buffers][u, d] + the shift row
     static_assert(KS % (4 * (FSPLIT ? NW : 1)) == 0, "whole k-steps (per wave)");
+    // the same variant on doubles: half the frames per K-step (the same bytes per plane)
+    static constexpr int KS64 = KS / 2;
+    static constexpr size_t LDS64 = (size_t)(2 * 2 * KS64 * FP + FP) * sizeof(double);
+    static_assert(KS64 % (4 * (FSPLIT ? NW : 1)) == 0, "whole k-steps (per wave), doubles");
+};
+// what depends on the element type
+template <typename Cfg, typename T>
+struct SymwK {
+    static constexpr int EPP = SymwTy<T>::EPP;
+    static constexpr int KS = sizeof(T) == 8 ? Cfg::KS64 : Cfg::KS;
+    static constexpr int PLANE = KS * Cfg::FP;
+    static constexpr int NV = (PLANE / EPP + Cfg::NTH - 1) / Cfg::NTH;
+    static constexpr bool NVX = PLANE % (EPP * Cfg::NTH) == 0;
 };
 
 // block `id` of the enumeration g, gp, a, b (diagonal pairs: a <= b) -- evaluated at compile time only
@@ -80,28 +111,31 @@ constexpr int symw_gid(int q)
 }
 
 // one k-step of the wave's share: acc[Q] += frag(A)^T frag(B) for its blocks, every register index a compile-time constant
-template <typename Cfg, int WAVE, int Q>
-__device__ __forceinline__ void symw_mfma_one(f32x4 (&acc)[Cfg::NACC], const float (&fu)[Cfg::NG][Cfg::IL], const float (&fd)[Cfg::NG][Cfg::IL])
+__device__ __forceinline__ f32x4 symw_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f64x4 symw_mfma(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+template <typename Cfg, int WAVE, int Q, typename T>
+__device__ __forceinline__ void symw_mfma_one(typename SymwTy<T>::acc_t (&acc)[Cfg::NACC], const T (&fu)[Cfg::NG][Cfg::IL], const T (&fd)[Cfg::NG][Cfg::IL])
 {
     constexpr int gid = symw_gid<Cfg, WAVE>(Q);
     if constexpr (gid < 2 * Cfg::NBLK) {
         constexpr SymwBlk k = symw_block<Cfg>(gid % Cfg::NBLK);
         if constexpr (gid < Cfg::NBLK)
-            acc[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[k.g][k.a], fu[k.gp][k.b], acc[Q], 0, 0, 0);
+            acc[Q] = symw_mfma(fu[k.g][k.a], fu[k.gp][k.b], acc[Q]);
         else
-            acc[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fd[k.g][k.a], fd[k.gp][k.b], acc[Q], 0, 0, 0);
+            acc[Q] = symw_mfma(fd[k.g][k.a], fd[k.gp][k.b], acc[Q]);
     }
 }
-template <typename Cfg, int WAVE, int... Q>
-__device__ __forceinline__ void symw_mfmas(f32x4 (&acc)[Cfg::NACC], const float (&fu)[Cfg::NG][Cfg::IL], const float (&fd)[Cfg::NG][Cfg::IL],
+template <typename Cfg, int WAVE, typename T, int... Q>
+__device__ __forceinline__ void symw_mfmas(typename SymwTy<T>::acc_t (&acc)[Cfg::NACC], const T (&fu)[Cfg::NG][Cfg::IL], const T (&fd)[Cfg::NG][Cfg::IL],
                                            std::integer_sequence<int, Q...>)
 {
-    (symw_mfma_one<Cfg, WAVE, Q>(acc, fu, fd), ...);
+    (symw_mfma_one<Cfg, WAVE, Q, T>(acc, fu, fd), ...);
 }
 
 // accumulator Q -> the fp64 slab: element (i = 4 kl + r, j = cl) of block (g, a | gp, b) is H[g W + IL i + a][gp W + IL j + b]
-template <typename Cfg, int WAVE, int Q>
-__device__ __forceinline__ void symw_merge_one(f32x4 (&acc)[Cfg::NACC], double* slab)
+template <typename Cfg, int WAVE, int Q, typename ACC>
+__device__ __forceinline__ void symw_merge_one(ACC (&acc)[Cfg::NACC], double* slab)
 {
     constexpr int gid = symw_gid<Cfg, WAVE>(Q);
     if constexpr (gid < 2 * Cfg::NBLK) {
@@ -110,23 +144,25 @@ __device__ __forceinline__ void symw_merge_one(f32x4 (&acc)[Cfg::NACC], double* 
         // `slab` arrives with the lane's part of the address folded in (element (4 kl, cl) of block (0, 0 | 0, 0)); the rest is
         // a compile-time constant per block and register
         double* base = slab + ((size_t)m * FP * FP + (size_t)(k.g * W + k.a) * FP + (k.gp * W + k.b));
+        // (result layout: float 16 x 16 x 4: row 4 kl + r; double 16 x 16 x 4: row kl + 4 r -- the lane's kl is in `slab`)
+        constexpr int RS = sizeof(acc[Q][0]) == 8 ? 4 * IL : IL;
         double old[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) old[r] = base[(size_t)(IL * r) * FP];
+        for (int r = 0; r < 4; ++r) old[r] = base[(size_t)(RS * r) * FP];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            base[(size_t)(IL * r) * FP] = old[r] + (double)acc[Q][r];
-            acc[Q][r] = 0.f;
+            base[(size_t)(RS * r) * FP] = old[r] + (double)acc[Q][r];
+            acc[Q][r] = 0;
         }
         // (one block at a time: left to itself the scheduler batches the loads of ALL the wave's blocks -- hundreds of
         //  registers for a merge that runs once per 8,192 frames -- and the MFMA loop pays for it in spills)
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <typename Cfg, int WAVE, int... Q>
-__device__ __forceinline__ void symw_merge_all(f32x4 (&acc)[Cfg::NACC], double* slab, std::integer_sequence<int, Q...>)
+template <typename Cfg, int WAVE, typename ACC, int... Q>
+__device__ __forceinline__ void symw_merge_all(ACC (&acc)[Cfg::NACC], double* slab, std::integer_sequence<int, Q...>)
 {
-    (symw_merge_one<Cfg, WAVE, Q>(acc, slab), ...);
+    (symw_merge_one<Cfg, WAVE, Q, ACC>(acc, slab), ...);
 }
 
 struct SymwArgs {
@@ -143,6 +179,15 @@ __device__ __forceinline__ float4 symw_fix(float4 v, int s)
     o.y = s == 0 ? v.y : s == 1 ? v.z : s == 2 ? v.w : 0.f;
     o.z = s == 0 ? v.z : s == 1 ? v.w : 0.f;
     o.w = s == 0 ? v.w : 0.f;
+    return o;
+}
+
+// ... and of a row of F doubles (8-byte aligned... 4-byte is enough for the hardware): pieces of two, s = 0, 1 or 2 (beyond the row)
+__device__ __forceinline__ raw_f64x2 symw_fix(raw_f64x2 v, int s)
+{
+    raw_f64x2 o;
+    o.x = s == 0 ? v.x : s == 1 ? v.y : 0.0;
+    o.y = s == 0 ? v.y : 0.0;
     return o;
 }
 
@@ -192,7 +237,7 @@ __device__ __forceinline__ void symw_body(const SymwArgs& A, float* lds, int wav
         asm volatile("" : "+v"(toff));
 #pragma unroll
         for (int turn = 0; turn < (FSPLIT ? NW : 1); ++turn) {
-            if (!FSPLIT || wave == turn) symw_merge_all<Cfg, WAVE>(acc, slab + toff, std::make_integer_sequence<int, NACC>{});
+            if (!FSPLIT || wave == turn) symw_merge_all<Cfg, WAVE, f32x4>(acc, slab + toff, std::make_integer_sequence<int, NACC>{});
             if (FSPLIT) __syncthreads();
         }
     };
@@ -270,7 +315,7 @@ __device__ __forceinline__ void symw_body(const SymwArgs& A, float* lds, int wav
                         fd[g][0] = q0[PLANE];
                     }
                 }
-                symw_mfmas<Cfg, WAVE>(acc, fu, fd, std::make_integer_sequence<int, NACC>{});
+                symw_mfmas<Cfg, WAVE, float>(acc, fu, fd, std::make_integer_sequence<int, NACC>{});
             }
             if (s + 1 < nsteps) SYMW_STORE((s + 1) * KS, buf ^ 1)
             __syncthreads();
@@ -305,6 +350,162 @@ __global__ __launch_bounds__(Cfg::NTH, 2) void tica_symw_f32_kernel(SymwArgs A) 
             case 5: symw_body<Cfg, VEC, 5 % Cfg::NW>(A, lds, wave); break;
             case 6: symw_body<Cfg, VEC, 6 % Cfg::NW>(A, lds, wave); break;
             default: symw_body<Cfg, VEC, 7 % Cfg::NW>(A, lds, wave); break;
+        }
+    }
+}
+
+// ---- the same kernel on DOUBLES (float64 rows, F <= 128): pieces of two doubles, K-steps of KS / 2 frames, the fp64 matrix pipe.
+// Accumulators stay in fp64 registers between merges; the shift row is applied as for the floats (the handle's column sums and
+// their un-shifting do not care which kernel formed the products).  Peak of the form: 2 NBLK MFMAs of 64 cycles (16 x 16 x 4
+// fp64: 2,048 flop at 78.6 TF) per 4 frames and CU-SIMD -- half the float variant's rate, HBM-bound up to 32 features.
+template <typename Cfg, bool VEC, int WAVE>
+__device__ __forceinline__ void symw_body64(const SymwArgs& A, double* lds, int wave)
+{
+    typedef SymwK<Cfg, double> K;
+    constexpr int IL = Cfg::IL, NG = Cfg::NG, KS = K::KS, NW = Cfg::NW, FP = Cfg::FP, W = Cfg::W, NTH = Cfg::NTH;
+    constexpr int NV = K::NV, PLANE = K::PLANE, NACC = Cfg::NACC;
+    constexpr bool FSPLIT = Cfg::FSPLIT;
+    constexpr int PPR = FP / 2;   // pieces per row
+    const TicaArgs& P = A.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kl = lane >> 4, cl = lane & 15;
+    const int F = P.F;
+    double* rs = lds + 4 * PLANE;   // the shift row r (zeros beyond F or without a shift)
+    for (int c = tid; c < FP; c += NTH) rs[c] = (P.shift && c < F) ? (double)P.shift[c] : 0.0;
+
+    f64x4 acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    int fr[NV], cs[NV], sh[NV], c2[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int e = tid + NTH * j;
+        fr[j] = e / PPR;
+        c2[j] = (e % PPR) * 2;
+        if (VEC) {
+            cs[j] = c2[j] + 2 <= F ? c2[j] : F - 2;
+            const int s = c2[j] - cs[j];
+            sh[j] = s > 2 ? 2 : s;
+        } else {
+            cs[j] = c2[j];
+            sh[j] = 0;
+        }
+    }
+    double* slab = A.slabs + (size_t)blockIdx.x * (2 * (size_t)FP * FP);
+    int rows_acc = 0;
+    auto merge = [&]() {
+        unsigned toff = (unsigned)((IL * kl) * FP + IL * cl);   // (double results: row kl + 4 r)
+        asm volatile("" : "+v"(toff));
+#pragma unroll
+        for (int turn = 0; turn < (FSPLIT ? NW : 1); ++turn) {
+            if (!FSPLIT || wave == turn) symw_merge_all<Cfg, WAVE, f64x4>(acc, slab + toff, std::make_integer_sequence<int, NACC>{});
+            if (FSPLIT) __syncthreads();
+        }
+    };
+
+    for (long long c = blockIdx.x; c < P.nchunks; c += gridDim.x) {
+        const TicaChunk ch = get_chunk(P, c);
+        const int nsteps = (ch.n + KS - 1) / KS;
+        ChunkCtx cx = make_ctx(P, ch);
+        cx.base = as_global<char>(ch.base) + (size_t)ch.row0 * (size_t)P.ld * sizeof(double);
+        cx.baseB = cx.base;
+        cx.ldb = (unsigned)(P.ld * sizeof(double));
+        set_lag(cx, P.lag, sizeof(double), P.ld);
+        raw_f64x2 xa[NV], xb[NV];
+        auto load = [&](int k0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int kr = k0 + (fr[j] < KS ? fr[j] : KS - 1);   // (a thread's last piece may lie beyond the plane)
+                const unsigned ra = (unsigned)(kr < cx.nmax ? kr : cx.nmax) * cx.ldb;
+                const unsigned rb = (unsigned)(kr < cx.nmaxB ? kr : cx.nmaxB) * cx.ldb;
+                if (VEC) {
+                    xa[j] = *(global_ptr<raw_f64x2>)(cx.base + (ra + 8u * (unsigned)cs[j]));
+                    xb[j] = *(global_ptr<raw_f64x2>)(cx.baseB + (rb + 8u * (unsigned)cs[j]));
+                } else {
+                    const unsigned c0 = 8u * (unsigned)(c2[j] < F ? c2[j] : F - 1), c1 = 8u * (unsigned)(c2[j] + 1 < F ? c2[j] + 1 : F - 1);
+                    xa[j].x = *(global_ptr<double>)(cx.base + (ra + c0));
+                    xa[j].y = *(global_ptr<double>)(cx.base + (ra + c1));
+                    xb[j].x = *(global_ptr<double>)(cx.baseB + (rb + c0));
+                    xb[j].y = *(global_ptr<double>)(cx.baseB + (rb + c1));
+                }
+            }
+        };
+        auto store = [&](int k0, int buf) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int kr = k0 + fr[j];
+                const bool live = kr < cx.hi;
+                raw_f64x2 a_ = xa[j], b_ = xb[j];
+                if (VEC) {
+                    a_ = symw_fix(a_, sh[j]);
+                    b_ = symw_fix(b_, sh[j]);
+                }
+                const double r0 = rs[c2[j]], r1 = rs[c2[j] + 1];
+                // (selects, not products with 0: a clamped row or column may hold anything)
+                const bool m0 = live && c2[j] + 0 < F, m1 = live && c2[j] + 1 < F;
+                const double ax = m0 ? a_.x - r0 : 0.0, ay = m1 ? a_.y - r1 : 0.0;
+                const double bx = m0 ? b_.x - r0 : 0.0, by = m1 ? b_.y - r1 : 0.0;
+                double* pu_ = lds + buf * 2 * PLANE + fr[j] * FP + c2[j];
+                if (K::NVX || fr[j] < KS) {
+                    *reinterpret_cast<raw_f64x2*>(pu_) = raw_f64x2{ax + bx, ay + by};
+                    *reinterpret_cast<raw_f64x2*>(pu_ + PLANE) = raw_f64x2{ax - bx, ay - by};
+                }
+            }
+        };
+        load(0);
+        __syncthreads();   // every wave is done with both buffers (previous chunk) -- and the shift row is in place
+        store(0, 0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nsteps) load((s + 1) * KS);
+            const double* pl = lds + buf * 2 * PLANE + kl * FP + IL * cl;
+#pragma unroll 2
+            for (int kk = FSPLIT ? wave : 0; kk < KS / 4; kk += (FSPLIT ? NW : 1)) {
+                double fu[NG][IL], fd[NG][IL];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const double* q0 = pl + kk * 4 * FP + g * W;
+#pragma unroll
+                    for (int a = 0; a < IL; a += 2) {
+                        if (IL >= 2) {
+                            const raw_f64x2 vu = *reinterpret_cast<const raw_f64x2*>(q0 + a), vd = *reinterpret_cast<const raw_f64x2*>(q0 + PLANE + a);
+                            fu[g][a] = vu.x; fu[g][(a + 1) % IL] = vu.y;
+                            fd[g][a] = vd.x; fd[g][(a + 1) % IL] = vd.y;
+                        } else {
+                            fu[g][0] = q0[0];
+                            fd[g][0] = q0[PLANE];
+                        }
+                    }
+                }
+                symw_mfmas<Cfg, WAVE, double>(acc, fu, fd, std::make_integer_sequence<int, NACC>{});
+            }
+            if (s + 1 < nsteps) store((s + 1) * KS, buf ^ 1);
+            __syncthreads();
+        }
+        rows_acc += ch.n;
+        if (rows_acc + P.kc > P.kflush || c + gridDim.x >= P.nchunks) {
+            rows_acc = 0;
+            merge();
+        }
+    }
+}
+
+template <typename Cfg, bool VEC>
+__global__ __launch_bounds__(Cfg::NTH, 2) void tica_symw_f64_kernel(SymwArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);   // [2 buffers][u, d][KS / 2][FP] | r [FP]
+    const int wave = threadIdx.x >> 6;
+    if (Cfg::FSPLIT) {
+        symw_body64<Cfg, VEC, 0>(A, lds, wave);
+    } else {
+        switch (wave) {
+            case 0: symw_body64<Cfg, VEC, 0>(A, lds, wave); break;
+            case 1: symw_body64<Cfg, VEC, 1 % Cfg::NW>(A, lds, wave); break;
+            case 2: symw_body64<Cfg, VEC, 2 % Cfg::NW>(A, lds, wave); break;
+            default: symw_body64<Cfg, VEC, 3 % Cfg::NW>(A, lds, wave); break;   // (the double variants have four waves)
         }
     }
 }
