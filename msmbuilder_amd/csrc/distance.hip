@@ -354,7 +354,21 @@ int cdist_impl(const T* XA, const T* XB, const char* metric, msm_idx_t na, msm_i
 #include "distance_screen_dev.h"   // kcenters_screen_pass_kernel, ksc_convert_kernel: k-centers passes screened on a low-precision copy
 #include "distance_kcbatch_dev.h"   // kcb_* kernels: several centres per pass (threshold lists), single GPU and row-sharded
 #include "distance_wscreen_dev.h"   // kcenters_wscreen_pass_kernel: screened passes of wide rows / float32 rows on a feature-major byte copy
+#include "distance_wbatch_dev.h"    // kwb_*: several centres per screened pass of wide rows (threshold lists)
+
 namespace msm {
+
+template <typename T, int JB, int R, int U>
+static void launch_kwb(int grid, size_t lds, const KwsArgs& A, KcbState* St)
+{
+    static bool attr_set = false;
+    if (!attr_set) {   // up to 64 KiB of centres beside the kernel's own ~40 KiB
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kwb_pass_kernel<T, JB, R, U>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((kwb_pass_kernel<T, JB, R, U>), dim3(grid), dim3(DT), lds, stream(), A, St);
+}
+
 
 
 // what the last k-centers fit streamed (for bench.py's bytes-per-pass figure): pass counts and the bytes a pass reads per row
@@ -585,6 +599,61 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
             const int gpass = (int)std::min<long long>(ceil_div(n, (long long)kr * DT), nblk0);
             // (the screened passes write `gpass` partials into arrays `nblk0` apart; the plain passes before them wrote `nblk`
             //  partials `nblk` apart: the first screened pass reads those)
+            // Several centres per pass (distance_wbatch_dev.h): as many as fit 64 KiB of LDS beside the pass's own 40 KiB --
+            // 16 up to 256 float32 / 170 float64 features, 8 up to twice that, one beyond.  MSM_KC_WBATCH=0: one centre per pass.
+            int jmax = 0;
+            {
+                const size_t per = (size_t)4 * nb4 * sizeof(float) + (size_t)m * sizeof(T);
+                if (16 * per <= 65536) jmax = 16;
+                else if (8 * per <= 65536) jmax = 8;
+                // Where it pays (scripts/kcwide.py, profiles/r06_kcenters_wide.txt): a round costs ~250 us on top of its streaming
+                // -- the selector replays up to 16 centres on up to 2,048 listed rows through ONE workgroup (1.4 MB of rows per
+                // centre at 171 float32 features), the pass carries 16 accumulators per row and re-evaluates the union of the
+                // batch's candidates -- against ~30 us of launch and latency per one-centre pass: passes of >= 90 MB, rows of
+                // <= 1 KiB (1M x 171, K = 500: 28.9 -> 19.0 ms; 280,000 x 171, K = 200: 6.6 -> 7.8 ms, left alone).
+                // MSM_KC_WBATCH=0 / 1 (read per fit) forces either.
+                const char* be = getenv("MSM_KC_WBATCH");
+                const double pass_bytes = (double)n * (4.0 * nb4 + 8.0);
+                const bool pays = (pass_bytes >= 9e7 && (size_t)m * sizeof(T) <= 1024) || (pass_bytes >= 5e7 && (size_t)m * sizeof(T) <= 192);   // (2M x 17 float64: 5.95 -> 4.97 ms)
+                if (be ? atoi(be) == 0 : !pays) jmax = 0;
+            }
+            if (jmax > 0) {
+                DevBuf& SB = pool(PS_W);
+                if ((rc = SB.reserve(sizeof(KcbState)))) return rc;
+                KcbState* St = SB.as<KcbState>();
+                hipLaunchKernelGGL(kcb_init_kernel, dim3(1), dim3(64), 0, stream(), St, (int)it);
+                const int it0 = (int)it;
+                const int kr2 = nb4 <= 16 ? 4 : 2;   // rows per thread: 16 (8) accumulators each
+                const int gp2 = (int)std::min<long long>(ceil_div(n, (long long)kr2 * DT), nblk0);
+                const size_t lds2 = (size_t)jmax * ((size_t)4 * nb4 * sizeof(float) + (size_t)m * sizeof(T));
+                int rounds = 0, done = it0;
+                const int wcap = getenv("MSM_KC_WCAP") ? std::max(64, std::min(KCB_CAP, atoi(getenv("MSM_KC_WCAP")))) : KCB_CAP;
+                int head4[4] = {it0, 0, 0, 0};   // k_done, J, rounds, fallbacks: the head of KcbState
+                while (done < (int)K) {
+                    const int group = kcb_group((int)K, done, rounds, it0);
+                    for (int r = 0; r < group; ++r, ++rounds) {
+                        S.prev = rounds == 0 ? part + (size_t)((it0 + 1) & 1) * nblk : part + (size_t)((it0 + rounds + 1) & 1) * nblk0;
+                        S.next = part + (size_t)((it0 + rounds) & 1) * nblk0;
+                        S.nblk = rounds == 0 ? nblk : gp2;
+                        hipLaunchKernelGGL((kwb_select_kernel<T>), dim3(1), dim3(1024), (size_t)m * sizeof(T), stream(), S, St, (int)K, jmax, wcap);
+                        if (jmax == 16) {
+                            if (kr2 == 4) launch_kwb<T, 16, 4, 8>(gp2, lds2, S, St);
+                            else launch_kwb<T, 16, 2, 24>(gp2, lds2, S, St);
+                        } else {
+                            if (kr2 == 4) launch_kwb<T, 8, 4, 8>(gp2, lds2, S, St);
+                            else launch_kwb<T, 8, 2, 24>(gp2, lds2, S, St);
+                        }
+                    }
+                    MSM_HIP_CHECK(hipGetLastError());
+                    MSM_HIP_CHECK(hipMemcpyAsync(head4, St, sizeof(head4), hipMemcpyDeviceToHost, stream()));
+                    MSM_HIP_CHECK(hipStreamSynchronize(stream()));
+                    done = head4[0];
+                    if (rounds > 4 * (int)K) return fail(MSM_ERR_HIP, "k-centers: the batched wide passes made no progress");
+                }
+                g_kc_stats.screened_passes = head4[2];
+                g_kc_stats.batch_fallbacks = head4[3];
+                it = K;
+            }
             for (; it < K; ++it) {
                 S.it = (int)it;
                 S.prev = it == KWS_PROBE ? part + (size_t)((it + 1) & 1) * nblk : part + (size_t)((it + 1) & 1) * nblk0;

@@ -29,6 +29,10 @@ for n, m, K, dt, note in shapes:
     else:
         X = data(n, m, 50, dt)
     os.environ["MSM_KC_WSCREEN"] = "1"
+    os.environ["MSM_KC_WBATCH"] = "1"
+    bat, stb = fit_ms(X, K)
+    print("KCenters(%4d).fit %8d x %3d %-8s batched  %8.2f ms (%d plain + %d batched passes)" % (K, n, m, str(dt)[6:], bat, stb[1], stb[2]), flush=True)
+    os.environ["MSM_KC_WBATCH"] = "0"
     on, st = fit_ms(X, K)
     os.environ["MSM_KC_WSCREEN"] = "0"
     off, _ = fit_ms(X, K)

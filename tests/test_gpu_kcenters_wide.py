@@ -63,6 +63,7 @@ def test_wide_screen_equals_plain_passes_device_rows(gpu, monkeypatch, dtype, n,
     X = (hubs[torch.randint(0, 12, (n,), generator=g, device="cuda")] + torch.randn(n, m, generator=g, device="cuda")).to(
         torch.float32 if dtype == np.float32 else torch.float64).contiguous()
     out = {}
+    monkeypatch.setenv("MSM_KC_WBATCH", "0")        # one centre per screened pass (the batched passes: the test below)
     for sw in ("1", "0"):
         monkeypatch.setenv("MSM_KC_WSCREEN", sw)
         kc = KCenters(n_clusters=k, random_state=1).fit([X])
@@ -73,3 +74,43 @@ def test_wide_screen_equals_plain_passes_device_rows(gpu, monkeypatch, dtype, n,
     assert a[0] == b[0]
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
     assert a[4][2] == k - 4 and b[4][2] == 0        # screened passes: all but the four plain ones / none
+
+
+@pytest.mark.parametrize("dtype,n,m,k,data", [(np.float32, 280_000, 171, 60, "hubs"), (np.float32, 200_000, 64, 100, "hubs"),
+                                              (np.float64, 150_000, 24, 80, "hubs"), (np.float32, 120_000, 512, 40, "hubs"),
+                                              (np.float64, 100_000, 100, 50, "blob"), (np.float32, 90_000, 33, 300, "ties"),
+                                              (np.float32, 70_000, 300, 30, "nan")])
+def test_wide_batched_passes_equal_plain_passes(gpu, monkeypatch, dtype, n, m, k, data):
+    """Several centres per screened pass of wide rows (distance_wbatch_dev.h: threshold lists, the selector replays the
+    algorithm on the listed rows, the pass applies the batch in order): centre ids / labels / distances / inertia of the
+    one-centre-per-pass loop, bit for bit, in fewer passes.  16 centres per pass (rows of <= 256 float32 features) and 8
+    (512 features); one blob (the list is always full), duplicated rows (exact ties: the lowest row wins), a NaN row."""
+    import ctypes as C
+    import torch
+    from msmbuilder_amd import KCenters, _lib
+    g = torch.Generator(device="cuda").manual_seed(m + k)
+    td = torch.float32 if dtype == np.float32 else torch.float64
+    if data == "blob":
+        X = torch.randn(n, m, generator=g, device="cuda").to(td)
+    else:
+        hubs = torch.randn(12, m, generator=g, device="cuda") * 2.0
+        X = (hubs[torch.randint(0, 12, (n,), generator=g, device="cuda")] + torch.randn(n, m, generator=g, device="cuda")).to(td)
+    if data == "ties":
+        X[n // 2:] = X[: n - n // 2]            # every row twice: every maximum is tied
+    if data == "nan":
+        X[12345, 7] = float("nan")
+    X = X.contiguous()
+    out = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("MSM_KC_WBATCH", sw)
+        monkeypatch.setenv("MSM_KC_WSCREEN", sw)
+        kc = KCenters(n_clusters=k, random_state=1).fit([X])
+        st = (C.c_int64 * 5)()
+        _lib.check(_lib.lib().msm_kcenters_last_stats(st))
+        out[sw] = (list(kc.cluster_ids_), kc.labels_[0].cpu().numpy(), kc.distances_[0].cpu().numpy(), kc.inertia_, list(st))
+    a, b = out["1"], out["0"]
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    assert a[3] == b[3] or (np.isnan(a[3]) and np.isnan(b[3]))
+    assert 0 < a[4][2] <= k - 4 and b[4][2] == 0    # batched passes: fewer than centres ...
+    assert data == "nan" or a[4][2] < (k - 4) // 2   # ... (a NaN distance makes every list unusable: one centre per pass, still exact)
