@@ -29,7 +29,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys:
                 full run's leading eigenvalues against that sample (loose)
   cpu_baseline  the oracle on the host cores (bounded sample): all-threads and 1-thread BLAS tICA, single-thread and
                 row-parallel exact KCenters, scikit-learn's own MiniBatchKMeans(k=1000)
-  f64, config2, config5_width, minibatchkmeans, strong_scaling_model   untimed secondary legs (N = 1 only)
+  f64, config2, config1_width[_f64], config3_width, config3_stress, kcenters_wide_1m, config4_label_wide, config5_width,
+  config5_per_gpu, minibatchkmeans, strong_scaling_model   untimed secondary legs (N = 1 only)
 """
 import argparse
 import ctypes as C
@@ -493,7 +494,9 @@ def main():
                          "algorithmic": algorithmic, "algorithmic_frac": algorithmic / peak,
                          "frac_note": "achieved = MFMA flop the kernel executes (%d tile products of 128x128 per frame = %.0f flop) / "
                                       "HIP-event kernel time; algorithmic = SURVEY 8d's 4 F^2 = %.0f flop per frame / the same time (the "
-                                      "sum/difference kernel needs fewer flops than 4 F^2, so algorithmic_frac can exceed 1)"
+                                      "sum/difference kernel needs fewer flops than 4 F^2, so algorithmic_frac can exceed 1 and is never a "
+                                      "utilisation).  The timed steps fit the same device tensors as the warm-up: the library re-uses the "
+                                      "device chunk table it built for that pointer table (about -0.3 ms of `fit` per step, 0.5 %%)"
                                       % (tiles, exe_flop, alg_flop),
                          "traffic_note": "bytes/launch at the L2 fabric side (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes); "
                                          "includes Infinity-Cache hits; algorithmic bytes/launch = %d" % (frames * F * 4),
@@ -720,6 +723,44 @@ def main():
                             "algorithmic_TFLOPs": 4.0 * Fw * Fw * nfw / kmw / 1e9,
                             "rows_TBps": nfw * Fw * 4 / kmw / 1e9, "hbm_peak_TBps": 8.0}
                 del Xw, seqs_w, mw
+            # --- float64 rows of configs[0]'s width (round 6: tica_symw_f64_kernel; scikit-learn scalers and tICA.transform emit
+            # float64, the reference computes in float64): 8M x 4 float64 as 800 x 10,000, lag 10
+            X64 = synth(torch, 800, 10_000, 4, 11, dev).double()
+            seqs64 = list(X64.view(800, 10_000, 4).unbind(0))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                kms, fts = [], []
+                for it in range(5):
+                    torch.cuda.synchronize()
+                    tw = time.perf_counter()
+                    m64 = tICA(n_components=4, lag_time=10).fit(seqs64)
+                    torch.cuda.synchronize()
+                    fts.append(time.perf_counter() - tw)
+                    kms.append(kernel_ms_of(m64, _lib))
+            out["config1_width_f64"] = {"workload": "8000000 x 4 float64 as 800 x 10,000, lag 10",
+                                        "kernel": "tica_symw_f64_kernel" if bool(m64._lagged_symmetrised) else "tica_mfma_f64_kernel",
+                                        "kernel_ms": min(kms[2:]), "fit_ms": 1e3 * min(fts[2:]),
+                                        "rows_TBps": 8_000_000 * 4 * 8 / min(kms[2:]) / 1e9, "hbm_peak_TBps": 8.0,
+                                        "note": "rounds 1-5: 13.4 ms (every float64 row took the 128-wide fp64 tile kernel)"}
+            del X64, seqs64, m64
+            # --- wide k-centers at scale (round 6: several centres per screened pass, distance_wbatch_dev.h): KCenters(500) on
+            # 1,000,000 x 171 float32 (50 blobs), fit only
+            gW = torch.Generator(device=dev).manual_seed(5)
+            cW = torch.randn(50, 171, generator=gW, device=dev) * 3
+            XW = (cW[torch.randint(0, 50, (1_000_000,), generator=gW, device=dev)] + torch.randn(1_000_000, 171, generator=gW, device=dev)).contiguous()
+            KCenters(n_clusters=500, random_state=0).fit([XW])
+            torch.cuda.synchronize()
+            tW = time.perf_counter()
+            kcW = KCenters(n_clusters=500, random_state=0).fit([XW])
+            torch.cuda.synchronize()
+            tW = time.perf_counter() - tW
+            stW = (C.c_int64 * 5)()
+            _lib.check(_lib.lib().msm_kcenters_last_stats(stW))
+            out["kcenters_wide_1m"] = {"workload": "1,000,000 x 171 fp32 (50 blobs), KCenters(k=500, euclidean) fit",
+                                       "kcenters_fit_ms": 1e3 * tW, "plain_passes": int(stW[1]), "screened_passes": int(stW[2]),
+                                       "screened_pass_bytes_per_row": int(stW[4]),
+                                       "note": "rounds 1-5: 500 plain passes, 78.5 ms; one centre per screened pass: 28.9 ms"}
+            del XW, kcW, cW
             # --- SURVEY 8(d)'s C3 stress variant: KCenters(200) and assign_nearest on RAW contact-like features, 280,000 x 171
             # float32 as 28 trajectories x 10,000, no tICA in front (odd row length: the scalar-staged exact kernels)
             gC = torch.Generator(device=dev).manual_seed(171)
