@@ -603,29 +603,54 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
             // 16 up to 256 float32 / 170 float64 features, 8 up to twice that, one beyond.  MSM_KC_WBATCH=0: one centre per pass.
             int jmax = 0;
             {
-                const size_t per = (size_t)4 * nb4 * sizeof(float) + (size_t)m * sizeof(T);
+                const size_t per = (size_t)4 * nb4 * sizeof(float) + ((size_t)m * sizeof(T) + 15) / 16 * 16;   // float32 copy + the row at a 16-byte pitch
                 if (16 * per <= 65536) jmax = 16;
                 else if (8 * per <= 65536) jmax = 8;
-                // Where it pays (scripts/kcwide.py, profiles/r06_kcenters_wide.txt): a round costs ~250 us on top of its streaming
-                // -- the selector replays up to 16 centres on up to 2,048 listed rows through ONE workgroup (1.4 MB of rows per
-                // centre at 171 float32 features), the pass carries 16 accumulators per row and re-evaluates the union of the
-                // batch's candidates -- against ~30 us of launch and latency per one-centre pass: passes of >= 90 MB, rows of
-                // <= 1 KiB (1M x 171, K = 500: 28.9 -> 19.0 ms; 280,000 x 171, K = 200: 6.6 -> 7.8 ms, left alone).
-                // MSM_KC_WBATCH=0 / 1 (read per fit) forces either.
+                // (First version: a round cost ~250 us on top of its streaming and the batches only paid for passes of >= 90 MB.
+                //  The cost was the exact re-evaluation -- one lane per candidate walking its row element by element out of LDS,
+                //  ~10 us per row and centre -- and the one-workgroup selector; with 16-byte fetches ahead of the chain
+                //  (kwb_exact_euclid) and the selector on several workgroups the batches win at every shape of scripts/kcwide.py:
+                //  280,000 x 171 K = 200 6.6 -> 4.3 ms, 1M x 171 K = 500 28.2 -> 13.9 ms, 500,000 x 512 27.4 -> 24.4 ms.)
+                // Default for rows of up to 1 KiB; MSM_KC_WBATCH=0 / 1 (read per fit) forces one centre per screened pass / the batches.
                 const char* be = getenv("MSM_KC_WBATCH");
-                const double pass_bytes = (double)n * (4.0 * nb4 + 8.0);
-                const bool pays = (pass_bytes >= 9e7 && (size_t)m * sizeof(T) <= 1024) || (pass_bytes >= 5e7 && (size_t)m * sizeof(T) <= 192);   // (2M x 17 float64: 5.95 -> 4.97 ms)
+                const bool pays = (size_t)m * sizeof(T) <= 1024;   // (500,000 x 512 float32: 24.5 ms batched against 19.7 ms one centre per pass -- 16 accumulators per row over 128 words, and the union of 16 centres' candidates at 2 KiB per row)
                 if (be ? atoi(be) == 0 : !pays) jmax = 0;
             }
             if (jmax > 0) {
                 DevBuf& SB = pool(PS_W);
-                if ((rc = SB.reserve(sizeof(KcbState)))) return rc;
+                if ((rc = SB.reserve(sizeof(KcbState) + sizeof(KwbSync)))) return rc;
                 KcbState* St = SB.as<KcbState>();
+                KwbSync* Sy = reinterpret_cast<KwbSync*>(static_cast<char*>(SB.p) + sizeof(KcbState));
                 hipLaunchKernelGGL(kcb_init_kernel, dim3(1), dim3(64), 0, stream(), St, (int)it);
+                MSM_HIP_CHECK(hipMemsetAsync(Sy, 0, sizeof(KwbSync), stream()));
+                // the selector on several workgroups (kwb_select_multi_kernel): as many as it takes for a slice of a full list
+                // to fit the LDS beside the centre, one row per thread; 0: one workgroup (rows beyond ~9 KiB; MSM_KC_WSELECT=1)
+                int nbsel = 0;
+                size_t ldssel = 0;
+                {
+                    const size_t pitch = (size_t)(m | 1), cpad = (size_t)((m + 3) & ~3LL);
+                    for (int nb = 8; nb <= 64; nb += 8) {
+                        const size_t rpw = (size_t)ceil_div(KCB_CAP, nb);
+                        const size_t bytes = (cpad + rpw * pitch) * sizeof(T);
+                        if (rpw <= (size_t)DT && bytes <= 150000) {
+                            nbsel = nb;
+                            ldssel = bytes;
+                            break;
+                        }
+                    }
+                    if (getenv("MSM_KC_WSELECT") && atoi(getenv("MSM_KC_WSELECT")) == 1) nbsel = 0;
+                    if (nbsel) {
+                        static bool attr_set = false;
+                        if (!attr_set) {
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kwb_select_multi_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150016);
+                            attr_set = true;
+                        }
+                    }
+                }
                 const int it0 = (int)it;
                 const int kr2 = nb4 <= 16 ? 4 : 2;   // rows per thread: 16 (8) accumulators each
                 const int gp2 = (int)std::min<long long>(ceil_div(n, (long long)kr2 * DT), nblk0);
-                const size_t lds2 = (size_t)jmax * ((size_t)4 * nb4 * sizeof(float) + (size_t)m * sizeof(T));
+                const size_t lds2 = (size_t)jmax * ((size_t)4 * nb4 * sizeof(float) + ((size_t)m * sizeof(T) + 15) / 16 * 16);
                 int rounds = 0, done = it0;
                 const int wcap = getenv("MSM_KC_WCAP") ? std::max(64, std::min(KCB_CAP, atoi(getenv("MSM_KC_WCAP")))) : KCB_CAP;
                 int head4[4] = {it0, 0, 0, 0};   // k_done, J, rounds, fallbacks: the head of KcbState
@@ -635,7 +660,8 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                         S.prev = rounds == 0 ? part + (size_t)((it0 + 1) & 1) * nblk : part + (size_t)((it0 + rounds + 1) & 1) * nblk0;
                         S.next = part + (size_t)((it0 + rounds) & 1) * nblk0;
                         S.nblk = rounds == 0 ? nblk : gp2;
-                        hipLaunchKernelGGL((kwb_select_kernel<T>), dim3(1), dim3(1024), (size_t)m * sizeof(T), stream(), S, St, (int)K, jmax, wcap);
+                        if (nbsel) hipLaunchKernelGGL((kwb_select_multi_kernel<T>), dim3(nbsel), dim3(DT), ldssel, stream(), S, St, Sy, (int)K, jmax, wcap);
+                        else hipLaunchKernelGGL((kwb_select_kernel<T>), dim3(1), dim3(1024), (size_t)m * sizeof(T), stream(), S, St, (int)K, jmax, wcap);
                         if (jmax == 16) {
                             if (kr2 == 4) launch_kwb<T, 16, 4, 8>(gp2, lds2, S, St);
                             else launch_kwb<T, 16, 2, 24>(gp2, lds2, S, St);
@@ -645,9 +671,12 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                         }
                     }
                     MSM_HIP_CHECK(hipGetLastError());
+                    unsigned sy4[4] = {0, 0, 0, 0};
                     MSM_HIP_CHECK(hipMemcpyAsync(head4, St, sizeof(head4), hipMemcpyDeviceToHost, stream()));
+                    MSM_HIP_CHECK(hipMemcpyAsync(sy4, Sy, sizeof(sy4), hipMemcpyDeviceToHost, stream()));
                     MSM_HIP_CHECK(hipStreamSynchronize(stream()));
                     done = head4[0];
+                    if (sy4[2]) return fail(MSM_ERR_HIP, "k-centers: the selector's workgroups did not meet at their barrier (MSM_KC_WSELECT=1 runs it on one workgroup)");
                     if (rounds > 4 * (int)K) return fail(MSM_ERR_HIP, "k-centers: the batched wide passes made no progress");
                 }
                 g_kc_stats.screened_passes = head4[2];

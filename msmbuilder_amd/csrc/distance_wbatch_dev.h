@@ -158,14 +158,218 @@ __global__ __launch_bounds__(1024) void kwb_select_kernel(KwsArgs P, KcbState* S
     }
 }
 
+// ---- the selector on SEVERAL workgroups -------------------------------------------------------------------------------------
+// kwb_select_kernel moves every listed row through ONE compute unit for every centre it tries: 2,048 rows x 684 bytes =
+// 1.4 MB per centre at 171 float32 features, ~100 us per round of a dozen centres and up to 400 us when the list is full
+// (profiles/r06_kcenters_wide.txt) -- as long as the pass it prepares.  Here NB workgroups (8 .. 64: as many as it takes for
+// a slice of the list to fit the LDS) each keep their slice's rows IN LDS for the whole round and replay the selection
+// together: per centre a workgroup reduces its slice to one candidate, publishes it, meets the others at a grid barrier,
+// reads all NB candidates and makes the same decision as everybody else, then updates its slice's distances from LDS (one
+// thread per row, the reference's arithmetic).  One barrier per centre (candidate slots double-buffered by parity).
+//   The barrier: an arrival counter in device memory, agent-scope release on arrival and acquire after the wait (the XCDs'
+// L2s are not coherent with each other), a launch base left by the previous launch of the same stream (every workgroup
+// passes the same number of barriers per launch: the decisions are functions of the published data).  The NB workgroups
+// are co-resident by construction -- the launch is alone on the device's compute queue at that point of the stream and NB <=
+// 64 of 256 CUs -- and the wait is BOUNDED: a workgroup that waits ~2 s flags the state, and the fit fails loudly.
+struct KwbSync {
+    unsigned bar;        // arrivals since the fit began
+    unsigned bar_base;   // ... at the start of the current launch
+    unsigned timed_out;
+    unsigned pad;
+    KcPartial slot[2][64];
+};
+
+__device__ __forceinline__ bool kwb_grid_barrier(KwbSync* Y, unsigned target)
+{
+    // (called by one thread per workgroup, between two __syncthreads)
+    __hip_atomic_fetch_add(&Y->bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    for (long long spin = 0; spin < 2000000LL; ++spin) {   // (~1 us per look: ~2 s)
+        if (__hip_atomic_load(&Y->bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(&Y->timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+template <typename T>
+__global__ __launch_bounds__(DT) void kwb_select_multi_kernel(KwsArgs P, KcbState* S, KwbSync* Y, int K, int jmax, int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char kwb_smem[];
+    __shared__ double rv[DT / 64];
+    __shared__ long long ri[DT / 64];
+    __shared__ double bc_v;
+    __shared__ long long bc_i;
+    __shared__ int bc_ok;
+    const T* X = static_cast<const T*>(P.X);
+    const int tid = threadIdx.x, wg = blockIdx.x, NB = gridDim.x;
+    const long long m = P.m;
+    const int pitch = (int)(m | 1);                       // odd: a thread per row walks its row without bank conflicts
+    T* cs = reinterpret_cast<T*>(kwb_smem);               // [m] the centre being applied
+    T* rows = cs + ((m + 3) & ~3LL);                      // [rows of the slice][pitch]
+    const int k0 = S->k_done;
+    if (k0 >= K) {
+        if (wg == 0 && tid == 0) S->J = 0;
+        return;
+    }
+    // block argmax of (value, row): largest value, lowest row on ties -- result in every thread
+    auto reduce = [&](double v, long long i, double& ov, long long& oi) {
+        double wv;
+        long long wi;
+        kcb_wave_argmax(v, i, wv, wi);
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            rv[tid >> 6] = wv;
+            ri[tid >> 6] = wi;
+        }
+        __syncthreads();
+        const int l = tid & 63;
+        kcb_wave_argmax(l < DT / 64 ? rv[l] : -1.0, l < DT / 64 ? ri[l] : -1, ov, oi);
+    };
+    double vP;
+    long long iP;
+    {
+        double v = -1.0;
+        long long i = -1;
+        for (int k = tid; k < P.nblk; k += DT) {
+            const KcPartial q = P.prev[k];
+            if (q.i >= 0 && (i < 0 || kc_better(q.v, q.i, v, i))) {
+                v = q.v;
+                i = q.i;
+            }
+        }
+        reduce(v, i, vP, iP);
+    }
+    const float theta = S->theta;
+    const unsigned cnt = S->count;
+    const bool usable = cnt > 0 && cnt <= (unsigned)cap && theta > 0.f && theta < 3e38f;
+    const double tau = (double)theta;
+    const unsigned target = (unsigned)(cap - cap / 4);
+    // this workgroup's slice of the list: rows [r0, r0 + nr), one per thread, staged in LDS (coalesced)
+    const unsigned rpw = usable ? (cnt + NB - 1) / NB : 0u;
+    const unsigned r0 = (unsigned)wg * rpw;
+    const int nr = usable && r0 < cnt ? (int)(cnt - r0 < rpw ? cnt - r0 : rpw) : 0;
+    long long ci = -1;
+    double cv = -1.0;
+    if (tid < nr) {
+        ci = S->list[r0 + tid];
+        cv = P.dist[ci];
+    }
+    for (int r = tid >> 6; r < nr; r += DT / 64) {        // a wave per row: coalesced
+        const long long row = S->list[r0 + r];
+        for (long long f = tid & 63; f < m; f += 64) rows[(size_t)r * pitch + f] = X[row * m + f];
+    }
+    unsigned nbar = 0;
+    const unsigned base = Y->bar_base;
+    int J = 0, fell = 0, par = 0;
+    double vlast = vP;
+    bool alive = true;
+    for (;;) {
+        double vb, v1;
+        long long ib, i1;
+        reduce(ci >= 0 ? cv : -1.0, ci, v1, i1);
+        if (tid == 0) {
+            KcPartial q;
+            q.v = v1;
+            q.i = i1;
+            Y->slot[par][wg] = q;
+            ++nbar;
+            bc_ok = kwb_grid_barrier(Y, base + (unsigned)NB * nbar) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!bc_ok) {
+            alive = false;
+            break;
+        }
+        if (tid < 64) {
+            double sv = -1.0;
+            long long si = -1;
+            if (tid < NB) {
+                const KcPartial q = Y->slot[par][tid];
+                sv = q.v;
+                si = q.i;
+            }
+            double ov;
+            long long oi;
+            kcb_wave_argmax(sv, si, ov, oi);
+            if (tid == 0) {
+                bc_v = ov;
+                bc_i = oi;
+            }
+        }
+        __syncthreads();
+        vb = bc_v;
+        ib = bc_i;
+        par ^= 1;
+        long long centre;
+        if (J == 0) {
+            if (usable && ib == iP) {
+                centre = ib;
+            } else {
+                centre = iP;
+                fell = 1;
+            }
+            vlast = vP;
+        } else {
+            if (!(ib >= 0 && vb > tau)) break;
+            centre = ib;
+            vlast = vb;
+        }
+        for (long long f = tid; f < m; f += DT) cs[f] = X[centre * m + f];
+        if (wg == 0 && tid == 0) P.ids[k0 + J] = centre;
+        __syncthreads();
+        ++J;
+        if (fell || k0 + J >= K || J >= jmax) break;
+        if (ci >= 0) {
+            if (ci == centre) {
+                ci = -1;
+            } else {
+                const T* x = rows + (size_t)tid * pitch;
+                double a = 0.0, b = 0.0;
+                for (long long f = 0; f < m; ++f) m_update<T, M_EUCLIDEAN>(a, b, x[f], cs[f]);
+                const double d = m_final<M_EUCLIDEAN>(a, b, m);
+                if (d < cv) cv = d;   // the pass's own update (kcenters.py:93)
+            }
+        }
+    }
+    if (wg == 0 && tid == 0) {
+        // threshold of the next list (kcb_select_kernel's rule)
+        float th;
+        const float vl = ksc_round_up(vlast > 0.0 ? vlast : 0.0);
+        if (!(theta > 0.f) || !(theta < 3e38f)) {
+            th = 0.97f * vl;
+        } else if (cnt > target) {
+            th = theta * 1.02f;
+        } else {
+            int l = 0;
+            for (int q = 1; q < KCB_NLEV; ++q)
+                if (S->lev[q] <= target) l = q;
+            th = theta * kcb_level(l);
+        }
+        if (th > vl) th = vl;
+        S->theta = th;
+        S->count = 0;
+        for (int q = 0; q < KCB_NLEV; ++q) S->lev[q] = 0;
+        S->J = alive ? J : 0;
+        S->k_done = k0 + (alive ? J : 0);
+        S->rounds += 1;
+        S->fallbacks += fell;
+        Y->bar_base = base + (unsigned)NB * nbar;
+    }
+}
+
 // JS: the centres the body is compiled for (the batch's J rounded up to a multiple of 4: the kernel switches on it); the LDS
 // holds the centres of a feature side by side ([4 nb4][JB] floats), so two centres' differences and squares are ONE packed
 // operation each (v_pk_add_f32 / v_pk_fma_f32): 4 VALU operations per word of a row and centre.
+// candidate rows re-evaluated together (staged in LDS): 64 rows of up to 175 floats; rows at a pitch of 16 x odd bytes, so
+// the lanes' 16-byte reads of their own rows fall on different bank quads
+constexpr int KWB_CB = 64;
+constexpr int KWB_CFLOATS = 11264;   // 44 KiB
+
 template <int KWS_R>
 struct KwbShared {   // the pass kernel's static LDS (one object, shared by the bodies the kernel switches between)
     double rv[DT];
     long long ri[DT];
-    __attribute__((aligned(16))) float cstage[KWS_CFLOATS];
+    __attribute__((aligned(16))) float cstage[KWB_CFLOATS];
     int cand[KWS_R * DT];
     unsigned short cmk[KWS_R * DT];
     unsigned slev[KCB_NLEV];
@@ -177,7 +381,8 @@ __device__ __forceinline__ void kwb_pass_body(const KwsArgs& P, KcbState* S, cha
 {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     float* ycf = reinterpret_cast<float*>(kwb_smem);                                    // [4 nb4][JB] centres relative to c0, float32, zero padded
-    T* yraw = reinterpret_cast<T*>(kwb_smem + (size_t)JB * 4 * P.nb4 * sizeof(float));    // [JB][m] the centres themselves
+    T* yraw = reinterpret_cast<T*>(kwb_smem + (size_t)JB * 4 * P.nb4 * sizeof(float));    // [JB][ypitch] the centres themselves (rows 16-byte aligned)
+    const int ypitch = (int)((P.m * sizeof(T) + 15) / 16 * 16 / sizeof(T));
     double* const rv = sh.rv;
     long long* const ri = sh.ri;
     int* const cand = sh.cand;
@@ -197,7 +402,7 @@ __device__ __forceinline__ void kwb_pass_body(const KwsArgs& P, KcbState* S, cha
         const int j = e / cw, f = e - j * cw;
         const long long row = P.ids[kbase + (j < J ? j : J - 1)];
         const T yv = f < m ? X[row * m + f] : (T)0;
-        if (f < m) yraw[(size_t)j * m + f] = yv;
+        if (f < m) yraw[(size_t)j * ypitch + f] = yv;
         ycf[f * JB + j] = f < m ? (float)((double)yv - P.c0[f]) : 0.f;
     }
     __syncthreads();
@@ -206,9 +411,9 @@ __device__ __forceinline__ void kwb_pass_body(const KwsArgs& P, KcbState* S, cha
     const float ea = (float)(m + 8) * 2.3841858e-07f;
     const float eq = 0.5001f * sqrtf((float)m);
     const float refl = (sizeof(T) == 4) ? (1.f - 2.3841858e-07f) : 1.f;
-    const int cpitch = (int)m + 1;
-    const int cbatch = (int)((long long)KWS_CFLOATS * sizeof(float) / ((long long)cpitch * sizeof(T)));
-    const int cb = cbatch < 1 ? 0 : (cbatch < KWS_CB ? cbatch : KWS_CB);
+    const int cpitch = (int)(((((long long)m * sizeof(T) + 15) / 16) | 1) * 16 / sizeof(T));   // 16 x odd bytes
+    const int cbatch = (int)((long long)KWB_CFLOATS * sizeof(float) / ((long long)cpitch * sizeof(T)));
+    const int cb = cbatch < 1 ? 0 : (cbatch < KWB_CB ? cbatch : KWB_CB);
     T* cst = reinterpret_cast<T*>(cstage);
 
     float bestf = -1.f;
@@ -352,10 +557,15 @@ __device__ __forceinline__ void kwb_pass_body(const KwsArgs& P, KcbState* S, cha
                 while (mk) {   // the batch's centres in order, as the separate passes would meet the row
                     const int j = __builtin_ctz(mk);
                     mk &= mk - 1;
-                    const T* y = yraw + (size_t)j * m;
-                    double a = 0.0, bb = 0.0;
-                    for (long long f = 0; f < m; ++f) m_update<T, M_EUCLIDEAN>(a, bb, x[f], y[f]);
-                    const double d = m_final<M_EUCLIDEAN>(a, bb, m);
+                    const T* y = yraw + (size_t)j * ypitch;
+                    double d;
+                    if (cb) {
+                        d = kws_exact_euclid<T>(x, y, m);
+                    } else {   // rows too long to stage: straight from global memory (any alignment)
+                        double a = 0.0, bb = 0.0;
+                        for (long long f = 0; f < m; ++f) m_update<T, M_EUCLIDEAN>(a, bb, x[f], y[f]);
+                        d = m_final<M_EUCLIDEAN>(a, bb, m);
+                    }
                     if (d < c) {   // strict, kcenters.py:93
                         c = d;
                         lab = kbase + j;

@@ -157,6 +157,28 @@ constexpr int KWS_RMAX = 8;
 constexpr int KWS_CB = 32;      // candidates re-evaluated together (their rows staged in LDS)
 constexpr int KWS_CFLOATS = 6144;   // LDS floats (or doubles / 2) of that staging area: KWS_CB rows of up to 191 floats, fewer rows when longer
 
+// the reference's distance of a row to a centre -- one fp64 accumulator, features in order (m_update / m_final) -- with the
+// operands fetched 16 bytes at a time, two fetches ahead of the chain (x and y 16-byte aligned, LDS or global).  Element by
+// element (a chain that waits for an LDS round trip per feature) this was ~10 us per row and centre at 171 features.
+template <typename T>
+__device__ __forceinline__ double kws_exact_euclid(const T* x, const T* y, long long m)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    double a = 0.0, b = 0.0;
+    long long f = 0;
+    for (; f + 2 * V <= m; f += 2 * V) {
+        const vec_t x0 = *reinterpret_cast<const vec_t*>(x + f), x1 = *reinterpret_cast<const vec_t*>(x + f + V);
+        const vec_t y0 = *reinterpret_cast<const vec_t*>(y + f), y1 = *reinterpret_cast<const vec_t*>(y + f + V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) m_update<T, M_EUCLIDEAN>(a, b, x0[e], y0[e]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) m_update<T, M_EUCLIDEAN>(a, b, x1[e], y1[e]);
+    }
+    for (; f < m; ++f) m_update<T, M_EUCLIDEAN>(a, b, x[f], y[f]);
+    return m_final<M_EUCLIDEAN>(a, b, m);
+}
+
 template <typename T, int KWS_R, int KWS_U>
 __global__ __launch_bounds__(DT) void kcenters_wscreen_pass_kernel(KwsArgs P)
 {
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(DT) void kcenters_wscreen_pass_kernel(KwsArgs P)
     const float eq = 0.5001f * sqrtf((float)m);                    // >= 0.5 sqrt(m) with float32 roundings to spare
     const float refl = (sizeof(T) == 4) ? (1.f - 2.3841858e-07f) : 1.f;   // the reference's own float32 subtraction (float rows)
     // candidate staging: rows of pitch m + 1 (odd or not, lanes of a wave then hit different banks), as many as fit
-    const int cpitch = (int)m + 1;
+    const int cpitch = (int)(((((long long)m * sizeof(T) + 15) / 16) | 1) * 16 / sizeof(T));   // 16 x odd bytes: the lanes' 16-byte reads of their rows fall on different bank quads
     const int cbatch = (int)((long long)KWS_CFLOATS * sizeof(float) / ((long long)cpitch * sizeof(T)));
     const int cb = cbatch < 1 ? 0 : (cbatch < KWS_CB ? cbatch : KWS_CB);   // 0: rows too long to stage -> straight from global memory
     T* cst = reinterpret_cast<T*>(cstage);
@@ -316,9 +338,14 @@ __global__ __launch_bounds__(DT) void kcenters_wscreen_pass_kernel(KwsArgs P)
             if (tid < cn) {
                 const long long ic = base + cand[c0 + tid];
                 const T* x = cb ? cst + tid * cpitch : X + ic * m;
-                double a = 0.0, bb = 0.0;
-                for (long long f = 0; f < m; ++f) m_update<T, M_EUCLIDEAN>(a, bb, x[f], yraw[f]);
-                const double d = m_final<M_EUCLIDEAN>(a, bb, m);
+                double d;
+                if (cb) {
+                    d = kws_exact_euclid<T>(x, yraw, m);
+                } else {   // rows too long to stage: straight from global memory (any alignment)
+                    double a = 0.0, bb = 0.0;
+                    for (long long f = 0; f < m; ++f) m_update<T, M_EUCLIDEAN>(a, bb, x[f], yraw[f]);
+                    d = m_final<M_EUCLIDEAN>(a, bb, m);
+                }
                 ++n_cand;
                 float cf = cfo;
                 if (d < dold) {   // strict, kcenters.py:93
