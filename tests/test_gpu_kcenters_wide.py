@@ -79,7 +79,8 @@ def test_wide_screen_equals_plain_passes_device_rows(gpu, monkeypatch, dtype, n,
 @pytest.mark.parametrize("dtype,n,m,k,data", [(np.float32, 280_000, 171, 60, "hubs"), (np.float32, 200_000, 64, 100, "hubs"),
                                               (np.float64, 150_000, 24, 80, "hubs"), (np.float32, 120_000, 512, 40, "hubs"),
                                               (np.float64, 100_000, 100, 50, "blob"), (np.float32, 90_000, 33, 300, "ties"),
-                                              (np.float32, 70_000, 300, 30, "nan")])
+                                              (np.float32, 70_000, 300, 30, "nan"), (np.float32, 70_000, 40, 12, "const"),
+                                              (np.float64, 66_000, 300, 24, "hubs"), (np.float32, 66_000, 2048, 12, "hubs")])
 def test_wide_batched_passes_equal_plain_passes(gpu, monkeypatch, dtype, n, m, k, data):
     """Several centres per screened pass of wide rows (distance_wbatch_dev.h: threshold lists, the selector replays the
     algorithm on the listed rows, the pass applies the batch in order): centre ids / labels / distances / inertia of the
@@ -95,6 +96,8 @@ def test_wide_batched_passes_equal_plain_passes(gpu, monkeypatch, dtype, n, m, k
     else:
         hubs = torch.randn(12, m, generator=g, device="cuda") * 2.0
         X = (hubs[torch.randint(0, 12, (n,), generator=g, device="cuda")] + torch.randn(n, m, generator=g, device="cuda")).to(td)
+    if data == "const":
+        X[:] = X[0]                             # every distance is 0: no usable threshold, one centre per pass
     if data == "ties":
         X[n // 2:] = X[: n - n // 2]            # every row twice: every maximum is tied
     if data == "nan":
@@ -113,4 +116,4 @@ def test_wide_batched_passes_equal_plain_passes(gpu, monkeypatch, dtype, n, m, k
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
     assert a[3] == b[3] or (np.isnan(a[3]) and np.isnan(b[3]))
     assert 0 < a[4][2] <= k - 4 and b[4][2] == 0    # batched passes: fewer than centres ...
-    assert data == "nan" or a[4][2] < (k - 4) // 2   # ... (a NaN distance makes every list unusable: one centre per pass, still exact)
+    assert data in ("nan", "const") or a[4][2] < (k - 4) // 2 or m == 2048   # (2,048 features: rows too long for the batches' LDS: one centre per pass)   # ... (a NaN distance makes every list unusable: one centre per pass, still exact)
