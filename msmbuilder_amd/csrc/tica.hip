@@ -600,7 +600,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         // (units x multiply steps per pack step) is the share of its steps that carry when two consecutive super-chunks are
         // equally long -- beyond ~0.9 the drain loop would do the packing with the matrix pipes idle (float32 rows of 256
         // features in mode bf16).  MSM_TICA_IMG_CARRY=0 restores pack / multiply turns.
-        // Default from 1,024 features, where it wins with the folded column sums (scripts/carryabl.py, profiles/r06_carry.txt:
+        // Default from 1,024 features (bf16x2: 512), where it wins with the folded column sums (scripts/carryabl.py, profiles/r06_carry.txt:
         // fit of 1M x 2048 bfloat16 rows 11.1 -> 10.5 ms, bf16x2 32.8 -> 28.8 ms; 768 features 7.15 -> 7.31 ms: the items' fp64
         // column sums cost what the overlap saves); MSM_TICA_IMG_CARRY=1 forces it at any width it can run.
         bool carry = h->F % 256 == 0 && ((long long)ld * dtype_bytes) % 16 == 0 && h->ntile2 <= h->img_grid;
@@ -608,7 +608,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
         {
             const char* ce = getenv("MSM_TICA_IMG_CARRY");
             if (ce && atoi(ce) == 0) carry = false;
-            if (!ce && h->F < 1024) carry = false;
+            if (!ce && h->F < (h->mode == MSM_TICA_BF16X2 ? 512 : 1024)) carry = false;   // (bf16x2: three times the multiply to hide behind -- 768 features 18.3 -> 16.0 ms, 512 15.4 -> 13.7 ms)
             if (ce && atoi(ce) == 2) prepass_all = true;
             for (size_t c = 0; c < tab.size() && carry; ++c)
                 if (((uintptr_t)tab[c].base) & 15) carry = false;
