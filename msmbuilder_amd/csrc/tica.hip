@@ -547,6 +547,7 @@ int tica_accumulate_device(msm_tica* h, const void* const* ptrs, const msm_idx_t
     MSM_HIP_CHECK(hipMemsetAsync(h->cosync, 0, (size_t)(std::max(h->S, h->S_sym) + 1) * sizeof(unsigned), stream()));
     if (!useimg && h->ev0) MSM_HIP_CHECK(hipEventRecord(h->ev0, stream()));   // (image path: recorded below, around the whole pipeline)
     h->last_fused = 0;
+    h->last_carried = 0;
     if (usefused && img_groups > 0 && img_groups / 2 < 0x7fffffffLL) {
         // ONE launch over every K-step of the call: step records from the chunk table, then the fused kernel
         const bool x2 = h->mode == MSM_TICA_BF16X2;
