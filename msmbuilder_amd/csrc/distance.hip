@@ -589,7 +589,11 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                                const_cast<double*>(S.c0), S.gmax2);
             const int crows = std::max(1, std::min(KWS_CROWS, KWS_CWORDS / (nb4 + 1)));   // rows a workgroup transposes at a time
             const int gconv = (int)std::min<long long>(ceil_div(n, crows), 16LL * num_cus());
-            hipLaunchKernelGGL(kws_convert_kernel<T>, dim3(gconv), dim3(DT), (size_t)m * sizeof(double), stream(), S, crows);
+            if ((size_t)m * sizeof(T) <= 192)   // short rows: a thread per row (2M x 17 float64: convert 0.99 -> 0.6 ms; from 256-byte rows the strided walks lose: 1M x 64 float32 fit 3.9 -> 4.5 ms)
+                hipLaunchKernelGGL(kws_convert_rowthread_kernel<T>, dim3((unsigned)std::min<long long>(ceil_div(n, DT), 16LL * num_cus())), dim3(DT),
+                                   (size_t)m * sizeof(double), stream(), S);
+            else
+                hipLaunchKernelGGL(kws_convert_kernel<T>, dim3(gconv), dim3(DT), (size_t)m * sizeof(double), stream(), S, crows);
             MSM_HIP_CHECK(hipGetLastError());
             g_kc_stats.plain_passes = it;
             g_kc_stats.screened_passes = K - it;

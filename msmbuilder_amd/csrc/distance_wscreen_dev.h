@@ -76,58 +76,96 @@ __global__ __launch_bounds__(DT) void kws_convert_kernel(KwsArgs P, int rows_per
     double gmax = 0.0;
     for (long long r0 = (long long)blockIdx.x * rows_per_block; r0 < P.n; r0 += (long long)gridDim.x * rows_per_block) {
         const int nr = (int)(P.n - r0 < rows_per_block ? P.n - r0 : rows_per_block);
-        for (int r = wave; r < nr; r += DT / 64) {
-            const long long i = r0 + r;
-            const T* x = X + i * P.m;
-            // pass 1 over the row (registers hold nothing: the second reading below hits the L1 / L2 lines of the first)
-            float mx = 0.f;
-            double n2 = 0.0;
-            bool bad = false;
+        // (TWO rows per wave and trip: a row is two dependent trips to memory -- one row at a time the kernel ran at 0.85 TB/s)
+        for (int rr = wave; rr < nr; rr += 2 * (DT / 64)) {
+            constexpr int NRW = 2;
+            int rw[NRW];
+            const T* xw[NRW];
+            bool on[NRW];
+#pragma unroll
+            for (int u = 0; u < NRW; ++u) {
+                rw[u] = rr + u * (DT / 64);
+                on[u] = rw[u] < nr;
+                xw[u] = X + (r0 + (on[u] ? rw[u] : rr)) * P.m;
+            }
+            // pass 1 over the rows (registers hold nothing: the second reading below hits the L1 / L2 lines of the first)
+            float mx[NRW];
+            double n2[NRW];
+            bool bad[NRW];
+#pragma unroll
+            for (int u = 0; u < NRW; ++u) {
+                mx[u] = 0.f;
+                n2[u] = 0.0;
+                bad[u] = false;
+            }
             for (long long f = lane; f < P.m; f += 64) {
-                const double d = (double)x[f] - c0s[f];
-                n2 = fma(d, d, n2);
-                const float a = fabsf((float)d);
-                mx = a > mx ? a : mx;
-                bad |= !(d == d);
+                double d[NRW];
+#pragma unroll
+                for (int u = 0; u < NRW; ++u) d[u] = (double)xw[u][f] - c0s[f];
+#pragma unroll
+                for (int u = 0; u < NRW; ++u) {
+                    n2[u] = fma(d[u], d[u], n2[u]);
+                    const float a = fabsf((float)d[u]);
+                    mx[u] = a > mx[u] ? a : mx[u];
+                    bad[u] |= !(d[u] == d[u]);
+                }
             }
 #pragma unroll
             for (int msk = 32; msk > 0; msk >>= 1) {
-                const float om = __shfl_xor(mx, msk, 64);
-                mx = om > mx ? om : mx;
-                n2 += __shfl_xor(n2, msk, 64);
-                bad |= (bool)__shfl_xor((int)bad, msk, 64);
+#pragma unroll
+                for (int u = 0; u < NRW; ++u) {
+                    const float om = __shfl_xor(mx[u], msk, 64);
+                    mx[u] = om > mx[u] ? om : mx[u];
+                    n2[u] += __shfl_xor(n2[u], msk, 64);
+                    bad[u] |= (bool)__shfl_xor((int)bad[u], msk, 64);
+                }
             }
-            if (bad || !(n2 == n2)) {
-                mx = NAN;
-                n2 = NAN;
+            float inv[NRW];
+            unsigned short sbw[NRW];
+#pragma unroll
+            for (int u = 0; u < NRW; ++u) {
+                if (bad[u] || !(n2[u] == n2[u])) {
+                    mx[u] = NAN;
+                    n2[u] = NAN;
+                }
+                if (on[u]) gmax = (n2[u] > gmax || !(n2[u] == n2[u])) ? n2[u] : gmax;
+                // the row's scale: the smallest bfloat16 >= mx / 127 (a zero row: any scale)
+                float s = mx[u] / 127.f;
+                if (!(s > 0.f)) s = (s == s) ? 1.f : s;   // zero row -> 1; NaN stays NaN
+                s = s * 1.0000002f;                        // (the division rounded to nearest: stay on the safe side of mx / 127)
+                sbw[u] = (unsigned short)ksc_bf16_up(s);
+                const float sfv = __uint_as_float((unsigned)sbw[u] << 16);
+                inv[u] = 1.f / sfv;
             }
-            gmax = (n2 > gmax || !(n2 == n2)) ? n2 : gmax;
-            // the row's scale: the smallest bfloat16 >= mx / 127 (a zero row: any scale)
-            float s = mx / 127.f;
-            if (!(s > 0.f)) s = (s == s) ? 1.f : s;   // zero row -> 1; NaN stays NaN
-            s = s * 1.0000002f;                        // (the division rounded to nearest: stay on the safe side of mx / 127)
-            const unsigned short sb = (unsigned short)ksc_bf16_up(s);
-            const float sfv = __uint_as_float((unsigned)sb << 16);
-            const float inv = 1.f / sfv;
             for (int b = lane; b < P.nb4; b += 64) {
-                unsigned w = 0;
+                unsigned w[NRW];
+#pragma unroll
+                for (int u = 0; u < NRW; ++u) w[u] = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const long long f = 4LL * b + e;
-                    int qv = 0;
                     if (f < P.m) {
-                        const float d = (float)((double)x[f] - c0s[f]);
-                        float q = rintf(d * inv);
-                        q = q > 127.f ? 127.f : (q < -127.f ? -127.f : q);   // (cannot bind for finite rows: sf >= mx / 127)
-                        qv = (q == q) ? (int)q : 0;
+#pragma unroll
+                        for (int u = 0; u < NRW; ++u) {
+                            const float d = (float)((double)xw[u][f] - c0s[f]);
+                            float q = rintf(d * inv[u]);
+                            q = q > 127.f ? 127.f : (q < -127.f ? -127.f : q);   // (cannot bind for finite rows: sf >= mx / 127)
+                            const int qv = (q == q) ? (int)q : 0;
+                            w[u] |= ((unsigned)qv & 0xffu) << (8 * e);
+                        }
                     }
-                    w |= ((unsigned)qv & 0xffu) << (8 * e);
                 }
-                words[r * pitch + b] = w;
+#pragma unroll
+                for (int u = 0; u < NRW; ++u)
+                    if (on[u]) words[rw[u] * pitch + b] = w[u];
             }
             if (lane == 0) {
-                P.sf[i] = sb;
-                P.curf[i] = ksc_round_up(P.dist[i]);
+#pragma unroll
+                for (int u = 0; u < NRW; ++u)
+                    if (on[u]) {
+                        P.sf[r0 + rw[u]] = sbw[u];
+                        P.curf[r0 + rw[u]] = ksc_round_up(P.dist[r0 + rw[u]]);
+                    }
             }
         }
         __syncthreads();
@@ -146,6 +184,79 @@ __global__ __launch_bounds__(DT) void kws_convert_kernel(KwsArgs P, int rows_per
         for (int w = 1; w < DT / 64; ++w)
             if (gred[w] > g || !(gred[w] == gred[w])) g = gred[w];
         if (!(g == g)) g = INFINITY;   // (non-negative doubles order like their bit patterns; +inf is the largest)
+        atomicMax(P.gmax2, (unsigned long long)__double_as_longlong(g));
+    }
+}
+
+// Short rows (up to 192 bytes): a THREAD per row.  With a wave per row only m of 64 lanes work and every row is two dependent trips
+// to memory: 2M x 17 float64 took 0.99 ms (0.33 TB/s), a fifth of the whole fit (profiles/r06_kcenters_wide.txt).  A thread
+// walks its own row twice (the lanes of a wave cover 64 consecutive rows: whole cache lines, the second walk out of the
+// L1 / L2) and writes its words of the planes coalesced -- no transposition through LDS.  Same scale, same bytes, same
+// rounded-up distance as kws_convert_kernel (the maximum is order-independent; the squared norm only feeds the bound G).
+template <typename T>
+__global__ __launch_bounds__(DT) void kws_convert_rowthread_kernel(KwsArgs P)
+{
+    extern __shared__ double c0s[];   // [m]
+    __shared__ double gred[DT / 64];
+    const T* X = static_cast<const T*>(P.X);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (long long f = tid; f < P.m; f += DT) c0s[f] = P.c0[f];
+    __syncthreads();
+    double gmax = 0.0;
+    for (long long i = (long long)blockIdx.x * DT + tid; i < P.n; i += (long long)gridDim.x * DT) {
+        const T* x = X + i * P.m;
+        float mx = 0.f;
+        double n2 = 0.0;
+        bool bad = false;
+        for (long long f = 0; f < P.m; ++f) {
+            const double d = (double)x[f] - c0s[f];
+            n2 = fma(d, d, n2);
+            const float a = fabsf((float)d);
+            mx = a > mx ? a : mx;
+            bad |= !(d == d);
+        }
+        if (bad || !(n2 == n2)) {
+            mx = NAN;
+            n2 = NAN;
+        }
+        gmax = (n2 > gmax || !(n2 == n2)) ? n2 : gmax;
+        float s = mx / 127.f;
+        if (!(s > 0.f)) s = (s == s) ? 1.f : s;   // zero row -> 1; NaN stays NaN
+        s = s * 1.0000002f;
+        const unsigned short sb = (unsigned short)ksc_bf16_up(s);
+        const float sfv = __uint_as_float((unsigned)sb << 16);
+        const float inv = 1.f / sfv;
+        for (int b = 0; b < P.nb4; ++b) {
+            unsigned w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long f = 4LL * b + e;
+                int qv = 0;
+                if (f < P.m) {
+                    const float d = (float)((double)x[f] - c0s[f]);
+                    float q = rintf(d * inv);
+                    q = q > 127.f ? 127.f : (q < -127.f ? -127.f : q);
+                    qv = (q == q) ? (int)q : 0;
+                }
+                w |= ((unsigned)qv & 0xffu) << (8 * e);
+            }
+            P.q[(size_t)b * P.n + i] = w;
+        }
+        P.sf[i] = sb;
+        P.curf[i] = ksc_round_up(P.dist[i]);
+    }
+    // maximum of the squared norms (NaN poisons it on purpose) -> one atomic per block
+    for (int msk = 32; msk > 0; msk >>= 1) {
+        const double o = __shfl_xor(gmax, msk, 64);
+        gmax = (o > gmax || !(o == o)) ? o : gmax;
+    }
+    if (lane == 0) gred[wave] = gmax;
+    __syncthreads();
+    if (tid == 0) {
+        double g = gred[0];
+        for (int w = 1; w < DT / 64; ++w)
+            if (gred[w] > g || !(gred[w] == gred[w])) g = gred[w];
+        if (!(g == g)) g = INFINITY;
         atomicMax(P.gmax2, (unsigned long long)__double_as_longlong(g));
     }
 }
