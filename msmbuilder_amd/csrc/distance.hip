@@ -656,7 +656,7 @@ int kcenters_impl(const T* X, msm_idx_t n, msm_idx_t m, msm_idx_t K, const char*
                 const int gp2 = (int)std::min<long long>(ceil_div(n, (long long)kr2 * DT), nblk0);
                 const size_t lds2 = (size_t)jmax * ((size_t)4 * nb4 * sizeof(float) + ((size_t)m * sizeof(T) + 15) / 16 * 16);
                 int rounds = 0, done = it0;
-                const int wcap = getenv("MSM_KC_WCAP") ? std::max(64, std::min(KCB_CAP, atoi(getenv("MSM_KC_WCAP")))) : KCB_CAP;
+                const int wcap = KCB_CAP;   // (shorter lists were tried: 512 rows -> three centres per round instead of twelve)
                 int head4[4] = {it0, 0, 0, 0};   // k_done, J, rounds, fallbacks: the head of KcbState
                 while (done < (int)K) {
                     const int group = kcb_group((int)K, done, rounds, it0);

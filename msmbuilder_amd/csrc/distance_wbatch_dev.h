@@ -27,8 +27,6 @@
 
 namespace msm {
 
-constexpr int KWB_JMAX = 16;
-
 template <typename T>
 __global__ __launch_bounds__(1024) void kwb_select_kernel(KwsArgs P, KcbState* S, int K, int jmax, int cap)
 {
